@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""Generate the golden input/output vectors under tests/golden/ by running the
+REFERENCE ITSELF (thiviyanT/torch-rgcn, mounted read-only at /root/reference).
+
+Runs only in the build container -- the reference cannot travel to the GPU box;
+the .npz files it writes (data only: inputs, expected outputs, expected grads) do.
+
+    python tests/golden/gen_golden.py            # rewrites tests/golden/*.npz
+
+Sets:
+  g1_nc_*    RelationalGraphConvolutionNC, tiny graph with duplicates + isolated node
+  g2_lp_*    RelationalGraphConvolutionLP, eval and deterministic train mode
+  g3_utils   add_inverse_and_self / stack_matrices / sum_sparse on random input
+  g4_model_* NodeClassifier / EmbeddingNodeClassifier: logits, loss, grads, 3 Adam steps
+  g5_distmult DistMult.forward (2-D, 3-D, +-bias) and s_penalty
+  g6_mid     N=2000, R0=10, E=20000, d=16 NC layer pair (int32 triples, fp32 tensors)
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+REF = os.environ.get("RGCN_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+warnings.filterwarnings("ignore")
+
+from torch_rgcn.layers import (DistMult, RelationalGraphConvolutionLP,  # noqa: E402
+                               RelationalGraphConvolutionNC)
+from torch_rgcn.models import EmbeddingNodeClassifier, NodeClassifier  # noqa: E402
+from torch_rgcn.utils import add_inverse_and_self, stack_matrices, sum_sparse  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def seeded_params(module, gen):
+    """Overwrite every parameter with seeded N(0, 0.5) values (bias included)."""
+    with torch.no_grad():
+        for p in module.parameters():
+            p.copy_(torch.randn(p.shape, generator=gen) * 0.5)
+
+
+def tiny_graph():
+    """N=8 (divisible by 2 and 4), R0=3, 15 distinct edges + 2 duplicates; node 7 isolated."""
+    base = [(0, 0, 1), (1, 0, 2), (2, 0, 3), (3, 0, 0), (0, 1, 4), (4, 1, 5), (5, 1, 6), (6, 1, 0),
+            (1, 2, 3), (3, 2, 5), (5, 2, 1), (2, 2, 6), (0, 0, 2), (0, 0, 3), (4, 1, 6),
+            (0, 0, 1), (5, 2, 1)]  # last two duplicate earlier edges
+    return torch.tensor(base, dtype=torch.long), 8, 3
+
+
+def grads_of(module, out, g, extra=()):
+    module.zero_grad()
+    for t in extra:
+        if t.grad is not None:
+            t.grad = None
+    out.backward(g)
+    res = {f"grad_{n}": p.grad.detach().numpy().copy() for n, p in module.named_parameters() if p.grad is not None}
+    return res
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"{name}: {os.path.getsize(path)} bytes")
+
+
+def params_np(module):
+    return {f"param_{n}": p.detach().numpy().copy() for n, p in module.named_parameters()}
+
+
+# ------------------------------------------------------------------ G1
+def g1():
+    T, N, R0 = tiny_graph()
+    Tp = add_inverse_and_self(T, N, R0)
+    R = 2 * R0 + 1
+    gen = torch.Generator().manual_seed(101)
+    cases = []
+    for vertical in (False, True):
+        for decomp in (None, {"type": "basis", "num_bases": 2}, {"type": "block", "num_blocks": 2}):
+            for featureless in (False, True):
+                if vertical and featureless:
+                    continue  # invalid in the reference (shape error)
+                cases.append((vertical, decomp, featureless, False))
+    cases.append((False, None, False, True))  # diag
+    for vertical, decomp, featureless, diag in cases:
+        d_in, d_out = 4, 6
+        layer = RelationalGraphConvolutionNC(triples=Tp, num_nodes=N, num_relations=R,
+                                             in_features=None if featureless else d_in, out_features=d_out,
+                                             decomposition=decomp, vertical_stacking=vertical,
+                                             diag_weight_matrix=diag)
+        seeded_params(layer, gen)
+        X = None if featureless else torch.randn(N, d_in, generator=gen).requires_grad_(True)
+        out = layer(X) if X is not None else layer()
+        g = torch.randn(out.shape, generator=gen)
+        grads = grads_of(layer, out, g)
+        tag = "{}_{}_{}".format("v" if vertical else "h",
+                                "diag" if diag else (decomp["type"] if decomp else "none"),
+                                "fl" if featureless else "ft")
+        arrs = dict(triples=T.numpy(), triples_plus=Tp.numpy(), num_nodes=N, num_rels=R0, vertical=int(vertical),
+                    out=out.detach().numpy(), g=g.numpy(), **params_np(layer), **grads)
+        if X is not None:
+            arrs["X"] = X.detach().numpy()
+            arrs["grad_X"] = X.grad.numpy()
+        save("g1_nc_" + tag, **arrs)
+
+
+# ------------------------------------------------------------------ G2
+def g2():
+    T, N, R0 = tiny_graph()
+    R = 2 * R0 + 1
+    gen = torch.Generator().manual_seed(202)
+    d_in, d_out = 4, 6
+    for train, sl_type in ((False, "schlichtkrull-dropout"), (True, "schlichtkrull-dropout"), (True, "other")):
+        for vertical in (False, True):
+            for decomp in (None, {"type": "basis", "num_bases": 2}, {"type": "block", "num_blocks": 2}):
+                if vertical and decomp is not None and decomp["type"] == "block":
+                    continue  # reference bug: cat of 3-D block_diag with 2-D blocks_self raises (layers.py:526-528)
+                ed = {"general": 0.5, "self_loop": 0.0, "self_loop_type": sl_type}
+                layer = RelationalGraphConvolutionLP(num_nodes=N, num_relations=R, in_features=d_in,
+                                                     out_features=d_out, edge_dropout=ed, decomposition=decomp,
+                                                     vertical_stacking=vertical, w_init="glorot-normal",
+                                                     b_init="zeros")
+                seeded_params(layer, gen)
+                layer.train(train)
+                X = torch.randn(N, d_in, generator=gen).requires_grad_(True)
+                out = layer(T, X)
+                g = torch.randn(out.shape, generator=gen)
+                grads = grads_of(layer, out, g)
+                tag = "{}_{}_{}_{}".format("train" if train else "eval", "sd" if sl_type.startswith("schl") else "ot",
+                                           "v" if vertical else "h", decomp["type"] if decomp else "none")
+                save("g2_lp_" + tag, triples=T.numpy(), num_nodes=N, num_rels=R0, vertical=int(vertical),
+                     train=int(train), self_loop_type=sl_type, X=X.detach().numpy(), grad_X=X.grad.numpy(),
+                     out=out.detach().numpy(), g=g.numpy(), **params_np(layer), **grads)
+
+
+# ------------------------------------------------------------------ G3
+def g3():
+    gen = torch.Generator().manual_seed(303)
+    N, R0, E = 11, 4, 40
+    T = torch.stack([torch.randint(0, N, (E,), generator=gen), torch.randint(0, R0, (E,), generator=gen),
+                     torch.randint(0, N, (E,), generator=gen)], dim=1)
+    Tp = add_inverse_and_self(T, N, R0)
+    R = 2 * R0 + 1
+    vi, vs = stack_matrices(Tp, N, R, vertical_stacking=True)
+    hi, hs = stack_matrices(Tp, N, R, vertical_stacking=False)
+    ones = torch.ones(Tp.size(0))
+    vsum = sum_sparse(vi, ones, vs, row_normalisation=True)
+    hsum = sum_sparse(hi, ones, hs, row_normalisation=False)
+    save("g3_utils", triples=T.numpy(), num_nodes=N, num_rels=R0, triples_plus=Tp.numpy(),
+         ver_idx=vi.numpy(), ver_size=np.array(vs), hor_idx=hi.numpy(), hor_size=np.array(hs),
+         ver_sums=vsum.numpy(), hor_sums=hsum.numpy())
+
+
+# ------------------------------------------------------------------ G4
+def g4():
+    gen = torch.Generator().manual_seed(404)
+    N, R0, E, ncls = 12, 3, 40, 2
+    T = torch.stack([torch.randint(0, N, (E,), generator=gen), torch.randint(0, R0, (E,), generator=gen),
+                     torch.randint(0, N, (E,), generator=gen)], dim=1)
+    labels = torch.randint(0, ncls, (N,), generator=gen)
+    train_idx = torch.arange(0, N, 2)
+    for name, decomp in (("none", None), ("basis", {"type": "basis", "num_bases": 2}),
+                         ("block", {"type": "block", "num_blocks": 2})):
+        model = NodeClassifier(triples=T.tolist(), nnodes=N, nrel=R0, nfeat=None, nhid=4, nlayers=2, nclass=ncls,
+                               edge_dropout=None, decomposition=decomp)
+        seeded_params(model, gen)
+        init = params_np(model)
+        logits = model()
+        loss = torch.nn.functional.cross_entropy(logits[train_idx], labels[train_idx])
+        model.zero_grad()
+        loss.backward()
+        grads = {f"grad_{n}": p.grad.numpy().copy() for n, p in model.named_parameters()}
+        opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=0.0)
+        traj = []
+        for _ in range(3):
+            opt.zero_grad()
+            l = torch.nn.functional.cross_entropy(model()[train_idx], labels[train_idx])
+            l.backward()
+            opt.step()
+            traj.append(l.item())
+        save("g4_model_nc_" + name, triples=T.numpy(), num_nodes=N, num_rels=R0, nclass=ncls, nhid=4,
+             labels=labels.numpy(), train_idx=train_idx.numpy(), logits=logits.detach().numpy(),
+             loss=loss.item(), adam_losses=np.array(traj), **init, **grads)
+    # e-rgcn
+    model = EmbeddingNodeClassifier(triples=T.tolist(), nnodes=N, nrel=R0, nfeat=None, nhid=4, nlayers=2,
+                                    nclass=ncls, edge_dropout=None, decomposition=None, nemb=4)
+    seeded_params(model, gen)
+    init = params_np(model)
+    logits = model()
+    loss = torch.nn.functional.cross_entropy(logits[train_idx], labels[train_idx])
+    model.zero_grad()
+    loss.backward()
+    grads = {f"grad_{n}": p.grad.numpy().copy() for n, p in model.named_parameters() if p.grad is not None}
+    save("g4_model_enc", triples=T.numpy(), num_nodes=N, num_rels=R0, nclass=ncls, nemb=4,
+         labels=labels.numpy(), train_idx=train_idx.numpy(), logits=logits.detach().numpy(), loss=loss.item(),
+         **init, **grads)
+
+
+# ------------------------------------------------------------------ G5
+def g5():
+    gen = torch.Generator().manual_seed(505)
+    N, R0, d = 9, 4, 5
+    nodes = torch.randn(N, d, generator=gen).requires_grad_(True)
+    tr2 = torch.stack([torch.randint(0, N, (14,), generator=gen), torch.randint(0, R0, (14,), generator=gen),
+                       torch.randint(0, N, (14,), generator=gen)], dim=1)
+    tr3 = torch.stack([torch.randint(0, N, (3, 7), generator=gen), torch.randint(0, R0, (3, 7), generator=gen),
+                       torch.randint(0, N, (3, 7), generator=gen)], dim=2)
+    arrs = dict(nodes=nodes.detach().numpy(), triples2=tr2.numpy(), triples3=tr3.numpy(), num_nodes=N, num_rels=R0)
+    for bias in (None, "normal"):
+        dm = DistMult(R0, d, N, R0, w_init="standard-normal", w_gain=False, b_init=bias)
+        seeded_params(dm, gen)
+        tag = "b" if bias else "nb"
+        for k, v in params_np(dm).items():
+            arrs[f"{tag}_{k}"] = v
+        for nm, tr in (("2", tr2), ("3", tr3)):
+            sc = dm(tr, nodes)
+            g = torch.randn(sc.shape, generator=gen)
+            dm.zero_grad()
+            nodes.grad = None
+            sc.backward(g)
+            arrs[f"{tag}_scores{nm}"] = sc.detach().numpy()
+            arrs[f"{tag}_g{nm}"] = g.numpy()
+            arrs[f"{tag}_grad_nodes{nm}"] = nodes.grad.numpy().copy()
+            for n, p in dm.named_parameters():
+                arrs[f"{tag}_grad_{n}{nm}"] = p.grad.numpy().copy()
+        arrs[f"{tag}_penalty2"] = dm.s_penalty(tr2, nodes).item()
+    save("g5_distmult", **arrs)
+
+
+# ------------------------------------------------------------------ G6
+def g6():
+    gen = torch.Generator().manual_seed(606)
+    N, R0, E, d = 2000, 10, 20000, 16
+    s = torch.randint(0, N, (E,), generator=gen)
+    # skew: a hub node receives many edges so long segments are exercised
+    s[:1500] = 7
+    T = torch.stack([s, torch.randint(0, R0, (E,), generator=gen), torch.randint(0, N, (E,), generator=gen)], dim=1)
+    T[100:200] = T[0:100]  # duplicates
+    Tp = add_inverse_and_self(T, N, R0)
+    R = 2 * R0 + 1
+    l1 = RelationalGraphConvolutionNC(triples=Tp, num_nodes=N, num_relations=R, in_features=d, out_features=d,
+                                      vertical_stacking=False)
+    l2 = RelationalGraphConvolutionNC(triples=Tp, num_nodes=N, num_relations=R, in_features=d, out_features=d,
+                                      vertical_stacking=True)
+    with torch.no_grad():
+        l1.bias.copy_(torch.randn(d, generator=gen) * 0.1)
+        l2.bias.copy_(torch.randn(d, generator=gen) * 0.1)
+    X = torch.randn(N, d, generator=gen).requires_grad_(True)
+    h = l1(X)
+    out = l2(torch.relu(h))
+    loss = out.pow(2).mean()
+    loss.backward()
+    save("g6_mid", triples=T.numpy().astype(np.int32), num_nodes=N, num_rels=R0, X=X.detach().numpy(),
+         w1=l1.weights.detach().numpy(), b1=l1.bias.detach().numpy(), w2=l2.weights.detach().numpy(),
+         b2=l2.bias.detach().numpy(), h=h.detach().numpy(), out=out.detach().numpy(), loss=loss.item(),
+         grad_X=X.grad.numpy(), grad_w1=l1.weights.grad.numpy(), grad_b1=l1.bias.grad.numpy(),
+         grad_w2=l2.weights.grad.numpy(), grad_b2=l2.bias.grad.numpy())
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    for fn in (g1, g2, g3, g4, g5, g6):
+        fn()
