@@ -1,0 +1,148 @@
+/*
+ * rgcn_hip.h -- C ABI of librgcn_hip.so: the MI355X (gfx950) implementation of the
+ * R-GCN relational message-passing hot path
+ *
+ *     out[s,:] = sum_{(s,p,o) in T+} val_e * X[o,:] @ W_p  (+ b)        and its backward.
+ *
+ * The reference (thiviyanT/torch-rgcn) has no native layer: the path is Python over
+ * ATen.  Each entry point therefore names the reference *Python*
+ * lines whose work it takes over; the Python modules under
+ * torch-rgcn_amd/torch_rgcn/ (same class names and signatures as
+ * torch_rgcn/layers.py) are the only callers.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / HIP types in signatures
+ *     (`stream` is a hipStream_t passed as void*; NULL = default stream)
+ *   - *_host functions run on the CPU and need no GPU; every other function takes
+ *     DEVICE pointers and only enqueues work on `stream` (no synchronisation)
+ *   - all floating point is fp32, indices are int32 on the device side and int64
+ *     where the reference hands over LongTensors
+ *   - return value: RGCN_OK or an error code; rgcn_last_error() gives the text.
+ *     The Python layer turns RGCN_ERANGE / RGCN_EINVAL into AssertionError the way
+ *     the reference's asserts do (layers.py:121,225,282-284,303; utils.py:148,162-164).
+ */
+#ifndef RGCN_HIP_H
+#define RGCN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGCN_API __attribute__((visibility("default")))
+
+#define RGCN_OK 0
+#define RGCN_EINVAL 1       /* bad argument / shape mismatch */
+#define RGCN_ENOMEM 2
+#define RGCN_ERANGE 3       /* node / relation index out of range */
+#define RGCN_EHIP 4         /* a HIP runtime call failed */
+#define RGCN_EUNSUPPORTED 5
+
+#define RGCN_CHUNK 16       /* slots per chunk: one MFMA 16x16x4 row block */
+
+RGCN_API const char *rgcn_version(void);
+RGCN_API const char *rgcn_last_error(void);
+
+/* ------------------------------------------------------------------ graph preparation (host) */
+
+/* [T | inverse(T) | self loops]; out has (2E+N) rows of 3.
+ * Replaces torch_rgcn/utils.py:127-141 (add_inverse_and_self). */
+RGCN_API int rgcn_add_inverse_and_self_host(const int64_t *triples, int64_t E, int64_t N, int64_t R0,
+                                            int64_t *out);
+
+/* Link-prediction augmentation [T | inverse(T) | T | kept self loops] (the original
+ * block enters twice -- SURVEY.md F5).  keep may be NULL (= keep all).  out must
+ * hold 3E+N rows.  Replaces utils.py:100-124 + layers.py:481-487. */
+RGCN_API int rgcn_lp_augment_host(const int64_t *triples, int64_t E, int64_t N, int64_t R0,
+                                  const uint8_t *keep, int64_t *out, int64_t *M_out, int64_t *n_self);
+
+/* Per-edge adjacency value by the layer's literal procedure: count edges sharing
+ * (p,s) [vertical] or (p,o) [horizontal], apply the block swap
+ * c = [k[n:2n] | k[0:n] | k[M-i:M]] when horizontal, val = 1/c.
+ * Replaces utils.py:143-166 (stack_matrices), utils.py:71-97 (sum_sparse) and
+ * layers.py:263-273 / :498-510.  RGCN_ERANGE where stack_matrices' asserts fire,
+ * RGCN_EINVAL where the reference hits a shape error (2n+i != M). */
+RGCN_API int rgcn_edge_norm_host(const int64_t *triples_plus, int64_t M, int64_t N, int64_t R, int vertical,
+                                 int64_t n_swap, int64_t i_tail, float *val);
+
+/* Relation-tile plan.  Messages (dst <- src, relation rel, weight val) are bucketed
+ * by (dst / tile_rows, rel), sorted by dst inside a bucket, and every bucket is
+ * padded to a multiple of RGCN_CHUNK slots (pad = copy of the bucket's last message
+ * with val = 0), so that each chunk of 16 slots has ONE relation and one dst tile.
+ * This replaces the sparse COO constructor + coalesce of layers.py:276-279 /
+ * :513-516 as the device-side graph layout.
+ *   rgcn_plan_count_host : sizes only
+ *   rgcn_plan_fill_host  : fills caller-allocated arrays
+ *       p_src, p_dst [m_pad] int32; p_val [m_pad] f32; p_perm [m_pad] (original
+ *       message index, -1 for pads; may be NULL); chunk_rel [n_chunks];
+ *       tile_ptr [n_tiles+1] (chunk offsets);  items [2*n_items] = (c0,c1) chunk
+ *       ranges of constant relation, at most max_item_chunks long (weight-gradient
+ *       work list; may be NULL). */
+RGCN_API int rgcn_plan_count_host(const int32_t *dst, const int32_t *rel, int64_t M, int64_t n_dst, int32_t R,
+                                  int32_t tile_rows, int32_t max_item_chunks, int64_t *m_pad,
+                                  int64_t *n_chunks, int64_t *n_tiles, int64_t *n_items);
+RGCN_API int rgcn_plan_fill_host(const int32_t *dst, const int32_t *src, const int32_t *rel, const float *val,
+                                 int64_t M, int64_t n_dst, int64_t n_src, int32_t R, int32_t tile_rows,
+                                 int32_t max_item_chunks, int32_t *p_src, int32_t *p_dst, float *p_val,
+                                 int32_t *p_perm, int32_t *chunk_rel, int32_t *tile_ptr, int32_t *items);
+
+/* splitmix64 synthetic graph: s,o ~ U[0,N), p ~ U[0,R0), three
+ * consecutive stream values per triple.  Same stream as oracle.synthetic_triples. */
+RGCN_API int rgcn_synthetic_triples_host(int64_t N, int64_t R0, int64_t E, uint64_t seed, int64_t *out);
+
+/* ------------------------------------------------------------------ device kernels */
+
+/* out[n_dst, d_out] = bias + sum over plan slots  val * X[src,:] @ W[rel]   (W: [R, d_in, d_out]).
+ * Forward of layers.py:293-301 / :524-551 (both stackings are the same function of
+ * (T+, val, X, W)); with the transposed plan, G in place of X and W^T in place of W
+ * it is the feature gradient dX.  bias may be NULL.
+ * relu_out != 0 fuses max(.,0) into the epilogue (caller-side F.relu of models.py:196). */
+RGCN_API int rgcn_spmm_f32(const float *X, const float *W, const float *bias, float *out, const int32_t *p_src,
+                           const int32_t *p_dst, const float *p_val, const int32_t *chunk_rel,
+                           const int32_t *tile_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst,
+                           int64_t n_src, int32_t R, int32_t d_in, int32_t d_out, int32_t relu_out,
+                           void *stream);
+
+/* dW[rel] += sum over slots val * X[src,:]^T G[dst,:]  for every work item; dW
+ * ([R, d_in, d_out]) is zeroed first.  Autograd dual of the einsum / sparse mm pair
+ * (dW_r = (A_r X)^T g). */
+RGCN_API int rgcn_wgrad_f32(const float *X, const float *G, float *dW, const int32_t *p_src,
+                            const int32_t *p_dst, const float *p_val, const int32_t *chunk_rel,
+                            const int32_t *items, int64_t n_items, int64_t n_dst, int64_t n_src, int32_t R,
+                            int32_t d_in, int32_t d_out, void *stream);
+
+/* Featureless layer (X = I, d_in = N): out[dst,:] = bias + sum val * table[rel*n_src + src, :].
+ * Replaces torch.mm(adj, weights.view(R*N, d_out)) of layers.py:286-288 / :518-523. */
+RGCN_API int rgcn_featureless_fwd_f32(const float *table, const float *bias, float *out, const int32_t *p_src,
+                                      const int32_t *p_dst, const float *p_val, const int32_t *chunk_rel,
+                                      const int32_t *tile_ptr, int64_t n_tiles, int32_t tile_rows,
+                                      int64_t n_dst, int64_t n_src, int32_t R, int32_t d_out, void *stream);
+
+/* Its weight gradient: dtable[rel*n_src + src, :] += val * G[dst,:]; dtable
+ * ([R*n_src, d_out]) is zeroed first. */
+RGCN_API int rgcn_featureless_wgrad_f32(const float *G, float *dtable, const int32_t *p_src,
+                                        const int32_t *p_dst, const float *p_val, const int32_t *chunk_rel,
+                                        int64_t n_chunks, int64_t n_dst, int64_t n_src, int32_t R,
+                                        int32_t d_out, void *stream);
+
+/* db[j] = sum_n G[n, j]  (bias gradient; deterministic two-stage reduction). */
+RGCN_API int rgcn_colsum_f32(const float *G, float *db, int64_t n, int32_t d, void *stream);
+
+/* DistMult decoder (torch_rgcn/layers.py:86-98):
+ * scores[t] = sum_k nodes[s,k] rel[p,k] nodes[o,k] (+ sbias[s] + pbias[p] + obias[o]);
+ * triples int64 [T,3] on the device.  Biases may all be NULL. */
+RGCN_API int rgcn_distmult_fwd_f32(const int64_t *triples, int64_t T, const float *nodes, const float *rel,
+                                   const float *sbias, const float *pbias, const float *obias, float *scores,
+                                   int64_t n_nodes, int32_t n_rel, int32_t d, void *stream);
+/* Gradients of sum_t gs[t] * scores[t]; dnodes / drel (and the bias grads when
+ * non-NULL) are zeroed first and accumulated with fp32 atomics. */
+RGCN_API int rgcn_distmult_bwd_f32(const int64_t *triples, int64_t T, const float *nodes, const float *rel,
+                                   const float *gs, float *dnodes, float *drel, float *dsbias, float *dpbias,
+                                   float *dobias, int64_t n_nodes, int32_t n_rel, int32_t d, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGCN_HIP_H */

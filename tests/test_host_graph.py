@@ -1,0 +1,137 @@
+"""Host-side graph preparation of librgcn_hip.so (C++, no GPU) against the oracle: index
+work is bit-exact; the relation-tile plan is checked through its invariants."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import oracle
+from torch_rgcn import _native as nat
+
+
+def rand_triples(rng, N, R0, E):
+    return np.stack([rng.integers(0, N, E), rng.integers(0, R0, E), rng.integers(0, N, E)], axis=1).astype(np.int64)
+
+
+@pytest.mark.parametrize("N,R0,E", [(1, 1, 0), (5, 2, 1), (17, 3, 60), (400, 11, 5000)])
+def test_augmentation_bit_exact(N, R0, E):
+    rng = np.random.default_rng(N * 1000 + E)
+    T = rand_triples(rng, N, R0, E)
+    assert np.array_equal(nat.add_inverse_and_self_host(T, N, R0), oracle.add_inverse_and_self(T, N, R0))
+    keep = rng.integers(0, 2, N).astype(np.uint8)
+    for k in (None, keep):
+        a, na = nat.lp_augment_host(T, N, R0, k)
+        b, nb = oracle.lp_augment(T, N, R0, k)
+        assert na == nb and np.array_equal(a, b)
+
+
+def test_synthetic_generator_matches_oracle():
+    a = nat.synthetic_triples_host(1000, 7, 5000, seed=42)
+    b = oracle.synthetic_triples(1000, 7, 5000, seed=42)
+    assert np.array_equal(a, b)
+    assert a[:, 0].max() < 1000 and a[:, 1].max() < 7
+
+
+@pytest.mark.parametrize("N,R0,E", [(5, 2, 1), (17, 3, 60), (400, 11, 5000), (3000, 50, 30000)])
+def test_edge_norm_bit_exact(N, R0, E):
+    rng = np.random.default_rng(7 * N + E)
+    T = rand_triples(rng, N, R0, E)
+    T[: E // 10] = T[E // 10: 2 * (E // 10)]  # duplicates
+    R = 2 * R0 + 1
+    tp = oracle.add_inverse_and_self(T, N, R0)
+    M = len(tp)
+    for vertical in (True, False):
+        a = nat.edge_norm_host(tp, N, R, vertical, (M - N) // 2, N)
+        b = oracle.edge_norm(tp, N, R, vertical, (M - N) // 2, N)
+        assert np.array_equal(a, b)
+    keep = rng.integers(0, 2, N).astype(np.uint8)
+    tl, ns = oracle.lp_augment(T, N, R0, keep)
+    for vertical in (True, False):
+        assert np.array_equal(nat.edge_norm_host(tl, N, R, vertical, E, ns), oracle.edge_norm(tl, N, R, vertical, E, ns))
+    # arbitrary (ill-formed) row order still follows the literal count / swap / divide procedure
+    perm = rng.permutation(M)
+    assert np.array_equal(nat.edge_norm_host(tp[perm], N, R, False, (M - N) // 2, N),
+                          oracle.edge_norm(tp[perm], N, R, False, (M - N) // 2, N))
+
+
+def test_edge_norm_golden_g3():
+    d = load_golden("g3_utils")
+    N, R0 = int(d["num_nodes"]), int(d["num_rels"])
+    tp = d["triples_plus"]
+    M = len(tp)
+    v = nat.edge_norm_host(tp, N, 2 * R0 + 1, True, (M - N) // 2, N)
+    assert np.array_equal(v, np.float32(1.0) / d["ver_sums"])
+    h = nat.edge_norm_host(tp, N, 2 * R0 + 1, False, (M - N) // 2, N)
+    n = (M - N) // 2
+    hs = d["hor_sums"]
+    assert np.array_equal(h, np.float32(1.0) / np.concatenate([hs[n:2 * n], hs[:n], hs[-N:]]))
+
+
+def test_edge_norm_errors():
+    tp = np.array([[0, 0, 1], [1, 1, 0], [0, 2, 0], [1, 2, 1]])
+    with pytest.raises(AssertionError):  # node id out of range -> stack_matrices' assert
+        nat.edge_norm_host(np.array([[0, 0, 5]]), 2, 3, True, 0, 0)
+    with pytest.raises(AssertionError):  # relation id out of range
+        nat.edge_norm_host(np.array([[0, 3, 1]]), 2, 3, False, 0, 1)
+    with pytest.raises(AssertionError):  # 2n + i != M: the reference's cat() yields a shape error
+        nat.edge_norm_host(tp, 2, 3, False, 2, 2)
+    assert nat.edge_norm_host(np.zeros((0, 3), np.int64), 2, 3, True, 0, 0).shape == (0,)
+
+
+def check_plan(hp, dst, src, rel, val, n_dst, R, tile_rows, max_item_chunks):
+    C = nat.CHUNK
+    M = len(dst)
+    assert hp.m_pad == hp.n_chunks * C and hp.n_tiles == -(-n_dst // tile_rows)
+    perm = hp.perm[:hp.m_pad]
+    real = perm >= 0
+    assert real.sum() == M and np.array_equal(np.sort(perm[real]), np.arange(M))  # each message exactly once
+    assert np.array_equal(hp.src[:hp.m_pad][real], src[perm[real]])
+    assert np.array_equal(hp.dst[:hp.m_pad][real], dst[perm[real]])
+    assert np.array_equal(hp.val[:hp.m_pad][real], val[perm[real]])
+    assert np.all(hp.val[:hp.m_pad][~real] == 0)
+    tp = hp.tile_ptr
+    assert tp[0] == 0 and tp[-1] == hp.n_chunks and np.all(np.diff(tp) >= 0)
+    pd = hp.dst[:hp.m_pad].reshape(-1, C)
+    pv = hp.val[:hp.m_pad].reshape(-1, C)
+    pr = perm.reshape(-1, C)
+    for t in range(hp.n_tiles):
+        for c in range(tp[t], tp[t + 1]):
+            assert np.all(pd[c] // tile_rows == t)               # one destination tile per chunk
+            r = hp.chunk_rel[c]
+            assert np.all(rel[pr[c][pr[c] >= 0]] == r)          # one relation per chunk
+            assert pr[c][0] >= 0                                 # never an all-pad chunk
+            assert np.all(np.diff(pd[c]) >= 0)                   # sorted by destination
+            assert np.all(pv[c][pr[c] < 0] == 0)
+        rels = hp.chunk_rel[tp[t]:tp[t + 1]]
+        assert np.all(np.diff(rels) >= 0)                        # relation-grouped inside the tile
+    # work items partition the chunks into constant-relation ranges
+    it = hp.items[:hp.n_items]
+    if hp.n_items:
+        assert it[0, 0] == 0 and it[-1, 1] == hp.n_chunks and np.array_equal(it[1:, 0], it[:-1, 1])
+        for c0, c1 in it:
+            assert 0 < c1 - c0 <= max_item_chunks and len(set(hp.chunk_rel[c0:c1])) == 1
+    else:
+        assert hp.n_chunks == 0
+
+
+@pytest.mark.parametrize("N,R,M,tile", [(1, 1, 0, 4), (7, 3, 1, 4), (50, 5, 700, 16), (50, 5, 700, 64),
+                                        (1000, 21, 20000, 512), (333, 9, 5000, 1000)])
+def test_plan_invariants(N, R, M, tile):
+    rng = np.random.default_rng(N + M)
+    dst = rng.integers(0, N, M).astype(np.int32)
+    if M > 100:
+        dst[:M // 4] = 3  # a hub
+    src = rng.integers(0, N, M).astype(np.int32)
+    rel = rng.integers(0, R, M).astype(np.int32)
+    val = (rng.random(M).astype(np.float32) + 0.1)
+    hp = nat.build_plan_host(dst, src, rel, val, N, N, R, tile, max_item_chunks=5, want_perm=True)
+    check_plan(hp, dst, src, rel, val, N, R, tile, 5)
+
+
+def test_plan_errors():
+    one = np.zeros(1, np.int32)
+    with pytest.raises(AssertionError):
+        nat.build_plan_host(np.array([9], np.int32), one, one, np.ones(1, np.float32), 4, 4, 2, 4)
+    with pytest.raises(AssertionError):
+        nat.build_plan_host(one, np.array([-1], np.int32), one, np.ones(1, np.float32), 4, 4, 2, 4)
+    with pytest.raises(AssertionError):
+        nat.build_plan_host(one, one, np.array([2], np.int32), np.ones(1, np.float32), 4, 4, 2, 4)

@@ -1,0 +1,300 @@
+"""ctypes binding of librgcn_hip.so (C ABI in include/rgcn_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a kernel
+launch fails, the caller gets an exception.  The library is built in-tree by
+`__graft_entry__.build()` / `make -C torch-rgcn_amd/csrc`.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librgcn_hip.so")
+_lib = None
+
+OK, EINVAL, ENOMEM, ERANGE, EHIP, EUNSUPPORTED = range(6)
+CHUNK = 16
+
+c_i64, c_i32, c_int, c_void_p = ctypes.c_int64, ctypes.c_int32, ctypes.c_int, ctypes.c_void_p
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise NativeLibraryError(
+                f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). torch_rgcn has no CPU/eager fallback.")
+        L = ctypes.CDLL(_LIB_PATH)
+        L.rgcn_version.restype = ctypes.c_char_p
+        L.rgcn_last_error.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+def version():
+    return lib().rgcn_version().decode()
+
+
+def _check(rc, what):
+    if rc == OK:
+        return
+    msg = lib().rgcn_last_error().decode()
+    if rc in (ERANGE, EINVAL):
+        # the reference signals these with Python asserts (utils.py:148,162-164; layers.py:282-284,303)
+        raise AssertionError(f"{what}: {msg}")
+    if rc == ENOMEM:
+        raise MemoryError(f"{what}: {msg}")
+    raise NativeLibraryError(f"{what}: {msg} (code {rc})")
+
+
+def _np(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _hp(a):
+    """host pointer of a numpy array (or None)"""
+    return None if a is None else c_void_p(a.ctypes.data)
+
+
+def _dp(t):
+    """device pointer of a torch tensor (or None)"""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+# ----------------------------------------------------------------------------- per-kernel timing
+# HIP events on the stream the kernels are launched on (torch's current stream), recorded
+# around every launch while profiling is on; bench.py uses this for the roofline figures.
+_PROF = None
+
+
+def profile_start():
+    global _PROF
+    _PROF = {}
+
+
+def profile_stop():
+    """-> {kernel name: [ms per launch, ...]} (synchronises)."""
+    global _PROF
+    rec, _PROF = _PROF or {}, None
+    torch.cuda.synchronize()
+    return {k: [a.elapsed_time(b) for a, b in v] for k, v in rec.items()}
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _PROF is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if _PROF is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            _PROF.setdefault(self.name, []).append((self.a, b))
+
+
+def _stream(device):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+# ----------------------------------------------------------------------------- host side
+
+def add_inverse_and_self_host(triples, num_nodes, num_rels):
+    t = _np(triples, np.int64).reshape(-1, 3)
+    out = np.empty((2 * t.shape[0] + num_nodes, 3), np.int64)
+    _check(lib().rgcn_add_inverse_and_self_host(_hp(t), c_i64(t.shape[0]), c_i64(num_nodes), c_i64(num_rels),
+                                                _hp(out)), "add_inverse_and_self")
+    return out
+
+
+def lp_augment_host(triples, num_nodes, num_rels, keep=None):
+    t = _np(triples, np.int64).reshape(-1, 3)
+    E = t.shape[0]
+    out = np.empty((3 * E + num_nodes, 3), np.int64)
+    k = None if keep is None else _np(keep, np.uint8)
+    M, ns = c_i64(0), c_i64(0)
+    _check(lib().rgcn_lp_augment_host(_hp(t), c_i64(E), c_i64(num_nodes), c_i64(num_rels), _hp(k), _hp(out),
+                                      ctypes.byref(M), ctypes.byref(ns)), "lp_augment")
+    return out[:M.value], ns.value
+
+
+def edge_norm_host(triples_plus, num_nodes, num_rels, vertical, n_swap, i_tail):
+    t = _np(triples_plus, np.int64).reshape(-1, 3)
+    val = np.empty(t.shape[0], np.float32)
+    _check(lib().rgcn_edge_norm_host(_hp(t), c_i64(t.shape[0]), c_i64(num_nodes), c_i64(num_rels),
+                                     c_int(int(bool(vertical))), c_i64(n_swap), c_i64(i_tail), _hp(val)),
+           "edge_norm")
+    return val
+
+
+def synthetic_triples_host(num_nodes, num_rels, num_edges, seed=0):
+    out = np.empty((num_edges, 3), np.int64)
+    _check(lib().rgcn_synthetic_triples_host(c_i64(num_nodes), c_i64(num_rels), c_i64(num_edges),
+                                             ctypes.c_uint64(seed), _hp(out)), "synthetic_triples")
+    return out
+
+
+class HostPlan:
+    """Relation-tile plan as numpy arrays (see rgcn_plan_fill_host)."""
+    __slots__ = ("src", "dst", "val", "perm", "chunk_rel", "tile_ptr", "items", "n_dst", "n_src", "num_rels",
+                 "tile_rows", "n_tiles", "n_chunks", "m_pad", "n_items", "n_messages")
+
+
+def build_plan_host(dst, src, rel, val, n_dst, n_src, num_rels, tile_rows, max_item_chunks=64, want_perm=False):
+    dst = _np(dst, np.int32)
+    src = _np(src, np.int32)
+    rel = _np(rel, np.int32)
+    val = _np(val, np.float32)
+    M = dst.shape[0]
+    assert src.shape[0] == M and rel.shape[0] == M and val.shape[0] == M
+    m_pad, n_chunks, n_tiles, n_items = c_i64(0), c_i64(0), c_i64(0), c_i64(0)
+    L = lib()
+    _check(L.rgcn_plan_count_host(_hp(dst), _hp(rel), c_i64(M), c_i64(n_dst), c_i32(num_rels), c_i32(tile_rows),
+                                  c_i32(max_item_chunks), ctypes.byref(m_pad), ctypes.byref(n_chunks),
+                                  ctypes.byref(n_tiles), ctypes.byref(n_items)), "plan_count")
+    p = HostPlan()
+    p.n_dst, p.n_src, p.num_rels, p.tile_rows = n_dst, n_src, num_rels, tile_rows
+    p.n_tiles, p.n_chunks, p.m_pad, p.n_items, p.n_messages = n_tiles.value, n_chunks.value, m_pad.value, n_items.value, M
+    p.src = np.empty(max(p.m_pad, 1), np.int32)
+    p.dst = np.empty(max(p.m_pad, 1), np.int32)
+    p.val = np.empty(max(p.m_pad, 1), np.float32)
+    p.perm = np.empty(max(p.m_pad, 1), np.int32) if want_perm else None
+    p.chunk_rel = np.empty(max(p.n_chunks, 1), np.int32)
+    p.tile_ptr = np.zeros(p.n_tiles + 1, np.int32)
+    p.items = np.empty((max(p.n_items, 1), 2), np.int32)
+    _check(L.rgcn_plan_fill_host(_hp(dst), _hp(src), _hp(rel), _hp(val), c_i64(M), c_i64(n_dst), c_i64(n_src),
+                                 c_i32(num_rels), c_i32(tile_rows), c_i32(max_item_chunks), _hp(p.src), _hp(p.dst),
+                                 _hp(p.val), _hp(p.perm), _hp(p.chunk_rel), _hp(p.tile_ptr), _hp(p.items)),
+           "plan_fill")
+    return p
+
+
+# ----------------------------------------------------------------------------- device side
+
+class DevicePlan:
+    """HostPlan uploaded to one GPU (int32 / fp32 tensors)."""
+
+    def __init__(self, hp, device):
+        self.device = torch.device(device)
+        up = lambda a: torch.from_numpy(a).to(self.device, non_blocking=False)
+        self.src, self.dst, self.val = up(hp.src), up(hp.dst), up(hp.val)
+        self.chunk_rel, self.tile_ptr, self.items = up(hp.chunk_rel), up(hp.tile_ptr), up(hp.items)
+        for k in ("n_dst", "n_src", "num_rels", "tile_rows", "n_tiles", "n_chunks", "m_pad", "n_items", "n_messages"):
+            setattr(self, k, getattr(hp, k))
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in (self.src, self.dst, self.val, self.chunk_rel,
+                                                           self.tile_ptr, self.items))
+
+
+def _req(t, name, dtype=torch.float32):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on a GPU: torch_rgcn runs on HIP kernels only (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+
+
+def spmm(X, W, bias, plan, relu=False):
+    """out[n_dst, d_out] = bias + sum_slots val * X[src] @ W[rel]"""
+    _req(X, "features"); _req(W, "weights"); _req(bias, "bias")
+    R, d_in, d_out = W.shape
+    assert X.shape == (plan.n_src, d_in), f"features {tuple(X.shape)} vs ({plan.n_src}, {d_in})"
+    assert R == plan.num_rels
+    out = torch.empty((plan.n_dst, d_out), device=X.device, dtype=torch.float32)
+    with torch.cuda.device(X.device), _timed("spmm"):
+        _check(lib().rgcn_spmm_f32(_dp(X), _dp(W), _dp(bias), _dp(out), _dp(plan.src), _dp(plan.dst), _dp(plan.val),
+                                   _dp(plan.chunk_rel), _dp(plan.tile_ptr), c_i64(plan.n_tiles),
+                                   c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i64(plan.n_src), c_i32(R),
+                                   c_i32(d_in), c_i32(d_out), c_i32(int(relu)), _stream(X.device)), "spmm")
+    return out
+
+
+def wgrad(X, G, plan, num_rels):
+    """dW[R, d_in, d_out] = sum_slots val * X[src]^T G[dst], grouped by relation"""
+    _req(X, "features"); _req(G, "grad_output")
+    d_in, d_out = X.shape[1], G.shape[1]
+    assert X.shape[0] == plan.n_src and G.shape[0] == plan.n_dst
+    dW = torch.empty((num_rels, d_in, d_out), device=X.device, dtype=torch.float32)
+    with torch.cuda.device(X.device), _timed("wgrad"):
+        _check(lib().rgcn_wgrad_f32(_dp(X), _dp(G), _dp(dW), _dp(plan.src), _dp(plan.dst), _dp(plan.val),
+                                    _dp(plan.chunk_rel), _dp(plan.items), c_i64(plan.n_items), c_i64(plan.n_dst),
+                                    c_i64(plan.n_src), c_i32(num_rels), c_i32(d_in), c_i32(d_out),
+                                    _stream(X.device)), "wgrad")
+    return dW
+
+
+def featureless_fwd(table, bias, plan):
+    """out[n_dst, d] = bias + sum_slots val * table[rel, src, :]   (table: [R, n_src, d])"""
+    _req(table, "weights"); _req(bias, "bias")
+    R, n_src, d = table.shape
+    assert R == plan.num_rels and n_src == plan.n_src
+    out = torch.empty((plan.n_dst, d), device=table.device, dtype=torch.float32)
+    with torch.cuda.device(table.device), _timed("featureless_fwd"):
+        _check(lib().rgcn_featureless_fwd_f32(_dp(table), _dp(bias), _dp(out), _dp(plan.src), _dp(plan.dst),
+                                              _dp(plan.val), _dp(plan.chunk_rel), _dp(plan.tile_ptr),
+                                              c_i64(plan.n_tiles), c_i32(plan.tile_rows), c_i64(plan.n_dst),
+                                              c_i64(n_src), c_i32(R), c_i32(d), _stream(table.device)),
+               "featureless_fwd")
+    return out
+
+
+def featureless_wgrad(G, plan, num_rels):
+    _req(G, "grad_output")
+    d = G.shape[1]
+    dT = torch.empty((num_rels, plan.n_src, d), device=G.device, dtype=torch.float32)
+    with torch.cuda.device(G.device), _timed("featureless_wgrad"):
+        _check(lib().rgcn_featureless_wgrad_f32(_dp(G), _dp(dT), _dp(plan.src), _dp(plan.dst), _dp(plan.val),
+                                                _dp(plan.chunk_rel), c_i64(plan.n_chunks), c_i64(plan.n_dst),
+                                                c_i64(plan.n_src), c_i32(num_rels), c_i32(d), _stream(G.device)),
+               "featureless_wgrad")
+    return dT
+
+
+def colsum(G):
+    _req(G, "grad_output")
+    db = torch.empty(G.shape[1], device=G.device, dtype=torch.float32)
+    with torch.cuda.device(G.device), _timed("colsum"):
+        _check(lib().rgcn_colsum_f32(_dp(G), _dp(db), c_i64(G.shape[0]), c_i32(G.shape[1]), _stream(G.device)),
+               "colsum")
+    return db
+
+
+def distmult_fwd(triples, nodes, rel, sbias, pbias, obias):
+    _req(nodes, "nodes"); _req(rel, "relations"); _req(triples, "triples", torch.int64)
+    for b, n in ((sbias, "sbias"), (pbias, "pbias"), (obias, "obias")):
+        _req(b, n)
+    T = triples.shape[0]
+    scores = torch.empty(T, device=nodes.device, dtype=torch.float32)
+    with torch.cuda.device(nodes.device), _timed("distmult_fwd"):
+        _check(lib().rgcn_distmult_fwd_f32(_dp(triples), c_i64(T), _dp(nodes), _dp(rel), _dp(sbias), _dp(pbias),
+                                           _dp(obias), _dp(scores), c_i64(nodes.shape[0]), c_i32(rel.shape[0]),
+                                           c_i32(nodes.shape[1]), _stream(nodes.device)), "distmult_fwd")
+    return scores
+
+
+def distmult_bwd(triples, nodes, rel, gs, with_bias):
+    _req(gs, "grad_scores")
+    dn = torch.empty_like(nodes)
+    dr = torch.empty_like(rel)
+    dsb = torch.empty(nodes.shape[0], device=nodes.device) if with_bias else None
+    dob = torch.empty(nodes.shape[0], device=nodes.device) if with_bias else None
+    dpb = torch.empty(rel.shape[0], device=nodes.device) if with_bias else None
+    with torch.cuda.device(nodes.device), _timed("distmult_bwd"):
+        _check(lib().rgcn_distmult_bwd_f32(_dp(triples), c_i64(triples.shape[0]), _dp(nodes), _dp(rel), _dp(gs),
+                                           _dp(dn), _dp(dr), _dp(dsb), _dp(dpb), _dp(dob), c_i64(nodes.shape[0]),
+                                           c_i32(rel.shape[0]), c_i32(nodes.shape[1]), _stream(nodes.device)),
+               "distmult_bwd")
+    return dn, dr, dsb, dpb, dob

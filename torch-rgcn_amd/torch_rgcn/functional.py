@@ -1,0 +1,98 @@
+"""autograd bindings of the HIP kernels.
+
+`relational_mp`  : out = sum_e val_e X[o_e] W[p_e] + b      (featured layers)
+`featureless_mp` : out = sum_e val_e W[p_e, o_e, :] + b     (X = I)
+
+Both are the custom-Function form of what the reference leaves to autograd
+(torch_rgcn/layers.py:286-306; duals in SURVEY.md 8 a-9).  backward runs on the
+autograd engine's thread and launches on that thread's current HIP stream; it uses
+nothing but the tensors saved on ctx and the immutable RelGraph.
+"""
+import torch
+
+from . import _native
+
+
+class _RelationalMP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, W, bias, graph):
+        X = X.contiguous()
+        W = W.contiguous()
+        b = None if bias is None else bias.contiguous()
+        out = _native.spmm(X, W, b, graph.fwd_plan(W.shape[2]))
+        ctx.graph = graph
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(X, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        X, W = ctx.saved_tensors
+        graph = ctx.graph
+        g = g.contiguous()
+        dX = dW = db = None
+        if ctx.needs_input_grad[0]:
+            Wt = W.transpose(1, 2).contiguous()
+            dX = _native.spmm(g, Wt, None, graph.bwd_plan(W.shape[1]))
+        if ctx.needs_input_grad[1]:
+            dW = _native.wgrad(X, g, graph.wgt_plan(), W.shape[0])
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _native.colsum(g)
+        return dX, dW, db, None
+
+
+class _FeaturelessMP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, bias, graph):
+        table = table.contiguous()
+        b = None if bias is None else bias.contiguous()
+        out = _native.featureless_fwd(table, b, graph.fwd_plan(table.shape[2]))
+        ctx.graph = graph
+        ctx.has_bias = bias is not None
+        ctx.num_rels = table.shape[0]
+        ctx.width = table.shape[2]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        dT = db = None
+        if ctx.needs_input_grad[0]:
+            dT = _native.featureless_wgrad(g, ctx.graph.fwd_plan(ctx.width), ctx.num_rels)
+        if ctx.has_bias and ctx.needs_input_grad[1]:
+            db = _native.colsum(g)
+        return dT, db, None
+
+
+def relational_mp(features, weights, bias, graph):
+    """features [N, d_in], weights [R, d_in, d_out] (dense), bias [d_out] or None -> [N, d_out]"""
+    return _RelationalMP.apply(features, weights, bias, graph)
+
+
+def featureless_mp(table, bias, graph):
+    """table [R, N, d_out] -> [N, d_out]"""
+    return _FeaturelessMP.apply(table, bias, graph)
+
+
+class _DistMultScore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, triples, nodes, relations, sbias, pbias, obias):
+        shape = triples.shape[:-1]
+        tr = triples.reshape(-1, 3).contiguous()
+        nodes = nodes.contiguous()
+        relations = relations.contiguous()
+        scores = _native.distmult_fwd(tr, nodes, relations, sbias, pbias, obias)
+        ctx.save_for_backward(tr, nodes, relations)
+        ctx.with_bias = sbias is not None
+        ctx.shape = shape
+        return scores.view(shape)
+
+    @staticmethod
+    def backward(ctx, gs):
+        tr, nodes, relations = ctx.saved_tensors
+        dn, dr, dsb, dpb, dob = _native.distmult_bwd(tr, nodes, relations, gs.reshape(-1).contiguous(), ctx.with_bias)
+        return None, dn, dr, dsb, dpb, dob
+
+
+def distmult_score(triples, nodes, relations, sbias=None, pbias=None, obias=None):
+    return _DistMultScore.apply(triples, nodes, relations, sbias, pbias, obias)

@@ -1,0 +1,99 @@
+"""Device-resident graph layout for the HIP message-passing kernels.
+
+A `RelGraph` is what replaces the per-forward `stack_matrices -> sum_sparse ->
+sparse COO` pipeline of the reference (torch_rgcn/utils.py:143-166, :71-97;
+torch_rgcn/layers.py:255-279, :490-516): the augmented triples are normalised once
+(literal procedure, so the horizontal/LP quirks are preserved), bucketed into
+relation-tile plans and uploaded.  NC layers build it once; LP layers per call.
+
+Three plans, all produced by the same host routine (csrc/rgcn_host.cpp):
+  fwd    destination = subject s, tiles over s      -> out = sum val X[o] W_p
+  bwd    destination = object  o, tiles over o      -> dX  = sum val G[s] W_p^T
+  wgt    one tile (relation-major)                  -> dW_p = sum val X[o]^T G[s]
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import _native
+
+_LDS_TILE_FLOATS = 8192  # 32 KiB of LDS per workgroup for the output tile
+
+
+def pick_tile_rows(width):
+    """Rows of the destination tile for an output width (floats per row)."""
+    env = os.environ.get("RGCN_TILE_ROWS")
+    if env:
+        return max(1, min(int(env), 16384 // max(1, width)))
+    rows = _LDS_TILE_FLOATS // max(1, width)
+    return int(max(8, min(512, rows)))
+
+
+class RelGraph:
+    def __init__(self, triples_plus, val, num_nodes, num_rels, device):
+        """triples_plus: int64 numpy [M,3] (s,p,o); val: float32 numpy [M]."""
+        self.num_nodes, self.num_rels = int(num_nodes), int(num_rels)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("RelGraph lives on a GPU: torch_rgcn runs on HIP kernels only (no CPU fallback)")
+        tp = np.ascontiguousarray(triples_plus, dtype=np.int64).reshape(-1, 3)
+        if self.num_nodes * self.num_rels >= 2 ** 31:
+            raise NotImplementedError("num_nodes * num_relations must stay below 2^31")
+        self._s = tp[:, 0].astype(np.int32)
+        self._p = tp[:, 1].astype(np.int32)
+        self._o = tp[:, 2].astype(np.int32)
+        self._val = np.ascontiguousarray(val, dtype=np.float32)
+        self.num_messages = tp.shape[0]
+        self._plans = {}
+
+    # -- plans are built lazily and cached per tile height
+    def _plan(self, kind, tile_rows, max_item_chunks=64):
+        key = (kind, tile_rows, max_item_chunks)
+        if key not in self._plans:
+            N, R = self.num_nodes, self.num_rels
+            if kind == "fwd":
+                hp = _native.build_plan_host(self._s, self._o, self._p, self._val, N, N, R, tile_rows, max_item_chunks)
+            elif kind == "bwd":
+                hp = _native.build_plan_host(self._o, self._s, self._p, self._val, N, N, R, tile_rows, max_item_chunks)
+            else:
+                raise KeyError(kind)
+            self._plans[key] = _native.DevicePlan(hp, self.device)
+        return self._plans[key]
+
+    def fwd_plan(self, d_out):
+        return self._plan("fwd", pick_tile_rows(d_out))
+
+    def bwd_plan(self, d_in):
+        return self._plan("bwd", pick_tile_rows(d_in))
+
+    def wgt_plan(self):
+        """relation-major (single tile): long runs per relation for the weight gradient"""
+        return self._plan("fwd", max(self.num_nodes, 1), int(os.environ.get("RGCN_WGRAD_ITEM_CHUNKS", "64")))
+
+    def selfloop_edges(self, self_rel):
+        """(s, o, val) device tensors of the messages of one relation (used by the LP block-dropout branch)."""
+        m = self._p == self_rel
+        dev = self.device
+        return (torch.from_numpy(self._s[m].astype(np.int64)).to(dev), torch.from_numpy(self._o[m].astype(np.int64)).to(dev),
+                torch.from_numpy(self._val[m]).to(dev))
+
+
+def graph_from_nc_triples(triples_plus, num_nodes, num_rels, vertical, device):
+    """NC layer: n = int((M - N) / 2), i = N  (torch_rgcn/layers.py:235-236, :269-271)."""
+    tp = triples_plus.detach().cpu().numpy() if torch.is_tensor(triples_plus) else np.asarray(triples_plus)
+    tp = np.ascontiguousarray(tp, dtype=np.int64).reshape(-1, 3)
+    M = tp.shape[0]
+    val = _native.edge_norm_host(tp, num_nodes, num_rels, vertical, int((M - num_nodes) / 2), num_nodes)
+    return RelGraph(tp, val, num_nodes, num_rels, device)
+
+
+def graph_from_lp_triples(triples, num_nodes, num_rels, vertical, keep_mask, device):
+    """LP layer: [T | inv | T | kept self loops], n = E, i = E + #kept (layers.py:481-487, :505-510)."""
+    t = triples.detach().cpu().numpy() if torch.is_tensor(triples) else np.asarray(triples)
+    t = np.ascontiguousarray(t, dtype=np.int64).reshape(-1, 3)
+    R0 = (num_rels - 1) // 2
+    keep = None if keep_mask is None else keep_mask.detach().cpu().numpy().astype(np.uint8)
+    tp, n_self = _native.lp_augment_host(t, num_nodes, R0, keep)
+    val = _native.edge_norm_host(tp, num_nodes, num_rels, vertical, t.shape[0], n_self)
+    return RelGraph(tp, val, num_nodes, num_rels, device)

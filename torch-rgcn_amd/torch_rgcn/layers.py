@@ -1,0 +1,307 @@
+"""Drop-in `torch_rgcn.layers` for MI355X: same class names, constructor / forward
+signatures, parameter names and shapes as thiviyanT/torch-rgcn's layers.py, with
+the message passing done by hand-written HIP kernels (csrc/) instead of ATen
+sparse ops.
+
+    RelationalGraphConvolutionNC   reference torch_rgcn/layers.py:101-308
+    RelationalGraphConvolutionLP   reference torch_rgcn/layers.py:311-565
+    DistMult                       reference torch_rgcn/layers.py:9-98
+
+What is the same: the function computed, out = sum_r A_r X W_r + b with the
+reference's exact per-edge normalisation (including the link-prediction
+double-count), parameter inventory, initialisers, asserts.
+What differs: tensors must be on a GPU (no CPU fallback -- a CPU tensor raises);
+the graph layout is cached (NC) instead of being rebuilt every forward; the dense
+R x N x d intermediates of the reference are never materialised for featured layers.
+"""
+import math
+
+import torch
+from torch import nn
+from torch.nn import Module, Parameter
+
+from . import functional as F_
+from .graph import graph_from_lp_triples, graph_from_nc_triples
+from .utils import block_diag, schlichtkrull_normal_, select_b_init, select_w_init, split_spo
+
+_RELU_GAIN = math.sqrt(2.0)  # nn.init.calculate_gain('relu')
+
+
+def _unpack_decomposition(decomposition):
+    d = decomposition or {}
+    return d.get('type'), d.get('num_bases'), d.get('num_blocks')
+
+
+def _require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} is on {t.device}: this build of torch_rgcn runs its message passing on "
+                           "HIP kernels only and has no CPU path; move the module and its inputs to a GPU")
+
+
+class DistMult(Module):
+    """DistMult decoder: score(s,p,o) = <e_s, r_p, e_o> (+ per-entity / per-relation biases)."""
+
+    def __init__(self, indim, outdim, num_nodes, num_rel, w_init='standard-normal', w_gain=False, b_init=None):
+        super().__init__()
+        self.w_init, self.w_gain, self.b_init = w_init, w_gain, b_init
+        self.relations = Parameter(torch.empty(indim, outdim))
+        if b_init:
+            self.sbias = Parameter(torch.empty(num_nodes))
+            self.obias = Parameter(torch.empty(num_nodes))
+            self.pbias = Parameter(torch.empty(num_rel))
+        else:
+            for name in ('sbias', 'obias', 'pbias'):
+                self.register_parameter(name, None)
+        self.initialise_parameters()
+
+    def initialise_parameters(self):
+        fill = select_w_init(self.w_init)
+        if self.w_gain:
+            fill(self.relations, gain=_RELU_GAIN)
+        else:
+            fill(self.relations)
+        if self.b_init:
+            fill_b = select_b_init(self.b_init)
+            for b in (self.sbias, self.pbias, self.obias):
+                fill_b(b)
+
+    def s_penalty(self, triples, nodes):
+        """Schlichtkrull L2 penalty: mean squares of the gathered s / p / o embeddings."""
+        s, p, o = split_spo(triples)
+        return nodes[s, :].pow(2).mean() + self.relations[p, :].pow(2).mean() + nodes[o, :].pow(2).mean()
+
+    def forward(self, triples, nodes):
+        _require_gpu(nodes, "DistMult node embeddings")
+        triples = triples.to(nodes.device)
+        if self.b_init:
+            return F_.distmult_score(triples, nodes, self.relations, self.sbias, self.pbias, self.obias)
+        return F_.distmult_score(triples, nodes, self.relations)
+
+
+class _RGCBase(Module):
+    """Parameter inventory shared by the NC and LP layers."""
+
+    def _make_weights(self, num_relations, in_dim, out_dim, lp):
+        kind = self.weight_decomp
+        if kind is None:
+            self.weights = Parameter(torch.empty(num_relations, in_dim, out_dim))
+        elif kind == 'basis':
+            assert self.num_bases > 0, 'Number of bases should be set to higher than zero for basis decomposition!'
+            self.bases = Parameter(torch.empty(self.num_bases, in_dim, out_dim))
+            self.comps = Parameter(torch.empty(num_relations, self.num_bases))
+        elif kind == 'block':
+            nb = self.num_blocks
+            assert nb > 0, 'Number of blocks should be set to a value higher than zero for block diagonal decomposition!'
+            assert in_dim % nb == 0 and out_dim % nb == 0, \
+                f'For block diagonal decomposition, input dimensions ({in_dim}, {out_dim}) must be divisible ' \
+                f'by number of blocks ({nb})'
+            if lp:  # the self-loop relation keeps a dense matrix of its own
+                self.blocks = Parameter(torch.empty(num_relations - 1, nb, in_dim // nb, out_dim // nb))
+                self.blocks_self = Parameter(torch.empty(in_dim, out_dim))
+            else:
+                self.blocks = Parameter(torch.empty(num_relations, nb, in_dim // nb, out_dim // nb))
+        else:
+            raise NotImplementedError(f'{kind} decomposition has not been implemented')
+
+    def _dense_weights(self):
+        """(R, in_dim, out_dim) view of the (possibly decomposed) relation weights."""
+        kind = self.weight_decomp
+        if kind is None:
+            return self.weights
+        if kind == 'basis':
+            B = self.bases.size(0)
+            return torch.matmul(self.comps, self.bases.reshape(B, -1)).view(self.comps.size(0), *self.bases.shape[1:])
+        if kind == 'block':
+            return block_diag(self.blocks)
+        raise NotImplementedError(f'{kind} decomposition has not been implemented')
+
+
+class RelationalGraphConvolutionNC(_RGCBase):
+    """R-GCN layer for node classification; the (already augmented) graph is fixed at construction."""
+
+    def __init__(self, triples=None, num_nodes=None, num_relations=None, in_features=None, out_features=None,
+                 edge_dropout=None, edge_dropout_self_loop=None, bias=True, decomposition=None,
+                 vertical_stacking=False, diag_weight_matrix=False, reset_mode='glorot_uniform'):
+        super().__init__()
+        assert (triples is not None or num_nodes is not None or num_relations is not None or
+                out_features is not None), \
+            "The following must be specified: triples, number of nodes, number of relations and output dimension!"
+        in_dim = num_nodes if in_features is None else in_features  # featureless: one-hot inputs
+        self.weight_decomp, self.num_bases, self.num_blocks = _unpack_decomposition(decomposition)
+        self.triples = triples
+        self.num_nodes, self.num_relations = num_nodes, num_relations
+        self.in_features, self.out_features = in_features, out_features
+        self.vertical_stacking = vertical_stacking
+        self.diag_weight_matrix = diag_weight_matrix
+        self.edge_dropout, self.edge_dropout_self_loop = edge_dropout, edge_dropout_self_loop  # stored, unused (as upstream)
+
+        if diag_weight_matrix:
+            self.weights = Parameter(torch.empty(num_relations, in_features))
+            self.out_features = in_features
+            self.weight_decomp = None
+            bias = False
+        else:
+            self._make_weights(num_relations, in_dim, out_features, lp=False)
+        if bias:
+            self.bias = Parameter(torch.empty(out_features))
+        else:
+            self.register_parameter('bias', None)
+        self._graph = None
+        self._graph_key = None
+        self.reset_parameters(reset_mode)
+
+    def reset_parameters(self, reset_mode='glorot_uniform'):
+        if reset_mode in ('glorot_uniform', 'schlichtkrull'):
+            targets = {'block': ('blocks',), 'basis': ('bases', 'comps')}.get(self.weight_decomp, ('weights',))
+            for name in targets:
+                nn.init.xavier_uniform_(getattr(self, name), gain=_RELU_GAIN)
+            if self.bias is not None:
+                nn.init.zeros_(self.bias)
+        elif reset_mode == 'uniform':
+            bound = 1.0 / math.sqrt(self.weights.size(1))  # AttributeError under decomposition, as upstream
+            targets = {'block': ('blocks',), 'basis': ('bases', 'comps')}.get(self.weight_decomp, ('weights',))
+            for name in targets:
+                getattr(self, name).data.uniform_(-bound, bound)
+            if self.bias is not None:
+                self.bias.data.uniform_(-bound, bound)
+        else:
+            raise NotImplementedError(f'{reset_mode} parameter initialisation method has not been implemented')
+
+    # the layer is handed a CPU LongTensor and never told about .cuda(): pick the device from the
+    # parameters at forward time and keep the device-resident layout until the triples change
+    def _graph_on(self, device):
+        t = self.triples
+        key = (id(t), t._version if torch.is_tensor(t) else None, str(device), self.vertical_stacking)
+        if self._graph is None or self._graph_key != key:
+            self._graph = graph_from_nc_triples(t, self.num_nodes, self.num_relations, self.vertical_stacking, device)
+            if getattr(self, "_shard_group", None) is not None and self._shard_keep == "lpt":
+                from .dist import filter_graph_for_rank
+                filter_graph_for_rank(self._graph, self._shard_group)
+            self._graph_key = key
+        return self._graph
+
+    def forward(self, features=None):
+        assert (features is None) == (self.in_features is None), "in_features not provided!"
+        any_param = self.weights if (self.diag_weight_matrix or self.weight_decomp is None) else \
+            (self.bases if self.weight_decomp == 'basis' else self.blocks)
+        _require_gpu(any_param, "RelationalGraphConvolutionNC parameters")
+        N, R, out_dim = self.num_nodes, self.num_relations, self.out_features
+        in_dim = N if self.in_features is None else self.in_features
+        graph = self._graph_on(any_param.device)
+
+        if self.diag_weight_matrix:
+            assert self.weights.size() == (R, in_dim)
+            weights = torch.diag_embed(self.weights)           # W_r = diag(w_r)
+        else:
+            weights = self._dense_weights()
+            assert weights.size() == (R, in_dim, out_dim)
+
+        if self.in_features is None:
+            if self.vertical_stacking:
+                raise RuntimeError("featureless message passing needs horizontal stacking "
+                                   f"(mat1 and mat2 shapes cannot be multiplied: {R * N}x{N} and {R * N}x{out_dim})")
+            local = lambda _x, b: F_.featureless_mp(weights, b, graph)
+        else:
+            _require_gpu(features, "features")
+            assert features.size() == (N, in_dim), f"features {tuple(features.size())} vs ({N}, {in_dim})"
+            local = lambda x, b: F_.relational_mp(x, weights, b, graph)
+        group = getattr(self, "_shard_group", None)
+        if group is None:
+            output = local(features, self.bias)
+        else:  # relation-sharded: partial sums joined by an all-reduce, bias added once afterwards
+            from .dist import sharded_apply
+            output = sharded_apply(lambda x: local(x, None), features, group)
+            if self.bias is not None:
+                output = output + self.bias
+        assert output.size() == (N, out_dim)
+        return output
+
+
+class RelationalGraphConvolutionLP(_RGCBase):
+    """R-GCN layer for link prediction; the message graph is supplied on every call."""
+
+    def __init__(self, num_nodes=None, num_relations=None, in_features=None, out_features=None, edge_dropout=None,
+                 edge_dropout_self_loop=None, decomposition=None, vertical_stacking=False, w_init='glorot-normal',
+                 w_gain=False, b_init=None):
+        super().__init__()
+        assert (num_nodes is not None or num_relations is not None or out_features is not None), \
+            "The following must be specified: number of nodes, number of relations and output dimension!"
+        in_dim = num_nodes if in_features is None else in_features
+        self.weight_decomp, self.num_bases, self.num_blocks = _unpack_decomposition(decomposition)
+        self.num_nodes, self.num_relations = num_nodes, num_relations
+        self.in_features, self.out_features = in_dim, out_features   # never None (upstream quirk)
+        self.vertical_stacking = vertical_stacking
+        self.edge_dropout, self.edge_dropout_self_loop = edge_dropout, edge_dropout_self_loop
+        self.w_init, self.w_gain, self.b_init = w_init, w_gain, b_init
+
+        self._make_weights(num_relations, in_dim, out_features, lp=True)
+        if b_init:
+            self.bias = Parameter(torch.empty(out_features))
+        else:
+            self.register_parameter('bias', None)
+        self.initialise_weights()
+        if self.bias is not None:
+            self.initialise_biases()
+        if torch.cuda.is_available():  # upstream creates its parameters on the GPU when there is one
+            self.cuda()
+
+    def initialise_biases(self):
+        select_b_init(self.b_init)(self.bias)
+
+    def initialise_weights(self):
+        gain = _RELU_GAIN if self.w_gain else 1.0
+        fill = select_w_init(self.w_init)
+        if self.weight_decomp == 'block':
+            fan = [(self.num_relations - 1) // 2, self.in_features // self.num_blocks]
+            schlichtkrull_normal_(self.blocks, shape=fan, gain=gain)
+            schlichtkrull_normal_(self.blocks_self, shape=fan, gain=gain)
+        elif self.weight_decomp == 'basis':
+            fill(self.bases, gain=gain)
+            fill(self.comps, gain=gain)
+        else:
+            fill(self.weights, gain=gain)
+
+    def forward(self, triples, features=None):
+        assert (features is None) == (self.in_features is None), "in_features not given"
+        N, R = self.num_nodes, self.num_relations
+        in_dim, out_dim = self.in_features, self.out_features
+        anchor = next(self.parameters())
+        _require_gpu(anchor, "RelationalGraphConvolutionLP parameters")
+        device = anchor.device
+        features = features.to(device)   # upstream moves both inputs to the GPU it found
+        training_dropout = self.training and self.edge_dropout["self_loop_type"] == 'schlichtkrull-dropout'
+        if self.training and self.edge_dropout["self_loop_type"] != 'schlichtkrull-dropout':
+            keep = 1 - self.edge_dropout["self_loop"]
+        else:
+            keep = 1
+
+        if self.weight_decomp == 'block' and self.vertical_stacking:
+            # upstream concatenates the 3-D block_diag(blocks) with the 2-D blocks_self and fails here
+            raise RuntimeError("Tensors must have same number of dimensions: got 3 and 2 "
+                               "(block decomposition is only usable with horizontal stacking)")
+
+        with torch.no_grad():
+            mask = torch.bernoulli(torch.full((N,), float(keep), dtype=torch.float, device=device)).to(torch.bool)
+            graph = graph_from_lp_triples(triples, N, R, self.vertical_stacking, mask, device)
+
+        self_drop = None
+        if self.weight_decomp == 'block':
+            dense = block_diag(self.blocks)
+            if training_dropout and self.edge_dropout["self_loop"] > 0:
+                # dense dropout on the self-loop messages X @ blocks_self before aggregation
+                self_drop = self.edge_dropout["self_loop"]
+                weights = torch.cat([dense, torch.zeros_like(self.blocks_self)[None]], dim=0)
+            else:
+                weights = torch.cat([dense, self.blocks_self[None]], dim=0)
+        else:
+            weights = self._dense_weights()
+        assert weights.size() == (R, in_dim, out_dim)
+        assert features.size() == (N, in_dim)
+
+        output = F_.relational_mp(features, weights, self.bias, graph)
+        if self_drop is not None:
+            msg = nn.functional.dropout(features @ self.blocks_self, p=self_drop, training=True)
+            s, o, v = graph.selfloop_edges(R - 1)
+            output = output.index_add(0, s, msg[o] * v[:, None])
+        assert output.size() == (N, out_dim)
+        return output
