@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmark on the S1 graph: times rgcn_spmm_f32 / rgcn_wgrad_f32 launches alone
+(HIP events on the launch stream).  Tuning knobs come from the environment (RGCN_SPMM_U,
+RGCN_TILE_ROWS, RGCN_WGRAD_ITEM_CHUNKS).  Usage: python tools/kbench.py [--nodes N --edges E]"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "torch-rgcn_amd"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from torch_rgcn import _native  # noqa: E402
+from torch_rgcn.graph import graph_from_nc_triples  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--nodes", type=int, default=1_000_000)
+ap.add_argument("--edges", type=int, default=10_000_000)
+ap.add_argument("--rels", type=int, default=50)
+ap.add_argument("--d", type=int, default=16)
+ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--what", default="spmm,wgrad")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+N, R0, E, d = a.nodes, a.rels, a.edges, a.d
+R = 2 * R0 + 1
+t0 = time.time()
+tp = _native.add_inverse_and_self_host(_native.synthetic_triples_host(N, R0, E, 0), N, R0)
+g = graph_from_nc_triples(tp, N, R, False, dev)
+X = torch.randn(N, d, device=dev)
+G = torch.randn(N, d, device=dev)
+W = torch.randn(R, d, d, device=dev) * 0.1
+b = torch.zeros(d, device=dev)
+M = tp.shape[0]
+alg = M * (4 * d + 8) + N * 4 * d
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e))
+    return float(np.median(ts)), float(np.min(ts))
+
+
+tag = f"U={os.environ.get('RGCN_SPMM_U', '-')} T={os.environ.get('RGCN_TILE_ROWS', '-')} IC={os.environ.get('RGCN_WGRAD_ITEM_CHUNKS', '-')}"
+if "spmm" in a.what:
+    plan = g.fwd_plan(d)
+    med, mn = timeit(lambda: _native.spmm(X, W, b, plan), a.iters)
+    print(f"[{tag}] spmm  tile={plan.tile_rows} pad={plan.m_pad / M:.3f} med {med:.3f} ms min {mn:.3f} ms -> {alg / med / 1e6:.0f} GB/s algorithmic", flush=True)
+if "wgrad" in a.what:
+    wp = g.wgt_plan()
+    med, mn = timeit(lambda: _native.wgrad(X, G, wp, R), a.iters)
+    print(f"[{tag}] wgrad items={wp.n_items} pad={wp.m_pad / M:.3f} med {med:.3f} ms min {mn:.3f} ms", flush=True)
+if "wgradtile" in a.what:
+    plan = g.fwd_plan(d)
+    med, mn = timeit(lambda: _native.wgrad(X, G, plan, R), a.iters)
+    print(f"[{tag}] wgrad(tile-major plan) items={plan.n_items} med {med:.3f} ms min {mn:.3f} ms", flush=True)
+print(f"setup {time.time() - t0:.1f}s", flush=True)

@@ -19,6 +19,7 @@
 // (row m, k-slot k) -- see cdna_hip_programming.md section 3.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "rgcn_hip.h"
 
@@ -40,64 +41,154 @@ namespace {
 constexpr int WG = 256;            // 4 wavefronts
 constexpr int LDS_TILE_BYTES = 64 * 1024;
 
-__device__ __forceinline__ void lds_add(float *p, float v) { atomicAdd(p, v); }
+// ------------------------------------------------------------------ spmm
+// One WAVE per destination tile (a workgroup = 4 independent waves = 4 tiles).  The wave is the
+// only writer of its tile's rows, so the LDS accumulation is a plain read-modify-write
+// (ds_read_b128 / ds_write_b128): LDS float atomics measured ~160 cycles per wave-instruction on
+// gfx950 and were 80% of the first version of this kernel; the RMW form is free and deterministic.
+//
+// Per chunk of 16 messages (one relation):   D^T[o][slot] = sum_f W_rel[f][o] * (val * X[src_slot][f])
+//   A operand = W fragment  (lane 16k+o, step c : W[f(c,k)][o])
+//   B operand = gathered rows (lane 16k+m, step c : val_m * X[src_m][f(c,k)])
+//   D         : lane 16q+m holds output features 4q..4q+3 of slot m  -> ONE 16-byte LDS update per lane
+// Slots are sorted by destination, so messages that share a destination sit in adjacent lanes of a
+// 16-lane DPP row: a 4-step segmented scan (v_*_dpp row_shr) folds them and only the last lane of
+// each segment touches LDS -- no two lanes of one instruction ever update the same address.
 
-// ------------------------------------------------------------------ spmm, d_in = d_out = 16
-// The S1 / hidden-16 fast path.  K-slot permutation: MFMA step c, k-slot k carries feature
-// 4k + c, so each lane's four A values are ONE 16-byte load of its source row.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float old, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                              CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int old, int src) {
+  return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, 0xF, false);
+}
+constexpr int ROW_SHR = 0x110;  // + n : lane m reads lane m-n of its 16-lane row
+constexpr int ROW_SHL = 0x100;  // + n : lane m reads lane m+n
+
+// In-place inclusive segmented sum over the slots (lanes m = 0..15 of a DPP row) of NV accumulators.
+// Returns true in the last lane of every run of equal `dst`.
+template <int NV>
+__device__ __forceinline__ bool fold_segments(f32x4 (&acc)[NV], int dst) {
+#define RGCN_FOLD_STEP(N)                                                      \
+  {                                                                            \
+    const bool same = dpp_i<ROW_SHR + N>(-1, dst) == dst;                      \
+    _Pragma("unroll") for (int v = 0; v < NV; ++v) {                           \
+      f32x4 t;                                                                 \
+      t[0] = dpp_f<ROW_SHR + N>(0.f, acc[v][0]);                               \
+      t[1] = dpp_f<ROW_SHR + N>(0.f, acc[v][1]);                               \
+      t[2] = dpp_f<ROW_SHR + N>(0.f, acc[v][2]);                               \
+      t[3] = dpp_f<ROW_SHR + N>(0.f, acc[v][3]);                               \
+      if (same) acc[v] += t;                                                   \
+    }                                                                          \
+  }
+  RGCN_FOLD_STEP(1)
+  RGCN_FOLD_STEP(2)
+  RGCN_FOLD_STEP(4)
+  RGCN_FOLD_STEP(8)
+#undef RGCN_FOLD_STEP
+  return dpp_i<ROW_SHL + 1>(-1, dst) != dst;
+}
+
+constexpr int SPMM_WAVES = WG / 64;
+
+// ---- d_in = d_out = 16 (the S1 / hidden-16 fast path).  K-slot permutation f(c,k) = 4k + c, so a
+// lane's four B values are ONE 16-byte load of its source row.
+template <int U>
+struct D16Stage {
+  int s[U];      // source row of slot m
+  float v[U];    // adjacency value of slot m
+  int d[U];      // destination row of slot m
+  int r[U];      // relation (same in every lane)
+  float4 x[U];   // gathered source-row quarter (features 4k..4k+3)
+  float4 w[U];   // W_rel fragment for the four MFMA steps
+};
+
+template <int U>
 __global__ __launch_bounds__(WG) void spmm_d16_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias,
     float *__restrict__ out, const int *__restrict__ p_src, const int *__restrict__ p_dst,
     const float *__restrict__ p_val, const int *__restrict__ chunk_rel, const int *__restrict__ tile_ptr,
-    int tile_rows, int n_dst, int relu_out) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];
-  const int t = blockIdx.x;
+    int n_tiles, int tile_rows, int n_dst, int relu_out, int ablate) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int t = blockIdx.x * SPMM_WAVES + wave;
+  if (t >= n_tiles) return;  // whole wave; no workgroup barrier is used anywhere below
+  float *tile = lds + wave * tile_rows * 16;
   const int row0 = t * tile_rows;
   const int nrows = min(tile_rows, n_dst - row0);
-  const int tid = threadIdx.x;
-  for (int i = tid; i < nrows * 4; i += WG) reinterpret_cast<float4 *>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
+  for (int i = lane; i < nrows * 4; i += 64) reinterpret_cast<float4 *>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  const int c0 = tile_ptr[t], c1 = tile_ptr[t + 1];
-  const int wave = tid >> 6, lane = tid & 63;
+  const int my0 = tile_ptr[t], my1 = tile_ptr[t + 1];
   const int m = lane & 15, k = lane >> 4;
-  const int per = (c1 - c0 + 3) >> 2;
-  const int my0 = c0 + wave * per;
-  const int my1 = min(c1, my0 + per);
-  int cur = -1;
-  float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-  for (int c = my0; c < my1; ++c) {
-    const int r = __builtin_amdgcn_readfirstlane(chunk_rel[c]);
-    if (r != cur) {
-      const float *wr = W + (size_t)r * 256 + (4 * k) * 16 + m;
-      b0 = wr[0];
-      b1 = wr[16];
-      b2 = wr[32];
-      b3 = wr[48];
-      cur = r;
+  const int woff = (4 * k) * 16 + m;
+
+  if (my0 < my1) {
+    const int last = my1 - 1;
+    // stage 1: slot indices (chunks past the range re-read the last chunk with val = 0)
+    auto load_idx = [&](int c, D16Stage<U> &g) {
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const int cc = min(c + j, last);
+        const int e = cc * RGCN_CHUNK + m;
+        g.s[j] = p_src[e];
+        const float vv = p_val[e];
+        g.v[j] = (c + j <= last) ? vv : 0.f;
+        g.d[j] = p_dst[e];
+        g.r[j] = chunk_rel[cc];
+      }
+    };
+    // stage 2: row gathers; the W_rel fragments ride along unconditionally (a branch on "relation
+    // changed" makes hipcc drain vmcnt to 0 at every join)
+    auto gather = [&](D16Stage<U> &g) {
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        g.x[j] = *reinterpret_cast<const float4 *>(X + (size_t)g.s[j] * 16 + 4 * k);
+        const float *wr = W + (size_t)g.r[j] * 256 + woff;
+        g.w[j] = make_float4(wr[0], wr[16], wr[32], wr[48]);
+      }
+    };
+    // stage 3: matrix cores, fold equal destinations, one LDS update per segment
+    auto compute = [&](const D16Stage<U> &g) {
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const float v = g.v[j];
+        const bool live = v != 0.f;
+        f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g.w[j].x, live ? g.x[j].x * v : 0.f, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g.w[j].y, live ? g.x[j].y * v : 0.f, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g.w[j].z, live ? g.x[j].z * v : 0.f, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g.w[j].w, live ? g.x[j].w * v : 0.f, acc[0], 0, 0, 0);
+        if (ablate & 1) {  // diagnosis: skip the accumulation
+          asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]), "v"(acc[0][3]), "v"(g.d[j]));
+          continue;
+        }
+        const bool tail = fold_segments<1>(acc, g.d[j]);
+        if (tail) {
+          f32x4 *p = reinterpret_cast<f32x4 *>(tile + (g.d[j] - row0) * 16 + 4 * k);
+          *p += acc[0];
+        }
+      }
+    };
+    for (int c = my0; c < my1; c += U) {
+      D16Stage<U> A;
+      load_idx(c, A);
+#pragma unroll
+      for (int j = 0; j < U; ++j)  // pin the index loads here: hipcc otherwise sinks them to their first use
+        asm volatile("" : "+v"(A.d[j]), "+v"(A.v[j]));
+      __builtin_amdgcn_sched_barrier(0);
+      gather(A);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(A);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    const int e = c * RGCN_CHUNK + m;
-    const int s = p_src[e];
-    const float v = p_val[e];
-    const int4 dd = *reinterpret_cast<const int4 *>(p_dst + c * RGCN_CHUNK + 4 * k);
-    const float4 x = *reinterpret_cast<const float4 *>(X + (size_t)s * 16 + 4 * k);
-    const bool live = v != 0.f;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(live ? x.x * v : 0.f, b0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(live ? x.y * v : 0.f, b1, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(live ? x.z * v : 0.f, b2, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(live ? x.w * v : 0.f, b3, acc, 0, 0, 0);
-    // D: lane (k, m) holds rows 4k..4k+3, column m
-    lds_add(&tile[(dd.x - row0) * 16 + m], acc[0]);
-    lds_add(&tile[(dd.y - row0) * 16 + m], acc[1]);
-    lds_add(&tile[(dd.z - row0) * 16 + m], acc[2]);
-    lds_add(&tile[(dd.w - row0) * 16 + m], acc[3]);
   }
-  __syncthreads();
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (bias) bv = reinterpret_cast<const float4 *>(bias)[tid & 3];
+  if (bias) bv = reinterpret_cast<const float4 *>(bias)[lane & 3];
   float4 *o4 = reinterpret_cast<float4 *>(out + (size_t)row0 * 16);
-  for (int i = tid; i < nrows * 4; i += WG) {  // (i & 3) == (tid & 3) because WG % 4 == 0
+  for (int i = lane; i < nrows * 4; i += 64) {  // (i & 3) == (lane & 3)
     float4 a = reinterpret_cast<const float4 *>(tile)[i];
     a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
     if (relu_out) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
@@ -105,35 +196,33 @@ __global__ __launch_bounds__(WG) void spmm_d16_kernel(
   }
 }
 
-// ------------------------------------------------------------------ spmm, any d_in / d_out
-// NJT = output column tiles (16 wide) kept in accumulators per pass over d_in.
+// ---- any d_in / d_out.  NJT = 16-wide output column tiles kept in accumulators per pass over d_in;
+// the LDS tile rows are padded to ldt = round_up(d_out, 4) floats so every update is one aligned b128.
 template <int NJT>
 __global__ __launch_bounds__(WG) void spmm_generic_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias,
     float *__restrict__ out, const int *__restrict__ p_src, const int *__restrict__ p_dst,
     const float *__restrict__ p_val, const int *__restrict__ chunk_rel, const int *__restrict__ tile_ptr,
-    int tile_rows, int n_dst, int d_in, int d_out, int relu_out) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];
-  const int t = blockIdx.x;
+    int n_tiles, int tile_rows, int n_dst, int d_in, int d_out, int ldt, int relu_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int t = blockIdx.x * SPMM_WAVES + wave;
+  if (t >= n_tiles) return;
+  float *tile = lds + (size_t)wave * tile_rows * ldt;
   const int row0 = t * tile_rows;
   const int nrows = min(tile_rows, n_dst - row0);
-  const int tid = threadIdx.x;
-  for (int i = tid; i < nrows * d_out; i += WG) tile[i] = 0.f;
-  __syncthreads();
+  for (int i = lane; i < nrows * ldt; i += 64) tile[i] = 0.f;
 
-  const int c0 = tile_ptr[t], c1 = tile_ptr[t + 1];
-  const int wave = tid >> 6, lane = tid & 63;
+  const int my0 = tile_ptr[t], my1 = tile_ptr[t + 1];
   const int m = lane & 15, k = lane >> 4;
-  const int per = (c1 - c0 + 3) >> 2;
-  const int my0 = c0 + wave * per;
-  const int my1 = min(c1, my0 + per);
   for (int c = my0; c < my1; ++c) {
     const int r = __builtin_amdgcn_readfirstlane(chunk_rel[c]);
     const int e = c * RGCN_CHUNK + m;
     const int s = p_src[e];
     const float v = p_val[e];
+    const int dst = p_dst[e];
     const bool live = v != 0.f;
-    const int4 dd = *reinterpret_cast<const int4 *>(p_dst + c * RGCN_CHUNK + 4 * k);
     const float *xrow = X + (size_t)s * d_in;
     const float *wr = W + (size_t)r * d_in * d_out;
     for (int jg = 0; jg < d_out; jg += 16 * NJT) {
@@ -143,30 +232,29 @@ __global__ __launch_bounds__(WG) void spmm_generic_kernel(
       for (int kc = 0; kc < d_in; kc += 4) {
         const int f = kc + k;
         const bool fin = f < d_in;
-        float a = (fin && live) ? xrow[f] * v : 0.f;
+        const float b = (fin && live) ? xrow[f] * v : 0.f;   // B: lane 16k+m -> feature f of slot m
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt) {
-          const int col = jg + jt * 16 + m;
-          const float b = (fin && col < d_out) ? wr[(size_t)f * d_out + col] : 0.f;
+          const int col = jg + jt * 16 + m;                   // A: lane 16k+o -> W[f][o]
+          const float a = (fin && col < d_out) ? wr[(size_t)f * d_out + col] : 0.f;
           acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[jt], 0, 0, 0);
         }
       }
+      const bool tail = fold_segments<NJT>(acc, dst);
+      if (tail) {
+        float *prow = tile + (size_t)(dst - row0) * ldt;
 #pragma unroll
-      for (int jt = 0; jt < NJT; ++jt) {
-        const int col = jg + jt * 16 + m;
-        if (col < d_out) {
-          lds_add(&tile[(dd.x - row0) * d_out + col], acc[jt][0]);
-          lds_add(&tile[(dd.y - row0) * d_out + col], acc[jt][1]);
-          lds_add(&tile[(dd.z - row0) * d_out + col], acc[jt][2]);
-          lds_add(&tile[(dd.w - row0) * d_out + col], acc[jt][3]);
+        for (int jt = 0; jt < NJT; ++jt) {
+          const int col = jg + jt * 16 + 4 * k;               // D: lane 16q+m -> features 4q..4q+3 of slot m
+          if (col < ldt) *reinterpret_cast<f32x4 *>(prow + col) += acc[jt];
         }
       }
     }
   }
-  __syncthreads();
   float *o = out + (size_t)row0 * d_out;
-  for (int i = tid; i < nrows * d_out; i += WG) {
-    float a = tile[i] + (bias ? bias[i % d_out] : 0.f);
+  for (int i = lane; i < nrows * d_out; i += 64) {
+    const int rr = i / d_out, cc = i - rr * d_out;
+    float a = tile[rr * ldt + cc] + (bias ? bias[cc] : 0.f);
     if (relu_out) a = fmaxf(a, 0.f);
     o[i] = a;
   }
@@ -236,39 +324,55 @@ __global__ __launch_bounds__(WG) void wgrad_generic_kernel(
 }
 
 // ------------------------------------------------------------------ featureless layer
-// lpr = lanes per table row (power of two <= 64, >= min(d,64) rounded up)
+// Forward: same wave-owned-tile scheme as spmm, without the matrix product: lane 16q+m carries
+// features jb+4q..jb+4q+3 of slot m's table row.
 __global__ __launch_bounds__(WG) void featureless_fwd_kernel(
     const float *__restrict__ table, const float *__restrict__ bias, float *__restrict__ out,
     const int *__restrict__ p_src, const int *__restrict__ p_dst, const float *__restrict__ p_val,
-    const int *__restrict__ chunk_rel, const int *__restrict__ tile_ptr, int tile_rows, int n_dst,
-    long long n_src, int d, int lpr) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];
-  const int t = blockIdx.x;
+    const int *__restrict__ chunk_rel, const int *__restrict__ tile_ptr, int n_tiles, int tile_rows, int n_dst,
+    long long n_src, int d, int ldt) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int t = blockIdx.x * SPMM_WAVES + wave;
+  if (t >= n_tiles) return;
+  float *tile = lds + (size_t)wave * tile_rows * ldt;
   const int row0 = t * tile_rows;
   const int nrows = min(tile_rows, n_dst - row0);
-  const int tid = threadIdx.x;
-  for (int i = tid; i < nrows * d; i += WG) tile[i] = 0.f;
-  __syncthreads();
-  const int c0 = tile_ptr[t], c1 = tile_ptr[t + 1];
-  const int wave = tid >> 6, lane = tid & 63;
-  const int rpi = 64 / lpr;  // rows per iteration
-  const int sub = lane / lpr, jj = lane % lpr;
-  for (int c = c0 + wave; c < c1; c += WG / 64) {
-    const long long r = chunk_rel[c];
-    for (int m0 = 0; m0 < RGCN_CHUNK; m0 += rpi) {
-      const int mm = m0 + sub;
-      if (mm >= RGCN_CHUNK) continue;
-      const int e = c * RGCN_CHUNK + mm;
-      const float v = p_val[e];
-      if (v == 0.f) continue;
-      const float *row = table + (size_t)(r * n_src + p_src[e]) * d;
-      float *dstp = tile + (size_t)(p_dst[e] - row0) * d;
-      for (int j = jj; j < d; j += lpr) lds_add(&dstp[j], v * row[j]);
+  for (int i = lane; i < nrows * ldt; i += 64) tile[i] = 0.f;
+  const int my0 = tile_ptr[t], my1 = tile_ptr[t + 1];
+  const int m = lane & 15, q = lane >> 4;
+  const bool vec4 = (d & 3) == 0;
+  for (int c = my0; c < my1; ++c) {
+    const long long r = __builtin_amdgcn_readfirstlane(chunk_rel[c]);
+    const int e = c * RGCN_CHUNK + m;
+    const float v = p_val[e];
+    const int dst = p_dst[e];
+    const float *row = table + (size_t)(r * n_src + p_src[e]) * d;
+    for (int jb = 0; jb < d; jb += 16) {
+      const int col = jb + 4 * q;
+      f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+      if (v != 0.f) {
+        if (vec4) {
+          if (col < d) {
+            const float4 x = *reinterpret_cast<const float4 *>(row + col);
+            acc[0] = f32x4{x.x * v, x.y * v, x.z * v, x.w * v};
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (col + i < d) acc[0][i] = row[col + i] * v;
+        }
+      }
+      const bool tail = fold_segments<1>(acc, dst);
+      if (tail && col < ldt) *reinterpret_cast<f32x4 *>(tile + (size_t)(dst - row0) * ldt + col) += acc[0];
     }
   }
-  __syncthreads();
   float *o = out + (size_t)row0 * d;
-  for (int i = tid; i < nrows * d; i += WG) o[i] = tile[i] + (bias ? bias[i % d] : 0.f);
+  for (int i = lane; i < nrows * d; i += 64) {
+    const int rr = i / d, cc = i - rr * d;
+    o[i] = tile[rr * ldt + cc] + (bias ? bias[cc] : 0.f);
+  }
 }
 
 __global__ __launch_bounds__(WG) void featureless_wgrad_kernel(
@@ -387,29 +491,40 @@ extern "C" int rgcn_spmm_f32(const float *X, const float *W, const float *bias, 
     return RGCN_EINVAL;
   }
   if (n_tiles == 0) return RGCN_OK;
-  const size_t lds = (size_t)tile_rows * d_out * sizeof(float);
+  const int ldt = (d_out + 3) & ~3;
+  const size_t lds = (size_t)SPMM_WAVES * tile_rows * ldt * sizeof(float);
   if (lds > LDS_TILE_BYTES) {
-    rgcn_set_error("spmm: tile_rows*d_out*4 = %zu exceeds the %d-byte LDS tile budget", lds, LDS_TILE_BYTES);
+    rgcn_set_error("spmm: %d waves x tile_rows*d_out*4 = %zu exceeds the %d-byte LDS budget", SPMM_WAVES, lds,
+                   LDS_TILE_BYTES);
     return RGCN_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((unsigned)n_tiles), block(WG);
+  dim3 grid((unsigned)((n_tiles + SPMM_WAVES - 1) / SPMM_WAVES)), block(WG);
+  const int nt = (int)n_tiles;
+#define RGCN_LAUNCH_GENERIC(NJT)                                                                                   \
+  hipLaunchKernelGGL(spmm_generic_kernel<NJT>, grid, block, lds, st, X, W, bias, out, p_src, p_dst, p_val,         \
+                     chunk_rel, tile_ptr, nt, tile_rows, (int)n_dst, d_in, d_out, ldt, relu_out)
+#define RGCN_LAUNCH_D16(U)                                                                                         \
+  hipLaunchKernelGGL(spmm_d16_kernel<U>, grid, block, lds, st, X, W, bias, out, p_src, p_dst, p_val, chunk_rel,    \
+                     tile_ptr, nt, tile_rows, (int)n_dst, relu_out, ABL)
   if (d_in == 16 && d_out == 16) {
-    hipLaunchKernelGGL(spmm_d16_kernel, grid, block, lds, st, X, W, bias, out, p_src, p_dst, p_val, chunk_rel,
-                       tile_ptr, tile_rows, (int)n_dst, relu_out);
+    static const int U = getenv("RGCN_SPMM_U") ? atoi(getenv("RGCN_SPMM_U")) : 4;
+    static const int ABL = getenv("RGCN_ABLATE") ? atoi(getenv("RGCN_ABLATE")) : 0;  // diagnosis only
+    if (U >= 8) RGCN_LAUNCH_D16(8);
+    else if (U >= 4) RGCN_LAUNCH_D16(4);
+    else if (U >= 2) RGCN_LAUNCH_D16(2);
+    else RGCN_LAUNCH_D16(1);
   } else if (d_out <= 16) {
-    hipLaunchKernelGGL(spmm_generic_kernel<1>, grid, block, lds, st, X, W, bias, out, p_src, p_dst, p_val,
-                       chunk_rel, tile_ptr, tile_rows, (int)n_dst, d_in, d_out, relu_out);
+    RGCN_LAUNCH_GENERIC(1);
   } else if (d_out <= 32) {
-    hipLaunchKernelGGL(spmm_generic_kernel<2>, grid, block, lds, st, X, W, bias, out, p_src, p_dst, p_val,
-                       chunk_rel, tile_ptr, tile_rows, (int)n_dst, d_in, d_out, relu_out);
+    RGCN_LAUNCH_GENERIC(2);
   } else if (d_out <= 64) {
-    hipLaunchKernelGGL(spmm_generic_kernel<4>, grid, block, lds, st, X, W, bias, out, p_src, p_dst, p_val,
-                       chunk_rel, tile_ptr, tile_rows, (int)n_dst, d_in, d_out, relu_out);
+    RGCN_LAUNCH_GENERIC(4);
   } else {
-    hipLaunchKernelGGL(spmm_generic_kernel<8>, grid, block, lds, st, X, W, bias, out, p_src, p_dst, p_val,
-                       chunk_rel, tile_ptr, tile_rows, (int)n_dst, d_in, d_out, relu_out);
+    RGCN_LAUNCH_GENERIC(8);
   }
+#undef RGCN_LAUNCH_GENERIC
+#undef RGCN_LAUNCH_D16
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
@@ -452,11 +567,12 @@ extern "C" int rgcn_featureless_fwd_f32(const float *table, const float *bias, f
     return RGCN_EINVAL;
   }
   if (n_tiles == 0) return RGCN_OK;
-  const size_t lds = (size_t)tile_rows * d_out * sizeof(float);
+  const int ldt = (d_out + 3) & ~3;
+  const size_t lds = (size_t)SPMM_WAVES * tile_rows * ldt * sizeof(float);
   if (lds > LDS_TILE_BYTES) { rgcn_set_error("featureless_fwd: LDS tile too large"); return RGCN_EINVAL; }
-  hipLaunchKernelGGL(featureless_fwd_kernel, dim3((unsigned)n_tiles), dim3(WG), lds, (hipStream_t)stream, table,
-                     bias, out, p_src, p_dst, p_val, chunk_rel, tile_ptr, tile_rows, (int)n_dst, (long long)n_src,
-                     d_out, pow2_lanes(d_out));
+  hipLaunchKernelGGL(featureless_fwd_kernel, dim3((unsigned)((n_tiles + SPMM_WAVES - 1) / SPMM_WAVES)), dim3(WG), lds,
+                     (hipStream_t)stream, table, bias, out, p_src, p_dst, p_val, chunk_rel, tile_ptr, (int)n_tiles,
+                     tile_rows, (int)n_dst, (long long)n_src, d_out, ldt);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

@@ -18,16 +18,18 @@ import torch
 
 from . import _native
 
-_LDS_TILE_FLOATS = 8192  # 32 KiB of LDS per workgroup for the output tile
+_LDS_WAVE_FLOATS = 2048  # 8 KiB of LDS per wave-owned destination tile (4 waves per workgroup)
 
 
 def pick_tile_rows(width):
-    """Rows of the destination tile for an output width (floats per row)."""
+    """Rows of a (wave-owned) destination tile for an output width in floats.  Padding of the
+    (tile, relation) buckets is measured to be free in the gather kernels, so small tiles
+    (more waves in flight) win; the LDS row stride is the width rounded up to 4 floats."""
+    ld = (max(1, width) + 3) & ~3
     env = os.environ.get("RGCN_TILE_ROWS")
     if env:
-        return max(1, min(int(env), 16384 // max(1, width)))
-    rows = _LDS_TILE_FLOATS // max(1, width)
-    return int(max(8, min(512, rows)))
+        return max(1, min(int(env), 4096 // ld))
+    return int(max(4, min(128, _LDS_WAVE_FLOATS // ld)))
 
 
 class RelGraph:
