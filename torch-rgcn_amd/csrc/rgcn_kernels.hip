@@ -323,6 +323,83 @@ __global__ __launch_bounds__(WG) void wgrad_generic_kernel(
     }
 }
 
+// ------------------------------------------------------------------ weight gradient, d_in = d_out = 16
+// v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 outer products per instruction, one per MESSAGE:
+// lane 4b+i supplies A_b[i], lane 4b+j supplies B_b[j], D_b[i][j] lands in lane 4b+j, register i.
+// Lane 4b+q loads ONE 16-byte quarter of message b's source row and of its gradient row, so the
+// sixteen (c,c') register pairs cover the whole 16x16 outer product:
+//     acc[c][c'] (block b, reg i, lane-col j)  +=  val * X[src_b][4i+c] * G[dst_b][4j+c']
+// The 16 blocks keep accumulating over all chunks of the work item and are summed once at the end.
+template <int U>
+__global__ __launch_bounds__(WG) void wgrad_d16_kernel(
+    const float *__restrict__ X, const float *__restrict__ G, float *__restrict__ dW,
+    const int *__restrict__ p_src, const int *__restrict__ p_dst, const float *__restrict__ p_val,
+    const int *__restrict__ chunk_rel, const int2 *__restrict__ items, int n_items) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int item = blockIdx.x * (WG / 64) + wave;
+  if (item >= n_items) return;
+  const int2 range = items[item];
+  const int r = __builtin_amdgcn_readfirstlane(chunk_rel[range.x]);
+  const int b = lane >> 2, q = lane & 3;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) acc[c][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int last = range.y - 1;
+  for (int c0 = range.x; c0 < range.y; c0 += U) {
+    int s[U], d[U];
+    float v[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int cc = min(c0 + j, last);
+      const int e = cc * RGCN_CHUNK + b;
+      s[j] = p_src[e];
+      d[j] = p_dst[e];
+      const float vv = p_val[e];
+      v[j] = (c0 + j <= last) ? vv : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) asm volatile("" : "+v"(s[j]), "+v"(d[j]), "+v"(v[j]));
+    __builtin_amdgcn_sched_barrier(0);
+    float4 x[U], g[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      x[j] = *reinterpret_cast<const float4 *>(X + (size_t)s[j] * 16 + 4 * q);
+      g[j] = *reinterpret_cast<const float4 *>(G + (size_t)d[j] * 16 + 4 * q);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const bool live = v[j] != 0.f;
+      const float xa[4] = {live ? x[j].x * v[j] : 0.f, live ? x[j].y * v[j] : 0.f, live ? x[j].z * v[j] : 0.f,
+                           live ? x[j].w * v[j] : 0.f};
+      const float gb[4] = {live ? g[j].x : 0.f, live ? g[j].y : 0.f, live ? g[j].z : 0.f, live ? g[j].w : 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          acc[c][cc] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[c], gb[cc], acc[c][cc], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // sum the 16 blocks: lanes with equal (lane & 3); rows of 16 lanes by DPP rotates, then across rows
+  float *wr = dW + (size_t)r * 256;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float a = acc[c][cc][i];
+        a += dpp_f<0x120 + 4>(0.f, a);   // row_ror:4
+        a += dpp_f<0x120 + 8>(0.f, a);   // row_ror:8
+        a += __shfl_xor(a, 16, 64);
+        a += __shfl_xor(a, 32, 64);
+        if (lane < 4) atomicAdd(&wr[(4 * i + c) * 16 + 4 * q + cc], a);
+      }
+}
+
 // ------------------------------------------------------------------ featureless layer
 // Forward: same wave-owned-tile scheme as spmm, without the matrix product: lane 16q+m carries
 // features jb+4q..jb+4q+3 of slot m's table row.
@@ -543,7 +620,10 @@ extern "C" int rgcn_wgrad_f32(const float *X, const float *G, float *dW, const i
   if (n_items == 0) return RGCN_OK;
   const unsigned gx = (unsigned)((n_items + WG / 64 - 1) / (WG / 64));
   const int2 *it2 = reinterpret_cast<const int2 *>(items);
-  if (d_in <= 16 && d_out <= 16) {
+  if (d_in == 16 && d_out == 16) {
+    hipLaunchKernelGGL(wgrad_d16_kernel<4>, dim3(gx), dim3(WG), 0, st, X, G, dW, p_src, p_dst, p_val, chunk_rel, it2,
+                       (int)n_items);
+  } else if (d_in <= 16 && d_out <= 16) {
     hipLaunchKernelGGL((wgrad_generic_kernel<1, 1>), dim3(gx, 1), dim3(WG), 0, st, X, G, dW, p_src, p_dst, p_val,
                        chunk_rel, it2, (int)n_items, d_in, d_out, 1);
   } else {
