@@ -79,14 +79,16 @@ RGCN_API int rgcn_edge_norm_host(const int64_t *triples_plus, int64_t M, int64_t
  *       message index, -1 for pads; may be NULL); chunk_rel [n_chunks];
  *       tile_ptr [n_tiles+1] (chunk offsets);  items [2*n_items] = (c0,c1) chunk
  *       ranges of constant relation, at most max_item_chunks long (weight-gradient
- *       work list; may be NULL). */
+ *       work list; may be NULL);  run_ptr [n_tiles*(R+1)] = first chunk of every
+ *       (tile, relation) run, row t ends with tile_ptr[t+1] (may be NULL). */
 RGCN_API int rgcn_plan_count_host(const int32_t *dst, const int32_t *rel, int64_t M, int64_t n_dst, int32_t R,
                                   int32_t tile_rows, int32_t max_item_chunks, int64_t *m_pad,
                                   int64_t *n_chunks, int64_t *n_tiles, int64_t *n_items);
 RGCN_API int rgcn_plan_fill_host(const int32_t *dst, const int32_t *src, const int32_t *rel, const float *val,
                                  int64_t M, int64_t n_dst, int64_t n_src, int32_t R, int32_t tile_rows,
                                  int32_t max_item_chunks, int32_t *p_src, int32_t *p_dst, float *p_val,
-                                 int32_t *p_perm, int32_t *chunk_rel, int32_t *tile_ptr, int32_t *items);
+                                 int32_t *p_perm, int32_t *chunk_rel, int32_t *tile_ptr, int32_t *items,
+                                 int32_t *run_ptr);
 
 /* splitmix64 synthetic graph: s,o ~ U[0,N), p ~ U[0,R0), three
  * consecutive stream values per triple.  Same stream as oracle.synthetic_triples. */
@@ -112,6 +114,17 @@ RGCN_API int rgcn_wgrad_f32(const float *X, const float *G, float *dW, const int
                             const int32_t *p_dst, const float *p_val, const int32_t *chunk_rel,
                             const int32_t *items, int64_t n_items, int64_t n_dst, int64_t n_src, int32_t R,
                             int32_t d_in, int32_t d_out, void *stream);
+
+/* Same gradient, tile-major: walks the FORWARD plan (destination tiles) so that the G rows of a
+ * tile are staged once in LDS and only X[src] is gathered from HBM (one random row read per
+ * message instead of two).  A wave owns 16 consecutive relations x tiles_per_item tiles and keeps
+ * their 16 gradient blocks in MFMA accumulators.  d_in = d_out = 16 only (RGCN_EUNSUPPORTED
+ * otherwise -- callers then use rgcn_wgrad_f32). */
+RGCN_API int rgcn_wgrad_tiled_f32(const float *X, const float *G, float *dW, const int32_t *p_src,
+                                  const int32_t *p_dst, const float *p_val, const int32_t *chunk_rel,
+                                  const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst,
+                                  int64_t n_src, int32_t R, int32_t d_in, int32_t d_out,
+                                  int32_t tiles_per_item, void *stream);
 
 /* Featureless layer (X = I, d_in = N): out[dst,:] = bias + sum val * table[rel*n_src + src, :].
  * Replaces torch.mm(adj, weights.view(R*N, d_out)) of layers.py:286-288 / :518-523. */

@@ -123,8 +123,14 @@ def test_plan_invariants(N, R, M, tile):
     src = rng.integers(0, N, M).astype(np.int32)
     rel = rng.integers(0, R, M).astype(np.int32)
     val = (rng.random(M).astype(np.float32) + 0.1)
-    hp = nat.build_plan_host(dst, src, rel, val, N, N, R, tile, max_item_chunks=5, want_perm=True)
+    hp = nat.build_plan_host(dst, src, rel, val, N, N, R, tile, max_item_chunks=5, want_perm=True, want_runs=True)
     check_plan(hp, dst, src, rel, val, N, R, tile, 5)
+    # run_ptr[t][r] .. run_ptr[t][r+1] = the chunks of (tile t, relation r); rows tile the chunk list
+    rp = hp.run_ptr.reshape(hp.n_tiles, R + 1) if hp.n_tiles else hp.run_ptr.reshape(0, R + 1)
+    for t in range(hp.n_tiles):
+        assert rp[t, 0] == hp.tile_ptr[t] and rp[t, R] == hp.tile_ptr[t + 1] and np.all(np.diff(rp[t]) >= 0)
+        for r in range(R):
+            assert np.all(hp.chunk_rel[rp[t, r]:rp[t, r + 1]] == r)
 
 
 def test_plan_errors():

@@ -63,4 +63,12 @@ if "wgradtile" in a.what:
     plan = g.fwd_plan(d)
     med, mn = timeit(lambda: _native.wgrad(X, G, plan, R), a.iters)
     print(f"[{tag}] wgrad(tile-major plan) items={plan.n_items} med {med:.3f} ms min {mn:.3f} ms", flush=True)
+if "wtiled" in a.what:
+    plan = g.fwd_plan(d)
+    tpi = int(os.environ.get("RGCN_WGRAD_TILES", "4"))
+    ref = _native.wgrad(X, G, g.wgt_plan(), R)
+    got = _native.wgrad_tiled(X, G, plan, R, tpi)
+    err = ((got - ref).abs().max() / ref.abs().max()).item()
+    med, mn = timeit(lambda: _native.wgrad_tiled(X, G, plan, R, tpi), a.iters)
+    print(f"[{tag}] wgrad_tiled tiles/item={tpi} relerr_vs_relmajor={err:.2e} med {med:.3f} ms min {mn:.3f} ms", flush=True)
 print(f"setup {time.time() - t0:.1f}s", flush=True)

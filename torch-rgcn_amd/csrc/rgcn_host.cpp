@@ -213,7 +213,8 @@ extern "C" int rgcn_plan_count_host(const int32_t *dst, const int32_t *rel, int6
 extern "C" int rgcn_plan_fill_host(const int32_t *dst, const int32_t *src, const int32_t *rel, const float *val,
                                    int64_t M, int64_t n_dst, int64_t n_src, int32_t R, int32_t tile_rows,
                                    int32_t max_item_chunks, int32_t *p_src, int32_t *p_dst, float *p_val,
-                                   int32_t *p_perm, int32_t *chunk_rel, int32_t *tile_ptr, int32_t *items) {
+                                   int32_t *p_perm, int32_t *chunk_rel, int32_t *tile_ptr, int32_t *items,
+                                   int32_t *run_ptr) {
   try {
     std::vector<int64_t> cnt;
     int64_t nt = 0;
@@ -251,6 +252,11 @@ extern "C" int rgcn_plan_fill_host(const int32_t *dst, const int32_t *src, const
     int64_t n_items = 0;
     for (size_t b = 0; b < nb; ++b) {
       if (b % size_t(R) == 0) tile_ptr[b / size_t(R)] = int32_t(slot0[b] / RGCN_CHUNK);
+      if (run_ptr) {
+        const size_t t = b / size_t(R), r = b % size_t(R);
+        run_ptr[t * size_t(R + 1) + r] = int32_t(slot0[b] / RGCN_CHUNK);
+        if (r + 1 == size_t(R)) run_ptr[t * size_t(R + 1) + size_t(R)] = int32_t(slot0[b + 1] / RGCN_CHUNK);
+      }
       if (!cnt[b]) continue;
       const int64_t last = cur[b] - 1;
       for (int64_t p = cur[b]; p < slot0[b + 1]; ++p) {  // pads: val 0, indices of the last real message

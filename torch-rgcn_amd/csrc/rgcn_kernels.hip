@@ -400,6 +400,104 @@ __global__ __launch_bounds__(WG) void wgrad_d16_kernel(
       }
 }
 
+// ------------------------------------------------------------------ weight gradient, tile-major, d = 16
+// Walks the forward plan.  Work item = (group of RG consecutive relations, range of tiles); the chunks
+// of a relation group are contiguous inside every tile.  X rows (random) are gathered in the natural
+// layout (lane 16q+m: quarter q of slot m's row) and transposed through a 1 KiB LDS scratch into the
+// MFMA operand layout (K over messages).  G rows are tile-local -- every row of the tile is reused by
+// ~deg messages -- so they are read straight from L1/L2 in operand layout (4 rows x 64 B per load).
+// dW[rel] += (val X[src])^T G[dst] accumulates in RG x 4 accumulator registers per lane.
+template <int RG, int U>
+__global__ __launch_bounds__(WG) void wgrad_tiled_d16_kernel(
+    const float *__restrict__ X, const float *__restrict__ G, float *__restrict__ dW,
+    const int *__restrict__ p_src, const int *__restrict__ p_dst, const float *__restrict__ p_val,
+    const int *__restrict__ chunk_rel, const int *__restrict__ run_ptr, int n_tiles, int R, int tiles_per_item,
+    int n_groups, int n_items) {
+  __shared__ __attribute__((aligned(16))) float lds_all[(WG / 64) * (256 + 16)];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int item = blockIdx.x * (WG / 64) + wave;
+  if (item >= n_items) return;
+  const int grp = item % n_groups, tb = item / n_groups;
+  const int t0 = tb * tiles_per_item, t1 = min(n_tiles, t0 + tiles_per_item);
+  const int r0 = grp * RG, r1 = min(R, r0 + RG);
+  float *xs = lds_all + wave * (256 + 16);                          // x scratch 16x16 | dst rows
+  int *dl = reinterpret_cast<int *>(xs + 256);
+  const int m = lane & 15, kq = lane >> 4;
+  f32x4 acc[RG];
+#pragma unroll
+  for (int i = 0; i < RG; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = t0; t < t1; ++t) {
+    const int cb = run_ptr[(size_t)t * (R + 1) + r0], ce = run_ptr[(size_t)t * (R + 1) + r1];
+    const int last = ce - 1;
+    for (int c0 = cb; c0 < ce; c0 += U) {
+      int s[U], d[U], rr[U];
+      float v[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const int cc = min(c0 + j, last);
+        const int e = cc * RGCN_CHUNK + m;
+        s[j] = p_src[e];
+        d[j] = p_dst[e];
+        const float vv = p_val[e];
+        v[j] = (c0 + j <= last) ? vv : 0.f;
+        rr[j] = chunk_rel[cc];
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) asm volatile("" : "+v"(s[j]), "+v"(d[j]), "+v"(v[j]), "+v"(rr[j]));
+      __builtin_amdgcn_sched_barrier(0);
+      float4 x[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) x[j] = *reinterpret_cast<const float4 *>(X + (size_t)s[j] * 16 + 4 * kq);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const bool live = v[j] != 0.f;
+        const f32x4 xv = {live ? x[j].x * v[j] : 0.f, live ? x[j].y * v[j] : 0.f, live ? x[j].z * v[j] : 0.f,
+                          live ? x[j].w * v[j] : 0.f};
+        asm volatile("" ::: "memory");   // LDS written as vectors, read as scalars: no compiler reordering
+        *reinterpret_cast<f32x4 *>(xs + m * 16 + 4 * kq) = xv;      // xs[slot m][4kq..4kq+3]
+        if (kq == 0) dl[m] = d[j];
+        asm volatile("" ::: "memory");
+        float av[4], bv[4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+          const int mu = 4 * t4 + kq;                                // message carried by K-slot kq at step t4
+          av[t4] = xs[mu * 16 + m];                                  // A[i = m][k] = val * X[src_mu][m]
+          bv[t4] = G[(size_t)dl[mu] * 16 + m];                       // B[k][j = m] = G[dst_mu][m]  (L1/L2)
+        }
+        const int rho = __builtin_amdgcn_readfirstlane(rr[j]) - r0;
+#define RGCN_ACC_CASE(N)                                                                       \
+  case N:                                                                                      \
+    if (N < RG) {                                                                              \
+      acc[N < RG ? N : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc[N < RG ? N : 0], 0, 0, 0); \
+      acc[N < RG ? N : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc[N < RG ? N : 0], 0, 0, 0); \
+      acc[N < RG ? N : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc[N < RG ? N : 0], 0, 0, 0); \
+      acc[N < RG ? N : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc[N < RG ? N : 0], 0, 0, 0); \
+    }                                                                                          \
+    break;
+        switch (rho) {
+          RGCN_ACC_CASE(0) RGCN_ACC_CASE(1) RGCN_ACC_CASE(2) RGCN_ACC_CASE(3) RGCN_ACC_CASE(4) RGCN_ACC_CASE(5)
+          RGCN_ACC_CASE(6) RGCN_ACC_CASE(7) RGCN_ACC_CASE(8) RGCN_ACC_CASE(9) RGCN_ACC_CASE(10) RGCN_ACC_CASE(11)
+          RGCN_ACC_CASE(12) RGCN_ACC_CASE(13) RGCN_ACC_CASE(14) RGCN_ACC_CASE(15)
+          default: break;
+        }
+#undef RGCN_ACC_CASE
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // D: lane 16q+j holds rows 4q..4q+3 (input feature), column j (output feature)
+#pragma unroll
+  for (int i = 0; i < RG; ++i)
+    if (r0 + i < R) {
+      float *wr = dW + (size_t)(r0 + i) * 256 + (4 * kq) * 16 + m;
+      atomicAdd(wr, acc[i][0]);
+      atomicAdd(wr + 16, acc[i][1]);
+      atomicAdd(wr + 32, acc[i][2]);
+      atomicAdd(wr + 48, acc[i][3]);
+    }
+}
+
 // ------------------------------------------------------------------ featureless layer
 // Forward: same wave-owned-tile scheme as spmm, without the matrix product: lane 16q+m carries
 // features jb+4q..jb+4q+3 of slot m's table row.
@@ -632,6 +730,43 @@ extern "C" int rgcn_wgrad_f32(const float *X, const float *G, float *dW, const i
     hipLaunchKernelGGL((wgrad_generic_kernel<NIT, NJT>), dim3(gx, (unsigned)(nig * njg)), dim3(WG), 0, st, X, G, dW,
                        p_src, p_dst, p_val, chunk_rel, it2, (int)n_items, d_in, d_out, njg);
   }
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_wgrad_tiled_f32(const float *X, const float *G, float *dW, const int32_t *p_src,
+                                    const int32_t *p_dst, const float *p_val, const int32_t *chunk_rel,
+                                    const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst,
+                                    int64_t n_src, int32_t R, int32_t d_in, int32_t d_out, int32_t tiles_per_item,
+                                    void *stream) {
+  (void)n_src;
+  if (!X || !G || !dW || !run_ptr || R <= 0 || tile_rows <= 0 || tiles_per_item <= 0 || n_tiles < 0) {
+    rgcn_set_error("wgrad_tiled: bad argument");
+    return RGCN_EINVAL;
+  }
+  if (d_in != 16 || d_out != 16) { rgcn_set_error("wgrad_tiled: only d_in = d_out = 16"); return RGCN_EUNSUPPORTED; }
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(dW, 0, (size_t)R * 256 * sizeof(float), st));
+  if (n_tiles == 0) return RGCN_OK;
+  static const int RGSEL = getenv("RGCN_WGRAD_RG") ? atoi(getenv("RGCN_WGRAD_RG")) : 1;
+  static const int USEL = getenv("RGCN_WGRAD_U") ? atoi(getenv("RGCN_WGRAD_U")) : 2;
+  const int RGv = RGSEL <= 1 ? 1 : RGSEL <= 2 ? 2 : RGSEL <= 4 ? 4 : RGSEL <= 8 ? 8 : 16;
+  const int n_groups = (R + RGv - 1) / RGv;
+  const int64_t n_items = ((n_tiles + tiles_per_item - 1) / tiles_per_item) * n_groups;
+  const unsigned gx = (unsigned)((n_items + WG / 64 - 1) / (WG / 64));
+#define RGCN_LAUNCH_WT(RGC, UC)                                                                                    \
+  hipLaunchKernelGGL((wgrad_tiled_d16_kernel<RGC, UC>), dim3(gx), dim3(WG), 0, st, X, G, dW, p_src, p_dst, p_val, \
+                     chunk_rel, run_ptr, (int)n_tiles, R, tiles_per_item, n_groups, (int)n_items)
+#define RGCN_LAUNCH_WTU(RGC) { if (USEL >= 4) RGCN_LAUNCH_WT(RGC, 4); else if (USEL >= 2) RGCN_LAUNCH_WT(RGC, 2); else RGCN_LAUNCH_WT(RGC, 1); }
+  switch (RGv) {
+    case 1: RGCN_LAUNCH_WTU(1) break;
+    case 2: RGCN_LAUNCH_WTU(2) break;
+    case 4: RGCN_LAUNCH_WTU(4) break;
+    case 8: RGCN_LAUNCH_WTU(8) break;
+    default: RGCN_LAUNCH_WTU(16) break;
+  }
+#undef RGCN_LAUNCH_WTU
+#undef RGCN_LAUNCH_WT
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

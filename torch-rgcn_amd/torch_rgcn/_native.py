@@ -145,11 +145,12 @@ def synthetic_triples_host(num_nodes, num_rels, num_edges, seed=0):
 
 class HostPlan:
     """Relation-tile plan as numpy arrays (see rgcn_plan_fill_host)."""
-    __slots__ = ("src", "dst", "val", "perm", "chunk_rel", "tile_ptr", "items", "n_dst", "n_src", "num_rels",
+    __slots__ = ("src", "dst", "val", "perm", "chunk_rel", "tile_ptr", "items", "run_ptr", "n_dst", "n_src", "num_rels",
                  "tile_rows", "n_tiles", "n_chunks", "m_pad", "n_items", "n_messages")
 
 
-def build_plan_host(dst, src, rel, val, n_dst, n_src, num_rels, tile_rows, max_item_chunks=64, want_perm=False):
+def build_plan_host(dst, src, rel, val, n_dst, n_src, num_rels, tile_rows, max_item_chunks=64, want_perm=False,
+                    want_runs=False):
     dst = _np(dst, np.int32)
     src = _np(src, np.int32)
     rel = _np(rel, np.int32)
@@ -171,10 +172,11 @@ def build_plan_host(dst, src, rel, val, n_dst, n_src, num_rels, tile_rows, max_i
     p.chunk_rel = np.empty(max(p.n_chunks, 1), np.int32)
     p.tile_ptr = np.zeros(p.n_tiles + 1, np.int32)
     p.items = np.empty((max(p.n_items, 1), 2), np.int32)
+    p.run_ptr = np.zeros(max(p.n_tiles, 1) * (num_rels + 1), np.int32) if want_runs else None
     _check(L.rgcn_plan_fill_host(_hp(dst), _hp(src), _hp(rel), _hp(val), c_i64(M), c_i64(n_dst), c_i64(n_src),
                                  c_i32(num_rels), c_i32(tile_rows), c_i32(max_item_chunks), _hp(p.src), _hp(p.dst),
-                                 _hp(p.val), _hp(p.perm), _hp(p.chunk_rel), _hp(p.tile_ptr), _hp(p.items)),
-           "plan_fill")
+                                 _hp(p.val), _hp(p.perm), _hp(p.chunk_rel), _hp(p.tile_ptr), _hp(p.items),
+                                 _hp(p.run_ptr)), "plan_fill")
     return p
 
 
@@ -188,6 +190,7 @@ class DevicePlan:
         up = lambda a: torch.from_numpy(a).to(self.device, non_blocking=False)
         self.src, self.dst, self.val = up(hp.src), up(hp.dst), up(hp.val)
         self.chunk_rel, self.tile_ptr, self.items = up(hp.chunk_rel), up(hp.tile_ptr), up(hp.items)
+        self.run_ptr = None if hp.run_ptr is None else up(hp.run_ptr)
         for k in ("n_dst", "n_src", "num_rels", "tile_rows", "n_tiles", "n_chunks", "m_pad", "n_items", "n_messages"):
             setattr(self, k, getattr(hp, k))
 
@@ -233,6 +236,20 @@ def wgrad(X, G, plan, num_rels):
                                     _dp(plan.chunk_rel), _dp(plan.items), c_i64(plan.n_items), c_i64(plan.n_dst),
                                     c_i64(plan.n_src), c_i32(num_rels), c_i32(d_in), c_i32(d_out),
                                     _stream(X.device)), "wgrad")
+    return dW
+
+
+def wgrad_tiled(X, G, plan, num_rels, tiles_per_item=4):
+    """same result as wgrad(), walking the forward (destination-tile) plan; d_in = d_out = 16 only"""
+    _req(X, "features"); _req(G, "grad_output")
+    assert plan.run_ptr is not None and X.shape[0] == plan.n_src and G.shape[0] == plan.n_dst
+    dW = torch.empty((num_rels, X.shape[1], G.shape[1]), device=X.device, dtype=torch.float32)
+    with torch.cuda.device(X.device), _timed("wgrad"):
+        _check(lib().rgcn_wgrad_tiled_f32(_dp(X), _dp(G), _dp(dW), _dp(plan.src), _dp(plan.dst), _dp(plan.val),
+                                          _dp(plan.chunk_rel), _dp(plan.run_ptr), c_i64(plan.n_tiles),
+                                          c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i64(plan.n_src),
+                                          c_i32(num_rels), c_i32(X.shape[1]), c_i32(G.shape[1]),
+                                          c_i32(tiles_per_item), _stream(X.device)), "wgrad_tiled")
     return dW
 
 

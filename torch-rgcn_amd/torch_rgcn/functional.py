@@ -8,6 +8,8 @@ Both are the custom-Function form of what the reference leaves to autograd
 autograd engine's thread and launches on that thread's current HIP stream; it uses
 nothing but the tensors saved on ctx and the immutable RelGraph.
 """
+import os
+
 import torch
 
 from . import _native
@@ -35,7 +37,11 @@ class _RelationalMP(torch.autograd.Function):
             Wt = W.transpose(1, 2).contiguous()
             dX = _native.spmm(g, Wt, None, graph.bwd_plan(W.shape[1]))
         if ctx.needs_input_grad[1]:
-            dW = _native.wgrad(X, g, graph.wgt_plan(), W.shape[0])
+            if W.shape[1] == 16 and W.shape[2] == 16 and os.environ.get("RGCN_WGRAD", "tiled") == "tiled":
+                dW = _native.wgrad_tiled(X, g, graph.fwd_plan(16), W.shape[0],
+                                         int(os.environ.get("RGCN_WGRAD_TILES", "4")))
+            else:
+                dW = _native.wgrad(X, g, graph.wgt_plan(), W.shape[0])
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _native.colsum(g)
         return dX, dW, db, None

@@ -55,7 +55,8 @@ class RelGraph:
         if key not in self._plans:
             N, R = self.num_nodes, self.num_rels
             if kind == "fwd":
-                hp = _native.build_plan_host(self._s, self._o, self._p, self._val, N, N, R, tile_rows, max_item_chunks)
+                hp = _native.build_plan_host(self._s, self._o, self._p, self._val, N, N, R, tile_rows, max_item_chunks,
+                                             want_runs=True)
             elif kind == "bwd":
                 hp = _native.build_plan_host(self._o, self._s, self._p, self._val, N, N, R, tile_rows, max_item_chunks)
             else:
