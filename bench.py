@@ -40,6 +40,27 @@ def algorithmic_bytes(M, N, d_in, d_out):
     return M * (4 * d_in + 8) + N * 4 * d_out
 
 
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_kernels.json")
+PMC_NOTE = ("profiles/r01_pmc_kernels.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/kbench.py "
+            "on the same S1 launch; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE tallies 128-B requests "
+            "at 64 B, MI355X_MICROARCH.md HBM section). Calibration on a known random-64B-row pattern "
+            "(profiles/r01_pmc_gather_probe_calibration.json) reads 1.0x, i.e. (FETCH+WRITE)*1024 = 1.48e9 B if row "
+            "requests are 64-B.")
+
+
+def pmc_traffic(kernel_substr):
+    """HBM-side bytes per launch of a kernel from the committed PMC summary (None when absent)."""
+    try:
+        with open(PMC_FILE) as f:
+            data = json.load(f)
+    except OSError:
+        return None
+    for name, c in data.items():
+        if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            return int((2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024)
+    return None
+
+
 def build_layers(N, R0, E, d, seed, device, group):
     from torch_rgcn import _native
     from torch_rgcn.dist import shard_layer
@@ -61,7 +82,9 @@ def cpu_baseline(steps=2):
     """The reference's op sequence (oracle/torch_cpu_port.py) on the host cores, 1/10-scale S1."""
     from oracle import oracle, torch_cpu_port
     N, R0, E, d = 100_000, 50, 1_000_000, 16
-    threads = os.cpu_count() or 1
+    # ATen's sparse kernels stop scaling (and then regress) long before 256 host threads: 13.1 s/step at
+    # 256 threads vs the figures below; the baseline gets the best thread count we measured, not the worst.
+    threads = int(os.environ.get("RGCN_CPU_THREADS", min(os.cpu_count() or 1, 32)))
     torch.set_num_threads(threads)
     tp = torch.from_numpy(oracle.add_inverse_and_self(oracle.synthetic_triples(N, R0, E, 0), N, R0))
     R = 2 * R0 + 1
@@ -99,9 +122,13 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     group = None
-    if world > 1:
+    if world > 1 or os.environ.get("RGCN_FORCE_DIST"):   # RGCN_FORCE_DIST=1: exercise the RCCL path on one GPU
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if "RANK" not in os.environ:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        else:
+            dist.init_process_group("nccl", device_id=device)
         group = dist.group.WORLD
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -121,7 +148,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if group is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -137,7 +164,7 @@ def main():
     prof = _native.profile_stop()
 
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if world > 1:
+    if group is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = t.item()
     ms = 1e3 * elapsed / args.steps
@@ -147,11 +174,12 @@ def main():
         spmm_ms = float(np.mean(kern)) if kern else None
         alg = algorithmic_bytes(M, N, d, d)
         roof = None
+        traffic = pmc_traffic("spmm_d16_kernel")
         if spmm_ms:
             ach = alg / (spmm_ms * 1e-3) / 1e9
             roof = {"kernel": "spmm_d16_kernel (forward and feature-gradient launches)", "bound": "hbm",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": None, "avg_launch_ms": round(spmm_ms, 4), "launches_per_step": len(kern) / args.steps,
+                    "traffic": traffic, "traffic_source": PMC_NOTE if traffic else None, "avg_launch_ms": round(spmm_ms, 4), "launches_per_step": len(kern) / args.steps,
                     "algorithmic_bytes_per_launch": alg,
                     "other_kernels_ms": {k: round(float(np.mean(v)), 4) for k, v in prof.items() if k != "spmm"}}
         res = {"metric": METRIC, "value": world * E / (ms * 1e-3), "unit": "edges/s", "n_gpus": world,
@@ -166,9 +194,13 @@ def main():
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(res))
-    if world > 1:
-        dist.destroy_process_group()
+    else:
+        res = None
+    if group is not None:
+        dist.destroy_process_group()   # RCCL prints its banner here; keep the JSON line last
+    if res is not None:
+        sys.stdout.flush()
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
