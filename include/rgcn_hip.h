@@ -80,7 +80,9 @@ RGCN_API int rgcn_edge_norm_host(const int64_t *triples_plus, int64_t M, int64_t
  *       tile_ptr [n_tiles+1] (chunk offsets);  items [2*n_items] = (c0,c1) chunk
  *       ranges of constant relation, at most max_item_chunks long (weight-gradient
  *       work list; may be NULL);  run_ptr [n_tiles*(R+1)] = first chunk of every
- *       (tile, relation) run, row t ends with tile_ptr[t+1] (may be NULL). */
+ *       (tile, relation) run, row t ends with tile_ptr[t+1] (may be NULL);
+ *       p_pack [2*m_pad] = 8-byte slots { src | (dst - tile_row0) << 24 , val bits } for the
+ *       hidden-16 kernels (needs n_src < 2^24 and tile_rows <= 256; may be NULL). */
 RGCN_API int rgcn_plan_count_host(const int32_t *dst, const int32_t *rel, int64_t M, int64_t n_dst, int32_t R,
                                   int32_t tile_rows, int32_t max_item_chunks, int64_t *m_pad,
                                   int64_t *n_chunks, int64_t *n_tiles, int64_t *n_items);
@@ -88,7 +90,7 @@ RGCN_API int rgcn_plan_fill_host(const int32_t *dst, const int32_t *src, const i
                                  int64_t M, int64_t n_dst, int64_t n_src, int32_t R, int32_t tile_rows,
                                  int32_t max_item_chunks, int32_t *p_src, int32_t *p_dst, float *p_val,
                                  int32_t *p_perm, int32_t *chunk_rel, int32_t *tile_ptr, int32_t *items,
-                                 int32_t *run_ptr);
+                                 int32_t *run_ptr, int32_t *p_pack);
 
 /* splitmix64 synthetic graph: s,o ~ U[0,N), p ~ U[0,R0), three
  * consecutive stream values per triple.  Same stream as oracle.synthetic_triples. */
@@ -100,12 +102,20 @@ RGCN_API int rgcn_synthetic_triples_host(int64_t N, int64_t R0, int64_t E, uint6
  * Forward of layers.py:293-301 / :524-551 (both stackings are the same function of
  * (T+, val, X, W)); with the transposed plan, G in place of X and W^T in place of W
  * it is the feature gradient dX.  bias may be NULL.
- * relu_out != 0 fuses max(.,0) into the epilogue (caller-side F.relu of models.py:196). */
+ * flags: RGCN_F_RELU fuses max(.,0) into the epilogue (caller-side F.relu of models.py:196).
+ * p_pack (may be NULL): packed slots from rgcn_plan_fill_host; with d_in = d_out = 16 the kernel then
+ * reads 8 bytes of index data per message instead of 12. */
+#define RGCN_F_RELU 1
+#define RGCN_F_WPACKED 2   /* W is in MFMA fragment order (rgcn_pack_w16_f32); d_in = d_out = 16 only */
 RGCN_API int rgcn_spmm_f32(const float *X, const float *W, const float *bias, float *out, const int32_t *p_src,
-                           const int32_t *p_dst, const float *p_val, const int32_t *chunk_rel,
-                           const int32_t *tile_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst,
-                           int64_t n_src, int32_t R, int32_t d_in, int32_t d_out, int32_t relu_out,
+                           const int32_t *p_dst, const float *p_val, const int32_t *p_pack,
+                           const int32_t *chunk_rel, const int32_t *tile_ptr, int64_t n_tiles, int32_t tile_rows,
+                           int64_t n_dst, int64_t n_src, int32_t R, int32_t d_in, int32_t d_out, int32_t flags,
                            void *stream);
+
+/* Wp[r][16k+o][c] = W[r][4k+c][o]: the per-lane float4 the hidden-16 kernel feeds to the matrix cores
+ * (weight assembly step of layers.py:239-244, device side).  W, Wp: [R,16,16]. */
+RGCN_API int rgcn_pack_w16_f32(const float *W, float *Wp, int32_t R, void *stream);
 
 /* dW[rel] += sum over slots val * X[src,:]^T G[dst,:]  for every work item; dW
  * ([R, d_in, d_out]) is zeroed first.  Autograd dual of the einsum / sparse mm pair

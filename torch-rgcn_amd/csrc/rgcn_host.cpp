@@ -214,7 +214,7 @@ extern "C" int rgcn_plan_fill_host(const int32_t *dst, const int32_t *src, const
                                    int64_t M, int64_t n_dst, int64_t n_src, int32_t R, int32_t tile_rows,
                                    int32_t max_item_chunks, int32_t *p_src, int32_t *p_dst, float *p_val,
                                    int32_t *p_perm, int32_t *chunk_rel, int32_t *tile_ptr, int32_t *items,
-                                   int32_t *run_ptr) {
+                                   int32_t *run_ptr, int32_t *p_pack) {
   try {
     std::vector<int64_t> cnt;
     int64_t nt = 0;
@@ -275,6 +275,18 @@ extern "C" int rgcn_plan_fill_host(const int32_t *dst, const int32_t *src, const
         }
     }
     tile_ptr[nt] = int32_t(slot0[nb] / RGCN_CHUNK);
+    if (p_pack) {
+      if (n_src >= (int64_t(1) << 24) || tile_rows > 256) {
+        rgcn_set_error("plan_fill: packed slots need n_src < 2^24 and tile_rows <= 256");
+        return RGCN_EUNSUPPORTED;
+      }
+      const int64_t m_pad = slot0[nb];
+      for (int64_t p = 0; p < m_pad; ++p) {
+        const uint32_t dl = uint32_t(p_dst[p] % tile_rows);
+        p_pack[2 * p] = int32_t(uint32_t(p_src[p]) | (dl << 24));
+        std::memcpy(&p_pack[2 * p + 1], &p_val[p], sizeof(float));
+      }
+    }
   } catch (const std::bad_alloc &) {
     rgcn_set_error("plan: out of host memory");
     return RGCN_ENOMEM;

@@ -105,12 +105,14 @@ struct D16Stage {
   float4 w[U];   // W_rel fragment for the four MFMA steps
 };
 
-template <int U>
+// PACKED: slots come as 8 bytes {src | dst_local << 24, val} and W_rel as pre-swizzled fragments
+// (one float4 per lane), i.e. 4 VMEM instructions per chunk instead of 8.
+template <int U, bool PACKED>
 __global__ __launch_bounds__(WG) void spmm_d16_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias,
     float *__restrict__ out, const int *__restrict__ p_src, const int *__restrict__ p_dst,
-    const float *__restrict__ p_val, const int *__restrict__ chunk_rel, const int *__restrict__ tile_ptr,
-    int n_tiles, int tile_rows, int n_dst, int relu_out, int ablate) {
+    const float *__restrict__ p_val, const int2 *__restrict__ p_pack, const int *__restrict__ chunk_rel,
+    const int *__restrict__ tile_ptr, int n_tiles, int tile_rows, int n_dst, int relu_out, int ablate) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -133,10 +135,17 @@ __global__ __launch_bounds__(WG) void spmm_d16_kernel(
       for (int j = 0; j < U; ++j) {
         const int cc = min(c + j, last);
         const int e = cc * RGCN_CHUNK + m;
-        g.s[j] = p_src[e];
-        const float vv = p_val[e];
-        g.v[j] = (c + j <= last) ? vv : 0.f;
-        g.d[j] = p_dst[e];
+        if (PACKED) {
+          const int2 pk = p_pack[e];
+          g.s[j] = pk.x & 0xFFFFFF;
+          g.d[j] = row0 + (int)((unsigned)pk.x >> 24);
+          g.v[j] = (c + j <= last) ? __builtin_bit_cast(float, pk.y) : 0.f;
+        } else {
+          g.s[j] = p_src[e];
+          const float vv = p_val[e];
+          g.v[j] = (c + j <= last) ? vv : 0.f;
+          g.d[j] = p_dst[e];
+        }
         g.r[j] = chunk_rel[cc];
       }
     };
@@ -146,8 +155,12 @@ __global__ __launch_bounds__(WG) void spmm_d16_kernel(
 #pragma unroll
       for (int j = 0; j < U; ++j) {
         g.x[j] = *reinterpret_cast<const float4 *>(X + (size_t)g.s[j] * 16 + 4 * k);
-        const float *wr = W + (size_t)g.r[j] * 256 + woff;
-        g.w[j] = make_float4(wr[0], wr[16], wr[32], wr[48]);
+        if (PACKED) {
+          g.w[j] = reinterpret_cast<const float4 *>(W)[(size_t)g.r[j] * 64 + lane];
+        } else {
+          const float *wr = W + (size_t)g.r[j] * 256 + woff;
+          g.w[j] = make_float4(wr[0], wr[16], wr[32], wr[48]);
+        }
       }
     };
     // stage 3: matrix cores, fold equal destinations, one LDS update per segment
@@ -189,6 +202,117 @@ __global__ __launch_bounds__(WG) void spmm_d16_kernel(
   if (bias) bv = reinterpret_cast<const float4 *>(bias)[lane & 3];
   float4 *o4 = reinterpret_cast<float4 *>(out + (size_t)row0 * 16);
   for (int i = lane; i < nrows * 4; i += 64) {  // (i & 3) == (lane & 3)
+    float4 a = reinterpret_cast<const float4 *>(tile)[i];
+    a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
+    if (relu_out) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+    o4[i] = a;
+  }
+}
+
+// W[r][f][o] -> fragment order Wp[r][lane = 16k+o][c] = W[r][4k+c][o]  (one float4 per lane and chunk)
+__global__ __launch_bounds__(WG) void pack_w16_kernel(const float *__restrict__ W, float *__restrict__ Wp, int n) {
+  const int i = blockIdx.x * WG + threadIdx.x;   // index into Wp
+  if (i >= n) return;
+  const int c = i & 3, o = (i >> 2) & 15, kk = (i >> 6) & 3, r = i >> 8;
+  Wp[i] = W[r * 256 + (4 * kk + c) * 16 + o];
+}
+
+// ---- variant: slot indices of block b+1 are fetched while block b is gathered and multiplied
+// (issue early / write late through a 1 KiB LDS double buffer).  The early loads are inline asm so that
+// hipcc can neither sink them to their use nor wait for them before the matrix work; they are older than
+// every compiler-visible load of the iteration, so the compiler's own counted vmcnt waits stay valid.
+__device__ __forceinline__ void asm_load_b32(int &dst, const void *p) {
+  asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+
+__global__ __launch_bounds__(WG) void spmm_d16_staged_kernel(
+    const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias,
+    float *__restrict__ out, const int *__restrict__ p_src, const int *__restrict__ p_dst,
+    const float *__restrict__ p_val, const int *__restrict__ chunk_rel, const int *__restrict__ tile_ptr,
+    int n_tiles, int tile_rows, int n_dst, int relu_out) {
+  constexpr int U = 4;                       // 4 chunks = 64 slots = one slot per lane
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int t = blockIdx.x * SPMM_WAVES + wave;
+  if (t >= n_tiles) return;
+  const int stride = tile_rows * 16 + 2 * 256;                     // tile | 2 x (src,val,dst,rel) x 64
+  float *tile = lds + (size_t)wave * stride;
+  int *stage = reinterpret_cast<int *>(tile + tile_rows * 16);
+  const int row0 = t * tile_rows;
+  const int nrows = min(tile_rows, n_dst - row0);
+  for (int i = lane; i < nrows * 4; i += 64) reinterpret_cast<float4 *>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  const int my0 = tile_ptr[t], my1 = tile_ptr[t + 1];
+  const int m = lane & 15, k = lane >> 4;
+  const int woff = (4 * k) * 16 + m;
+  if (my0 < my1) {
+    const int last_slot = my1 * RGCN_CHUNK - 1;
+    const int last = my1 - 1;
+    int ts, td, tv, tr;
+    auto issue = [&](int c) {   // lane l <- slot c*16 + l  (clamped; slots past the end get val = 0 when staged)
+      const int e = min(c * RGCN_CHUNK + lane, last_slot);
+      asm_load_b32(ts, p_src + e);
+      asm_load_b32(tv, p_val + e);
+      asm_load_b32(td, p_dst + e);
+      asm_load_b32(tr, chunk_rel + min(c + k, last));
+    };
+    auto land = [&](int c, int buf) {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(ts), "+v"(tv), "+v"(td), "+v"(tr)::"memory");
+      int *sb = stage + buf * 256;
+      sb[lane] = ts;
+      sb[64 + lane] = (c * RGCN_CHUNK + lane <= last_slot) ? tv : 0;
+      sb[128 + lane] = td;
+      sb[192 + lane] = tr;
+      asm volatile("" ::: "memory");
+    };
+    issue(my0);
+    land(my0, 0);
+    int buf = 0;
+    for (int c = my0; c < my1; c += U, buf ^= 1) {
+      issue(c + U);                                        // next block's indices: in flight during this block
+      const int *sb = stage + buf * 256;
+      int s[U], d[U], r[U];
+      float v[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        s[j] = sb[j * 16 + m];
+        v[j] = __builtin_bit_cast(float, sb[64 + j * 16 + m]);
+        d[j] = sb[128 + j * 16 + m];
+        r[j] = sb[192 + j * 16];
+      }
+      float4 x[U], w[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        x[j] = *reinterpret_cast<const float4 *>(X + (size_t)s[j] * 16 + 4 * k);
+        const float *wr = W + (size_t)r[j] * 256 + woff;
+        w[j] = make_float4(wr[0], wr[16], wr[32], wr[48]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const float vv = v[j];
+        const bool live = vv != 0.f;
+        f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].x, live ? x[j].x * vv : 0.f, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].y, live ? x[j].y * vv : 0.f, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].z, live ? x[j].z * vv : 0.f, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].w, live ? x[j].w * vv : 0.f, acc[0], 0, 0, 0);
+        const bool tail = fold_segments<1>(acc, d[j]);
+        if (tail) {
+          f32x4 *p = reinterpret_cast<f32x4 *>(tile + (d[j] - row0) * 16 + 4 * k);
+          *p += acc[0];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      land(c + U, buf ^ 1);
+    }
+  }
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) bv = reinterpret_cast<const float4 *>(bias)[lane & 3];
+  float4 *o4 = reinterpret_cast<float4 *>(out + (size_t)row0 * 16);
+  asm volatile("" ::: "memory");
+  for (int i = lane; i < nrows * 4; i += 64) {
     float4 a = reinterpret_cast<const float4 *>(tile)[i];
     a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
     if (relu_out) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
@@ -653,16 +777,30 @@ int pow2_lanes(int d) {
 
 // =================================================================== C ABI launchers
 
+extern "C" int rgcn_pack_w16_f32(const float *W, float *Wp, int32_t R, void *stream) {
+  if (!W || !Wp || R <= 0) { rgcn_set_error("pack_w16: bad argument"); return RGCN_EINVAL; }
+  const int n = R * 256;
+  hipLaunchKernelGGL(pack_w16_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, (hipStream_t)stream, W, Wp, n);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
 extern "C" int rgcn_spmm_f32(const float *X, const float *W, const float *bias, float *out, const int32_t *p_src,
-                             const int32_t *p_dst, const float *p_val, const int32_t *chunk_rel,
-                             const int32_t *tile_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst,
-                             int64_t n_src, int32_t R, int32_t d_in, int32_t d_out, int32_t relu_out,
+                             const int32_t *p_dst, const float *p_val, const int32_t *p_pack,
+                             const int32_t *chunk_rel, const int32_t *tile_ptr, int64_t n_tiles, int32_t tile_rows,
+                             int64_t n_dst, int64_t n_src, int32_t R, int32_t d_in, int32_t d_out, int32_t flags,
                              void *stream) {
   (void)n_src;
   (void)R;
   if (!X || !W || !out || !tile_ptr || d_in <= 0 || d_out <= 0 || tile_rows <= 0 || n_dst < 0 ||
       n_tiles != (n_dst + tile_rows - 1) / tile_rows) {
     rgcn_set_error("spmm: bad argument");
+    return RGCN_EINVAL;
+  }
+  const int relu_out = flags & RGCN_F_RELU;
+  const bool packed = (flags & RGCN_F_WPACKED) != 0;
+  if (packed && (d_in != 16 || d_out != 16 || !p_pack)) {
+    rgcn_set_error("spmm: RGCN_F_WPACKED needs d_in = d_out = 16 and packed slots");
     return RGCN_EINVAL;
   }
   if (n_tiles == 0) return RGCN_OK;
@@ -676,19 +814,32 @@ extern "C" int rgcn_spmm_f32(const float *X, const float *W, const float *bias, 
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)((n_tiles + SPMM_WAVES - 1) / SPMM_WAVES)), block(WG);
   const int nt = (int)n_tiles;
+  const int2 *pk = reinterpret_cast<const int2 *>(p_pack);
 #define RGCN_LAUNCH_GENERIC(NJT)                                                                                   \
   hipLaunchKernelGGL(spmm_generic_kernel<NJT>, grid, block, lds, st, X, W, bias, out, p_src, p_dst, p_val,         \
                      chunk_rel, tile_ptr, nt, tile_rows, (int)n_dst, d_in, d_out, ldt, relu_out)
-#define RGCN_LAUNCH_D16(U)                                                                                         \
-  hipLaunchKernelGGL(spmm_d16_kernel<U>, grid, block, lds, st, X, W, bias, out, p_src, p_dst, p_val, chunk_rel,    \
-                     tile_ptr, nt, tile_rows, (int)n_dst, relu_out, ABL)
-  if (d_in == 16 && d_out == 16) {
+#define RGCN_LAUNCH_D16(U, P)                                                                                      \
+  hipLaunchKernelGGL((spmm_d16_kernel<U, P>), grid, block, lds, st, X, W, bias, out, p_src, p_dst, p_val, pk,      \
+                     chunk_rel, tile_ptr, nt, tile_rows, (int)n_dst, relu_out, ABL)
+  static const int STAGED = getenv("RGCN_SPMM_STAGE") ? atoi(getenv("RGCN_SPMM_STAGE")) : 0;
+  if (d_in == 16 && d_out == 16 && STAGED && !packed) {
+    const size_t lds2 = (size_t)SPMM_WAVES * (tile_rows * 16 + 512) * sizeof(float);
+    hipLaunchKernelGGL(spmm_d16_staged_kernel, grid, block, lds2, st, X, W, bias, out, p_src, p_dst, p_val, chunk_rel,
+                       tile_ptr, nt, tile_rows, (int)n_dst, relu_out);
+  } else if (d_in == 16 && d_out == 16) {
     static const int U = getenv("RGCN_SPMM_U") ? atoi(getenv("RGCN_SPMM_U")) : 4;
     static const int ABL = getenv("RGCN_ABLATE") ? atoi(getenv("RGCN_ABLATE")) : 0;  // diagnosis only
-    if (U >= 8) RGCN_LAUNCH_D16(8);
-    else if (U >= 4) RGCN_LAUNCH_D16(4);
-    else if (U >= 2) RGCN_LAUNCH_D16(2);
-    else RGCN_LAUNCH_D16(1);
+    if (packed) {
+      if (U >= 8) RGCN_LAUNCH_D16(8, true);
+      else if (U >= 4) RGCN_LAUNCH_D16(4, true);
+      else if (U >= 2) RGCN_LAUNCH_D16(2, true);
+      else RGCN_LAUNCH_D16(1, true);
+    } else {
+      if (U >= 8) RGCN_LAUNCH_D16(8, false);
+      else if (U >= 4) RGCN_LAUNCH_D16(4, false);
+      else if (U >= 2) RGCN_LAUNCH_D16(2, false);
+      else RGCN_LAUNCH_D16(1, false);
+    }
   } else if (d_out <= 16) {
     RGCN_LAUNCH_GENERIC(1);
   } else if (d_out <= 32) {

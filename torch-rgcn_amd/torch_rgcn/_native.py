@@ -145,12 +145,12 @@ def synthetic_triples_host(num_nodes, num_rels, num_edges, seed=0):
 
 class HostPlan:
     """Relation-tile plan as numpy arrays (see rgcn_plan_fill_host)."""
-    __slots__ = ("src", "dst", "val", "perm", "chunk_rel", "tile_ptr", "items", "run_ptr", "n_dst", "n_src", "num_rels",
+    __slots__ = ("src", "dst", "val", "perm", "chunk_rel", "tile_ptr", "items", "run_ptr", "pack", "n_dst", "n_src", "num_rels",
                  "tile_rows", "n_tiles", "n_chunks", "m_pad", "n_items", "n_messages")
 
 
 def build_plan_host(dst, src, rel, val, n_dst, n_src, num_rels, tile_rows, max_item_chunks=64, want_perm=False,
-                    want_runs=False):
+                    want_runs=False, want_pack=False):
     dst = _np(dst, np.int32)
     src = _np(src, np.int32)
     rel = _np(rel, np.int32)
@@ -173,10 +173,12 @@ def build_plan_host(dst, src, rel, val, n_dst, n_src, num_rels, tile_rows, max_i
     p.tile_ptr = np.zeros(p.n_tiles + 1, np.int32)
     p.items = np.empty((max(p.n_items, 1), 2), np.int32)
     p.run_ptr = np.zeros(max(p.n_tiles, 1) * (num_rels + 1), np.int32) if want_runs else None
+    can_pack = want_pack and n_src < (1 << 24) and tile_rows <= 256
+    p.pack = np.empty((max(p.m_pad, 1), 2), np.int32) if can_pack else None
     _check(L.rgcn_plan_fill_host(_hp(dst), _hp(src), _hp(rel), _hp(val), c_i64(M), c_i64(n_dst), c_i64(n_src),
                                  c_i32(num_rels), c_i32(tile_rows), c_i32(max_item_chunks), _hp(p.src), _hp(p.dst),
                                  _hp(p.val), _hp(p.perm), _hp(p.chunk_rel), _hp(p.tile_ptr), _hp(p.items),
-                                 _hp(p.run_ptr)), "plan_fill")
+                                 _hp(p.run_ptr), _hp(p.pack)), "plan_fill")
     return p
 
 
@@ -191,6 +193,7 @@ class DevicePlan:
         self.src, self.dst, self.val = up(hp.src), up(hp.dst), up(hp.val)
         self.chunk_rel, self.tile_ptr, self.items = up(hp.chunk_rel), up(hp.tile_ptr), up(hp.items)
         self.run_ptr = None if hp.run_ptr is None else up(hp.run_ptr)
+        self.pack = None if hp.pack is None else up(hp.pack)
         for k in ("n_dst", "n_src", "num_rels", "tile_rows", "n_tiles", "n_chunks", "m_pad", "n_items", "n_messages"):
             setattr(self, k, getattr(hp, k))
 
@@ -210,6 +213,17 @@ def _req(t, name, dtype=torch.float32):
         raise ValueError(f"{name} must be contiguous")
 
 
+F_RELU, F_WPACKED = 1, 2
+
+
+def pack_w16(W):
+    """[R,16,16] weights -> MFMA fragment order (one float4 per lane), see rgcn_pack_w16_f32"""
+    Wp = torch.empty_like(W)
+    with torch.cuda.device(W.device):
+        _check(lib().rgcn_pack_w16_f32(_dp(W), _dp(Wp), c_i32(W.shape[0]), _stream(W.device)), "pack_w16")
+    return Wp
+
+
 def spmm(X, W, bias, plan, relu=False):
     """out[n_dst, d_out] = bias + sum_slots val * X[src] @ W[rel]"""
     _req(X, "features"); _req(W, "weights"); _req(bias, "bias")
@@ -217,11 +231,15 @@ def spmm(X, W, bias, plan, relu=False):
     assert X.shape == (plan.n_src, d_in), f"features {tuple(X.shape)} vs ({plan.n_src}, {d_in})"
     assert R == plan.num_rels
     out = torch.empty((plan.n_dst, d_out), device=X.device, dtype=torch.float32)
+    flags = F_RELU if relu else 0
+    if d_in == 16 and d_out == 16 and plan.pack is not None and not os.environ.get("RGCN_NO_PACK"):
+        W = pack_w16(W)
+        flags |= F_WPACKED
     with torch.cuda.device(X.device), _timed("spmm"):
         _check(lib().rgcn_spmm_f32(_dp(X), _dp(W), _dp(bias), _dp(out), _dp(plan.src), _dp(plan.dst), _dp(plan.val),
-                                   _dp(plan.chunk_rel), _dp(plan.tile_ptr), c_i64(plan.n_tiles),
+                                   _dp(plan.pack), _dp(plan.chunk_rel), _dp(plan.tile_ptr), c_i64(plan.n_tiles),
                                    c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i64(plan.n_src), c_i32(R),
-                                   c_i32(d_in), c_i32(d_out), c_i32(int(relu)), _stream(X.device)), "spmm")
+                                   c_i32(d_in), c_i32(d_out), c_i32(flags), _stream(X.device)), "spmm")
     return out
 
 

@@ -56,9 +56,10 @@ class RelGraph:
             N, R = self.num_nodes, self.num_rels
             if kind == "fwd":
                 hp = _native.build_plan_host(self._s, self._o, self._p, self._val, N, N, R, tile_rows, max_item_chunks,
-                                             want_runs=True)
+                                             want_runs=True, want_pack=True)
             elif kind == "bwd":
-                hp = _native.build_plan_host(self._o, self._s, self._p, self._val, N, N, R, tile_rows, max_item_chunks)
+                hp = _native.build_plan_host(self._o, self._s, self._p, self._val, N, N, R, tile_rows, max_item_chunks,
+                                             want_pack=True)
             else:
                 raise KeyError(kind)
             self._plans[key] = _native.DevicePlan(hp, self.device)
