@@ -92,6 +92,16 @@ RGCN_API int rgcn_plan_fill_host(const int32_t *dst, const int32_t *src, const i
                                  int32_t *p_perm, int32_t *chunk_rel, int32_t *tile_ptr, int32_t *items,
                                  int32_t *run_ptr, int32_t *p_pack);
 
+/* Work units of the tile kernels: normally one per destination tile (flags 0: the wave owns the tile and
+ * writes its rows); a tile with more than max_unit_chunks chunks (a hub node) is cut into several units
+ * (flags RGCN_U_SHARED: partial sums are added to `out` with fp32 atomics; RGCN_U_FIRST marks the piece
+ * that also adds the bias).  units = int32 [n_units][4] = {tile, chunk_begin, chunk_end, flags}; pass
+ * units = NULL to get the count only.  *n_split receives the number of shared units. */
+#define RGCN_U_SHARED 1
+#define RGCN_U_FIRST 2
+RGCN_API int rgcn_plan_units_host(const int32_t *tile_ptr, int64_t n_tiles, int32_t max_unit_chunks,
+                                  int32_t *units, int64_t *n_units, int64_t *n_split);
+
 /* splitmix64 synthetic graph: s,o ~ U[0,N), p ~ U[0,R0), three
  * consecutive stream values per triple.  Same stream as oracle.synthetic_triples. */
 RGCN_API int rgcn_synthetic_triples_host(int64_t N, int64_t R0, int64_t E, uint64_t seed, int64_t *out);
@@ -109,9 +119,9 @@ RGCN_API int rgcn_synthetic_triples_host(int64_t N, int64_t R0, int64_t E, uint6
 #define RGCN_F_WPACKED 2   /* W is in MFMA fragment order (rgcn_pack_w16_f32); d_in = d_out = 16 only */
 RGCN_API int rgcn_spmm_f32(const float *X, const float *W, const float *bias, float *out, const int32_t *p_src,
                            const int32_t *p_dst, const float *p_val, const int32_t *p_pack,
-                           const int32_t *chunk_rel, const int32_t *tile_ptr, int64_t n_tiles, int32_t tile_rows,
-                           int64_t n_dst, int64_t n_src, int32_t R, int32_t d_in, int32_t d_out, int32_t flags,
-                           void *stream);
+                           const int32_t *chunk_rel, const int32_t *units, int64_t n_units, int64_t n_split,
+                           int32_t tile_rows, int64_t n_dst, int64_t n_src, int32_t R, int32_t d_in,
+                           int32_t d_out, int32_t flags, void *stream);
 
 /* Wp[r][16k+o][c] = W[r][4k+c][o]: the per-lane float4 the hidden-16 kernel feeds to the matrix cores
  * (weight assembly step of layers.py:239-244, device side).  W, Wp: [R,16,16]. */
@@ -140,7 +150,7 @@ RGCN_API int rgcn_wgrad_tiled_f32(const float *X, const float *G, float *dW, con
  * Replaces torch.mm(adj, weights.view(R*N, d_out)) of layers.py:286-288 / :518-523. */
 RGCN_API int rgcn_featureless_fwd_f32(const float *table, const float *bias, float *out, const int32_t *p_src,
                                       const int32_t *p_dst, const float *p_val, const int32_t *chunk_rel,
-                                      const int32_t *tile_ptr, int64_t n_tiles, int32_t tile_rows,
+                                      const int32_t *units, int64_t n_units, int64_t n_split, int32_t tile_rows,
                                       int64_t n_dst, int64_t n_src, int32_t R, int32_t d_out, void *stream);
 
 /* Its weight gradient: dtable[rel*n_src + src, :] += val * G[dst,:]; dtable

@@ -141,3 +141,27 @@ def test_plan_errors():
         nat.build_plan_host(one, np.array([-1], np.int32), one, np.ones(1, np.float32), 4, 4, 2, 4)
     with pytest.raises(AssertionError):
         nat.build_plan_host(one, one, np.array([2], np.int32), np.ones(1, np.float32), 4, 4, 2, 4)
+
+
+def test_work_units_split_hub_tiles():
+    rng = np.random.default_rng(3)
+    N, R, M = 600, 5, 40000
+    dst = rng.integers(0, N, M).astype(np.int32)
+    dst[: M // 2] = 7   # hub
+    src = rng.integers(0, N, M).astype(np.int32)
+    rel = rng.integers(0, R, M).astype(np.int32)
+    hp = nat.build_plan_host(dst, src, rel, np.ones(M, np.float32), N, N, R, 64, max_unit_chunks=50)
+    u = hp.units[:hp.n_units]
+    assert hp.n_split > 0 and hp.n_units > hp.n_tiles
+    # units tile the chunk list in order; whole-tile units carry flags 0; pieces are <= 50 chunks, first piece marked
+    assert u[0, 1] == 0 and u[-1, 2] == hp.n_chunks and np.array_equal(u[1:, 1], u[:-1, 2])
+    for t, c0, c1, fl in u:
+        assert hp.tile_ptr[t] <= c0 < c1 <= hp.tile_ptr[t + 1] or (c0 == c1 == hp.tile_ptr[t])
+        if fl == 0:
+            assert (c0, c1) == (hp.tile_ptr[t], hp.tile_ptr[t + 1])
+        else:
+            assert c1 - c0 <= 50 and bool(fl & 2) == (c0 == hp.tile_ptr[t])
+    assert int((u[:, 3] != 0).sum()) == hp.n_split
+    assert hp.max_run_chunks >= 50
+    # every tile appears (also empty ones)
+    assert set(u[:, 0].tolist()) == set(range(hp.n_tiles))

@@ -22,12 +22,22 @@ ap.add_argument("--rels", type=int, default=50)
 ap.add_argument("--d", type=int, default=16)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--what", default="spmm,wgrad")
+ap.add_argument("--skew", type=float, default=0.0, help="Zipf exponent for subjects/objects/relations (0 = uniform S1 graph)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 N, R0, E, d = a.nodes, a.rels, a.edges, a.d
 R = 2 * R0 + 1
 t0 = time.time()
-tp = _native.add_inverse_and_self_host(_native.synthetic_triples_host(N, R0, E, 0), N, R0)
+if a.skew > 0:
+    rng = np.random.default_rng(0)
+    def zipf(n, size):   # heavy-tailed ids: a few hubs / dominant relations
+        w = 1.0 / np.arange(1, n + 1) ** a.skew
+        return rng.choice(n, size=size, p=w / w.sum())
+    T = np.stack([zipf(N, E), zipf(R0, E), rng.permutation(N)[zipf(N, E)]], axis=1).astype(np.int64)
+    print("skewed graph: max in-degree", np.bincount(T[:, 0]).max(), "largest relation", np.bincount(T[:, 1]).max(), flush=True)
+else:
+    T = _native.synthetic_triples_host(N, R0, E, 0)
+tp = _native.add_inverse_and_self_host(T, N, R0)
 g = graph_from_nc_triples(tp, N, R, False, dev)
 X = torch.randn(N, d, device=dev)
 G = torch.randn(N, d, device=dev)

@@ -294,6 +294,30 @@ extern "C" int rgcn_plan_fill_host(const int32_t *dst, const int32_t *src, const
   return RGCN_OK;
 }
 
+extern "C" int rgcn_plan_units_host(const int32_t *tile_ptr, int64_t n_tiles, int32_t max_unit_chunks, int32_t *units,
+                                    int64_t *n_units, int64_t *n_split) {
+  if (n_tiles < 0 || (n_tiles && !tile_ptr) || max_unit_chunks <= 0 || !n_units) { rgcn_set_error("plan_units: bad argument"); return RGCN_EINVAL; }
+  int64_t n = 0, ns = 0;
+  for (int64_t t = 0; t < n_tiles; ++t) {
+    const int64_t c0 = tile_ptr[t], c1 = tile_ptr[t + 1];
+    if (c1 - c0 <= max_unit_chunks) {
+      if (units) { units[4 * n] = int32_t(t); units[4 * n + 1] = int32_t(c0); units[4 * n + 2] = int32_t(c1); units[4 * n + 3] = 0; }
+      ++n;
+    } else {
+      for (int64_t c = c0; c < c1; c += max_unit_chunks, ++n, ++ns)
+        if (units) {
+          units[4 * n] = int32_t(t);
+          units[4 * n + 1] = int32_t(c);
+          units[4 * n + 2] = int32_t(std::min<int64_t>(c + max_unit_chunks, c1));
+          units[4 * n + 3] = RGCN_U_SHARED | (c == c0 ? RGCN_U_FIRST : 0);
+        }
+    }
+  }
+  *n_units = n;
+  if (n_split) *n_split = ns;
+  return RGCN_OK;
+}
+
 extern "C" int rgcn_synthetic_triples_host(int64_t N, int64_t R0, int64_t E, uint64_t seed, int64_t *out) {
   if (N <= 0 || R0 <= 0 || E < 0 || (!out && E)) { rgcn_set_error("synthetic_triples: bad argument"); return RGCN_EINVAL; }
   uint64_t x = seed;

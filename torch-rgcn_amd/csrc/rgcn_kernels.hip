@@ -112,18 +112,20 @@ __global__ __launch_bounds__(WG) void spmm_d16_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias,
     float *__restrict__ out, const int *__restrict__ p_src, const int *__restrict__ p_dst,
     const float *__restrict__ p_val, const int2 *__restrict__ p_pack, const int *__restrict__ chunk_rel,
-    const int *__restrict__ tile_ptr, int n_tiles, int tile_rows, int n_dst, int relu_out, int ablate) {
+    const int4 *__restrict__ units, int n_units, int tile_rows, int n_dst, int relu_out, int ablate) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int t = blockIdx.x * SPMM_WAVES + wave;
-  if (t >= n_tiles) return;  // whole wave; no workgroup barrier is used anywhere below
+  const int u = blockIdx.x * SPMM_WAVES + wave;
+  if (u >= n_units) return;  // whole wave; no workgroup barrier is used anywhere below
+  const int4 unit = units[u];
+  const int t = unit.x;
   float *tile = lds + wave * tile_rows * 16;
   const int row0 = t * tile_rows;
   const int nrows = min(tile_rows, n_dst - row0);
   for (int i = lane; i < nrows * 4; i += 64) reinterpret_cast<float4 *>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  const int my0 = tile_ptr[t], my1 = tile_ptr[t + 1];
+  const int my0 = unit.y, my1 = unit.z;
   const int m = lane & 15, k = lane >> 4;
   const int woff = (4 * k) * 16 + m;
 
@@ -199,8 +201,16 @@ __global__ __launch_bounds__(WG) void spmm_d16_kernel(
     }
   }
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (bias) bv = reinterpret_cast<const float4 *>(bias)[lane & 3];
+  if (bias && (!(unit.w & RGCN_U_SHARED) || (unit.w & RGCN_U_FIRST))) bv = reinterpret_cast<const float4 *>(bias)[lane & 3];
   float4 *o4 = reinterpret_cast<float4 *>(out + (size_t)row0 * 16);
+  if (unit.w & RGCN_U_SHARED) {   // piece of a hub tile: out was zeroed by the launcher, pieces are summed atomically
+    for (int i = lane; i < nrows * 4; i += 64) {
+      const float4 a = reinterpret_cast<const float4 *>(tile)[i];
+      float *o = reinterpret_cast<float *>(o4 + i);
+      atomicAdd(o, a.x + bv.x); atomicAdd(o + 1, a.y + bv.y); atomicAdd(o + 2, a.z + bv.z); atomicAdd(o + 3, a.w + bv.w);
+    }
+    return;
+  }
   for (int i = lane; i < nrows * 4; i += 64) {  // (i & 3) == (lane & 3)
     float4 a = reinterpret_cast<const float4 *>(tile)[i];
     a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
@@ -228,14 +238,17 @@ __device__ __forceinline__ void asm_load_b32(int &dst, const void *p) {
 __global__ __launch_bounds__(WG) void spmm_d16_staged_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias,
     float *__restrict__ out, const int *__restrict__ p_src, const int *__restrict__ p_dst,
-    const float *__restrict__ p_val, const int *__restrict__ chunk_rel, const int *__restrict__ tile_ptr,
-    int n_tiles, int tile_rows, int n_dst, int relu_out) {
+    const float *__restrict__ p_val, const int *__restrict__ chunk_rel, const int4 *__restrict__ units,
+    int n_units, int tile_rows, int n_dst, int relu_out) {
   constexpr int U = 4;                       // 4 chunks = 64 slots = one slot per lane
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int t = blockIdx.x * SPMM_WAVES + wave;
-  if (t >= n_tiles) return;
+  const int uu = blockIdx.x * SPMM_WAVES + wave;
+  if (uu >= n_units) return;
+  const int4 unit = units[uu];
+  if (unit.w) return;   // experimental variant: whole-tile units only
+  const int t = unit.x;
   const int stride = tile_rows * 16 + 2 * 256;                     // tile | 2 x (src,val,dst,rel) x 64
   float *tile = lds + (size_t)wave * stride;
   int *stage = reinterpret_cast<int *>(tile + tile_rows * 16);
@@ -243,7 +256,7 @@ __global__ __launch_bounds__(WG) void spmm_d16_staged_kernel(
   const int nrows = min(tile_rows, n_dst - row0);
   for (int i = lane; i < nrows * 4; i += 64) reinterpret_cast<float4 *>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  const int my0 = tile_ptr[t], my1 = tile_ptr[t + 1];
+  const int my0 = unit.y, my1 = unit.z;
   const int m = lane & 15, k = lane >> 4;
   const int woff = (4 * k) * 16 + m;
   if (my0 < my1) {
@@ -326,19 +339,21 @@ template <int NJT>
 __global__ __launch_bounds__(WG) void spmm_generic_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias,
     float *__restrict__ out, const int *__restrict__ p_src, const int *__restrict__ p_dst,
-    const float *__restrict__ p_val, const int *__restrict__ chunk_rel, const int *__restrict__ tile_ptr,
-    int n_tiles, int tile_rows, int n_dst, int d_in, int d_out, int ldt, int relu_out) {
+    const float *__restrict__ p_val, const int *__restrict__ chunk_rel, const int4 *__restrict__ units,
+    int n_units, int tile_rows, int n_dst, int d_in, int d_out, int ldt, int relu_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int t = blockIdx.x * SPMM_WAVES + wave;
-  if (t >= n_tiles) return;
+  const int u = blockIdx.x * SPMM_WAVES + wave;
+  if (u >= n_units) return;
+  const int4 unit = units[u];
+  const int t = unit.x;
   float *tile = lds + (size_t)wave * tile_rows * ldt;
   const int row0 = t * tile_rows;
   const int nrows = min(tile_rows, n_dst - row0);
   for (int i = lane; i < nrows * ldt; i += 64) tile[i] = 0.f;
 
-  const int my0 = tile_ptr[t], my1 = tile_ptr[t + 1];
+  const int my0 = unit.y, my1 = unit.z;
   const int m = lane & 15, k = lane >> 4;
   for (int c = my0; c < my1; ++c) {
     const int r = __builtin_amdgcn_readfirstlane(chunk_rel[c]);
@@ -376,9 +391,12 @@ __global__ __launch_bounds__(WG) void spmm_generic_kernel(
     }
   }
   float *o = out + (size_t)row0 * d_out;
+  const bool shared = unit.w & RGCN_U_SHARED;
+  const bool add_bias = bias && (!shared || (unit.w & RGCN_U_FIRST));
   for (int i = lane; i < nrows * d_out; i += 64) {
     const int rr = i / d_out, cc = i - rr * d_out;
-    float a = tile[rr * ldt + cc] + (bias ? bias[cc] : 0.f);
+    float a = tile[rr * ldt + cc] + (add_bias ? bias[cc] : 0.f);
+    if (shared) { atomicAdd(&o[i], a); continue; }
     if (relu_out) a = fmaxf(a, 0.f);
     o[i] = a;
   }
@@ -628,18 +646,20 @@ __global__ __launch_bounds__(WG) void wgrad_tiled_d16_kernel(
 __global__ __launch_bounds__(WG) void featureless_fwd_kernel(
     const float *__restrict__ table, const float *__restrict__ bias, float *__restrict__ out,
     const int *__restrict__ p_src, const int *__restrict__ p_dst, const float *__restrict__ p_val,
-    const int *__restrict__ chunk_rel, const int *__restrict__ tile_ptr, int n_tiles, int tile_rows, int n_dst,
+    const int *__restrict__ chunk_rel, const int4 *__restrict__ units, int n_units, int tile_rows, int n_dst,
     long long n_src, int d, int ldt) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int t = blockIdx.x * SPMM_WAVES + wave;
-  if (t >= n_tiles) return;
+  const int u = blockIdx.x * SPMM_WAVES + wave;
+  if (u >= n_units) return;
+  const int4 unit = units[u];
+  const int t = unit.x;
   float *tile = lds + (size_t)wave * tile_rows * ldt;
   const int row0 = t * tile_rows;
   const int nrows = min(tile_rows, n_dst - row0);
   for (int i = lane; i < nrows * ldt; i += 64) tile[i] = 0.f;
-  const int my0 = tile_ptr[t], my1 = tile_ptr[t + 1];
+  const int my0 = unit.y, my1 = unit.z;
   const int m = lane & 15, q = lane >> 4;
   const bool vec4 = (d & 3) == 0;
   for (int c = my0; c < my1; ++c) {
@@ -668,9 +688,13 @@ __global__ __launch_bounds__(WG) void featureless_fwd_kernel(
     }
   }
   float *o = out + (size_t)row0 * d;
+  const bool shared = unit.w & RGCN_U_SHARED;
+  const bool add_bias = bias && (!shared || (unit.w & RGCN_U_FIRST));
   for (int i = lane; i < nrows * d; i += 64) {
     const int rr = i / d, cc = i - rr * d;
-    o[i] = tile[rr * ldt + cc] + (bias ? bias[cc] : 0.f);
+    const float a = tile[rr * ldt + cc] + (add_bias ? bias[cc] : 0.f);
+    if (shared) atomicAdd(&o[i], a);
+    else o[i] = a;
   }
 }
 
@@ -787,13 +811,14 @@ extern "C" int rgcn_pack_w16_f32(const float *W, float *Wp, int32_t R, void *str
 
 extern "C" int rgcn_spmm_f32(const float *X, const float *W, const float *bias, float *out, const int32_t *p_src,
                              const int32_t *p_dst, const float *p_val, const int32_t *p_pack,
-                             const int32_t *chunk_rel, const int32_t *tile_ptr, int64_t n_tiles, int32_t tile_rows,
-                             int64_t n_dst, int64_t n_src, int32_t R, int32_t d_in, int32_t d_out, int32_t flags,
-                             void *stream) {
+                             const int32_t *chunk_rel, const int32_t *units, int64_t n_units, int64_t n_split,
+                             int32_t tile_rows, int64_t n_dst, int64_t n_src, int32_t R, int32_t d_in,
+                             int32_t d_out, int32_t flags, void *stream) {
   (void)n_src;
   (void)R;
-  if (!X || !W || !out || !tile_ptr || d_in <= 0 || d_out <= 0 || tile_rows <= 0 || n_dst < 0 ||
-      n_tiles != (n_dst + tile_rows - 1) / tile_rows) {
+  const int64_t n_tiles = n_units;   // one wave per work unit
+  if (!X || !W || !out || (n_units && !units) || d_in <= 0 || d_out <= 0 || tile_rows <= 0 || n_dst < 0 ||
+      n_units < (n_dst + tile_rows - 1) / tile_rows || n_split < 0 || ((flags & RGCN_F_RELU) && n_split)) {
     rgcn_set_error("spmm: bad argument");
     return RGCN_EINVAL;
   }
@@ -812,9 +837,11 @@ extern "C" int rgcn_spmm_f32(const float *X, const float *W, const float *bias, 
     return RGCN_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (n_split) HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_dst * d_out * sizeof(float), st));  // hub tiles are summed atomically
   dim3 grid((unsigned)((n_tiles + SPMM_WAVES - 1) / SPMM_WAVES)), block(WG);
   const int nt = (int)n_tiles;
   const int2 *pk = reinterpret_cast<const int2 *>(p_pack);
+  const int4 *tile_ptr = reinterpret_cast<const int4 *>(units);
 #define RGCN_LAUNCH_GENERIC(NJT)                                                                                   \
   hipLaunchKernelGGL(spmm_generic_kernel<NJT>, grid, block, lds, st, X, W, bias, out, p_src, p_dst, p_val,         \
                      chunk_rel, tile_ptr, nt, tile_rows, (int)n_dst, d_in, d_out, ldt, relu_out)
@@ -924,11 +951,12 @@ extern "C" int rgcn_wgrad_tiled_f32(const float *X, const float *G, float *dW, c
 
 extern "C" int rgcn_featureless_fwd_f32(const float *table, const float *bias, float *out, const int32_t *p_src,
                                         const int32_t *p_dst, const float *p_val, const int32_t *chunk_rel,
-                                        const int32_t *tile_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst,
-                                        int64_t n_src, int32_t R, int32_t d_out, void *stream) {
+                                        const int32_t *units, int64_t n_units, int64_t n_split, int32_t tile_rows,
+                                        int64_t n_dst, int64_t n_src, int32_t R, int32_t d_out, void *stream) {
   (void)R;
-  if (!table || !out || !tile_ptr || d_out <= 0 || tile_rows <= 0 ||
-      n_tiles != (n_dst + tile_rows - 1) / tile_rows) {
+  const int64_t n_tiles = n_units;
+  if (!table || !out || (n_units && !units) || d_out <= 0 || tile_rows <= 0 ||
+      n_units < (n_dst + tile_rows - 1) / tile_rows || n_split < 0) {
     rgcn_set_error("featureless_fwd: bad argument");
     return RGCN_EINVAL;
   }
@@ -936,8 +964,10 @@ extern "C" int rgcn_featureless_fwd_f32(const float *table, const float *bias, f
   const int ldt = (d_out + 3) & ~3;
   const size_t lds = (size_t)SPMM_WAVES * tile_rows * ldt * sizeof(float);
   if (lds > LDS_TILE_BYTES) { rgcn_set_error("featureless_fwd: LDS tile too large"); return RGCN_EINVAL; }
+  if (n_split) HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_dst * d_out * sizeof(float), (hipStream_t)stream));
   hipLaunchKernelGGL(featureless_fwd_kernel, dim3((unsigned)((n_tiles + SPMM_WAVES - 1) / SPMM_WAVES)), dim3(WG), lds,
-                     (hipStream_t)stream, table, bias, out, p_src, p_dst, p_val, chunk_rel, tile_ptr, (int)n_tiles,
+                     (hipStream_t)stream, table, bias, out, p_src, p_dst, p_val, chunk_rel,
+                     reinterpret_cast<const int4 *>(units), (int)n_tiles,
                      tile_rows, (int)n_dst, (long long)n_src, d_out, ldt);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;

@@ -145,12 +145,12 @@ def synthetic_triples_host(num_nodes, num_rels, num_edges, seed=0):
 
 class HostPlan:
     """Relation-tile plan as numpy arrays (see rgcn_plan_fill_host)."""
-    __slots__ = ("src", "dst", "val", "perm", "chunk_rel", "tile_ptr", "items", "run_ptr", "pack", "n_dst", "n_src", "num_rels",
+    __slots__ = ("src", "dst", "val", "perm", "chunk_rel", "tile_ptr", "items", "run_ptr", "pack", "units", "n_units", "n_split", "max_run_chunks", "n_dst", "n_src", "num_rels",
                  "tile_rows", "n_tiles", "n_chunks", "m_pad", "n_items", "n_messages")
 
 
 def build_plan_host(dst, src, rel, val, n_dst, n_src, num_rels, tile_rows, max_item_chunks=64, want_perm=False,
-                    want_runs=False, want_pack=False):
+                    want_runs=False, want_pack=False, max_unit_chunks=256):
     dst = _np(dst, np.int32)
     src = _np(src, np.int32)
     rel = _np(rel, np.int32)
@@ -179,6 +179,21 @@ def build_plan_host(dst, src, rel, val, n_dst, n_src, num_rels, tile_rows, max_i
                                  c_i32(num_rels), c_i32(tile_rows), c_i32(max_item_chunks), _hp(p.src), _hp(p.dst),
                                  _hp(p.val), _hp(p.perm), _hp(p.chunk_rel), _hp(p.tile_ptr), _hp(p.items),
                                  _hp(p.run_ptr), _hp(p.pack)), "plan_fill")
+    # work units of the tile kernels (hub tiles are cut into pieces)
+    nu, ns = c_i64(0), c_i64(0)
+    _check(L.rgcn_plan_units_host(_hp(p.tile_ptr), c_i64(p.n_tiles), c_i32(max_unit_chunks), None, ctypes.byref(nu),
+                                  ctypes.byref(ns)), "plan_units")
+    p.n_units, p.n_split = nu.value, ns.value
+    p.units = np.zeros((max(p.n_units, 1), 4), np.int32)
+    _check(L.rgcn_plan_units_host(_hp(p.tile_ptr), c_i64(p.n_tiles), c_i32(max_unit_chunks), _hp(p.units),
+                                  ctypes.byref(nu), ctypes.byref(ns)), "plan_units")
+    if p.n_chunks:
+        cr = p.chunk_rel[:p.n_chunks]
+        edges = np.flatnonzero(np.diff(cr) != 0)
+        runs = np.diff(np.concatenate(([-1], edges, [p.n_chunks - 1])))
+        p.max_run_chunks = int(runs.max())
+    else:
+        p.max_run_chunks = 0
     return p
 
 
@@ -194,7 +209,9 @@ class DevicePlan:
         self.chunk_rel, self.tile_ptr, self.items = up(hp.chunk_rel), up(hp.tile_ptr), up(hp.items)
         self.run_ptr = None if hp.run_ptr is None else up(hp.run_ptr)
         self.pack = None if hp.pack is None else up(hp.pack)
-        for k in ("n_dst", "n_src", "num_rels", "tile_rows", "n_tiles", "n_chunks", "m_pad", "n_items", "n_messages"):
+        self.units = up(hp.units)
+        for k in ("n_dst", "n_src", "num_rels", "tile_rows", "n_tiles", "n_chunks", "m_pad", "n_items", "n_messages",
+                  "n_units", "n_split", "max_run_chunks"):
             setattr(self, k, getattr(hp, k))
 
     def nbytes(self):
@@ -231,16 +248,17 @@ def spmm(X, W, bias, plan, relu=False):
     assert X.shape == (plan.n_src, d_in), f"features {tuple(X.shape)} vs ({plan.n_src}, {d_in})"
     assert R == plan.num_rels
     out = torch.empty((plan.n_dst, d_out), device=X.device, dtype=torch.float32)
-    flags = F_RELU if relu else 0
+    flags = F_RELU if (relu and not plan.n_split) else 0
+    relu_after = relu and plan.n_split
     if d_in == 16 and d_out == 16 and plan.pack is not None and not os.environ.get("RGCN_NO_PACK"):
         W = pack_w16(W)
         flags |= F_WPACKED
     with torch.cuda.device(X.device), _timed("spmm"):
         _check(lib().rgcn_spmm_f32(_dp(X), _dp(W), _dp(bias), _dp(out), _dp(plan.src), _dp(plan.dst), _dp(plan.val),
-                                   _dp(plan.pack), _dp(plan.chunk_rel), _dp(plan.tile_ptr), c_i64(plan.n_tiles),
-                                   c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i64(plan.n_src), c_i32(R),
-                                   c_i32(d_in), c_i32(d_out), c_i32(flags), _stream(X.device)), "spmm")
-    return out
+                                   _dp(plan.pack), _dp(plan.chunk_rel), _dp(plan.units), c_i64(plan.n_units),
+                                   c_i64(plan.n_split), c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i64(plan.n_src),
+                                   c_i32(R), c_i32(d_in), c_i32(d_out), c_i32(flags), _stream(X.device)), "spmm")
+    return torch.relu_(out) if relu_after else out
 
 
 def wgrad(X, G, plan, num_rels):
@@ -279,8 +297,8 @@ def featureless_fwd(table, bias, plan):
     out = torch.empty((plan.n_dst, d), device=table.device, dtype=torch.float32)
     with torch.cuda.device(table.device), _timed("featureless_fwd"):
         _check(lib().rgcn_featureless_fwd_f32(_dp(table), _dp(bias), _dp(out), _dp(plan.src), _dp(plan.dst),
-                                              _dp(plan.val), _dp(plan.chunk_rel), _dp(plan.tile_ptr),
-                                              c_i64(plan.n_tiles), c_i32(plan.tile_rows), c_i64(plan.n_dst),
+                                              _dp(plan.val), _dp(plan.chunk_rel), _dp(plan.units),
+                                              c_i64(plan.n_units), c_i64(plan.n_split), c_i32(plan.tile_rows), c_i64(plan.n_dst),
                                               c_i64(n_src), c_i32(R), c_i32(d), _stream(table.device)),
                "featureless_fwd")
     return out

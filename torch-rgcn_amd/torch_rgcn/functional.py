@@ -37,9 +37,12 @@ class _RelationalMP(torch.autograd.Function):
             Wt = W.transpose(1, 2).contiguous()
             dX = _native.spmm(g, Wt, None, graph.bwd_plan(W.shape[1]))
         if ctx.needs_input_grad[1]:
-            if W.shape[1] == 16 and W.shape[2] == 16 and os.environ.get("RGCN_WGRAD", "tiled") == "tiled":
-                dW = _native.wgrad_tiled(X, g, graph.fwd_plan(16), W.shape[0],
-                                         int(os.environ.get("RGCN_WGRAD_TILES", "4")))
+            fp = graph.fwd_plan(W.shape[2])
+            # tile-major walk (one random gather per message) unless a (tile, relation) run is so long that
+            # one wave would serialise it (hub nodes): then the relation-major kernel with bounded work items
+            tiled_ok = W.shape[1] == 16 and W.shape[2] == 16 and fp.max_run_chunks <= 64
+            if tiled_ok and os.environ.get("RGCN_WGRAD", "tiled") == "tiled":
+                dW = _native.wgrad_tiled(X, g, fp, W.shape[0], int(os.environ.get("RGCN_WGRAD_TILES", "4")))
             else:
                 dW = _native.wgrad(X, g, graph.wgt_plan(), W.shape[0])
         if ctx.has_bias and ctx.needs_input_grad[2]:
