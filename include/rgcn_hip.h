@@ -69,8 +69,8 @@ RGCN_API int rgcn_edge_norm_host(const int64_t *triples_plus, int64_t M, int64_t
 
 /* Relation-tile plan.  Messages (dst <- src, relation rel, weight val) are bucketed
  * by (dst / tile_rows, rel), sorted by dst inside a bucket, and every bucket is
- * padded to a multiple of RGCN_CHUNK slots (pad = copy of the bucket's last message
- * with val = 0), so that each chunk of 16 slots has ONE relation and one dst tile.
+ * padded to a multiple of RGCN_CHUNK slots (pad: val = 0, dst = -1, src = the bucket's
+ * last source row), so that each chunk of 16 slots has ONE relation and one dst tile.
  * This replaces the sparse COO constructor + coalesce of layers.py:276-279 /
  * :513-516 as the device-side graph layout.
  *   rgcn_plan_count_host : sizes only
@@ -82,7 +82,7 @@ RGCN_API int rgcn_edge_norm_host(const int64_t *triples_plus, int64_t M, int64_t
  *       work list; may be NULL);  run_ptr [n_tiles*(R+1)] = first chunk of every
  *       (tile, relation) run, row t ends with tile_ptr[t+1] (may be NULL);
  *       p_pack [2*m_pad] = 8-byte slots { src | (dst - tile_row0) << 24 , val bits } for the
- *       hidden-16 kernels (needs n_src < 2^24 and tile_rows <= 256; may be NULL). */
+ *       hidden-16 kernels (dst field 0xFF = pad; needs n_src < 2^24 and tile_rows <= 255; may be NULL). */
 RGCN_API int rgcn_plan_count_host(const int32_t *dst, const int32_t *rel, int64_t M, int64_t n_dst, int32_t R,
                                   int32_t tile_rows, int32_t max_item_chunks, int64_t *m_pad,
                                   int64_t *n_chunks, int64_t *n_tiles, int64_t *n_items);

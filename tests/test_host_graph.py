@@ -85,7 +85,7 @@ def check_plan(hp, dst, src, rel, val, n_dst, R, tile_rows, max_item_chunks):
     real = perm >= 0
     assert real.sum() == M and np.array_equal(np.sort(perm[real]), np.arange(M))  # each message exactly once
     assert np.array_equal(hp.src[:hp.m_pad][real], src[perm[real]])
-    assert np.array_equal(hp.dst[:hp.m_pad][real], dst[perm[real]])
+    assert np.array_equal(hp.dst[:hp.m_pad][real], dst[perm[real]]) and np.all(hp.dst[:hp.m_pad][~real] == -1)
     assert np.array_equal(hp.val[:hp.m_pad][real], val[perm[real]])
     assert np.all(hp.val[:hp.m_pad][~real] == 0)
     tp = hp.tile_ptr
@@ -95,11 +95,12 @@ def check_plan(hp, dst, src, rel, val, n_dst, R, tile_rows, max_item_chunks):
     pr = perm.reshape(-1, C)
     for t in range(hp.n_tiles):
         for c in range(tp[t], tp[t + 1]):
-            assert np.all(pd[c] // tile_rows == t)               # one destination tile per chunk
+            rl = pr[c] >= 0
+            assert np.all(pd[c][rl] // tile_rows == t)           # one destination tile per chunk
             r = hp.chunk_rel[c]
             assert np.all(rel[pr[c][pr[c] >= 0]] == r)          # one relation per chunk
             assert pr[c][0] >= 0                                 # never an all-pad chunk
-            assert np.all(np.diff(pd[c]) >= 0)                   # sorted by destination
+            assert np.all(np.diff(pd[c][rl]) >= 0) and np.all(np.diff(rl.astype(int)) <= 0)  # sorted; pads trail
             assert np.all(pv[c][pr[c] < 0] == 0)
         rels = hp.chunk_rel[tp[t]:tp[t + 1]]
         assert np.all(np.diff(rels) >= 0)                        # relation-grouped inside the tile

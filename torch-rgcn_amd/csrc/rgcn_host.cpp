@@ -259,9 +259,9 @@ extern "C" int rgcn_plan_fill_host(const int32_t *dst, const int32_t *src, const
       }
       if (!cnt[b]) continue;
       const int64_t last = cur[b] - 1;
-      for (int64_t p = cur[b]; p < slot0[b + 1]; ++p) {  // pads: val 0, indices of the last real message
+      for (int64_t p = cur[b]; p < slot0[b + 1]; ++p) {  // pads: val 0, dst -1, source row of the last real message
         p_src[p] = p_src[last];
-        p_dst[p] = p_dst[last];
+        p_dst[p] = -1;
         p_val[p] = 0.0f;
         if (p_perm) p_perm[p] = -1;
       }
@@ -276,13 +276,13 @@ extern "C" int rgcn_plan_fill_host(const int32_t *dst, const int32_t *src, const
     }
     tile_ptr[nt] = int32_t(slot0[nb] / RGCN_CHUNK);
     if (p_pack) {
-      if (n_src >= (int64_t(1) << 24) || tile_rows > 256) {
-        rgcn_set_error("plan_fill: packed slots need n_src < 2^24 and tile_rows <= 256");
+      if (n_src >= (int64_t(1) << 24) || tile_rows > 255) {
+        rgcn_set_error("plan_fill: packed slots need n_src < 2^24 and tile_rows <= 255");
         return RGCN_EUNSUPPORTED;
       }
       const int64_t m_pad = slot0[nb];
       for (int64_t p = 0; p < m_pad; ++p) {
-        const uint32_t dl = uint32_t(p_dst[p] % tile_rows);
+        const uint32_t dl = p_dst[p] < 0 ? 0xFFu : uint32_t(p_dst[p] % tile_rows);   // 0xFF marks a pad
         p_pack[2 * p] = int32_t(uint32_t(p_src[p]) | (dl << 24));
         std::memcpy(&p_pack[2 * p + 1], &p_val[p], sizeof(float));
       }

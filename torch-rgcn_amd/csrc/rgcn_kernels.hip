@@ -68,27 +68,44 @@ constexpr int ROW_SHR = 0x110;  // + n : lane m reads lane m-n of its 16-lane ro
 constexpr int ROW_SHL = 0x100;  // + n : lane m reads lane m+n
 
 // In-place inclusive segmented sum over the slots (lanes m = 0..15 of a DPP row) of NV accumulators.
-// Returns true in the last lane of every run of equal `dst`.
+// Branch-free: lane m adds lane m-N's value times a 0/1 mask (same destination), N = 1, 2, 4, 8; the
+// DPP shift is foldable into the multiply-add.  Returns true in the last lane of every run of equal `dst`.
+template <int N>
+__device__ __forceinline__ float dpp_shr0(float src) {   // lane m <- lane m-N of the 16-lane row, 0 when m < N
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), ROW_SHR + N, 0xF, 0xF, true));
+}
+
 template <int NV>
 __device__ __forceinline__ bool fold_segments(f32x4 (&acc)[NV], int dst) {
-#define RGCN_FOLD_STEP(N)                                                      \
+#define RGCN_FOLD_STEP(N, SAME)                                                \
   {                                                                            \
-    const bool same = dpp_i<ROW_SHR + N>(-1, dst) == dst;                      \
+    const float sf = (SAME) ? 1.f : 0.f;                                       \
     _Pragma("unroll") for (int v = 0; v < NV; ++v) {                           \
-      f32x4 t;                                                                 \
-      t[0] = dpp_f<ROW_SHR + N>(0.f, acc[v][0]);                               \
-      t[1] = dpp_f<ROW_SHR + N>(0.f, acc[v][1]);                               \
-      t[2] = dpp_f<ROW_SHR + N>(0.f, acc[v][2]);                               \
-      t[3] = dpp_f<ROW_SHR + N>(0.f, acc[v][3]);                               \
-      if (same) acc[v] += t;                                                   \
+      acc[v][0] = fmaf(dpp_shr0<N>(acc[v][0]), sf, acc[v][0]);                 \
+      acc[v][1] = fmaf(dpp_shr0<N>(acc[v][1]), sf, acc[v][1]);                 \
+      acc[v][2] = fmaf(dpp_shr0<N>(acc[v][2]), sf, acc[v][2]);                 \
+      acc[v][3] = fmaf(dpp_shr0<N>(acc[v][3]), sf, acc[v][3]);                 \
     }                                                                          \
   }
-  RGCN_FOLD_STEP(1)
-  RGCN_FOLD_STEP(2)
-  RGCN_FOLD_STEP(4)
-  RGCN_FOLD_STEP(8)
+  // runs of equal destinations are contiguous (slots are sorted): a step of distance N is needed only if some
+  // run is longer than N -- most chunks stop after step 1 or need no step at all (wave-uniform early exits)
+  // pads carry dst = -1 and never join a run
+  const bool s1 = dpp_i<ROW_SHR + 1>(-1, dst) == dst && dst >= 0;
+  if (__builtin_amdgcn_ballot_w64(s1)) {
+    RGCN_FOLD_STEP(1, s1)
+    const bool s2 = dpp_i<ROW_SHR + 2>(-1, dst) == dst && dst >= 0;
+    if (__builtin_amdgcn_ballot_w64(s2)) {
+      RGCN_FOLD_STEP(2, s2)
+      const bool s4 = dpp_i<ROW_SHR + 4>(-1, dst) == dst && dst >= 0;
+      if (__builtin_amdgcn_ballot_w64(s4)) {
+        RGCN_FOLD_STEP(4, s4)
+        const bool s8 = dpp_i<ROW_SHR + 8>(-1, dst) == dst && dst >= 0;
+        RGCN_FOLD_STEP(8, s8)
+      }
+    }
+  }
 #undef RGCN_FOLD_STEP
-  return dpp_i<ROW_SHL + 1>(-1, dst) != dst;
+  return dpp_i<ROW_SHL + 1>(-2, dst) != dst && dst >= 0;   // last lane of a run of real slots
 }
 
 constexpr int SPMM_WAVES = WG / 64;
@@ -140,7 +157,8 @@ __global__ __launch_bounds__(WG) void spmm_d16_kernel(
         if (PACKED) {
           const int2 pk = p_pack[e];
           g.s[j] = pk.x & 0xFFFFFF;
-          g.d[j] = row0 + (int)((unsigned)pk.x >> 24);
+          const int dl = (int)((unsigned)pk.x >> 24);
+          g.d[j] = dl == 0xFF ? -1 : row0 + dl;
           g.v[j] = (c + j <= last) ? __builtin_bit_cast(float, pk.y) : 0.f;
         } else {
           g.s[j] = p_src[e];
@@ -508,7 +526,7 @@ __global__ __launch_bounds__(WG) void wgrad_d16_kernel(
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       x[j] = *reinterpret_cast<const float4 *>(X + (size_t)s[j] * 16 + 4 * q);
-      g[j] = *reinterpret_cast<const float4 *>(G + (size_t)d[j] * 16 + 4 * q);
+      g[j] = *reinterpret_cast<const float4 *>(G + (size_t)max(d[j], 0) * 16 + 4 * q);   // pads: dst = -1, val = 0
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -605,7 +623,8 @@ __global__ __launch_bounds__(WG) void wgrad_tiled_d16_kernel(
         for (int t4 = 0; t4 < 4; ++t4) {
           const int mu = 4 * t4 + kq;                                // message carried by K-slot kq at step t4
           av[t4] = xs[mu * 16 + m];                                  // A[i = m][k] = val * X[src_mu][m]
-          bv[t4] = G[(size_t)dl[mu] * 16 + m];                       // B[k][j = m] = G[dst_mu][m]  (L1/L2)
+          const int dmu = dl[mu];                                    // pads: dst = -1 (their A column is 0)
+          bv[t4] = dmu < 0 ? 0.f : G[(size_t)dmu * 16 + m];          // B[k][j = m] = G[dst_mu][m]  (L1/L2)
         }
         const int rho = __builtin_amdgcn_readfirstlane(rr[j]) - r0;
 #define RGCN_ACC_CASE(N)                                                                       \

@@ -173,7 +173,7 @@ def build_plan_host(dst, src, rel, val, n_dst, n_src, num_rels, tile_rows, max_i
     p.tile_ptr = np.zeros(p.n_tiles + 1, np.int32)
     p.items = np.empty((max(p.n_items, 1), 2), np.int32)
     p.run_ptr = np.zeros(max(p.n_tiles, 1) * (num_rels + 1), np.int32) if want_runs else None
-    can_pack = want_pack and n_src < (1 << 24) and tile_rows <= 256
+    can_pack = want_pack and n_src < (1 << 24) and tile_rows <= 255
     p.pack = np.empty((max(p.m_pad, 1), 2), np.int32) if can_pack else None
     _check(L.rgcn_plan_fill_host(_hp(dst), _hp(src), _hp(rel), _hp(val), c_i64(M), c_i64(n_dst), c_i64(n_src),
                                  c_i32(num_rels), c_i32(tile_rows), c_i32(max_item_chunks), _hp(p.src), _hp(p.dst),
