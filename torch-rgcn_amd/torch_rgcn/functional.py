@@ -40,7 +40,9 @@ class _RelationalMP(torch.autograd.Function):
             fp = graph.fwd_plan(W.shape[2])
             # tile-major walk (one random gather per message) unless a (tile, relation) run is so long that
             # one wave would serialise it (hub nodes): then the relation-major kernel with bounded work items
-            tiled_ok = W.shape[1] == 16 and W.shape[2] == 16 and fp.max_run_chunks <= 64
+            # and unless the (tile, relation) buckets are so sparse that a work item is a fraction of a chunk
+            dense = fp.m_pad > 0 and fp.n_messages >= 0.5 * fp.m_pad
+            tiled_ok = W.shape[1] == 16 and W.shape[2] == 16 and fp.max_run_chunks <= 64 and dense
             if tiled_ok and os.environ.get("RGCN_WGRAD", "tiled") == "tiled":
                 dW = _native.wgrad_tiled(X, g, fp, W.shape[0], int(os.environ.get("RGCN_WGRAD_TILES", "4")))
             else:
