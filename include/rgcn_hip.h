@@ -106,6 +106,36 @@ RGCN_API int rgcn_plan_units_host(const int32_t *tile_ptr, int64_t n_tiles, int3
  * consecutive stream values per triple.  Same stream as oracle.synthetic_triples. */
 RGCN_API int rgcn_synthetic_triples_host(int64_t N, int64_t R0, int64_t E, uint64_t seed, int64_t *out);
 
+/* ------------------------------------------------------------------ graph preparation (device)
+ * The same work as the *_host functions above without leaving the GPU (the LP layer builds its graph on
+ * every call, layers.py:481-516).  Dense counting: workspaces are one int per (tile, relation, row) cell.
+ * All pointers are device pointers; nothing synchronises.  err_flag (1 int) becomes 1 when an index is out
+ * of range (the caller turns that into the reference's AssertionError). */
+RGCN_API int rgcn_dev_split_triples(const int64_t *triples_plus, int64_t M, int64_t N, int32_t R, int32_t *s,
+                                    int32_t *p, int32_t *o, int32_t *err_flag, void *stream);
+/* [T | inverse(T) | T | self loops] as s/p/o int32 arrays of length 3E+N; dropped self loops (keep[n] == 0)
+ * stay in the list with alive = 0 and are ignored by everything downstream. */
+RGCN_API int rgcn_dev_lp_expand(const int64_t *triples, int64_t E, int64_t N, int32_t R0, const uint8_t *keep,
+                                int32_t *s, int32_t *p, int32_t *o, uint8_t *alive, int32_t *err_flag, void *stream);
+/* val by the literal procedure (see rgcn_edge_norm_host); table = R*N ints of workspace; alive may be NULL.
+ * The caller checks 2*n_swap + i_tail == number of live messages (the reference's shape error). */
+RGCN_API int rgcn_dev_edge_norm(const int32_t *s, const int32_t *p, const int32_t *o, const uint8_t *alive, int64_t M,
+                                int64_t N, int32_t R, int vertical, int64_t n_swap, int32_t *table, float *val,
+                                void *stream);
+/* Relation-tile plan in two steps.  count: cells [n_tiles*R*tile_rows], bucket_cnt [n_tiles*R],
+ * bucket_base [n_tiles*R + 1] (last entry = m_pad, which the host reads back to size the outputs),
+ * scan_tmp [n_tiles*R/1024 + 2].  fill: same layout as rgcn_plan_fill_host (message order inside one
+ * (relation, destination) cell is arbitrary). */
+RGCN_API int rgcn_dev_plan_count(const int32_t *dst, const int32_t *rel, const uint8_t *alive, int64_t M, int64_t n_dst,
+                                 int32_t R, int32_t tile_rows, int32_t *cells, int32_t *bucket_cnt,
+                                 int32_t *bucket_base, int32_t *scan_tmp, void *stream);
+RGCN_API int rgcn_dev_plan_fill(const int32_t *dst, const int32_t *src, const int32_t *rel, const float *val,
+                                const uint8_t *alive, int64_t M, int64_t n_dst, int64_t n_src, int32_t R,
+                                int32_t tile_rows, int32_t *cells, const int32_t *bucket_cnt,
+                                const int32_t *bucket_base, int32_t *p_src, int32_t *p_dst, float *p_val,
+                                int32_t *p_pack, int32_t *chunk_rel, int32_t *tile_ptr, int32_t *run_ptr,
+                                void *stream);
+
 /* ------------------------------------------------------------------ device kernels */
 
 /* out[n_dst, d_out] = bias + sum over plan slots  val * X[src,:] @ W[rel]   (W: [R, d_in, d_out]).

@@ -1,0 +1,328 @@
+// Device-side graph preparation: the per-call work of the link-prediction
+// layer -- augmentation, literal normalisation, relation-tile plan -- without leaving the GPU.
+// Reference lines taken over: utils.py:100-124 / layers.py:481-487 (augmentation), utils.py:143-166 +
+// :71-97 + layers.py:498-510 (stack, degree count, swap, 1/c), layers.py:513-516 (sparse ctor).
+//
+// Method: dense counting.  With 288 GB of HBM a table with one int per (tile, relation, row) cell
+// (= N_pad x R ints: 1.5 M for WN18, 101 M for S1, 445 M for AM) is affordable, so both the degree count
+// and the bucket sort are ONE pass of fp-free integer atomics over the messages plus scans over the table:
+//     cells[cell(e)]++                       cell = ((dst / T) * R + rel) * T + dst % T
+//     per bucket: size, exclusive offsets of its T cells, size rounded up to 16
+//     exclusive scan over the buckets -> first slot of every bucket (-> tile_ptr, run_ptr, chunk_rel)
+//     slot(e) = bucket_base + atomicAdd(&cells[cell(e)], 1)   (cells now hold running offsets)
+// The order of messages inside one (relation, destination) cell is arbitrary (they are summed anyway).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "rgcn_hip.h"
+
+extern "C" void rgcn_set_error(const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      rgcn_set_error("%s failed: %s", #expr, hipGetErrorString(e_));                    \
+      return RGCN_EHIP;                                                                 \
+    }                                                                                   \
+  } while (0)
+
+namespace {
+
+constexpr int TB = 256;
+inline unsigned blocks_for(int64_t n, int per = TB) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + per - 1) / per, 1 << 20)); }
+
+// ------------------------------------------------------------------ message lists
+__global__ void split_triples_kernel(const long long *__restrict__ tp, long long M, long long N, int R,
+                                     int *__restrict__ s, int *__restrict__ p, int *__restrict__ o,
+                                     int *__restrict__ err) {
+  for (long long e = (long long)blockIdx.x * TB + threadIdx.x; e < M; e += (long long)gridDim.x * TB) {
+    const long long a = tp[3 * e], b = tp[3 * e + 1], c = tp[3 * e + 2];
+    if (a < 0 || a >= N || c < 0 || c >= N || b < 0 || b >= R) atomicMax(err, 1);
+    s[e] = (int)a; p[e] = (int)b; o[e] = (int)c;
+  }
+}
+
+// [T | inverse(T) | T | self loops]; dropped self loops stay in the list but are marked dead
+__global__ void lp_expand_kernel(const long long *__restrict__ t, long long E, long long N, int R0,
+                                 const unsigned char *__restrict__ keep, int *__restrict__ s, int *__restrict__ p,
+                                 int *__restrict__ o, unsigned char *__restrict__ alive, int *__restrict__ err) {
+  const long long M = 3 * E + N;
+  for (long long e = (long long)blockIdx.x * TB + threadIdx.x; e < M; e += (long long)gridDim.x * TB) {
+    if (e < 3 * E) {
+      const long long j = e % E, blk = e / E;
+      const long long a = t[3 * j], b = t[3 * j + 1], c = t[3 * j + 2];
+      if (a < 0 || a >= N || c < 0 || c >= N || b < 0 || b >= R0) atomicMax(err, 1);
+      if (blk == 1) { s[e] = (int)c; p[e] = (int)b + R0; o[e] = (int)a; }
+      else { s[e] = (int)a; p[e] = (int)b; o[e] = (int)c; }
+      alive[e] = 1;
+    } else {
+      const long long n = e - 3 * E;
+      s[e] = (int)n; p[e] = 2 * R0; o[e] = (int)n;
+      alive[e] = keep ? (keep[n] != 0) : 1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ literal normalisation
+__global__ void norm_count_kernel(const int *__restrict__ s, const int *__restrict__ p, const int *__restrict__ o,
+                                  const unsigned char *__restrict__ alive, long long M, long long N, int vertical,
+                                  int *__restrict__ table) {
+  for (long long e = (long long)blockIdx.x * TB + threadIdx.x; e < M; e += (long long)gridDim.x * TB) {
+    if (alive && !alive[e]) continue;
+    atomicAdd(&table[(long long)p[e] * N + (vertical ? s[e] : o[e])], 1);
+  }
+}
+
+// vertical: val = 1 / count(p, s).  horizontal: the count of the PARTNER position after the block swap
+// c = [k[n:2n] | k[0:n] | k[2n:]] (third block maps to itself because 2n + i = length of the list).
+__global__ void norm_val_kernel(const int *__restrict__ s, const int *__restrict__ p, const int *__restrict__ o,
+                                const unsigned char *__restrict__ alive, long long M, long long N, int vertical,
+                                long long n_swap, const int *__restrict__ table, float *__restrict__ val) {
+  for (long long e = (long long)blockIdx.x * TB + threadIdx.x; e < M; e += (long long)gridDim.x * TB) {
+    if (alive && !alive[e]) { val[e] = 0.f; continue; }
+    long long q = e;
+    if (!vertical) q = e < n_swap ? e + n_swap : (e < 2 * n_swap ? e - n_swap : e);
+    const int c = table[(long long)p[q] * N + (vertical ? s[q] : o[q])];
+    val[e] = 1.0f / (float)c;
+  }
+}
+
+// ------------------------------------------------------------------ plan: counting sort on a dense cell table
+__device__ __forceinline__ long long cell_of(int d, int r, int R, int T) {
+  return ((long long)(d / T) * R + r) * T + d % T;
+}
+
+__global__ void cell_count_kernel(const int *__restrict__ dst, const int *__restrict__ rel,
+                                  const unsigned char *__restrict__ alive, long long M, int R, int T,
+                                  int *__restrict__ cells) {
+  for (long long e = (long long)blockIdx.x * TB + threadIdx.x; e < M; e += (long long)gridDim.x * TB) {
+    if (alive && !alive[e]) continue;
+    atomicAdd(&cells[cell_of(dst[e], rel[e], R, T)], 1);
+  }
+}
+
+// one wave per bucket: bucket size, cells -> exclusive offsets inside the bucket, padded size
+__global__ void bucket_scan_kernel(int *__restrict__ cells, long long n_buckets, int T, int *__restrict__ bucket_cnt,
+                                   int *__restrict__ bucket_pad) {
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = ((long long)blockIdx.x * TB + threadIdx.x) >> 6, nw = ((long long)gridDim.x * TB) >> 6;
+  for (long long b = wave0; b < n_buckets; b += nw) {
+    int *c = cells + b * T;
+    int run = 0;
+    for (int base = 0; base < T; base += 64) {
+      const int i = base + lane;
+      const int v = i < T ? c[i] : 0;
+      int incl = v;                                  // inclusive scan across the wave
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+      }
+      if (i < T) c[i] = run + incl - v;
+      run += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) {
+      bucket_cnt[b] = run;
+      bucket_pad[b] = (run + RGCN_CHUNK - 1) / RGCN_CHUNK * RGCN_CHUNK;
+    }
+  }
+}
+
+// exclusive scan of n ints, three launches: per-block (1024 items) scan + totals, scan of totals, add back
+__global__ __launch_bounds__(TB) void scan_blocks_kernel(const int *in, int *out, int *__restrict__ totals, long long n) {  // in may alias out
+  __shared__ int wsum[TB / 64];
+  const long long base = (long long)blockIdx.x * (TB * 4);
+  int v[4], sum = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long long i = base + (long long)threadIdx.x * 4 + j;
+    v[j] = i < n ? in[i] : 0;
+    sum += v[j];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int woff = 0;
+  for (int w = 0; w < wave; ++w) woff += wsum[w];
+  int excl = woff + incl - sum;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long long i = base + (long long)threadIdx.x * 4 + j;
+    if (i < n) out[i] = excl;
+    excl += v[j];
+  }
+  if (threadIdx.x == TB - 1) totals[blockIdx.x] = woff + incl;
+}
+
+__global__ __launch_bounds__(TB) void scan_totals_kernel(int *__restrict__ totals, long long nb, int *__restrict__ grand) {
+  // single block, sequential over chunks of TB
+  __shared__ int wsum[TB / 64];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (long long base = 0; base < nb; base += TB) {
+    const long long i = base + threadIdx.x;
+    const int v = i < nb ? totals[i] : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = carry_s;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    if (i < nb) totals[i] = woff + incl - v;
+    __syncthreads();
+    if (threadIdx.x == TB - 1) carry_s = woff + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *grand = carry_s;
+}
+
+__global__ void scan_add_kernel(int *__restrict__ out, const int *__restrict__ totals, long long n) {
+  for (long long i = (long long)blockIdx.x * TB + threadIdx.x; i < n; i += (long long)gridDim.x * TB)
+    out[i] += totals[i / (TB * 4)];
+}
+
+__global__ void plan_scatter_kernel(const int *__restrict__ dst, const int *__restrict__ src, const int *__restrict__ rel,
+                                    const float *__restrict__ val, const unsigned char *__restrict__ alive, long long M,
+                                    int R, int T, int *__restrict__ cells, const int *__restrict__ bucket_base,
+                                    int *__restrict__ p_src, int *__restrict__ p_dst, float *__restrict__ p_val,
+                                    int2 *__restrict__ p_pack) {
+  for (long long e = (long long)blockIdx.x * TB + threadIdx.x; e < M; e += (long long)gridDim.x * TB) {
+    if (alive && !alive[e]) continue;
+    const int d = dst[e], r = rel[e];
+    const long long bucket = (long long)(d / T) * R + r;
+    const int pos = bucket_base[bucket] + atomicAdd(&cells[bucket * T + d % T], 1);
+    p_src[pos] = src[e];
+    p_dst[pos] = d;
+    p_val[pos] = val[e];
+    if (p_pack) p_pack[pos] = make_int2((int)((unsigned)src[e] | ((unsigned)(d % T) << 24)), __builtin_bit_cast(int, val[e]));
+  }
+}
+
+// pads, chunk relations, tile / run pointers: one thread per bucket
+__global__ void plan_finish_kernel(long long n_buckets, int R, const int *__restrict__ bucket_cnt,
+                                   const int *__restrict__ bucket_base, int *__restrict__ p_src, int *__restrict__ p_dst,
+                                   float *__restrict__ p_val, int2 *__restrict__ p_pack, int *__restrict__ chunk_rel,
+                                   int *__restrict__ tile_ptr, int *__restrict__ run_ptr) {
+  for (long long b = (long long)blockIdx.x * TB + threadIdx.x; b <= n_buckets; b += (long long)gridDim.x * TB) {
+    const int base = bucket_base[b];
+    const long long t = b / R;
+    const int r = (int)(b % R);
+    if (r == 0) tile_ptr[t] = base / RGCN_CHUNK;          // also writes tile_ptr[n_tiles] for b == n_buckets
+    if (b == n_buckets) {
+      if (run_ptr) run_ptr[(t - 1) * (R + 1) + R] = base / RGCN_CHUNK;
+      break;
+    }
+    if (run_ptr) {
+      run_ptr[t * (R + 1) + r] = base / RGCN_CHUNK;
+      if (r == R - 1) run_ptr[t * (R + 1) + R] = bucket_base[b + 1] / RGCN_CHUNK;
+    }
+    const int cnt = bucket_cnt[b], end = bucket_base[b + 1];
+    if (!cnt) continue;
+    const int last_src = p_src[base + cnt - 1];
+    for (int q = base + cnt; q < end; ++q) {
+      p_src[q] = last_src;
+      p_dst[q] = -1;
+      p_val[q] = 0.f;
+      if (p_pack) p_pack[q] = make_int2((int)((unsigned)last_src | (0xFFu << 24)), 0);
+    }
+    for (int c = base / RGCN_CHUNK; c < end / RGCN_CHUNK; ++c) chunk_rel[c] = r;
+  }
+}
+
+int exclusive_scan(const int *in, int *out, int *totals, long long n, int *grand, hipStream_t st) {
+  const long long nb = (n + TB * 4 - 1) / (TB * 4);
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3((unsigned)nb), dim3(TB), 0, st, in, out, totals, n);
+  hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(TB), 0, st, totals, nb, grand);
+  hipLaunchKernelGGL(scan_add_kernel, dim3(blocks_for(n)), dim3(TB), 0, st, out, totals, n);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+}  // namespace
+
+extern "C" int rgcn_dev_split_triples(const int64_t *triples_plus, int64_t M, int64_t N, int32_t R, int32_t *s, int32_t *p,
+                                      int32_t *o, int32_t *err_flag, void *stream) {
+  if (M < 0 || N <= 0 || R <= 0 || !err_flag || (M && (!triples_plus || !s || !p || !o))) { rgcn_set_error("dev_split_triples: bad argument"); return RGCN_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(err_flag, 0, sizeof(int), st));
+  if (!M) return RGCN_OK;
+  hipLaunchKernelGGL(split_triples_kernel, dim3(blocks_for(M)), dim3(TB), 0, st, (const long long *)triples_plus,
+                     (long long)M, (long long)N, R, s, p, o, err_flag);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_dev_lp_expand(const int64_t *triples, int64_t E, int64_t N, int32_t R0, const uint8_t *keep, int32_t *s,
+                                  int32_t *p, int32_t *o, uint8_t *alive, int32_t *err_flag, void *stream) {
+  if (E < 0 || N <= 0 || R0 <= 0 || !s || !p || !o || !alive || !err_flag || (E && !triples)) { rgcn_set_error("dev_lp_expand: bad argument"); return RGCN_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(err_flag, 0, sizeof(int), st));
+  hipLaunchKernelGGL(lp_expand_kernel, dim3(blocks_for(3 * E + N)), dim3(TB), 0, st, (const long long *)triples,
+                     (long long)E, (long long)N, R0, keep, s, p, o, alive, err_flag);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_dev_edge_norm(const int32_t *s, const int32_t *p, const int32_t *o, const uint8_t *alive, int64_t M,
+                                  int64_t N, int32_t R, int vertical, int64_t n_swap, int32_t *table, float *val,
+                                  void *stream) {
+  if (M < 0 || N <= 0 || R <= 0 || !table || (M && (!s || !p || !o || !val)) || n_swap < 0 || 2 * n_swap > M) { rgcn_set_error("dev_edge_norm: bad argument"); return RGCN_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(table, 0, (size_t)R * N * sizeof(int), st));
+  if (!M) return RGCN_OK;
+  hipLaunchKernelGGL(norm_count_kernel, dim3(blocks_for(M)), dim3(TB), 0, st, s, p, o, alive, (long long)M, (long long)N,
+                     vertical, table);
+  hipLaunchKernelGGL(norm_val_kernel, dim3(blocks_for(M)), dim3(TB), 0, st, s, p, o, alive, (long long)M, (long long)N,
+                     vertical, (long long)n_swap, table, val);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_dev_plan_count(const int32_t *dst, const int32_t *rel, const uint8_t *alive, int64_t M, int64_t n_dst,
+                                   int32_t R, int32_t tile_rows, int32_t *cells, int32_t *bucket_cnt,
+                                   int32_t *bucket_base, int32_t *scan_tmp, void *stream) {
+  if (M < 0 || n_dst <= 0 || R <= 0 || tile_rows <= 0 || !cells || !bucket_cnt || !bucket_base || !scan_tmp || (M && (!dst || !rel))) { rgcn_set_error("dev_plan_count: bad argument"); return RGCN_EINVAL; }
+  const int64_t n_tiles = (n_dst + tile_rows - 1) / tile_rows, nbk = n_tiles * R;
+  if (nbk * tile_rows >= (int64_t(1) << 40)) { rgcn_set_error("dev_plan_count: cell table too large"); return RGCN_EUNSUPPORTED; }
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(cells, 0, (size_t)nbk * tile_rows * sizeof(int), st));
+  if (M) hipLaunchKernelGGL(cell_count_kernel, dim3(blocks_for(M)), dim3(TB), 0, st, dst, rel, alive, (long long)M, R, tile_rows, cells);
+  // bucket_base doubles as the padded-size array before the scan
+  hipLaunchKernelGGL(bucket_scan_kernel, dim3(blocks_for(nbk * 64)), dim3(TB), 0, st, cells, (long long)nbk, tile_rows,
+                     bucket_cnt, bucket_base);
+  HIP_TRY(hipGetLastError());
+  return exclusive_scan(bucket_base, bucket_base, scan_tmp, nbk, bucket_base + nbk, st);
+}
+
+extern "C" int rgcn_dev_plan_fill(const int32_t *dst, const int32_t *src, const int32_t *rel, const float *val,
+                                  const uint8_t *alive, int64_t M, int64_t n_dst, int64_t n_src, int32_t R,
+                                  int32_t tile_rows, int32_t *cells, const int32_t *bucket_cnt, const int32_t *bucket_base,
+                                  int32_t *p_src, int32_t *p_dst, float *p_val, int32_t *p_pack, int32_t *chunk_rel,
+                                  int32_t *tile_ptr, int32_t *run_ptr, void *stream) {
+  if (M < 0 || n_dst <= 0 || R <= 0 || tile_rows <= 0 || !cells || !bucket_cnt || !bucket_base || !tile_ptr ||
+      (M && (!dst || !src || !rel || !val || !p_src || !p_dst || !p_val || !chunk_rel))) { rgcn_set_error("dev_plan_fill: bad argument"); return RGCN_EINVAL; }
+  if (p_pack && (n_src >= (int64_t(1) << 24) || tile_rows > 255)) { rgcn_set_error("dev_plan_fill: packed slots need n_src < 2^24 and tile_rows <= 255"); return RGCN_EUNSUPPORTED; }
+  const int64_t n_tiles = (n_dst + tile_rows - 1) / tile_rows, nbk = n_tiles * R;
+  hipStream_t st = (hipStream_t)stream;
+  if (M) hipLaunchKernelGGL(plan_scatter_kernel, dim3(blocks_for(M)), dim3(TB), 0, st, dst, src, rel, val, alive, (long long)M, R,
+                            tile_rows, cells, bucket_base, p_src, p_dst, p_val, reinterpret_cast<int2 *>(p_pack));
+  hipLaunchKernelGGL(plan_finish_kernel, dim3(blocks_for(nbk + 1)), dim3(TB), 0, st, (long long)nbk, R, bucket_cnt, bucket_base,
+                     p_src, p_dst, p_val, reinterpret_cast<int2 *>(p_pack), chunk_rel, tile_ptr, run_ptr);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}

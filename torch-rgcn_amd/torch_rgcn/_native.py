@@ -219,6 +219,109 @@ class DevicePlan:
                                                            self.tile_ptr, self.items))
 
 
+# ----------------------------------------------------------------------------- device-side graph build
+
+def _i32(n, device):
+    return torch.empty(max(int(n), 1), dtype=torch.int32, device=device)
+
+
+def dev_check_err(err_flag, what):
+    if int(err_flag.item()):
+        raise AssertionError(f"{what}: node or relation index out of range")
+
+
+def dev_split_triples(triples_plus, num_nodes, num_rels):
+    """int64 [M,3] device tensor -> (s, p, o) int32 device tensors (range-checked)"""
+    t = triples_plus.contiguous()
+    M, dev = t.shape[0], t.device
+    s, p, o, err = _i32(M, dev), _i32(M, dev), _i32(M, dev), _i32(1, dev)
+    with torch.cuda.device(dev):
+        _check(lib().rgcn_dev_split_triples(_dp(t), c_i64(M), c_i64(num_nodes), c_i32(num_rels), _dp(s), _dp(p), _dp(o),
+                                            _dp(err), _stream(dev)), "dev_split_triples")
+    return s[:M], p[:M], o[:M], err
+
+
+def dev_lp_expand(triples, num_nodes, num_rels0, keep):
+    """[T | inv | T | self loops] on the device; keep: uint8/bool [N] device tensor or None"""
+    t = triples.contiguous()
+    E, dev = t.shape[0], t.device
+    M = 3 * E + num_nodes
+    s, p, o, err = _i32(M, dev), _i32(M, dev), _i32(M, dev), _i32(1, dev)
+    alive = torch.empty(M, dtype=torch.uint8, device=dev)
+    k = None if keep is None else keep.to(torch.uint8).contiguous()
+    with torch.cuda.device(dev):
+        _check(lib().rgcn_dev_lp_expand(_dp(t), c_i64(E), c_i64(num_nodes), c_i32(num_rels0), _dp(k), _dp(s), _dp(p),
+                                        _dp(o), _dp(alive), _dp(err), _stream(dev)), "dev_lp_expand")
+    return s, p, o, alive, err
+
+
+def dev_edge_norm(s, p, o, alive, num_nodes, num_rels, vertical, n_swap):
+    M, dev = s.shape[0], s.device
+    table = _i32(num_nodes * num_rels, dev)
+    val = torch.empty(max(M, 1), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib().rgcn_dev_edge_norm(_dp(s), _dp(p), _dp(o), _dp(alive), c_i64(M), c_i64(num_nodes), c_i32(num_rels),
+                                        c_int(int(bool(vertical))), c_i64(n_swap), _dp(table), _dp(val), _stream(dev)),
+               "dev_edge_norm")
+    return val[:M]
+
+
+class BuiltPlan:
+    """Same fields as DevicePlan, produced on the device."""
+
+
+def build_plan_device(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_rows, n_live, max_item_chunks=64,
+                      want_runs=False, want_pack=False, max_unit_chunks=256):
+    dev = dst.device
+    M = dst.shape[0]
+    n_tiles = (n_dst + tile_rows - 1) // tile_rows
+    nbk = n_tiles * num_rels
+    cells = _i32(nbk * tile_rows, dev)
+    bucket_cnt, bucket_base, scan_tmp = _i32(nbk, dev), _i32(nbk + 1, dev), _i32(nbk // 1024 + 2, dev)
+    L = lib()
+    with torch.cuda.device(dev):
+        _check(L.rgcn_dev_plan_count(_dp(dst), _dp(rel), _dp(alive), c_i64(M), c_i64(n_dst), c_i32(num_rels),
+                                     c_i32(tile_rows), _dp(cells), _dp(bucket_cnt), _dp(bucket_base), _dp(scan_tmp),
+                                     _stream(dev)), "dev_plan_count")
+    m_pad = int(bucket_base[nbk].item())        # the one host round trip: output sizes
+    p = BuiltPlan()
+    p.device = dev
+    p.n_dst, p.n_src, p.num_rels, p.tile_rows = n_dst, n_src, num_rels, tile_rows
+    p.n_tiles, p.m_pad, p.n_chunks, p.n_messages = n_tiles, m_pad, m_pad // CHUNK, int(n_live)
+    p.src, p.dst = _i32(m_pad, dev), _i32(m_pad, dev)
+    p.val = torch.empty(max(m_pad, 1), dtype=torch.float32, device=dev)
+    can_pack = want_pack and n_src < (1 << 24) and tile_rows <= 255
+    p.pack = torch.empty((max(m_pad, 1), 2), dtype=torch.int32, device=dev) if can_pack else None
+    p.chunk_rel = _i32(p.n_chunks, dev)
+    p.tile_ptr = _i32(n_tiles + 1, dev)
+    p.run_ptr = _i32(n_tiles * (num_rels + 1), dev) if want_runs else None
+    with torch.cuda.device(dev):
+        _check(L.rgcn_dev_plan_fill(_dp(dst), _dp(src), _dp(rel), _dp(val), _dp(alive), c_i64(M), c_i64(n_dst),
+                                    c_i64(n_src), c_i32(num_rels), c_i32(tile_rows), _dp(cells), _dp(bucket_cnt),
+                                    _dp(bucket_base), _dp(p.src), _dp(p.dst), _dp(p.val), _dp(p.pack), _dp(p.chunk_rel),
+                                    _dp(p.tile_ptr), _dp(p.run_ptr), _stream(dev)), "dev_plan_fill")
+    # work units (hub tiles split) and the relation-major work list are tiny: host side
+    tp_host = p.tile_ptr[:n_tiles + 1].cpu().numpy()
+    nu, ns = c_i64(0), c_i64(0)
+    _check(L.rgcn_plan_units_host(_hp(tp_host), c_i64(n_tiles), c_i32(max_unit_chunks), None, ctypes.byref(nu),
+                                  ctypes.byref(ns)), "plan_units")
+    units = np.zeros((max(nu.value, 1), 4), np.int32)
+    _check(L.rgcn_plan_units_host(_hp(tp_host), c_i64(n_tiles), c_i32(max_unit_chunks), _hp(units), ctypes.byref(nu),
+                                  ctypes.byref(ns)), "plan_units")
+    p.n_units, p.n_split = nu.value, ns.value
+    p.units = torch.from_numpy(units).to(dev)
+    p.max_run_chunks = int((int(bucket_cnt[:nbk].max().item()) + CHUNK - 1) // CHUNK) if nbk else 0
+    if n_tiles == 1:   # relation-major plan: work items = chunk ranges of one relation, at most max_item_chunks long
+        base = (bucket_base[:nbk + 1].cpu().numpy() // CHUNK).astype(np.int64)
+        items = [(c, min(c + max_item_chunks, base[r + 1])) for r in range(num_rels)
+                 for c in range(base[r], base[r + 1], max_item_chunks)]
+        p.n_items = len(items)
+        p.items = torch.tensor(items if items else [[0, 0]], dtype=torch.int32, device=dev)
+    else:
+        p.n_items, p.items = 0, _i32(2, dev).view(1, 2)
+    return p
+
+
 def _req(t, name, dtype=torch.float32):
     if t is None:
         return

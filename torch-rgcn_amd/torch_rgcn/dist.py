@@ -81,6 +81,16 @@ def shard_layer(layer, group=None, keep="all"):
 def filter_graph_for_rank(graph, group):
     """Drop the messages of relations owned by other ranks (in place, before any plan is built)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if getattr(graph, "_dev", None) is not None:   # message list lives on the GPU: shard through the alive mask
+        s, p, o, val, alive = graph._dev
+        live = torch.ones_like(p, dtype=torch.bool) if alive is None else alive != 0
+        counts = torch.bincount(p[live].long(), minlength=graph.num_rels).cpu().numpy()
+        owner = partition_relations(counts, world)
+        mine = torch.from_numpy(owner == rank).to(p.device)[p.long()] & live
+        graph._dev = (s, p, o, val, mine.to(torch.uint8))
+        graph.num_messages = int(mine.sum().item())
+        graph.owned_relations = np.nonzero(owner == rank)[0]
+        return graph
     counts = np.bincount(graph._p, minlength=graph.num_rels)
     owner = partition_relations(counts, world)
     m = owner[graph._p] == rank

@@ -34,24 +34,42 @@ def pick_tile_rows(width):
 
 class RelGraph:
     def __init__(self, triples_plus, val, num_nodes, num_rels, device):
-        """triples_plus: int64 numpy [M,3] (s,p,o); val: float32 numpy [M]."""
+        """triples_plus: int64 numpy [M,3] (s,p,o); val: float32 numpy [M].  (host-built plans)"""
         self.num_nodes, self.num_rels = int(num_nodes), int(num_rels)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("RelGraph lives on a GPU: torch_rgcn runs on HIP kernels only (no CPU fallback)")
-        tp = np.ascontiguousarray(triples_plus, dtype=np.int64).reshape(-1, 3)
         if self.num_nodes * self.num_rels >= 2 ** 31:
             raise NotImplementedError("num_nodes * num_relations must stay below 2^31")
+        self._dev = None
+        self._plans = {}
+        if triples_plus is None:
+            return
+        tp = np.ascontiguousarray(triples_plus, dtype=np.int64).reshape(-1, 3)
         self._s = tp[:, 0].astype(np.int32)
         self._p = tp[:, 1].astype(np.int32)
         self._o = tp[:, 2].astype(np.int32)
         self._val = np.ascontiguousarray(val, dtype=np.float32)
         self.num_messages = tp.shape[0]
-        self._plans = {}
+
+    @classmethod
+    def on_device(cls, s, p, o, val, alive, n_live, num_nodes, num_rels):
+        """Message list already on the GPU (int32 s/p/o, fp32 val, optional uint8 alive): plans are built by
+        the device-side counting sort (csrc/rgcn_build.hip)."""
+        g = cls(None, None, num_nodes, num_rels, s.device)
+        g._dev = (s, p, o, val, alive)
+        g.num_messages = int(n_live)
+        return g
 
     # -- plans are built lazily and cached per tile height
     def _plan(self, kind, tile_rows, max_item_chunks=64):
         key = (kind, tile_rows, max_item_chunks)
+        if key not in self._plans and self._dev is not None:
+            N, R = self.num_nodes, self.num_rels
+            s, p, o, val, alive = self._dev
+            dst, src = (s, o) if kind == "fwd" else (o, s)
+            self._plans[key] = _native.build_plan_device(dst, src, p, val, alive, N, N, R, tile_rows, self.num_messages,
+                                                         max_item_chunks, want_runs=(kind == "fwd"), want_pack=True)
         if key not in self._plans:
             N, R = self.num_nodes, self.num_rels
             if kind == "fwd":
@@ -77,14 +95,34 @@ class RelGraph:
 
     def selfloop_edges(self, self_rel):
         """(s, o, val) device tensors of the messages of one relation (used by the LP block-dropout branch)."""
+        if self._dev is not None:
+            s, p, o, val, alive = self._dev
+            m = p == self_rel
+            if alive is not None:
+                m = m & (alive != 0)
+            return s[m].long(), o[m].long(), val[m]
         m = self._p == self_rel
         dev = self.device
         return (torch.from_numpy(self._s[m].astype(np.int64)).to(dev), torch.from_numpy(self._o[m].astype(np.int64)).to(dev),
                 torch.from_numpy(self._val[m]).to(dev))
 
 
+def _device_build_enabled():
+    return os.environ.get("RGCN_GRAPH_BUILD", "device") == "device"
+
+
 def graph_from_nc_triples(triples_plus, num_nodes, num_rels, vertical, device):
     """NC layer: n = int((M - N) / 2), i = N  (torch_rgcn/layers.py:235-236, :269-271)."""
+    if _device_build_enabled() and num_nodes * num_rels < 2 ** 31:
+        t = torch.as_tensor(triples_plus, dtype=torch.long).reshape(-1, 3).to(device)
+        M = t.shape[0]
+        n_swap = int((M - num_nodes) / 2)
+        assert vertical or (n_swap >= 0 and 2 * n_swap + num_nodes == M), \
+            f"edge_norm: horizontal swap needs 2n+i == M (n={n_swap} i={num_nodes} M={M})"
+        s, p, o, err = _native.dev_split_triples(t, num_nodes, num_rels)
+        _native.dev_check_err(err, "stack_matrices")
+        val = _native.dev_edge_norm(s, p, o, None, num_nodes, num_rels, vertical, max(n_swap, 0))
+        return RelGraph.on_device(s, p, o, val, None, M, num_nodes, num_rels)
     tp = triples_plus.detach().cpu().numpy() if torch.is_tensor(triples_plus) else np.asarray(triples_plus)
     tp = np.ascontiguousarray(tp, dtype=np.int64).reshape(-1, 3)
     M = tp.shape[0]
@@ -94,6 +132,14 @@ def graph_from_nc_triples(triples_plus, num_nodes, num_rels, vertical, device):
 
 def graph_from_lp_triples(triples, num_nodes, num_rels, vertical, keep_mask, device):
     """LP layer: [T | inv | T | kept self loops], n = E, i = E + #kept (layers.py:481-487, :505-510)."""
+    if _device_build_enabled() and num_nodes * num_rels < 2 ** 31:
+        t = torch.as_tensor(triples, dtype=torch.long).reshape(-1, 3).to(device)
+        E = t.shape[0]
+        s, p, o, alive, err = _native.dev_lp_expand(t, num_nodes, (num_rels - 1) // 2, keep_mask)
+        _native.dev_check_err(err, "stack_matrices")
+        val = _native.dev_edge_norm(s, p, o, alive, num_nodes, num_rels, vertical, E)
+        n_live = 3 * E + (num_nodes if keep_mask is None else int(keep_mask.sum().item()))
+        return RelGraph.on_device(s, p, o, val, alive, n_live, num_nodes, num_rels)
     t = triples.detach().cpu().numpy() if torch.is_tensor(triples) else np.asarray(triples)
     t = np.ascontiguousarray(t, dtype=np.int64).reshape(-1, 3)
     R0 = (num_rels - 1) // 2
