@@ -134,7 +134,25 @@ RGCN_API int rgcn_dev_plan_fill(const int32_t *dst, const int32_t *src, const in
                                 int32_t tile_rows, int32_t *cells, const int32_t *bucket_cnt,
                                 const int32_t *bucket_base, int32_t *p_src, int32_t *p_dst, float *p_val,
                                 int32_t *p_pack, int32_t *chunk_rel, int32_t *tile_ptr, int32_t *run_ptr,
-                                void *stream);
+                                const int32_t *aux, int32_t *p_aux, void *stream);
+/* (aux / p_aux, may be NULL: one extra int32 per message carried into slot order -- with R = 1 and
+ * tile_rows >= n_dst the plan degenerates to a destination-major CSR, aux = relation, and `cells` holds the
+ * row pointers: that is the layout of the basis-aggregation kernels below.) */
+
+/* Basis decomposition at large width (W_r = sum_b comps[r,b] bases[b], layers.py:241-242 / :468-469):
+ * aggregate first, contract afterwards --  ag[s, b, :] = sum_{e -> s} comps[rel_e, b] * val_e * X[src_e, :],
+ * then ONE dense GEMM  out = ag.view(N, B*d) @ bases.view(B*d, d_out)  (rocBLAS; MFMA).  rowptr/p_src/p_rel/
+ * p_val: destination-major CSR (see rgcn_dev_plan_fill).  n_b_in = 1: X rows are [d] and the output rows
+ * [B*d] (forward);  n_b_in = B: X rows are [B*d] and the B blocks are summed into [d] rows (feature gradient
+ * on the source-major CSR). */
+RGCN_API int rgcn_basis_aggregate_f32(const float *X, const float *comps, float *out, const int32_t *rowptr,
+                                      const int32_t *p_src, const int32_t *p_rel, const float *p_val,
+                                      int64_t n_rows, int32_t R, int32_t B, int32_t d, int32_t n_b_in,
+                                      void *stream);
+/* dcomps[r, b] = sum_{e in r} val_e <X[src_e], D[dst_e, b, :]>   (D = d ag, rows of B*d). */
+RGCN_API int rgcn_basis_dcomps_f32(const float *X, const float *D, float *dcomps, const int32_t *rowptr,
+                                   const int32_t *p_src, const int32_t *p_rel, const float *p_val, int64_t n_rows,
+                                   int32_t R, int32_t B, int32_t d, void *stream);
 
 /* ------------------------------------------------------------------ device kernels */
 

@@ -200,7 +200,7 @@ __global__ void plan_scatter_kernel(const int *__restrict__ dst, const int *__re
                                     const float *__restrict__ val, const unsigned char *__restrict__ alive, long long M,
                                     int R, int T, int *__restrict__ cells, const int *__restrict__ bucket_base,
                                     int *__restrict__ p_src, int *__restrict__ p_dst, float *__restrict__ p_val,
-                                    int2 *__restrict__ p_pack) {
+                                    int2 *__restrict__ p_pack, const int *__restrict__ aux, int *__restrict__ p_aux) {
   for (long long e = (long long)blockIdx.x * TB + threadIdx.x; e < M; e += (long long)gridDim.x * TB) {
     if (alive && !alive[e]) continue;
     const int d = dst[e], r = rel[e];
@@ -210,6 +210,7 @@ __global__ void plan_scatter_kernel(const int *__restrict__ dst, const int *__re
     p_dst[pos] = d;
     p_val[pos] = val[e];
     if (p_pack) p_pack[pos] = make_int2((int)((unsigned)src[e] | ((unsigned)(d % T) << 24)), __builtin_bit_cast(int, val[e]));
+    if (p_aux) p_aux[pos] = aux[e];
   }
 }
 
@@ -313,16 +314,123 @@ extern "C" int rgcn_dev_plan_fill(const int32_t *dst, const int32_t *src, const 
                                   const uint8_t *alive, int64_t M, int64_t n_dst, int64_t n_src, int32_t R,
                                   int32_t tile_rows, int32_t *cells, const int32_t *bucket_cnt, const int32_t *bucket_base,
                                   int32_t *p_src, int32_t *p_dst, float *p_val, int32_t *p_pack, int32_t *chunk_rel,
-                                  int32_t *tile_ptr, int32_t *run_ptr, void *stream) {
+                                  int32_t *tile_ptr, int32_t *run_ptr, const int32_t *aux, int32_t *p_aux,
+                                  void *stream) {
   if (M < 0 || n_dst <= 0 || R <= 0 || tile_rows <= 0 || !cells || !bucket_cnt || !bucket_base || !tile_ptr ||
       (M && (!dst || !src || !rel || !val || !p_src || !p_dst || !p_val || !chunk_rel))) { rgcn_set_error("dev_plan_fill: bad argument"); return RGCN_EINVAL; }
   if (p_pack && (n_src >= (int64_t(1) << 24) || tile_rows > 255)) { rgcn_set_error("dev_plan_fill: packed slots need n_src < 2^24 and tile_rows <= 255"); return RGCN_EUNSUPPORTED; }
   const int64_t n_tiles = (n_dst + tile_rows - 1) / tile_rows, nbk = n_tiles * R;
   hipStream_t st = (hipStream_t)stream;
   if (M) hipLaunchKernelGGL(plan_scatter_kernel, dim3(blocks_for(M)), dim3(TB), 0, st, dst, src, rel, val, alive, (long long)M, R,
-                            tile_rows, cells, bucket_base, p_src, p_dst, p_val, reinterpret_cast<int2 *>(p_pack));
+                            tile_rows, cells, bucket_base, p_src, p_dst, p_val, reinterpret_cast<int2 *>(p_pack), aux, p_aux);
   hipLaunchKernelGGL(plan_finish_kernel, dim3(blocks_for(nbk + 1)), dim3(TB), 0, st, (long long)nbk, R, bucket_cnt, bucket_base,
                      p_src, p_dst, p_val, reinterpret_cast<int2 *>(p_pack), chunk_rel, tile_ptr, run_ptr);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+// ------------------------------------------------------------------ basis decomposition, aggregate-then-contract
+namespace {
+
+// One wave per destination row.  NB_IN = 1: out[row][b][:] = sum_e comps[rel_e][b] * val_e * X[src_e][:]
+// NB_IN = B: out[row][:] = sum_e sum_b comps[rel_e][b] * val_e * X[src_e][b][:]
+__global__ __launch_bounds__(TB) void basis_aggregate_kernel(
+    const float *__restrict__ X, const float *__restrict__ comps, float *__restrict__ out,
+    const int *__restrict__ rowptr, const int *__restrict__ p_src, const int *__restrict__ p_rel,
+    const float *__restrict__ p_val, long long n_rows, int B, int d, int n_b_in) {
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = ((long long)blockIdx.x * TB + threadIdx.x) >> 6, nw = ((long long)gridDim.x * TB) >> 6;
+  for (long long row = wave0; row < n_rows; row += nw) {
+    const int e0 = rowptr[row], e1 = rowptr[row + 1];
+    if (n_b_in == 1) {
+      for (int i0 = 0; i0 < d; i0 += 64) {           // feature block of 64 per pass
+        const int i = i0 + lane;
+        for (int b0 = 0; b0 < B; b0 += 4) {           // up to 4 bases per pass in registers
+          float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+          for (int e = e0; e < e1; ++e) {
+            const float x = i < d ? X[(size_t)p_src[e] * d + i] : 0.f;
+            const float v = p_val[e];
+            const float *c = comps + (size_t)p_rel[e] * B + b0;
+            a0 += c[0] * v * x;
+            if (b0 + 1 < B) a1 += c[1] * v * x;
+            if (b0 + 2 < B) a2 += c[2] * v * x;
+            if (b0 + 3 < B) a3 += c[3] * v * x;
+          }
+          if (i < d) {
+            float *o = out + ((size_t)row * B + b0) * d + i;
+            o[0] = a0;
+            if (b0 + 1 < B) o[d] = a1;
+            if (b0 + 2 < B) o[2 * (size_t)d] = a2;
+            if (b0 + 3 < B) o[3 * (size_t)d] = a3;
+          }
+        }
+      }
+    } else {
+      for (int i0 = 0; i0 < d; i0 += 64) {
+        const int i = i0 + lane;
+        float a = 0.f;
+        for (int e = e0; e < e1; ++e) {
+          const float v = p_val[e];
+          const float *c = comps + (size_t)p_rel[e] * B;
+          const float *x = X + (size_t)p_src[e] * B * d + i;
+          float t = 0.f;
+          if (i < d)
+            for (int b = 0; b < B; ++b) t += c[b] * x[(size_t)b * d];
+          a += v * t;
+        }
+        if (i < d) out[(size_t)row * d + i] = a;
+      }
+    }
+  }
+}
+
+// one wave per destination row; per message and basis a d-long dot product, wave-reduced, one atomic per (message, b)
+__global__ __launch_bounds__(TB) void basis_dcomps_kernel(
+    const float *__restrict__ X, const float *__restrict__ D, float *__restrict__ dcomps,
+    const int *__restrict__ rowptr, const int *__restrict__ p_src, const int *__restrict__ p_rel,
+    const float *__restrict__ p_val, long long n_rows, int B, int d) {
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = ((long long)blockIdx.x * TB + threadIdx.x) >> 6, nw = ((long long)gridDim.x * TB) >> 6;
+  for (long long row = wave0; row < n_rows; row += nw) {
+    const int e0 = rowptr[row], e1 = rowptr[row + 1];
+    for (int e = e0; e < e1; ++e) {
+      const float *x = X + (size_t)p_src[e] * d;
+      const float v = p_val[e];
+      for (int b = 0; b < B; ++b) {
+        const float *dd = D + ((size_t)row * B + b) * d;
+        float a = 0.f;
+        for (int i = lane; i < d; i += 64) a += x[i] * dd[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+        if (lane == 0) atomicAdd(&dcomps[(size_t)p_rel[e] * B + b], v * a);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int rgcn_basis_aggregate_f32(const float *X, const float *comps, float *out, const int32_t *rowptr,
+                                        const int32_t *p_src, const int32_t *p_rel, const float *p_val, int64_t n_rows,
+                                        int32_t R, int32_t B, int32_t d, int32_t n_b_in, void *stream) {
+  (void)R;
+  if (!X || !comps || !out || !rowptr || n_rows < 0 || B <= 0 || d <= 0 || (n_b_in != 1 && n_b_in != B)) { rgcn_set_error("basis_aggregate: bad argument"); return RGCN_EINVAL; }
+  if (!n_rows) return RGCN_OK;
+  hipLaunchKernelGGL(basis_aggregate_kernel, dim3(blocks_for(n_rows * 64)), dim3(TB), 0, (hipStream_t)stream, X, comps, out,
+                     rowptr, p_src, p_rel, p_val, (long long)n_rows, B, d, n_b_in);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_basis_dcomps_f32(const float *X, const float *D, float *dcomps, const int32_t *rowptr,
+                                     const int32_t *p_src, const int32_t *p_rel, const float *p_val, int64_t n_rows,
+                                     int32_t R, int32_t B, int32_t d, void *stream) {
+  if (!X || !D || !dcomps || !rowptr || n_rows < 0 || R <= 0 || B <= 0 || d <= 0) { rgcn_set_error("basis_dcomps: bad argument"); return RGCN_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(dcomps, 0, (size_t)R * B * sizeof(float), st));
+  if (!n_rows) return RGCN_OK;
+  hipLaunchKernelGGL(basis_dcomps_kernel, dim3(blocks_for(n_rows * 64)), dim3(TB), 0, st, X, D, dcomps, rowptr, p_src, p_rel,
+                     p_val, (long long)n_rows, B, d);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

@@ -299,7 +299,7 @@ def build_plan_device(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_ro
         _check(L.rgcn_dev_plan_fill(_dp(dst), _dp(src), _dp(rel), _dp(val), _dp(alive), c_i64(M), c_i64(n_dst),
                                     c_i64(n_src), c_i32(num_rels), c_i32(tile_rows), _dp(cells), _dp(bucket_cnt),
                                     _dp(bucket_base), _dp(p.src), _dp(p.dst), _dp(p.val), _dp(p.pack), _dp(p.chunk_rel),
-                                    _dp(p.tile_ptr), _dp(p.run_ptr), _stream(dev)), "dev_plan_fill")
+                                    _dp(p.tile_ptr), _dp(p.run_ptr), None, None, _stream(dev)), "dev_plan_fill")
     # work units (hub tiles split) and the relation-major work list are tiny: host side
     tp_host = p.tile_ptr[:n_tiles + 1].cpu().numpy()
     nu, ns = c_i64(0), c_i64(0)
@@ -320,6 +320,57 @@ def build_plan_device(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_ro
     else:
         p.n_items, p.items = 0, _i32(2, dev).view(1, 2)
     return p
+
+
+class CsrPlan:
+    """destination-major CSR (rowptr, src, rel, val) built on the device: the layout of the basis kernels"""
+
+
+def build_csr_device(dst, src, rel, val, alive, n_rows):
+    dev = dst.device
+    M = dst.shape[0]
+    cells = _i32(n_rows + 1, dev)
+    bucket_cnt, bucket_base, scan_tmp = _i32(1, dev), _i32(2, dev), _i32(2, dev)
+    zeros = torch.zeros(max(M, 1), dtype=torch.int32, device=dev)
+    L = lib()
+    with torch.cuda.device(dev):
+        _check(L.rgcn_dev_plan_count(_dp(dst), _dp(zeros), _dp(alive), c_i64(M), c_i64(n_rows), c_i32(1), c_i32(n_rows),
+                                     _dp(cells), _dp(bucket_cnt), _dp(bucket_base), _dp(scan_tmp), _stream(dev)),
+               "dev_plan_count")
+    m_pad = int(bucket_base[1].item())
+    p = CsrPlan()
+    p.n_rows = n_rows
+    p.rowptr = cells.clone()                      # exclusive offsets; the fill pass advances `cells` itself
+    p.rowptr[n_rows] = bucket_cnt[0]
+    p.src, pdst, p.rel = _i32(m_pad, dev), _i32(m_pad, dev), _i32(m_pad, dev)
+    p.val = torch.empty(max(m_pad, 1), dtype=torch.float32, device=dev)
+    chunk_rel, tile_ptr = _i32(m_pad // CHUNK, dev), _i32(2, dev)
+    with torch.cuda.device(dev):
+        _check(L.rgcn_dev_plan_fill(_dp(dst), _dp(src), _dp(zeros), _dp(val), _dp(alive), c_i64(M), c_i64(n_rows),
+                                    c_i64(n_rows), c_i32(1), c_i32(n_rows), _dp(cells), _dp(bucket_cnt), _dp(bucket_base),
+                                    _dp(p.src), _dp(pdst), _dp(p.val), None, _dp(chunk_rel), _dp(tile_ptr), None,
+                                    _dp(rel), _dp(p.rel), _stream(dev)), "dev_plan_fill")
+    return p
+
+
+def basis_aggregate(X, comps, csr, B, d, n_b_in):
+    _req(X, "features"); _req(comps, "comps")
+    out = torch.empty((csr.n_rows, B * d) if n_b_in == 1 else (csr.n_rows, d), device=X.device, dtype=torch.float32)
+    with torch.cuda.device(X.device), _timed("basis_aggregate"):
+        _check(lib().rgcn_basis_aggregate_f32(_dp(X), _dp(comps), _dp(out), _dp(csr.rowptr), _dp(csr.src), _dp(csr.rel),
+                                              _dp(csr.val), c_i64(csr.n_rows), c_i32(comps.shape[0]), c_i32(B), c_i32(d),
+                                              c_i32(n_b_in), _stream(X.device)), "basis_aggregate")
+    return out
+
+
+def basis_dcomps(X, D, csr, R, B, d):
+    _req(X, "features"); _req(D, "grad")
+    dc = torch.empty((R, B), device=X.device, dtype=torch.float32)
+    with torch.cuda.device(X.device), _timed("basis_dcomps"):
+        _check(lib().rgcn_basis_dcomps_f32(_dp(X), _dp(D), _dp(dc), _dp(csr.rowptr), _dp(csr.src), _dp(csr.rel),
+                                           _dp(csr.val), c_i64(csr.n_rows), c_i32(R), c_i32(B), c_i32(d),
+                                           _stream(X.device)), "basis_dcomps")
+    return dc
 
 
 def _req(t, name, dtype=torch.float32):

@@ -75,6 +75,51 @@ class _FeaturelessMP(torch.autograd.Function):
         return dT, db, None
 
 
+class _BasisMP(torch.autograd.Function):
+    """W_r = sum_b comps[r,b] bases[b] at large width: aggregate per basis, then one dense GEMM
+    (rocBLAS) -- never touches an R x d x d weight tensor (reference: layers.py:241-242, :468-469)."""
+
+    @staticmethod
+    def forward(ctx, X, bases, comps, bias, graph):
+        X, bases, comps = X.contiguous(), bases.contiguous(), comps.contiguous()
+        B, d_in, d_out = bases.shape
+        ag = _native.basis_aggregate(X, comps, graph.csr("fwd"), B, d_in, 1)          # [N, B*d_in]
+        flat = bases.view(B * d_in, d_out)
+        out = torch.addmm(bias, ag, flat) if bias is not None else ag @ flat
+        ctx.graph, ctx.has_bias = graph, bias is not None
+        ctx.save_for_backward(X, bases, comps, ag)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        X, bases, comps, ag = ctx.saved_tensors
+        B, d_in, d_out = bases.shape
+        g = g.contiguous()
+        flat = bases.view(B * d_in, d_out)
+        dX = dB = dC = db = None
+        d_ag = g @ flat.t()                                                            # [N, B*d_in]
+        if ctx.needs_input_grad[1]:
+            dB = (ag.t() @ g).view(B, d_in, d_out)
+        if ctx.needs_input_grad[0]:
+            dX = _native.basis_aggregate(d_ag, comps, ctx.graph.csr("bwd"), B, d_in, B)
+        if ctx.needs_input_grad[2]:
+            dC = _native.basis_dcomps(X, d_ag, ctx.graph.csr("fwd"), comps.shape[0], B, d_in)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = _native.colsum(g)
+        return dX, dB, dC, db, None
+
+
+def basis_mp(features, bases, comps, bias, graph):
+    return _BasisMP.apply(features, bases, comps, bias, graph)
+
+
+def use_basis_path(num_bases, d_in, d_out, graph):
+    """aggregate-then-contract pays when the per-message d_in x d_out product is large and B is small"""
+    if os.environ.get("RGCN_BASIS_PATH") == "0" or getattr(graph, "_dev", None) is None:
+        return False
+    return d_in * d_out >= 64 * 64 and num_bases <= 8
+
+
 def relational_mp(features, weights, bias, graph):
     """features [N, d_in], weights [R, d_in, d_out] (dense), bias [d_out] or None -> [N, d_out]"""
     return _RelationalMP.apply(features, weights, bias, graph)

@@ -93,6 +93,17 @@ class RelGraph:
         """relation-major (single tile): long runs per relation for the weight gradient"""
         return self._plan("fwd", max(self.num_nodes, 1), int(os.environ.get("RGCN_WGRAD_ITEM_CHUNKS", "64")))
 
+    def csr(self, kind):
+        """destination-major ("fwd": rows = subjects) or source-major ("bwd") CSR for the basis kernels"""
+        key = ("csr", kind)
+        if key not in self._plans:
+            if self._dev is None:
+                raise RuntimeError("the basis-aggregation path needs the device-side graph build")
+            s, p, o, val, alive = self._dev
+            dst, src = (s, o) if kind == "fwd" else (o, s)
+            self._plans[key] = _native.build_csr_device(dst, src, p, val, alive, self.num_nodes)
+        return self._plans[key]
+
     def selfloop_edges(self, self_rel):
         """(s, o, val) device tensors of the messages of one relation (used by the LP block-dropout branch)."""
         if self._dev is not None:

@@ -204,7 +204,11 @@ class RelationalGraphConvolutionNC(_RGCBase):
         else:
             _require_gpu(features, "features")
             assert features.size() == (N, in_dim), f"features {tuple(features.size())} vs ({N}, {in_dim})"
-            local = lambda x, b: F_.relational_mp(x, weights, b, graph)
+            if self.weight_decomp == 'basis' and not self.diag_weight_matrix and \
+                    F_.use_basis_path(self.num_bases, in_dim, out_dim, graph):
+                local = lambda x, b: F_.basis_mp(x, self.bases, self.comps, b, graph)
+            else:
+                local = lambda x, b: F_.relational_mp(x, weights, b, graph)
         group = getattr(self, "_shard_group", None)
         if group is None:
             output = local(features, self.bias)
@@ -298,7 +302,10 @@ class RelationalGraphConvolutionLP(_RGCBase):
         assert weights.size() == (R, in_dim, out_dim)
         assert features.size() == (N, in_dim)
 
-        output = F_.relational_mp(features, weights, self.bias, graph)
+        if self.weight_decomp == 'basis' and F_.use_basis_path(self.num_bases, in_dim, out_dim, graph):
+            output = F_.basis_mp(features, self.bases, self.comps, self.bias, graph)
+        else:
+            output = F_.relational_mp(features, weights, self.bias, graph)
         if self_drop is not None:
             msg = nn.functional.dropout(features @ self.blocks_self, p=self_drop, training=True)
             s, o, v = graph.selfloop_edges(R - 1)
