@@ -124,17 +124,19 @@ RGCN_API int rgcn_dev_edge_norm(const int32_t *s, const int32_t *p, const int32_
                                 void *stream);
 /* Relation-tile plan in two steps.  count: cells [n_tiles*R*tile_rows], bucket_cnt [n_tiles*R],
  * bucket_base [n_tiles*R + 1] (last entry = m_pad, which the host reads back to size the outputs),
- * scan_tmp [n_tiles*R/1024 + 2].  fill: same layout as rgcn_plan_fill_host (message order inside one
+ * scan_tmp [n_tiles*R/1024 + 2].  cells_tmp (may be NULL): a second cell table; with it and tile_rows > 1024
+ * (relation-major plan, CSR) the cells are scanned globally instead of one wave per bucket, and scan_tmp must
+ * hold n_cells/1024 + 3 ints.  n_chunks (fill) = m_pad / 16 as read back from bucket_base.  fill: same layout as rgcn_plan_fill_host (message order inside one
  * (relation, destination) cell is arbitrary). */
 RGCN_API int rgcn_dev_plan_count(const int32_t *dst, const int32_t *rel, const uint8_t *alive, int64_t M, int64_t n_dst,
                                  int32_t R, int32_t tile_rows, int32_t *cells, int32_t *bucket_cnt,
-                                 int32_t *bucket_base, int32_t *scan_tmp, void *stream);
+                                 int32_t *bucket_base, int32_t *scan_tmp, int32_t *cells_tmp, void *stream);
 RGCN_API int rgcn_dev_plan_fill(const int32_t *dst, const int32_t *src, const int32_t *rel, const float *val,
                                 const uint8_t *alive, int64_t M, int64_t n_dst, int64_t n_src, int32_t R,
                                 int32_t tile_rows, int32_t *cells, const int32_t *bucket_cnt,
                                 const int32_t *bucket_base, int32_t *p_src, int32_t *p_dst, float *p_val,
                                 int32_t *p_pack, int32_t *chunk_rel, int32_t *tile_ptr, int32_t *run_ptr,
-                                const int32_t *aux, int32_t *p_aux, void *stream);
+                                const int32_t *aux, int32_t *p_aux, int64_t n_chunks, void *stream);
 /* (aux / p_aux, may be NULL: one extra int32 per message carried into slot order -- with R = 1 and
  * tile_rows >= n_dst the plan degenerates to a destination-major CSR, aux = relation, and `cells` holds the
  * row pointers: that is the layout of the basis-aggregation kernels below.) */
@@ -149,10 +151,12 @@ RGCN_API int rgcn_basis_aggregate_f32(const float *X, const float *comps, float 
                                       const int32_t *p_src, const int32_t *p_rel, const float *p_val,
                                       int64_t n_rows, int32_t R, int32_t B, int32_t d, int32_t n_b_in,
                                       void *stream);
-/* dcomps[r, b] = sum_{e in r} val_e <X[src_e], D[dst_e, b, :]>   (D = d ag, rows of B*d). */
-RGCN_API int rgcn_basis_dcomps_f32(const float *X, const float *D, float *dcomps, const int32_t *rowptr,
-                                   const int32_t *p_src, const int32_t *p_rel, const float *p_val, int64_t n_rows,
-                                   int32_t R, int32_t B, int32_t d, void *stream);
+/* dcomps[r, b] = sum_{e in r} val_e <X[src_e], D[dst_e, b, :]>   (D = d ag, rows of B*d), over the work
+ * items of the relation-major plan (rgcn_plan_fill_host / rgcn_dev_plan_fill with tile_rows >= n_dst). */
+RGCN_API int rgcn_basis_dcomps_f32(const float *X, const float *D, float *dcomps, const int32_t *p_src,
+                                   const int32_t *p_dst, const float *p_val, const int32_t *chunk_rel,
+                                   const int32_t *items, int64_t n_items, int32_t R, int32_t B, int32_t d,
+                                   void *stream);
 
 /* ------------------------------------------------------------------ device kernels */
 

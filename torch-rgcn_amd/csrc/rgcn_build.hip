@@ -131,6 +131,38 @@ __global__ void bucket_scan_kernel(int *__restrict__ cells, long long n_buckets,
   }
 }
 
+// Few, very tall buckets (relation-major plan: T = N; CSR: one bucket): a wave per bucket would walk millions of
+// cells serially, so scan ALL cells at once (G) and take the bucket-local offsets as differences.
+__global__ void cells_from_global_scan_kernel(const int *__restrict__ G, int *__restrict__ cells, long long n_cells, int T) {
+  for (long long i = (long long)blockIdx.x * TB + threadIdx.x; i < n_cells; i += (long long)gridDim.x * TB)
+    cells[i] = G[i] - G[(i / T) * T];
+}
+__global__ void buckets_from_global_scan_kernel(const int *__restrict__ G, const int *__restrict__ total, long long n_buckets,
+                                                int T, int *__restrict__ bucket_cnt, int *__restrict__ bucket_pad) {
+  for (long long b = (long long)blockIdx.x * TB + threadIdx.x; b < n_buckets; b += (long long)gridDim.x * TB) {
+    const int end = b + 1 < n_buckets ? G[(b + 1) * T] : *total;
+    const int cnt = end - G[b * T];
+    bucket_cnt[b] = cnt;
+    bucket_pad[b] = (cnt + RGCN_CHUNK - 1) / RGCN_CHUNK * RGCN_CHUNK;
+  }
+}
+
+// chunk -> relation of its bucket (binary search over the bucket bases)
+__global__ void chunk_rel_kernel(const int *__restrict__ bucket_base, long long n_buckets, int R, long long n_chunks,
+                                 int *__restrict__ chunk_rel) {
+  for (long long c = (long long)blockIdx.x * TB + threadIdx.x; c < n_chunks; c += (long long)gridDim.x * TB) {
+    const int slot = (int)(c * RGCN_CHUNK);
+    long long lo = 0, hi = n_buckets;            // last bucket with base <= slot
+    while (hi - lo > 1) {
+      const long long mid = (lo + hi) >> 1;
+      if (bucket_base[mid] <= slot) lo = mid; else hi = mid;
+    }
+    // empty buckets share a base with the next non-empty one: move to the last bucket having this base
+    while (lo + 1 < n_buckets && bucket_base[lo + 1] <= slot) ++lo;
+    chunk_rel[c] = (int)(lo % R);
+  }
+}
+
 // exclusive scan of n ints, three launches: per-block (1024 items) scan + totals, scan of totals, add back
 __global__ __launch_bounds__(TB) void scan_blocks_kernel(const int *in, int *out, int *__restrict__ totals, long long n) {  // in may alias out
   __shared__ int wsum[TB / 64];
@@ -233,6 +265,7 @@ __global__ void plan_finish_kernel(long long n_buckets, int R, const int *__rest
       if (r == R - 1) run_ptr[t * (R + 1) + R] = bucket_base[b + 1] / RGCN_CHUNK;
     }
     const int cnt = bucket_cnt[b], end = bucket_base[b + 1];
+    (void)chunk_rel;
     if (!cnt) continue;
     const int last_src = p_src[base + cnt - 1];
     for (int q = base + cnt; q < end; ++q) {
@@ -241,7 +274,6 @@ __global__ void plan_finish_kernel(long long n_buckets, int R, const int *__rest
       p_val[q] = 0.f;
       if (p_pack) p_pack[q] = make_int2((int)((unsigned)last_src | (0xFFu << 24)), 0);
     }
-    for (int c = base / RGCN_CHUNK; c < end / RGCN_CHUNK; ++c) chunk_rel[c] = r;
   }
 }
 
@@ -296,7 +328,7 @@ extern "C" int rgcn_dev_edge_norm(const int32_t *s, const int32_t *p, const int3
 
 extern "C" int rgcn_dev_plan_count(const int32_t *dst, const int32_t *rel, const uint8_t *alive, int64_t M, int64_t n_dst,
                                    int32_t R, int32_t tile_rows, int32_t *cells, int32_t *bucket_cnt,
-                                   int32_t *bucket_base, int32_t *scan_tmp, void *stream) {
+                                   int32_t *bucket_base, int32_t *scan_tmp, int32_t *cells_tmp, void *stream) {
   if (M < 0 || n_dst <= 0 || R <= 0 || tile_rows <= 0 || !cells || !bucket_cnt || !bucket_base || !scan_tmp || (M && (!dst || !rel))) { rgcn_set_error("dev_plan_count: bad argument"); return RGCN_EINVAL; }
   const int64_t n_tiles = (n_dst + tile_rows - 1) / tile_rows, nbk = n_tiles * R;
   if (nbk * tile_rows >= (int64_t(1) << 40)) { rgcn_set_error("dev_plan_count: cell table too large"); return RGCN_EUNSUPPORTED; }
@@ -304,8 +336,20 @@ extern "C" int rgcn_dev_plan_count(const int32_t *dst, const int32_t *rel, const
   HIP_TRY(hipMemsetAsync(cells, 0, (size_t)nbk * tile_rows * sizeof(int), st));
   if (M) hipLaunchKernelGGL(cell_count_kernel, dim3(blocks_for(M)), dim3(TB), 0, st, dst, rel, alive, (long long)M, R, tile_rows, cells);
   // bucket_base doubles as the padded-size array before the scan
-  hipLaunchKernelGGL(bucket_scan_kernel, dim3(blocks_for(nbk * 64)), dim3(TB), 0, st, cells, (long long)nbk, tile_rows,
-                     bucket_cnt, bucket_base);
+  if (cells_tmp && tile_rows > 1024) {
+    // scan_tmp must then hold (n_cells / 1024 + 2) + 1 ints: block totals and the grand total
+    const long long n_cells = (long long)nbk * tile_rows;
+    int *total = scan_tmp + (n_cells / (TB * 4) + 2);
+    int rc = exclusive_scan(cells, cells_tmp, scan_tmp, n_cells, total, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(buckets_from_global_scan_kernel, dim3(blocks_for(nbk)), dim3(TB), 0, st, cells_tmp, total,
+                       (long long)nbk, tile_rows, bucket_cnt, bucket_base);
+    hipLaunchKernelGGL(cells_from_global_scan_kernel, dim3(blocks_for(n_cells)), dim3(TB), 0, st, cells_tmp, cells, n_cells,
+                       tile_rows);
+  } else {
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(blocks_for(nbk * 64)), dim3(TB), 0, st, cells, (long long)nbk, tile_rows,
+                       bucket_cnt, bucket_base);
+  }
   HIP_TRY(hipGetLastError());
   return exclusive_scan(bucket_base, bucket_base, scan_tmp, nbk, bucket_base + nbk, st);
 }
@@ -315,7 +359,7 @@ extern "C" int rgcn_dev_plan_fill(const int32_t *dst, const int32_t *src, const 
                                   int32_t tile_rows, int32_t *cells, const int32_t *bucket_cnt, const int32_t *bucket_base,
                                   int32_t *p_src, int32_t *p_dst, float *p_val, int32_t *p_pack, int32_t *chunk_rel,
                                   int32_t *tile_ptr, int32_t *run_ptr, const int32_t *aux, int32_t *p_aux,
-                                  void *stream) {
+                                  int64_t n_chunks, void *stream) {
   if (M < 0 || n_dst <= 0 || R <= 0 || tile_rows <= 0 || !cells || !bucket_cnt || !bucket_base || !tile_ptr ||
       (M && (!dst || !src || !rel || !val || !p_src || !p_dst || !p_val || !chunk_rel))) { rgcn_set_error("dev_plan_fill: bad argument"); return RGCN_EINVAL; }
   if (p_pack && (n_src >= (int64_t(1) << 24) || tile_rows > 255)) { rgcn_set_error("dev_plan_fill: packed slots need n_src < 2^24 and tile_rows <= 255"); return RGCN_EUNSUPPORTED; }
@@ -325,6 +369,9 @@ extern "C" int rgcn_dev_plan_fill(const int32_t *dst, const int32_t *src, const 
                             tile_rows, cells, bucket_base, p_src, p_dst, p_val, reinterpret_cast<int2 *>(p_pack), aux, p_aux);
   hipLaunchKernelGGL(plan_finish_kernel, dim3(blocks_for(nbk + 1)), dim3(TB), 0, st, (long long)nbk, R, bucket_cnt, bucket_base,
                      p_src, p_dst, p_val, reinterpret_cast<int2 *>(p_pack), chunk_rel, tile_ptr, run_ptr);
+  if (n_chunks > 0)
+    hipLaunchKernelGGL(chunk_rel_kernel, dim3(blocks_for(n_chunks)), dim3(TB), 0, st, bucket_base, (long long)nbk, R,
+                       (long long)n_chunks, chunk_rel);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
@@ -384,26 +431,48 @@ __global__ __launch_bounds__(TB) void basis_aggregate_kernel(
   }
 }
 
-// one wave per destination row; per message and basis a d-long dot product, wave-reduced, one atomic per (message, b)
+// Relation-major work items (chunk ranges of one relation, relation-major plan): per-lane partial sums over the
+// whole item, ONE wave reduction and one atomic per (item, basis) -- not per message.
 __global__ __launch_bounds__(TB) void basis_dcomps_kernel(
     const float *__restrict__ X, const float *__restrict__ D, float *__restrict__ dcomps,
-    const int *__restrict__ rowptr, const int *__restrict__ p_src, const int *__restrict__ p_rel,
-    const float *__restrict__ p_val, long long n_rows, int B, int d) {
+    const int *__restrict__ p_src, const int *__restrict__ p_dst, const float *__restrict__ p_val,
+    const int *__restrict__ chunk_rel, const int2 *__restrict__ items, int n_items, int B, int d) {
   const int lane = threadIdx.x & 63;
-  const long long wave0 = ((long long)blockIdx.x * TB + threadIdx.x) >> 6, nw = ((long long)gridDim.x * TB) >> 6;
-  for (long long row = wave0; row < n_rows; row += nw) {
-    const int e0 = rowptr[row], e1 = rowptr[row + 1];
-    for (int e = e0; e < e1; ++e) {
-      const float *x = X + (size_t)p_src[e] * d;
+  const int item = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
+  if (item >= n_items) return;
+  const int2 whole = items[item];
+  const int r = chunk_rel[whole.x];
+  // blockIdx.y = piece of the item (an item of the shared work list can hold 1024 messages: too long for one wave)
+  const int per = (whole.y - whole.x + (int)gridDim.y - 1) / (int)gridDim.y;
+  int2 range;
+  range.x = whole.x + (int)blockIdx.y * per;
+  range.y = min(whole.y, range.x + per);
+  if (range.x >= range.y) return;
+  for (int b0 = 0; b0 < B; b0 += 4) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int e = range.x * RGCN_CHUNK; e < range.y * RGCN_CHUNK; ++e) {
       const float v = p_val[e];
-      for (int b = 0; b < B; ++b) {
-        const float *dd = D + ((size_t)row * B + b) * d;
-        float a = 0.f;
-        for (int i = lane; i < d; i += 64) a += x[i] * dd[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
-        if (lane == 0) atomicAdd(&dcomps[(size_t)p_rel[e] * B + b], v * a);
+      if (v == 0.f) continue;                    // pad (uniform across the wave)
+      const float *x = X + (size_t)p_src[e] * d;
+      const float *dd = D + ((size_t)p_dst[e] * B + b0) * d;
+      for (int i = lane; i < d; i += 64) {
+        const float xv = v * x[i];
+        a0 += xv * dd[i];
+        if (b0 + 1 < B) a1 += xv * dd[(size_t)d + i];
+        if (b0 + 2 < B) a2 += xv * dd[2 * (size_t)d + i];
+        if (b0 + 3 < B) a3 += xv * dd[3 * (size_t)d + i];
       }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64);
+      a2 += __shfl_xor(a2, off, 64); a3 += __shfl_xor(a3, off, 64);
+    }
+    if (lane == 0) {
+      atomicAdd(&dcomps[(size_t)r * B + b0], a0);
+      if (b0 + 1 < B) atomicAdd(&dcomps[(size_t)r * B + b0 + 1], a1);
+      if (b0 + 2 < B) atomicAdd(&dcomps[(size_t)r * B + b0 + 2], a2);
+      if (b0 + 3 < B) atomicAdd(&dcomps[(size_t)r * B + b0 + 3], a3);
     }
   }
 }
@@ -422,15 +491,16 @@ extern "C" int rgcn_basis_aggregate_f32(const float *X, const float *comps, floa
   return RGCN_OK;
 }
 
-extern "C" int rgcn_basis_dcomps_f32(const float *X, const float *D, float *dcomps, const int32_t *rowptr,
-                                     const int32_t *p_src, const int32_t *p_rel, const float *p_val, int64_t n_rows,
-                                     int32_t R, int32_t B, int32_t d, void *stream) {
-  if (!X || !D || !dcomps || !rowptr || n_rows < 0 || R <= 0 || B <= 0 || d <= 0) { rgcn_set_error("basis_dcomps: bad argument"); return RGCN_EINVAL; }
+extern "C" int rgcn_basis_dcomps_f32(const float *X, const float *D, float *dcomps, const int32_t *p_src,
+                                     const int32_t *p_dst, const float *p_val, const int32_t *chunk_rel,
+                                     const int32_t *items, int64_t n_items, int32_t R, int32_t B, int32_t d,
+                                     void *stream) {
+  if (!X || !D || !dcomps || n_items < 0 || R <= 0 || B <= 0 || d <= 0) { rgcn_set_error("basis_dcomps: bad argument"); return RGCN_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(hipMemsetAsync(dcomps, 0, (size_t)R * B * sizeof(float), st));
-  if (!n_rows) return RGCN_OK;
-  hipLaunchKernelGGL(basis_dcomps_kernel, dim3(blocks_for(n_rows * 64)), dim3(TB), 0, st, X, D, dcomps, rowptr, p_src, p_rel,
-                     p_val, (long long)n_rows, B, d);
+  if (!n_items) return RGCN_OK;
+  hipLaunchKernelGGL(basis_dcomps_kernel, dim3((unsigned)((n_items + TB / 64 - 1) / (TB / 64)), 16), dim3(TB), 0, st, X, D, dcomps,
+                     p_src, p_dst, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), (int)n_items, B, d);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

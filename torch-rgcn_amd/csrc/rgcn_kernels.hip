@@ -786,26 +786,55 @@ __global__ __launch_bounds__(WG) void distmult_fwd_kernel(
   }
 }
 
+// Each wave walks 64 consecutive triples.  The relation gradient is accumulated in registers while the
+// predicate stays the same and flushed with one atomic per (run, feature): callers that sort the triples by
+// predicate (functional.py does) turn T*d contended atomics on R*d addresses into ~(T/64 + R)*d.
 __global__ __launch_bounds__(WG) void distmult_bwd_kernel(
     const long long *__restrict__ tr, long long T, const float *__restrict__ nodes, const float *__restrict__ rel,
     const float *__restrict__ gs, float *__restrict__ dnodes, float *__restrict__ drel, float *__restrict__ dsb,
     float *__restrict__ dpb, float *__restrict__ dob, int d) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long long wstride = (long long)gridDim.x * (WG / 64);
-  for (long long t = (long long)blockIdx.x * (WG / 64) + wave; t < T; t += wstride) {
-    const long long s = tr[3 * t], p = tr[3 * t + 1], o = tr[3 * t + 2];
-    const float g = gs[t];
-    const float *ns = nodes + (size_t)s * d, *rp = rel + (size_t)p * d, *no = nodes + (size_t)o * d;
-    for (int j = lane; j < d; j += 64) {
-      const float a = ns[j], b = rp[j], c = no[j];
-      atomicAdd(&dnodes[(size_t)s * d + j], g * b * c);
-      atomicAdd(&dnodes[(size_t)o * d + j], g * b * a);
-      atomicAdd(&drel[(size_t)p * d + j], g * a * c);
-    }
-    if (dsb && lane == 0) {
-      atomicAdd(&dsb[s], g);
-      atomicAdd(&dpb[p], g);
-      atomicAdd(&dob[o], g);
+  const long long wstride = (long long)gridDim.x * (WG / 64) * 64;
+  for (long long t0 = ((long long)blockIdx.x * (WG / 64) + wave) * 64; t0 < T; t0 += wstride) {
+    const long long t1 = min(T, t0 + 64);
+    for (int i0 = 0; i0 < d; i0 += 256) {                 // 4 features per lane and pass
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      long long cur = -1;
+      for (long long t = t0; t < t1; ++t) {
+        const long long s = tr[3 * t], p = tr[3 * t + 1], o = tr[3 * t + 2];
+        if (p != cur) {
+          if (cur >= 0)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int j = i0 + q * 64 + lane;
+              if (j < d) atomicAdd(&drel[(size_t)cur * d + j], acc[q]);
+              acc[q] = 0.f;
+            }
+          cur = p;
+        }
+        const float g = gs[t];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j = i0 + q * 64 + lane;
+          if (j < d) {
+            const float a = nodes[(size_t)s * d + j], b = rel[(size_t)p * d + j], c = nodes[(size_t)o * d + j];
+            atomicAdd(&dnodes[(size_t)s * d + j], g * b * c);
+            atomicAdd(&dnodes[(size_t)o * d + j], g * b * a);
+            acc[q] += g * a * c;
+          }
+        }
+        if (i0 == 0 && dsb && lane == 0) {
+          atomicAdd(&dsb[s], g);
+          atomicAdd(&dpb[p], g);
+          atomicAdd(&dob[o], g);
+        }
+      }
+      if (cur >= 0)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j = i0 + q * 64 + lane;
+          if (j < d) atomicAdd(&drel[(size_t)cur * d + j], acc[q]);
+        }
     }
   }
 }
@@ -1048,7 +1077,7 @@ extern "C" int rgcn_distmult_bwd_f32(const int64_t *triples, int64_t T, const fl
     HIP_TRY(hipMemsetAsync(dpbias, 0, (size_t)n_rel * sizeof(float), st));
   }
   if (T == 0) return RGCN_OK;
-  const unsigned gx = (unsigned)std::min<int64_t>((T + 3) / 4, 256 * 32);
+  const unsigned gx = (unsigned)std::min<int64_t>((T + 255) / 256, 256 * 32);
   hipLaunchKernelGGL(distmult_bwd_kernel, dim3(gx), dim3(WG), 0, st, reinterpret_cast<const long long *>(triples),
                      (long long)T, nodes, rel, gs, dnodes, drel, dsbias, dpbias, dobias, d);
   HIP_TRY(hipGetLastError());

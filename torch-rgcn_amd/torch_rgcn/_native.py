@@ -277,12 +277,15 @@ def build_plan_device(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_ro
     n_tiles = (n_dst + tile_rows - 1) // tile_rows
     nbk = n_tiles * num_rels
     cells = _i32(nbk * tile_rows, dev)
-    bucket_cnt, bucket_base, scan_tmp = _i32(nbk, dev), _i32(nbk + 1, dev), _i32(nbk // 1024 + 2, dev)
+    tall = tile_rows > 1024
+    cells_tmp = _i32(nbk * tile_rows, dev) if tall else None
+    bucket_cnt, bucket_base = _i32(nbk, dev), _i32(nbk + 1, dev)
+    scan_tmp = _i32(max(nbk, nbk * tile_rows if tall else 0) // 1024 + 4, dev)
     L = lib()
     with torch.cuda.device(dev):
         _check(L.rgcn_dev_plan_count(_dp(dst), _dp(rel), _dp(alive), c_i64(M), c_i64(n_dst), c_i32(num_rels),
                                      c_i32(tile_rows), _dp(cells), _dp(bucket_cnt), _dp(bucket_base), _dp(scan_tmp),
-                                     _stream(dev)), "dev_plan_count")
+                                     _dp(cells_tmp), _stream(dev)), "dev_plan_count")
     m_pad = int(bucket_base[nbk].item())        # the one host round trip: output sizes
     p = BuiltPlan()
     p.device = dev
@@ -299,7 +302,8 @@ def build_plan_device(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_ro
         _check(L.rgcn_dev_plan_fill(_dp(dst), _dp(src), _dp(rel), _dp(val), _dp(alive), c_i64(M), c_i64(n_dst),
                                     c_i64(n_src), c_i32(num_rels), c_i32(tile_rows), _dp(cells), _dp(bucket_cnt),
                                     _dp(bucket_base), _dp(p.src), _dp(p.dst), _dp(p.val), _dp(p.pack), _dp(p.chunk_rel),
-                                    _dp(p.tile_ptr), _dp(p.run_ptr), None, None, _stream(dev)), "dev_plan_fill")
+                                    _dp(p.tile_ptr), _dp(p.run_ptr), None, None, c_i64(p.n_chunks), _stream(dev)),
+               "dev_plan_fill")
     # work units (hub tiles split) and the relation-major work list are tiny: host side
     tp_host = p.tile_ptr[:n_tiles + 1].cpu().numpy()
     nu, ns = c_i64(0), c_i64(0)
@@ -329,14 +333,14 @@ class CsrPlan:
 def build_csr_device(dst, src, rel, val, alive, n_rows):
     dev = dst.device
     M = dst.shape[0]
-    cells = _i32(n_rows + 1, dev)
-    bucket_cnt, bucket_base, scan_tmp = _i32(1, dev), _i32(2, dev), _i32(2, dev)
+    cells, cells_tmp = _i32(n_rows + 1, dev), _i32(n_rows + 1, dev)
+    bucket_cnt, bucket_base, scan_tmp = _i32(1, dev), _i32(2, dev), _i32(n_rows // 1024 + 4, dev)
     zeros = torch.zeros(max(M, 1), dtype=torch.int32, device=dev)
     L = lib()
     with torch.cuda.device(dev):
         _check(L.rgcn_dev_plan_count(_dp(dst), _dp(zeros), _dp(alive), c_i64(M), c_i64(n_rows), c_i32(1), c_i32(n_rows),
-                                     _dp(cells), _dp(bucket_cnt), _dp(bucket_base), _dp(scan_tmp), _stream(dev)),
-               "dev_plan_count")
+                                     _dp(cells), _dp(bucket_cnt), _dp(bucket_base), _dp(scan_tmp), _dp(cells_tmp),
+                                     _stream(dev)), "dev_plan_count")
     m_pad = int(bucket_base[1].item())
     p = CsrPlan()
     p.n_rows = n_rows
@@ -349,7 +353,7 @@ def build_csr_device(dst, src, rel, val, alive, n_rows):
         _check(L.rgcn_dev_plan_fill(_dp(dst), _dp(src), _dp(zeros), _dp(val), _dp(alive), c_i64(M), c_i64(n_rows),
                                     c_i64(n_rows), c_i32(1), c_i32(n_rows), _dp(cells), _dp(bucket_cnt), _dp(bucket_base),
                                     _dp(p.src), _dp(pdst), _dp(p.val), None, _dp(chunk_rel), _dp(tile_ptr), None,
-                                    _dp(rel), _dp(p.rel), _stream(dev)), "dev_plan_fill")
+                                    _dp(rel), _dp(p.rel), c_i64(m_pad // CHUNK), _stream(dev)), "dev_plan_fill")
     return p
 
 
@@ -363,13 +367,14 @@ def basis_aggregate(X, comps, csr, B, d, n_b_in):
     return out
 
 
-def basis_dcomps(X, D, csr, R, B, d):
+def basis_dcomps(X, D, plan, R, B, d):
+    """plan: relation-major plan (graph.wgt_plan())"""
     _req(X, "features"); _req(D, "grad")
     dc = torch.empty((R, B), device=X.device, dtype=torch.float32)
     with torch.cuda.device(X.device), _timed("basis_dcomps"):
-        _check(lib().rgcn_basis_dcomps_f32(_dp(X), _dp(D), _dp(dc), _dp(csr.rowptr), _dp(csr.src), _dp(csr.rel),
-                                           _dp(csr.val), c_i64(csr.n_rows), c_i32(R), c_i32(B), c_i32(d),
-                                           _stream(X.device)), "basis_dcomps")
+        _check(lib().rgcn_basis_dcomps_f32(_dp(X), _dp(D), _dp(dc), _dp(plan.src), _dp(plan.dst), _dp(plan.val),
+                                           _dp(plan.chunk_rel), _dp(plan.items), c_i64(plan.n_items), c_i32(R), c_i32(B),
+                                           c_i32(d), _stream(X.device)), "basis_dcomps")
     return dc
 
 

@@ -103,7 +103,7 @@ class _BasisMP(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dX = _native.basis_aggregate(d_ag, comps, ctx.graph.csr("bwd"), B, d_in, B)
         if ctx.needs_input_grad[2]:
-            dC = _native.basis_dcomps(X, d_ag, ctx.graph.csr("fwd"), comps.shape[0], B, d_in)
+            dC = _native.basis_dcomps(X, d_ag, ctx.graph.wgt_plan(), comps.shape[0], B, d_in)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             db = _native.colsum(g)
         return dX, dB, dC, db, None
@@ -146,7 +146,10 @@ class _DistMultScore(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gs):
         tr, nodes, relations = ctx.saved_tensors
-        dn, dr, dsb, dpb, dob = _native.distmult_bwd(tr, nodes, relations, gs.reshape(-1).contiguous(), ctx.with_bias)
+        gs = gs.reshape(-1)
+        order = torch.argsort(tr[:, 1], stable=True)   # predicate runs -> relation gradient accumulates in registers
+        dn, dr, dsb, dpb, dob = _native.distmult_bwd(tr[order].contiguous(), nodes, relations, gs[order].contiguous(),
+                                                     ctx.with_bias)
         return None, dn, dr, dsb, dpb, dob
 
 
