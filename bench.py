@@ -44,11 +44,11 @@ PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_kernels.json")
 PMC_NOTE = ("profiles/r01_pmc_kernels.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/kbench.py "
             "on the same S1 launch; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE tallies 128-B requests "
             "at 64 B, MI355X_MICROARCH.md HBM section). Calibration on a known random-64B-row pattern "
-            "(profiles/r01_pmc_gather_probe_calibration.json) reads 1.0x, i.e. (FETCH+WRITE)*1024 = 1.48e9 B if row "
-            "requests are 64-B.")
+            "(profiles/r01_pmc_gather_probe_calibration.json) reads 1.0x: if the row gathers are 64-B requests the "
+            "HBM-side bytes are (FETCH_SIZE + WRITE_SIZE)*1024 (see traffic_if_64B_requests).")
 
 
-def pmc_traffic(kernel_substr):
+def pmc_traffic(kernel_substr, doubled=True):
     """HBM-side bytes per launch of a kernel from the committed PMC summary (None when absent)."""
     try:
         with open(PMC_FILE) as f:
@@ -57,7 +57,7 @@ def pmc_traffic(kernel_substr):
         return None
     for name, c in data.items():
         if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            return int((2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024)
+            return int(((2.0 if doubled else 1.0) * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024)
     return None
 
 
@@ -179,7 +179,8 @@ def main():
             ach = alg / (spmm_ms * 1e-3) / 1e9
             roof = {"kernel": "spmm_d16_kernel (forward and feature-gradient launches)", "bound": "hbm",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "traffic_source": PMC_NOTE if traffic else None, "avg_launch_ms": round(spmm_ms, 4), "launches_per_step": len(kern) / args.steps,
+                    "traffic": traffic, "traffic_if_64B_requests": pmc_traffic("spmm_d16_kernel", doubled=False),
+                    "traffic_source": PMC_NOTE if traffic else None, "avg_launch_ms": round(spmm_ms, 4), "launches_per_step": len(kern) / args.steps,
                     "algorithmic_bytes_per_launch": alg,
                     "other_kernels_ms": {k: round(float(np.mean(v)), 4) for k, v in prof.items() if k != "spmm"}}
         res = {"metric": METRIC, "value": world * E / (ms * 1e-3), "unit": "edges/s", "n_gpus": world,
