@@ -27,6 +27,11 @@ for p in (ROOT, os.path.join(ROOT, "torch-rgcn_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# This image exports NCCL_DEBUG=VERSION, which makes RCCL print a banner on STDOUT when the communicator is torn
+# down, i.e. after our result line.  The contract is "rank 0 prints ONE JSON line": keep it the last line.
+if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+    del os.environ["NCCL_DEBUG"]
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

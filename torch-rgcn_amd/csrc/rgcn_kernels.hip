@@ -865,8 +865,9 @@ extern "C" int rgcn_spmm_f32(const float *X, const float *W, const float *bias, 
   (void)n_src;
   (void)R;
   const int64_t n_tiles = n_units;   // one wave per work unit
+  // n_units may cover only a slab of the tiles (callers that overlap a collective with the remaining slabs)
   if (!X || !W || !out || (n_units && !units) || d_in <= 0 || d_out <= 0 || tile_rows <= 0 || n_dst < 0 ||
-      n_units < (n_dst + tile_rows - 1) / tile_rows || n_split < 0 || ((flags & RGCN_F_RELU) && n_split)) {
+      n_units < 0 || n_split < 0 || ((flags & RGCN_F_RELU) && n_split)) {
     rgcn_set_error("spmm: bad argument");
     return RGCN_EINVAL;
   }

@@ -210,6 +210,7 @@ class DevicePlan:
         self.run_ptr = None if hp.run_ptr is None else up(hp.run_ptr)
         self.pack = None if hp.pack is None else up(hp.pack)
         self.units = up(hp.units)
+        self.units_host = hp.units
         for k in ("n_dst", "n_src", "num_rels", "tile_rows", "n_tiles", "n_chunks", "m_pad", "n_items", "n_messages",
                   "n_units", "n_split", "max_run_chunks"):
             setattr(self, k, getattr(hp, k))
@@ -313,6 +314,7 @@ def build_plan_device(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_ro
     _check(L.rgcn_plan_units_host(_hp(tp_host), c_i64(n_tiles), c_i32(max_unit_chunks), _hp(units), ctypes.byref(nu),
                                   ctypes.byref(ns)), "plan_units")
     p.n_units, p.n_split = nu.value, ns.value
+    p.units_host = units
     p.units = torch.from_numpy(units).to(dev)
     p.max_run_chunks = int((int(bucket_cnt[:nbk].max().item()) + CHUNK - 1) // CHUNK) if nbk else 0
     if n_tiles == 1:   # relation-major plan: work items = chunk ranges of one relation, at most max_item_chunks long
@@ -400,24 +402,74 @@ def pack_w16(W):
     return Wp
 
 
-def spmm(X, W, bias, plan, relu=False):
-    """out[n_dst, d_out] = bias + sum_slots val * X[src] @ W[rel]"""
+def _spmm_launch(X, W, bias, plan, out, flags, u0, u1, n_split, tag):
+    R, d_in, d_out = plan.num_rels, X.shape[1], out.shape[1]
+    units = plan.units if u0 == 0 else plan.units[u0:]
+    with torch.cuda.device(X.device), _timed(tag):
+        _check(lib().rgcn_spmm_f32(_dp(X), _dp(W), _dp(bias), _dp(out), _dp(plan.src), _dp(plan.dst), _dp(plan.val),
+                                   _dp(plan.pack), _dp(plan.chunk_rel), _dp(units), c_i64(u1 - u0), c_i64(n_split),
+                                   c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i64(plan.n_src), c_i32(R), c_i32(d_in),
+                                   c_i32(d_out), c_i32(flags), _stream(X.device)), "spmm")
+
+
+def _spmm_prepare(X, W, bias, plan):
     _req(X, "features"); _req(W, "weights"); _req(bias, "bias")
     R, d_in, d_out = W.shape
     assert X.shape == (plan.n_src, d_in), f"features {tuple(X.shape)} vs ({plan.n_src}, {d_in})"
     assert R == plan.num_rels
-    out = torch.empty((plan.n_dst, d_out), device=X.device, dtype=torch.float32)
-    flags = F_RELU if (relu and not plan.n_split) else 0
-    relu_after = relu and plan.n_split
+    flags = 0
     if d_in == 16 and d_out == 16 and plan.pack is not None and not os.environ.get("RGCN_NO_PACK"):
         W = pack_w16(W)
         flags |= F_WPACKED
-    with torch.cuda.device(X.device), _timed("spmm"):
-        _check(lib().rgcn_spmm_f32(_dp(X), _dp(W), _dp(bias), _dp(out), _dp(plan.src), _dp(plan.dst), _dp(plan.val),
-                                   _dp(plan.pack), _dp(plan.chunk_rel), _dp(plan.units), c_i64(plan.n_units),
-                                   c_i64(plan.n_split), c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i64(plan.n_src),
-                                   c_i32(R), c_i32(d_in), c_i32(d_out), c_i32(flags), _stream(X.device)), "spmm")
-    return torch.relu_(out) if relu_after else out
+    return W, flags
+
+
+def spmm(X, W, bias, plan, relu=False):
+    """out[n_dst, d_out] = bias + sum_slots val * X[src] @ W[rel]"""
+    W, flags = _spmm_prepare(X, W, bias, plan)
+    out = torch.empty((plan.n_dst, W.shape[2] if W.dim() == 3 else 16), device=X.device, dtype=torch.float32)
+    if relu and not plan.n_split:
+        flags |= F_RELU
+    _spmm_launch(X, W, bias, plan, out, flags, 0, plan.n_units, plan.n_split, "spmm")
+    return torch.relu_(out) if (relu and plan.n_split) else out
+
+
+def slab_bounds(plan, n_slabs):
+    """Cut the work units into <= n_slabs contiguous groups of whole tiles with about equal chunk counts:
+    [(unit_begin, unit_end, row_begin, row_end)].  Cached on the plan."""
+    key = ("slabs", n_slabs)
+    cache = plan.__dict__.setdefault("_cache", {})
+    if key not in cache:
+        u = plan.units_host[:plan.n_units]
+        cum = np.cumsum(u[:, 2] - u[:, 1])
+        cuts = [0]
+        for k in range(1, n_slabs):
+            i = int(np.searchsorted(cum, cum[-1] * k / n_slabs)) if len(cum) else 0
+            while 0 < i < len(u) and u[i, 0] == u[i - 1, 0]:
+                i += 1                                     # never cut inside a split (hub) tile
+            if cuts[-1] < i < len(u):
+                cuts.append(i)
+        cuts.append(len(u))
+        out = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            r0 = int(u[a, 0]) * plan.tile_rows
+            r1 = plan.n_dst if b == len(u) else int(u[b, 0]) * plan.tile_rows
+            out.append((a, b, r0, r1))
+        cache[key] = out
+    return cache[key]
+
+
+def spmm_slabs(X, W, bias, plan, n_slabs, after_slab):
+    """spmm launched slab by slab (whole tiles); after_slab(out, row_begin, row_end) is called right after each
+    launch -- the relation-sharded layer starts an asynchronous all-reduce of those rows there, so the
+    collective of slab k overlaps the kernels of slab k+1."""
+    W, flags = _spmm_prepare(X, W, bias, plan)
+    alloc = torch.zeros if plan.n_split else torch.empty
+    out = alloc((plan.n_dst, W.shape[2] if W.dim() == 3 else 16), device=X.device, dtype=torch.float32)
+    for (u0, u1, r0, r1) in slab_bounds(plan, n_slabs):
+        _spmm_launch(X, W, bias, plan, out, flags, u0, u1, 0, "spmm_slab")
+        after_slab(out, r0, r1)
+    return out
 
 
 def wgrad(X, G, plan, num_rels):

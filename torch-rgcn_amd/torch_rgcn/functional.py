@@ -52,6 +52,57 @@ class _RelationalMP(torch.autograd.Function):
         return dX, dW, db, None
 
 
+class _ShardedRelationalMP(torch.autograd.Function):
+    """Relation shard of the featured layer with the collective overlapped: the output (and, in backward, the
+    feature gradient) is produced slab by slab and every finished slab is all-reduced asynchronously (RCCL
+    on its own stream) while the next slab's kernels run.  Features and upstream gradient are replicated;
+    rank 0 alone adds the bias (it is summed once)."""
+
+    @staticmethod
+    def forward(ctx, X, W, bias, graph, group, n_slabs):
+        import torch.distributed as dist
+        X, W = X.contiguous(), W.contiguous()
+        rank = dist.get_rank(group)
+        b = bias.contiguous() if (bias is not None and rank == 0) else None
+        works = []
+        out = _native.spmm_slabs(X, W, b, graph.fwd_plan(W.shape[2]), n_slabs,
+                                 lambda o, r0, r1: works.append(dist.all_reduce(o[r0:r1], group=group, async_op=True)))
+        for w in works:
+            w.wait()
+        ctx.graph, ctx.group, ctx.n_slabs, ctx.has_bias = graph, group, n_slabs, bias is not None
+        ctx.save_for_backward(X, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import torch.distributed as dist
+        X, W = ctx.saved_tensors
+        graph = ctx.graph
+        g = g.contiguous()
+        dX = dW = db = None
+        works = []
+        if ctx.needs_input_grad[0]:
+            Wt = W.transpose(1, 2).contiguous()
+            dX = _native.spmm_slabs(g, Wt, None, graph.bwd_plan(W.shape[1]), ctx.n_slabs,
+                                    lambda o, r0, r1: works.append(dist.all_reduce(o[r0:r1], group=ctx.group, async_op=True)))
+        if ctx.needs_input_grad[1]:   # owner-local: runs while the last slabs are still being reduced
+            fp = graph.fwd_plan(W.shape[2])
+            dense = fp.m_pad > 0 and fp.n_messages >= 0.5 * fp.m_pad
+            if W.shape[1] == 16 and W.shape[2] == 16 and fp.max_run_chunks <= 64 and dense:
+                dW = _native.wgrad_tiled(X, g, fp, W.shape[0], int(os.environ.get("RGCN_WGRAD_TILES", "4")))
+            else:
+                dW = _native.wgrad(X, g, graph.wgt_plan(), W.shape[0])
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _native.colsum(g)
+        for w in works:
+            w.wait()
+        return dX, dW, db, None, None, None
+
+
+def sharded_relational_mp(features, weights, bias, graph, group, n_slabs=4):
+    return _ShardedRelationalMP.apply(features, weights, bias, graph, group, n_slabs)
+
+
 class _FeaturelessMP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, bias, graph):

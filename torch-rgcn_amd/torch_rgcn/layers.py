@@ -15,6 +15,7 @@ the graph layout is cached (NC) instead of being rebuilt every forward; the dens
 R x N x d intermediates of the reference are never materialised for featured layers.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -212,6 +213,11 @@ class RelationalGraphConvolutionNC(_RGCBase):
         group = getattr(self, "_shard_group", None)
         if group is None:
             output = local(features, self.bias)
+        elif self.in_features is not None and os.environ.get("RGCN_DIST_SLABS", "2") != "0" and not (
+                self.weight_decomp == 'basis' and F_.use_basis_path(self.num_bases, in_dim, out_dim, graph)):
+            # relation-sharded, collective overlapped with the kernels slab by slab
+            output = F_.sharded_relational_mp(features, weights, self.bias, graph, group,
+                                              int(os.environ.get("RGCN_DIST_SLABS", "2")))
         else:  # relation-sharded: partial sums joined by an all-reduce, bias added once afterwards
             from .dist import sharded_apply
             output = sharded_apply(lambda x: local(x, None), features, group)
