@@ -166,3 +166,25 @@ def test_work_units_split_hub_tiles():
     assert hp.max_run_chunks >= 50
     # every tile appears (also empty ones)
     assert set(u[:, 0].tolist()) == set(range(hp.n_tiles))
+
+
+def test_slab_bounds_are_rank_independent():
+    """relation-sharded ranks hold different messages but must all-reduce identical row ranges"""
+    rng = np.random.default_rng(0)
+    N, R, T = 1000, 7, 64
+    rows = []
+    for seed, M in ((1, 3000), (2, 9000), (3, 50)):
+        r = np.random.default_rng(seed)
+        dst = r.integers(0, N, M).astype(np.int32)
+        if seed == 2:
+            dst[:4000] = 5   # a hub: this "rank" has a split tile
+        hp = nat.build_plan_host(dst, r.integers(0, N, M).astype(np.int32), r.integers(0, R, M).astype(np.int32),
+                                 np.ones(M, np.float32), N, N, R, T, max_unit_chunks=20)
+        b = nat.slab_bounds(hp, 3)
+        rows.append([(r0, r1) for _, _, r0, r1 in b])
+        # units of a slab are exactly the units of its tiles, in order, covering everything once
+        assert b[0][0] == 0 and b[-1][1] == hp.n_units and all(x[1] == y[0] for x, y in zip(b[:-1], b[1:]))
+        for u0, u1, r0, r1 in b:
+            t = hp.units[u0:u1, 0]
+            assert np.all(t * T >= r0) and np.all(t * T < r1)
+    assert rows[0] == rows[1] == rows[2] and rows[0][0][0] == 0 and rows[0][-1][1] == N

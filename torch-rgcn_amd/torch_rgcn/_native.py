@@ -145,7 +145,7 @@ def synthetic_triples_host(num_nodes, num_rels, num_edges, seed=0):
 
 class HostPlan:
     """Relation-tile plan as numpy arrays (see rgcn_plan_fill_host)."""
-    __slots__ = ("src", "dst", "val", "perm", "chunk_rel", "tile_ptr", "items", "run_ptr", "pack", "units", "n_units", "n_split", "max_run_chunks", "n_dst", "n_src", "num_rels",
+    __slots__ = ("src", "dst", "val", "perm", "chunk_rel", "tile_ptr", "items", "run_ptr", "pack", "units", "units_host", "_cache", "n_units", "n_split", "max_run_chunks", "n_dst", "n_src", "num_rels",
                  "tile_rows", "n_tiles", "n_chunks", "m_pad", "n_items", "n_messages")
 
 
@@ -185,6 +185,8 @@ def build_plan_host(dst, src, rel, val, n_dst, n_src, num_rels, tile_rows, max_i
                                   ctypes.byref(ns)), "plan_units")
     p.n_units, p.n_split = nu.value, ns.value
     p.units = np.zeros((max(p.n_units, 1), 4), np.int32)
+    p.units_host = p.units
+    p._cache = {}
     _check(L.rgcn_plan_units_host(_hp(p.tile_ptr), c_i64(p.n_tiles), c_i32(max_unit_chunks), _hp(p.units),
                                   ctypes.byref(nu), ctypes.byref(ns)), "plan_units")
     if p.n_chunks:
@@ -435,26 +437,21 @@ def spmm(X, W, bias, plan, relu=False):
 
 
 def slab_bounds(plan, n_slabs):
-    """Cut the work units into <= n_slabs contiguous groups of whole tiles with about equal chunk counts:
-    [(unit_begin, unit_end, row_begin, row_end)].  Cached on the plan."""
+    """Cut the destination tiles into <= n_slabs contiguous groups of EQUAL TILE COUNT:
+    [(unit_begin, unit_end, row_begin, row_end)].  The row boundaries depend only on (n_dst, tile_rows), so every
+    rank of a relation-sharded layer -- each with its own messages -- all-reduces identical row ranges."""
     key = ("slabs", n_slabs)
-    cache = plan.__dict__.setdefault("_cache", {})
+    if getattr(plan, "_cache", None) is None:
+        plan._cache = {}
+    cache = plan._cache
     if key not in cache:
         u = plan.units_host[:plan.n_units]
-        cum = np.cumsum(u[:, 2] - u[:, 1])
-        cuts = [0]
-        for k in range(1, n_slabs):
-            i = int(np.searchsorted(cum, cum[-1] * k / n_slabs)) if len(cum) else 0
-            while 0 < i < len(u) and u[i, 0] == u[i - 1, 0]:
-                i += 1                                     # never cut inside a split (hub) tile
-            if cuts[-1] < i < len(u):
-                cuts.append(i)
-        cuts.append(len(u))
+        tile_cuts = sorted({(plan.n_tiles * k) // n_slabs for k in range(n_slabs + 1)})
         out = []
-        for a, b in zip(cuts[:-1], cuts[1:]):
-            r0 = int(u[a, 0]) * plan.tile_rows
-            r1 = plan.n_dst if b == len(u) else int(u[b, 0]) * plan.tile_rows
-            out.append((a, b, r0, r1))
+        for ta, tb in zip(tile_cuts[:-1], tile_cuts[1:]):
+            a = int(np.searchsorted(u[:, 0], ta, side="left"))
+            b = int(np.searchsorted(u[:, 0], tb, side="left"))
+            out.append((a, b, ta * plan.tile_rows, min(plan.n_dst, tb * plan.tile_rows)))
         cache[key] = out
     return cache[key]
 
