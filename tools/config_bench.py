@@ -56,6 +56,25 @@ def nc_model(name, N, R0, E, nhid, ncls, decomp, labelled):
                       "params": sum(p.numel() for p in model.parameters())}), flush=True)
 
 
+def s2_featureless_basis():
+    """S1 with a featureless first layer (weight-table gather), basis B = 2."""
+    N, R0, E, d = 1_000_000, 50, 10_000_000, 16
+    T = _native.synthetic_triples_host(N, R0, E, 0)
+    tp = torch.from_numpy(_native.add_inverse_and_self_host(T, N, R0))
+    kw = dict(triples=tp, num_nodes=N, num_relations=2 * R0 + 1, out_features=d)
+    l1 = RelationalGraphConvolutionNC(in_features=None, vertical_stacking=False,
+                                      decomposition={"type": "basis", "num_bases": 2}, **kw).to(DEV)
+    l2 = RelationalGraphConvolutionNC(in_features=d, vertical_stacking=True, **kw).to(DEV)
+
+    def step():
+        for p in list(l1.parameters()) + list(l2.parameters()):
+            p.grad = None
+        l2(torch.relu(l1())).pow(2).mean().backward()
+    ms = timed(step, iters=5, warm=2)
+    print(json.dumps({"config": "S2: S1 graph, featureless layer 1 with basis B=2 (no R x N x 16 table is materialised), layer 2 16->16",
+                      "N": N, "R0": R0, "E": E, "ms_per_fwd_bwd": round(ms, 3), "edges_per_s": round(E / ms * 1e3)}), flush=True)
+
+
 def am_block_layers():
     N, R0, E, d = 1_666_764, 133, 5_988_321, 16
     T = _native.synthetic_triples_host(N, R0, E, 2)
@@ -109,7 +128,9 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     a = ap.parse_args()
-    todo = a.only.split(",") if a.only else ["aifb", "mutag", "am", "wn18"]
+    todo = a.only.split(",") if a.only else ["aifb", "mutag", "am", "wn18", "s2"]
+    if "s2" in todo:
+        s2_featureless_basis()
     if "aifb" in todo:
         nc_model("AIFB-shaped NodeClassifier (featureless L1, hidden 16, 4 classes)", 8285, 45, 29043, 16, 4, None, 176)
     if "mutag" in todo:

@@ -379,31 +379,40 @@ extern "C" int rgcn_dev_plan_fill(const int32_t *dst, const int32_t *src, const 
 // ------------------------------------------------------------------ basis decomposition, aggregate-then-contract
 namespace {
 
-// One wave per destination row.  NB_IN = 1: out[row][b][:] = sum_e comps[rel_e][b] * val_e * X[src_e][:]
-// NB_IN = B: out[row][:] = sum_e sum_b comps[rel_e][b] * val_e * X[src_e][b][:]
+// One wave per destination row; the wave is split into 64/lpr groups of lpr = min(64, pow2 >= d) lanes and every
+// group takes every (64/lpr)-th message of the row (narrow rows keep all lanes busy), reduced across groups at the end.
+// NB_IN = 1: out[row][b][:] = sum_e comps[rel_e][b] * val_e * X[src_e][:]
+// NB_IN = B: out[row][:]    = sum_e sum_b comps[rel_e][b] * val_e * X[src_e][b][:]
+__device__ __forceinline__ float group_sum(float a, int lpr) {   // sum over the lane groups; result valid in group 0
+  for (int off = lpr; off < 64; off <<= 1) a += __shfl_xor(a, off, 64);
+  return a;
+}
+
 __global__ __launch_bounds__(TB) void basis_aggregate_kernel(
     const float *__restrict__ X, const float *__restrict__ comps, float *__restrict__ out,
     const int *__restrict__ rowptr, const int *__restrict__ p_src, const int *__restrict__ p_rel,
-    const float *__restrict__ p_val, long long n_rows, int B, int d, int n_b_in) {
+    const float *__restrict__ p_val, long long n_rows, int B, int d, int n_b_in, int lpr) {
   const int lane = threadIdx.x & 63;
+  const int sub = lane / lpr, il = lane % lpr, ngrp = 64 / lpr;
   const long long wave0 = ((long long)blockIdx.x * TB + threadIdx.x) >> 6, nw = ((long long)gridDim.x * TB) >> 6;
   for (long long row = wave0; row < n_rows; row += nw) {
     const int e0 = rowptr[row], e1 = rowptr[row + 1];
-    if (n_b_in == 1) {
-      for (int i0 = 0; i0 < d; i0 += 64) {           // feature block of 64 per pass
-        const int i = i0 + lane;
+    for (int i0 = 0; i0 < d; i0 += lpr) {
+      const int i = i0 + il;
+      if (n_b_in == 1) {
         for (int b0 = 0; b0 < B; b0 += 4) {           // up to 4 bases per pass in registers
           float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-          for (int e = e0; e < e1; ++e) {
+          for (int e = e0 + sub; e < e1; e += ngrp) {
             const float x = i < d ? X[(size_t)p_src[e] * d + i] : 0.f;
-            const float v = p_val[e];
+            const float v = p_val[e] * x;
             const float *c = comps + (size_t)p_rel[e] * B + b0;
-            a0 += c[0] * v * x;
-            if (b0 + 1 < B) a1 += c[1] * v * x;
-            if (b0 + 2 < B) a2 += c[2] * v * x;
-            if (b0 + 3 < B) a3 += c[3] * v * x;
+            a0 += c[0] * v;
+            if (b0 + 1 < B) a1 += c[1] * v;
+            if (b0 + 2 < B) a2 += c[2] * v;
+            if (b0 + 3 < B) a3 += c[3] * v;
           }
-          if (i < d) {
+          a0 = group_sum(a0, lpr); a1 = group_sum(a1, lpr); a2 = group_sum(a2, lpr); a3 = group_sum(a3, lpr);
+          if (sub == 0 && i < d) {
             float *o = out + ((size_t)row * B + b0) * d + i;
             o[0] = a0;
             if (b0 + 1 < B) o[d] = a1;
@@ -411,33 +420,32 @@ __global__ __launch_bounds__(TB) void basis_aggregate_kernel(
             if (b0 + 3 < B) o[3 * (size_t)d] = a3;
           }
         }
-      }
-    } else {
-      for (int i0 = 0; i0 < d; i0 += 64) {
-        const int i = i0 + lane;
+      } else {
         float a = 0.f;
-        for (int e = e0; e < e1; ++e) {
-          const float v = p_val[e];
+        for (int e = e0 + sub; e < e1; e += ngrp) {
           const float *c = comps + (size_t)p_rel[e] * B;
           const float *x = X + (size_t)p_src[e] * B * d + i;
           float t = 0.f;
           if (i < d)
             for (int b = 0; b < B; ++b) t += c[b] * x[(size_t)b * d];
-          a += v * t;
+          a += p_val[e] * t;
         }
-        if (i < d) out[(size_t)row * d + i] = a;
+        a = group_sum(a, lpr);
+        if (sub == 0 && i < d) out[(size_t)row * d + i] = a;
       }
     }
   }
 }
 
 // Relation-major work items (chunk ranges of one relation, relation-major plan): per-lane partial sums over the
-// whole item, ONE wave reduction and one atomic per (item, basis) -- not per message.
+// whole item, ONE wave reduction and one atomic per (item piece, basis) -- not per message.  Lane groups of lpr
+// lanes take alternate slots so that narrow rows keep all 64 lanes busy.
 __global__ __launch_bounds__(TB) void basis_dcomps_kernel(
     const float *__restrict__ X, const float *__restrict__ D, float *__restrict__ dcomps,
     const int *__restrict__ p_src, const int *__restrict__ p_dst, const float *__restrict__ p_val,
-    const int *__restrict__ chunk_rel, const int2 *__restrict__ items, int n_items, int B, int d) {
+    const int *__restrict__ chunk_rel, const int2 *__restrict__ items, int n_items, int B, int d, int lpr) {
   const int lane = threadIdx.x & 63;
+  const int sub = lane / lpr, il = lane % lpr, ngrp = 64 / lpr;
   const int item = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
   if (item >= n_items) return;
   const int2 whole = items[item];
@@ -450,12 +458,12 @@ __global__ __launch_bounds__(TB) void basis_dcomps_kernel(
   if (range.x >= range.y) return;
   for (int b0 = 0; b0 < B; b0 += 4) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int e = range.x * RGCN_CHUNK; e < range.y * RGCN_CHUNK; ++e) {
+    for (int e = range.x * RGCN_CHUNK + sub; e < range.y * RGCN_CHUNK; e += ngrp) {
       const float v = p_val[e];
-      if (v == 0.f) continue;                    // pad (uniform across the wave)
+      if (v == 0.f) continue;                    // pad
       const float *x = X + (size_t)p_src[e] * d;
       const float *dd = D + ((size_t)p_dst[e] * B + b0) * d;
-      for (int i = lane; i < d; i += 64) {
+      for (int i = il; i < d; i += lpr) {
         const float xv = v * x[i];
         a0 += xv * dd[i];
         if (b0 + 1 < B) a1 += xv * dd[(size_t)d + i];
@@ -477,6 +485,12 @@ __global__ __launch_bounds__(TB) void basis_dcomps_kernel(
   }
 }
 
+int lanes_per_row(int d) {
+  int l = 1;
+  while (l < d && l < 64) l <<= 1;
+  return l;
+}
+
 }  // namespace
 
 extern "C" int rgcn_basis_aggregate_f32(const float *X, const float *comps, float *out, const int32_t *rowptr,
@@ -486,7 +500,7 @@ extern "C" int rgcn_basis_aggregate_f32(const float *X, const float *comps, floa
   if (!X || !comps || !out || !rowptr || n_rows < 0 || B <= 0 || d <= 0 || (n_b_in != 1 && n_b_in != B)) { rgcn_set_error("basis_aggregate: bad argument"); return RGCN_EINVAL; }
   if (!n_rows) return RGCN_OK;
   hipLaunchKernelGGL(basis_aggregate_kernel, dim3(blocks_for(n_rows * 64)), dim3(TB), 0, (hipStream_t)stream, X, comps, out,
-                     rowptr, p_src, p_rel, p_val, (long long)n_rows, B, d, n_b_in);
+                     rowptr, p_src, p_rel, p_val, (long long)n_rows, B, d, n_b_in, lanes_per_row(d));
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
@@ -500,7 +514,7 @@ extern "C" int rgcn_basis_dcomps_f32(const float *X, const float *D, float *dcom
   HIP_TRY(hipMemsetAsync(dcomps, 0, (size_t)R * B * sizeof(float), st));
   if (!n_items) return RGCN_OK;
   hipLaunchKernelGGL(basis_dcomps_kernel, dim3((unsigned)((n_items + TB / 64 - 1) / (TB / 64)), 16), dim3(TB), 0, st, X, D, dcomps,
-                     p_src, p_dst, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), (int)n_items, B, d);
+                     p_src, p_dst, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), (int)n_items, B, d, lanes_per_row(d));
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

@@ -371,12 +371,15 @@ def basis_aggregate(X, comps, csr, B, d, n_b_in):
     return out
 
 
-def basis_dcomps(X, D, plan, R, B, d):
-    """plan: relation-major plan (graph.wgt_plan())"""
+def basis_dcomps(X, D, plan, R, B, d, swap=False):
+    """dcomps[r,b] = sum_e val <X[src_e], D[dst_e, b]>; plan: relation-major plan (graph.wgt_plan()).
+    swap=True exchanges the roles of the two index arrays (featureless layers: X = grad rows by destination,
+    D = the basis table by source)."""
     _req(X, "features"); _req(D, "grad")
     dc = torch.empty((R, B), device=X.device, dtype=torch.float32)
+    a, b = (plan.dst, plan.src) if swap else (plan.src, plan.dst)
     with torch.cuda.device(X.device), _timed("basis_dcomps"):
-        _check(lib().rgcn_basis_dcomps_f32(_dp(X), _dp(D), _dp(dc), _dp(plan.src), _dp(plan.dst), _dp(plan.val),
+        _check(lib().rgcn_basis_dcomps_f32(_dp(X), _dp(D), _dp(dc), _dp(a), _dp(b), _dp(plan.val),
                                            _dp(plan.chunk_rel), _dp(plan.items), c_i64(plan.n_items), c_i32(R), c_i32(B),
                                            c_i32(d), _stream(X.device)), "basis_dcomps")
     return dc

@@ -190,9 +190,14 @@ class RelationalGraphConvolutionNC(_RGCBase):
         in_dim = N if self.in_features is None else self.in_features
         graph = self._graph_on(any_param.device)
 
+        fl_basis = (self.in_features is None and self.weight_decomp == 'basis' and not self.vertical_stacking and
+                    getattr(graph, "_dev", None) is not None and os.environ.get("RGCN_BASIS_PATH") != "0")
         if self.diag_weight_matrix:
             assert self.weights.size() == (R, in_dim)
             weights = torch.diag_embed(self.weights)           # W_r = diag(w_r)
+        elif fl_basis:
+            weights = None                                     # never materialise the R x N x d_out table
+            assert self.bases.size() == (self.num_bases, in_dim, out_dim) and self.comps.size() == (R, self.num_bases)
         else:
             weights = self._dense_weights()
             assert weights.size() == (R, in_dim, out_dim)
@@ -201,7 +206,10 @@ class RelationalGraphConvolutionNC(_RGCBase):
             if self.vertical_stacking:
                 raise RuntimeError("featureless message passing needs horizontal stacking "
                                    f"(mat1 and mat2 shapes cannot be multiplied: {R * N}x{N} and {R * N}x{out_dim})")
-            local = lambda _x, b: F_.featureless_mp(weights, b, graph)
+            if fl_basis:
+                local = lambda _x, b: F_.featureless_basis_mp(self.bases, self.comps, b, graph)
+            else:
+                local = lambda _x, b: F_.featureless_mp(weights, b, graph)
         else:
             _require_gpu(features, "features")
             assert features.size() == (N, in_dim), f"features {tuple(features.size())} vs ({N}, {in_dim})"
