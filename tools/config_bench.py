@@ -51,7 +51,29 @@ def nc_model(name, N, R0, E, nhid, ncls, decomp, labelled):
     torch.cuda.synchronize()
     build = time.time() - t0
     ms = timed(step)
+    # the same step captured in a hipGraph (static NC graph, static shapes): launch-bound at this size
+    ms_graph = None
+    try:
+        opt_g = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                opt_g.zero_grad(set_to_none=True)
+                torch.nn.functional.cross_entropy(model()[idx], y).backward()
+                opt_g.step()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        opt_g.zero_grad(set_to_none=True)
+        with torch.cuda.graph(g):
+            loss_g = torch.nn.functional.cross_entropy(model()[idx], y)
+            loss_g.backward()
+            opt_g.step()
+        ms_graph = timed(g.replay)
+    except Exception as exc:  # noqa: BLE001
+        ms_graph = f"capture failed: {type(exc).__name__}: {exc}"[:200]
     print(json.dumps({"config": name, "N": N, "R0": R0, "E": E, "ms_per_train_step": round(ms, 3),
+                      "ms_per_train_step_hipgraph": round(ms_graph, 3) if isinstance(ms_graph, float) else ms_graph,
                       "edges_per_s": round(E / ms * 1e3), "first_step_incl_graph_build_s": round(build, 2),
                       "params": sum(p.numel() for p in model.parameters())}), flush=True)
 
