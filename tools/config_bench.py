@@ -160,5 +160,8 @@ if __name__ == "__main__":
                  {"type": "basis", "num_bases": 30}, 340)
     if "am" in todo:
         am_block_layers()
+    if "amreal" in todo:
+        nc_model("AM-shaped NodeClassifier as shipped (featureless L1, basis 40, hidden 10, 11 classes)", 1666764, 133,
+                 5988321, 10, 11, {"type": "basis", "num_bases": 40}, 802)
     if "wn18" in todo:
         wn18_lp()
