@@ -573,58 +573,100 @@ __global__ __launch_bounds__(WG) void wgrad_tiled_d16_kernel(
     const int *__restrict__ p_src, const int *__restrict__ p_dst, const float *__restrict__ p_val,
     const int *__restrict__ chunk_rel, const int *__restrict__ run_ptr, int n_tiles, int R, int tiles_per_item,
     int n_groups, int n_items) {
-  __shared__ __attribute__((aligned(16))) float lds_all[(WG / 64) * (256 + 16)];
+  __shared__ __attribute__((aligned(16))) float lds_all[(WG / 64) * (512 + 64)];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int item = blockIdx.x * (WG / 64) + wave;
   if (item >= n_items) return;
   const int grp = item % n_groups, tb = item / n_groups;
   const int t0 = tb * tiles_per_item, t1 = min(n_tiles, t0 + tiles_per_item);
   const int r0 = grp * RG, r1 = min(R, r0 + RG);
-  float *xs = lds_all + wave * (256 + 16);                          // x scratch 16x16 | dst rows
-  int *dl = reinterpret_cast<int *>(xs + 256);
+  float *xs = lds_all + wave * (512 + 64);                          // 2 x scratch 16x16 | dst rows of U chunks
+  int *dl = reinterpret_cast<int *>(xs + 512);
   const int m = lane & 15, kq = lane >> 4;
   f32x4 acc[RG];
 #pragma unroll
   for (int i = 0; i < RG; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int t = t0; t < t1; ++t) {
-    const int cb = run_ptr[(size_t)t * (R + 1) + r0], ce = run_ptr[(size_t)t * (R + 1) + r1];
-    const int last = ce - 1;
-    for (int c0 = cb; c0 < ce; c0 += U) {
+  // The item's chunks live in (t1 - t0) separate runs of one or two chunks each.  Fetch all run bounds at once and
+  // walk the chunks as ONE flat sequence in groups of U: per item that is 1 + 2 * ceil(chunks / U) dependent memory
+  // latencies instead of 3 per tile.
+  constexpr int MAXT = 8;
+  int run_b[MAXT], run_n[MAXT], total = 0;
+  {
+    const int tl = min(lane, t1 - t0 - 1);
+    const int vb = run_ptr[(size_t)(t0 + tl) * (R + 1) + r0], ve = run_ptr[(size_t)(t0 + tl) * (R + 1) + r1];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int bb = __builtin_amdgcn_readlane(vb, t), ee = __builtin_amdgcn_readlane(ve, t);
+      run_b[t] = bb;
+      run_n[t] = (t < t1 - t0) ? ee - bb : 0;
+      total += run_n[t];
+    }
+  }
+  auto chunk_at = [&](int q) {   // q-th chunk of the item (wave-uniform); q >= total -> the last chunk
+    q = min(q, total - 1);
+    int c = run_b[0];
+    bool found = false;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      if (!found && q < run_n[t]) { c = run_b[t] + q; found = true; }
+      if (!found) q -= run_n[t];
+    }
+    return c;
+  };
+  if (total > 0) {
+    for (int q0 = 0; q0 < total; q0 += U) {
       int s[U], d[U], rr[U];
       float v[U];
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        const int cc = min(c0 + j, last);
+        const int cc = chunk_at(q0 + j);
         const int e = cc * RGCN_CHUNK + m;
         s[j] = p_src[e];
         d[j] = p_dst[e];
         const float vv = p_val[e];
-        v[j] = (c0 + j <= last) ? vv : 0.f;
-        rr[j] = chunk_rel[cc];
+        v[j] = (q0 + j < total) ? vv : 0.f;
+        rr[j] = (RG == 1) ? r0 : chunk_rel[cc];
       }
 #pragma unroll
       for (int j = 0; j < U; ++j) asm volatile("" : "+v"(s[j]), "+v"(d[j]), "+v"(v[j]), "+v"(rr[j]));
       __builtin_amdgcn_sched_barrier(0);
+      // destination rows into MFMA K-slot order (slot 4*t4 + kq for step t4) through the LDS scratch, for all U chunks
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < U; ++j)
+        if (kq == 0) dl[j * 16 + m] = d[j];
+      asm volatile("" ::: "memory");
+      int dmu[U][4];
+#pragma unroll
+      for (int j = 0; j < U; ++j)
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) dmu[j][t4] = dl[j * 16 + 4 * t4 + kq];
+      __builtin_amdgcn_sched_barrier(0);
+      // all loads of the group in flight together: U random X row gathers + 4U tile-local G operand loads (L1/L2)
       float4 x[U];
+      float gl[U][4];
 #pragma unroll
       for (int j = 0; j < U; ++j) x[j] = *reinterpret_cast<const float4 *>(X + (size_t)s[j] * 16 + 4 * kq);
+#pragma unroll
+      for (int j = 0; j < U; ++j)
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) gl[j][t4] = G[(size_t)max(dmu[j][t4], 0) * 16 + m];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < U; ++j) {
         const bool live = v[j] != 0.f;
         const f32x4 xv = {live ? x[j].x * v[j] : 0.f, live ? x[j].y * v[j] : 0.f, live ? x[j].z * v[j] : 0.f,
                           live ? x[j].w * v[j] : 0.f};
+        float *xj = xs + (j & 1) * 256;                              // two scratch tiles: no wait on the previous chunk's reads
         asm volatile("" ::: "memory");   // LDS written as vectors, read as scalars: no compiler reordering
-        *reinterpret_cast<f32x4 *>(xs + m * 16 + 4 * kq) = xv;      // xs[slot m][4kq..4kq+3]
-        if (kq == 0) dl[m] = d[j];
+        *reinterpret_cast<f32x4 *>(xj + m * 16 + 4 * kq) = xv;      // xs[slot m][4kq..4kq+3]
         asm volatile("" ::: "memory");
         float av[4], bv[4];
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
           const int mu = 4 * t4 + kq;                                // message carried by K-slot kq at step t4
-          av[t4] = xs[mu * 16 + m];                                  // A[i = m][k] = val * X[src_mu][m]
-          const int dmu = dl[mu];                                    // pads: dst = -1 (their A column is 0)
-          bv[t4] = dmu < 0 ? 0.f : G[(size_t)dmu * 16 + m];          // B[k][j = m] = G[dst_mu][m]  (L1/L2)
+          av[t4] = xj[mu * 16 + m];                                  // A[i = m][k] = val * X[src_mu][m]
+          bv[t4] = dmu[j][t4] < 0 ? 0.f : gl[j][t4];                 // B[k][j = m] = G[dst_mu][m]; pads: dst = -1
         }
         const int rho = __builtin_amdgcn_readfirstlane(rr[j]) - r0;
 #define RGCN_ACC_CASE(N)                                                                       \
@@ -636,11 +678,18 @@ __global__ __launch_bounds__(WG) void wgrad_tiled_d16_kernel(
       acc[N < RG ? N : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc[N < RG ? N : 0], 0, 0, 0); \
     }                                                                                          \
     break;
-        switch (rho) {
-          RGCN_ACC_CASE(0) RGCN_ACC_CASE(1) RGCN_ACC_CASE(2) RGCN_ACC_CASE(3) RGCN_ACC_CASE(4) RGCN_ACC_CASE(5)
-          RGCN_ACC_CASE(6) RGCN_ACC_CASE(7) RGCN_ACC_CASE(8) RGCN_ACC_CASE(9) RGCN_ACC_CASE(10) RGCN_ACC_CASE(11)
-          RGCN_ACC_CASE(12) RGCN_ACC_CASE(13) RGCN_ACC_CASE(14) RGCN_ACC_CASE(15)
-          default: break;
+        if (RG == 1) {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc[0], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc[0], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc[0], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc[0], 0, 0, 0);
+        } else {
+          switch (rho) {
+            RGCN_ACC_CASE(0) RGCN_ACC_CASE(1) RGCN_ACC_CASE(2) RGCN_ACC_CASE(3) RGCN_ACC_CASE(4) RGCN_ACC_CASE(5)
+            RGCN_ACC_CASE(6) RGCN_ACC_CASE(7) RGCN_ACC_CASE(8) RGCN_ACC_CASE(9) RGCN_ACC_CASE(10) RGCN_ACC_CASE(11)
+            RGCN_ACC_CASE(12) RGCN_ACC_CASE(13) RGCN_ACC_CASE(14) RGCN_ACC_CASE(15)
+            default: break;
+          }
         }
 #undef RGCN_ACC_CASE
       }
@@ -979,6 +1028,7 @@ extern "C" int rgcn_wgrad_tiled_f32(const float *X, const float *G, float *dW, c
   static const int USEL = getenv("RGCN_WGRAD_U") ? atoi(getenv("RGCN_WGRAD_U")) : 2;
   const int RGv = RGSEL <= 1 ? 1 : RGSEL <= 2 ? 2 : RGSEL <= 4 ? 4 : RGSEL <= 8 ? 8 : 16;
   const int n_groups = (R + RGv - 1) / RGv;
+  tiles_per_item = std::min(tiles_per_item, 8);   // the kernel keeps the run bounds of one item in registers
   const int64_t n_items = ((n_tiles + tiles_per_item - 1) / tiles_per_item) * n_groups;
   const unsigned gx = (unsigned)((n_items + WG / 64 - 1) / (WG / 64));
 #define RGCN_LAUNCH_WT(RGC, UC)                                                                                    \
