@@ -66,6 +66,22 @@ def pmc_traffic(kernel_substr, doubled=True):
     return None
 
 
+def pmc_detail(kernel_key):
+    """fabric request counters / MFMA busy of a kernel from profiles/r01_pmc_detail.json (None when absent)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_detail.json")) as f:
+            c = json.load(f)[kernel_key]
+        return {"fabric_read_requests": int(c["TCC_EA0_RDREQ_sum"]),
+                "share_of_128B_requests": round(c["TCC_EA0_RDREQ_128B_sum"] / c["TCC_EA0_RDREQ_sum"], 4),
+                "l2_hit_rate": round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3),
+                "mfma_busy_frac": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * 1024), 4),
+                "note": "profiles/r01_pmc_detail.json (tools/pmc_passes.sh): every 64-B row gather is a 128-B fabric request "
+                        "(profiles/r01_gather_probe2.txt), so traffic ~ 1.75x the algorithmic bytes is the floor of this "
+                        "access pattern, not re-reads"}
+    except (OSError, KeyError, ZeroDivisionError):
+        return None
+
+
 def build_layers(N, R0, E, d, seed, device, group):
     from torch_rgcn import _native
     from torch_rgcn.dist import shard_layer
@@ -185,7 +201,8 @@ def main():
             roof = {"kernel": "spmm_d16_kernel (forward and feature-gradient launches)", "bound": "hbm",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "traffic_if_64B_requests": pmc_traffic("spmm_d16_kernel", doubled=False),
-                    "traffic_source": PMC_NOTE if traffic else None, "avg_launch_ms": round(spmm_ms, 4), "launches_per_step": len(kern) / args.steps,
+                    "traffic_rate_GBs": round(traffic / (spmm_ms * 1e-3) / 1e9, 1) if traffic else None,
+                    "traffic_source": PMC_NOTE if traffic else None, "pmc": pmc_detail("spmm"), "avg_launch_ms": round(spmm_ms, 4), "launches_per_step": len(kern) / args.steps,
                     "algorithmic_bytes_per_launch": alg,
                     "other_kernels_ms": {k: round(float(np.mean(v)), 4) for k, v in prof.items() if k != "spmm"}}
         res = {"metric": METRIC, "value": world * E / (ms * 1e-3), "unit": "edges/s", "n_gpus": world,
