@@ -136,8 +136,10 @@ RGCN_API int rgcn_dev_plan_fill(const int32_t *dst, const int32_t *src, const in
                                 int32_t tile_rows, int32_t *cells, const int32_t *bucket_cnt,
                                 const int32_t *bucket_base, int32_t *p_src, int32_t *p_dst, float *p_val,
                                 int32_t *p_pack, int32_t *chunk_rel, int32_t *tile_ptr, int32_t *run_ptr,
-                                const int32_t *aux, int32_t *p_aux, int64_t n_chunks, void *stream);
-/* (aux / p_aux, may be NULL: one extra int32 per message carried into slot order -- with R = 1 and
+                                const int32_t *aux, int32_t *p_aux, int32_t *msg_slot, int64_t n_chunks,
+                                void *stream);
+/* (msg_slot, may be NULL: slot index of every input message.)
+ * (aux / p_aux, may be NULL: one extra int32 per message carried into slot order -- with R = 1 and
  * tile_rows >= n_dst the plan degenerates to a destination-major CSR, aux = relation, and `cells` holds the
  * row pointers: that is the layout of the basis-aggregation kernels below.) */
 
@@ -178,6 +180,18 @@ RGCN_API int rgcn_spmm_f32(const float *X, const float *W, const float *bias, fl
 /* Wp[r][16k+o][c] = W[r][4k+c][o]: the per-lane float4 the hidden-16 kernel feeds to the matrix cores
  * (weight assembly step of layers.py:239-244, device side).  W, Wp: [R,16,16]. */
 RGCN_API int rgcn_pack_w16_f32(const float *W, float *Wp, int32_t R, void *stream);
+
+/* Sparse-bucket variant of rgcn_spmm_f32 for d_in = d_out = 16 (graphs with many relations per tile, e.g. AM:
+ * (tile, relation) buckets of a few messages would leave the 16-slot chunks mostly empty).  Two passes:
+ *   1. relation-major plan (dense chunks): Y[pos[slot], :] = val * X[src,:] @ W[rel]   -- rgcn_spmm_scatter_f32
+ *      (p_pos = position of the message in destination-major order; Wp packed by rgcn_pack_w16_f32)
+ *   2. out[row,:] = bias + sum_{j in rowptr[row] .. rowptr[row+1]} Y[j,:]              -- rgcn_segment_sum_f32
+ * Y is a [n_messages, 16] scratch the caller provides. */
+RGCN_API int rgcn_spmm_scatter_f32(const float *X, const float *Wp, float *Y, const int32_t *p_src,
+                                   const float *p_val, const int32_t *p_pos, const int32_t *chunk_rel,
+                                   const int32_t *items, int64_t n_items, int32_t d, void *stream);
+RGCN_API int rgcn_segment_sum_f32(const float *Y, const int32_t *rowptr, const float *bias, float *out,
+                                  int64_t n_rows, int32_t d, int32_t flags, void *stream);
 
 /* dW[rel] += sum over slots val * X[src,:]^T G[dst,:]  for every work item; dW
  * ([R, d_in, d_out]) is zeroed first.  Autograd dual of the einsum / sparse mm pair

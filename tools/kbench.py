@@ -73,6 +73,16 @@ if "wgradtile" in a.what:
     plan = g.fwd_plan(d)
     med, mn = timeit(lambda: _native.wgrad(X, G, plan, R), a.iters)
     print(f"[{tag}] wgrad(tile-major plan) items={plan.n_items} med {med:.3f} ms min {mn:.3f} ms", flush=True)
+if "twopass" in a.what:
+    sp, csr = g.scatter_plan("fwd"), g.csr("fwd")
+    ref = _native.spmm(X, W, b, g.fwd_plan(d))
+    got = _native.spmm_two_pass(X, W, b, sp, csr)
+    err = ((got - ref).abs().max() / ref.abs().max()).item()
+    _native.profile_start()
+    med, mn = timeit(lambda: _native.spmm_two_pass(X, W, b, sp, csr), a.iters)
+    prof = _native.profile_stop()
+    print(f"[{tag}] spmm_two_pass relerr={err:.2e} items={sp.n_items} med {med:.3f} ms min {mn:.3f} ms; "
+          + " ".join(f"{k} {np.median(v):.3f}" for k, v in prof.items()), flush=True)
 if "wtiled" in a.what:
     plan = g.fwd_plan(d)
     tpi = int(os.environ.get("RGCN_WGRAD_TILES", "4"))

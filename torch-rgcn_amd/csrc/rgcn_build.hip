@@ -232,7 +232,8 @@ __global__ void plan_scatter_kernel(const int *__restrict__ dst, const int *__re
                                     const float *__restrict__ val, const unsigned char *__restrict__ alive, long long M,
                                     int R, int T, int *__restrict__ cells, const int *__restrict__ bucket_base,
                                     int *__restrict__ p_src, int *__restrict__ p_dst, float *__restrict__ p_val,
-                                    int2 *__restrict__ p_pack, const int *__restrict__ aux, int *__restrict__ p_aux) {
+                                    int2 *__restrict__ p_pack, const int *__restrict__ aux, int *__restrict__ p_aux,
+                                    int *__restrict__ msg_slot) {
   for (long long e = (long long)blockIdx.x * TB + threadIdx.x; e < M; e += (long long)gridDim.x * TB) {
     if (alive && !alive[e]) continue;
     const int d = dst[e], r = rel[e];
@@ -243,6 +244,7 @@ __global__ void plan_scatter_kernel(const int *__restrict__ dst, const int *__re
     p_val[pos] = val[e];
     if (p_pack) p_pack[pos] = make_int2((int)((unsigned)src[e] | ((unsigned)(d % T) << 24)), __builtin_bit_cast(int, val[e]));
     if (p_aux) p_aux[pos] = aux[e];
+    if (msg_slot) msg_slot[e] = pos;
   }
 }
 
@@ -359,14 +361,15 @@ extern "C" int rgcn_dev_plan_fill(const int32_t *dst, const int32_t *src, const 
                                   int32_t tile_rows, int32_t *cells, const int32_t *bucket_cnt, const int32_t *bucket_base,
                                   int32_t *p_src, int32_t *p_dst, float *p_val, int32_t *p_pack, int32_t *chunk_rel,
                                   int32_t *tile_ptr, int32_t *run_ptr, const int32_t *aux, int32_t *p_aux,
-                                  int64_t n_chunks, void *stream) {
+                                  int32_t *msg_slot, int64_t n_chunks, void *stream) {
   if (M < 0 || n_dst <= 0 || R <= 0 || tile_rows <= 0 || !cells || !bucket_cnt || !bucket_base || !tile_ptr ||
       (M && (!dst || !src || !rel || !val || !p_src || !p_dst || !p_val || !chunk_rel))) { rgcn_set_error("dev_plan_fill: bad argument"); return RGCN_EINVAL; }
   if (p_pack && (n_src >= (int64_t(1) << 24) || tile_rows > 255)) { rgcn_set_error("dev_plan_fill: packed slots need n_src < 2^24 and tile_rows <= 255"); return RGCN_EUNSUPPORTED; }
   const int64_t n_tiles = (n_dst + tile_rows - 1) / tile_rows, nbk = n_tiles * R;
   hipStream_t st = (hipStream_t)stream;
   if (M) hipLaunchKernelGGL(plan_scatter_kernel, dim3(blocks_for(M)), dim3(TB), 0, st, dst, src, rel, val, alive, (long long)M, R,
-                            tile_rows, cells, bucket_base, p_src, p_dst, p_val, reinterpret_cast<int2 *>(p_pack), aux, p_aux);
+                            tile_rows, cells, bucket_base, p_src, p_dst, p_val, reinterpret_cast<int2 *>(p_pack), aux, p_aux,
+                            msg_slot);
   hipLaunchKernelGGL(plan_finish_kernel, dim3(blocks_for(nbk + 1)), dim3(TB), 0, st, (long long)nbk, R, bucket_cnt, bucket_base,
                      p_src, p_dst, p_val, reinterpret_cast<int2 *>(p_pack), chunk_rel, tile_ptr, run_ptr);
   if (n_chunks > 0)

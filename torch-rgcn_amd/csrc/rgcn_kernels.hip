@@ -351,6 +351,74 @@ __global__ __launch_bounds__(WG) void spmm_d16_staged_kernel(
   }
 }
 
+// ---- sparse-bucket path, pass 1: relation-major chunks (dense), transformed messages scattered to their slot in
+// destination-major order.  One wave per work item (<= 64 chunks of ONE relation): the W fragment is loaded once.
+template <int U>
+__global__ __launch_bounds__(WG) void spmm_scatter_d16_kernel(
+    const float *__restrict__ X, const float *__restrict__ Wp, float *__restrict__ Y, const int *__restrict__ p_src,
+    const float *__restrict__ p_val, const int *__restrict__ p_pos, const int *__restrict__ chunk_rel,
+    const int2 *__restrict__ items, int n_items) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int item = blockIdx.x * (WG / 64) + wave;
+  if (item >= n_items) return;
+  const int2 range = items[item];
+  const int r = __builtin_amdgcn_readfirstlane(chunk_rel[range.x]);
+  const int m = lane & 15, k = lane >> 4;
+  const float4 w = reinterpret_cast<const float4 *>(Wp)[(size_t)r * 64 + lane];
+  const int last = range.y - 1;
+  for (int c = range.x; c < range.y; c += U) {
+    int s[U], pos[U];
+    float v[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int cc = min(c + j, last);
+      const int e = cc * RGCN_CHUNK + m;
+      s[j] = p_src[e];
+      pos[j] = p_pos[e];
+      const float vv = p_val[e];
+      v[j] = (c + j <= last) ? vv : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) asm volatile("" : "+v"(s[j]), "+v"(pos[j]), "+v"(v[j]));
+    __builtin_amdgcn_sched_barrier(0);
+    float4 x[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) x[j] = *reinterpret_cast<const float4 *>(X + (size_t)s[j] * 16 + 4 * k);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const float vv = v[j];
+      const bool live = vv != 0.f;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, live ? x[j].x * vv : 0.f, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, live ? x[j].y * vv : 0.f, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, live ? x[j].z * vv : 0.f, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, live ? x[j].w * vv : 0.f, acc, 0, 0, 0);
+      if (live) *reinterpret_cast<f32x4 *>(Y + (size_t)pos[j] * 16 + 4 * k) = acc;   // lane 16q+m: features 4q..4q+3 of slot m
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ---- pass 2: out[row] = bias + sum of the row's (contiguous) transformed messages.  4 lanes per row (16 B each).
+__global__ __launch_bounds__(WG) void segment_sum_d16_kernel(const float *__restrict__ Y, const int *__restrict__ rowptr,
+                                                             const float *__restrict__ bias, float *__restrict__ out,
+                                                             long long n_rows, int relu_out) {
+  const int q = threadIdx.x & 3;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) bv = reinterpret_cast<const float4 *>(bias)[q];
+  for (long long row = ((long long)blockIdx.x * WG + threadIdx.x) >> 2; row < n_rows; row += ((long long)gridDim.x * WG) >> 2) {
+    const int e0 = rowptr[row], e1 = rowptr[row + 1];
+    float4 a = bv;
+    for (int e = e0; e < e1; ++e) {
+      const float4 y = *reinterpret_cast<const float4 *>(Y + (size_t)e * 16 + 4 * q);
+      a.x += y.x; a.y += y.y; a.z += y.z; a.w += y.w;
+    }
+    if (relu_out) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+    *reinterpret_cast<float4 *>(out + (size_t)row * 16 + 4 * q) = a;
+  }
+}
+
 // ---- any d_in / d_out.  NJT = 16-wide output column tiles kept in accumulators per pass over d_in;
 // the LDS tile rows are padded to ldt = round_up(d_out, 4) floats so every update is one aligned b128.
 template <int NJT>
@@ -976,6 +1044,31 @@ extern "C" int rgcn_spmm_f32(const float *X, const float *W, const float *bias, 
   }
 #undef RGCN_LAUNCH_GENERIC
 #undef RGCN_LAUNCH_D16
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_spmm_scatter_f32(const float *X, const float *Wp, float *Y, const int32_t *p_src, const float *p_val,
+                                     const int32_t *p_pos, const int32_t *chunk_rel, const int32_t *items,
+                                     int64_t n_items, int32_t d, void *stream) {
+  if (!X || !Wp || !Y || n_items < 0 || (n_items && (!p_src || !p_val || !p_pos || !chunk_rel || !items))) { rgcn_set_error("spmm_scatter: bad argument"); return RGCN_EINVAL; }
+  if (d != 16) { rgcn_set_error("spmm_scatter: only d = 16"); return RGCN_EUNSUPPORTED; }
+  if (!n_items) return RGCN_OK;
+  hipLaunchKernelGGL(spmm_scatter_d16_kernel<4>, dim3((unsigned)((n_items + WG / 64 - 1) / (WG / 64))), dim3(WG), 0,
+                     (hipStream_t)stream, X, Wp, Y, p_src, p_val, p_pos, chunk_rel, reinterpret_cast<const int2 *>(items),
+                     (int)n_items);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_segment_sum_f32(const float *Y, const int32_t *rowptr, const float *bias, float *out, int64_t n_rows,
+                                    int32_t d, int32_t flags, void *stream) {
+  if (!Y || !rowptr || !out || n_rows < 0) { rgcn_set_error("segment_sum: bad argument"); return RGCN_EINVAL; }
+  if (d != 16) { rgcn_set_error("segment_sum: only d = 16"); return RGCN_EUNSUPPORTED; }
+  if (!n_rows) return RGCN_OK;
+  const unsigned gx = (unsigned)std::min<int64_t>((n_rows * 4 + WG - 1) / WG, 256 * 64);
+  hipLaunchKernelGGL(segment_sum_d16_kernel, dim3(gx), dim3(WG), 0, (hipStream_t)stream, Y, rowptr, bias, out,
+                     (long long)n_rows, flags & RGCN_F_RELU);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

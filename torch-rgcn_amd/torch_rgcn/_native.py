@@ -274,7 +274,7 @@ class BuiltPlan:
 
 
 def build_plan_device(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_rows, n_live, max_item_chunks=64,
-                      want_runs=False, want_pack=False, max_unit_chunks=256):
+                      want_runs=False, want_pack=False, max_unit_chunks=256, aux=None):
     dev = dst.device
     M = dst.shape[0]
     n_tiles = (n_dst + tile_rows - 1) // tile_rows
@@ -301,12 +301,13 @@ def build_plan_device(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_ro
     p.chunk_rel = _i32(p.n_chunks, dev)
     p.tile_ptr = _i32(n_tiles + 1, dev)
     p.run_ptr = _i32(n_tiles * (num_rels + 1), dev) if want_runs else None
+    p.aux = _i32(m_pad, dev) if aux is not None else None
     with torch.cuda.device(dev):
         _check(L.rgcn_dev_plan_fill(_dp(dst), _dp(src), _dp(rel), _dp(val), _dp(alive), c_i64(M), c_i64(n_dst),
                                     c_i64(n_src), c_i32(num_rels), c_i32(tile_rows), _dp(cells), _dp(bucket_cnt),
                                     _dp(bucket_base), _dp(p.src), _dp(p.dst), _dp(p.val), _dp(p.pack), _dp(p.chunk_rel),
-                                    _dp(p.tile_ptr), _dp(p.run_ptr), None, None, c_i64(p.n_chunks), _stream(dev)),
-               "dev_plan_fill")
+                                    _dp(p.tile_ptr), _dp(p.run_ptr), _dp(aux), _dp(p.aux), None, c_i64(p.n_chunks),
+                                    _stream(dev)), "dev_plan_fill")
     # work units (hub tiles split) and the relation-major work list are tiny: host side
     tp_host = p.tile_ptr[:n_tiles + 1].cpu().numpy()
     nu, ns = c_i64(0), c_i64(0)
@@ -350,6 +351,8 @@ def build_csr_device(dst, src, rel, val, alive, n_rows):
     p.n_rows = n_rows
     p.rowptr = cells.clone()                      # exclusive offsets; the fill pass advances `cells` itself
     p.rowptr[n_rows] = bucket_cnt[0]
+    p.msg_slot = _i32(M, dev)                     # CSR position of every input message
+    p.n_messages = None
     p.src, pdst, p.rel = _i32(m_pad, dev), _i32(m_pad, dev), _i32(m_pad, dev)
     p.val = torch.empty(max(m_pad, 1), dtype=torch.float32, device=dev)
     chunk_rel, tile_ptr = _i32(m_pad // CHUNK, dev), _i32(2, dev)
@@ -357,7 +360,8 @@ def build_csr_device(dst, src, rel, val, alive, n_rows):
         _check(L.rgcn_dev_plan_fill(_dp(dst), _dp(src), _dp(zeros), _dp(val), _dp(alive), c_i64(M), c_i64(n_rows),
                                     c_i64(n_rows), c_i32(1), c_i32(n_rows), _dp(cells), _dp(bucket_cnt), _dp(bucket_base),
                                     _dp(p.src), _dp(pdst), _dp(p.val), None, _dp(chunk_rel), _dp(tile_ptr), None,
-                                    _dp(rel), _dp(p.rel), c_i64(m_pad // CHUNK), _stream(dev)), "dev_plan_fill")
+                                    _dp(rel), _dp(p.rel), _dp(p.msg_slot), c_i64(m_pad // CHUNK), _stream(dev)),
+               "dev_plan_fill")
     return p
 
 
@@ -469,6 +473,23 @@ def spmm_slabs(X, W, bias, plan, n_slabs, after_slab):
     for (u0, u1, r0, r1) in slab_bounds(plan, n_slabs):
         _spmm_launch(X, W, bias, plan, out, flags, u0, u1, 0, "spmm_slab")
         after_slab(out, r0, r1)
+    return out
+
+
+def spmm_two_pass(X, W, bias, scatter_plan, csr, relu=False):
+    """sparse-bucket path (d = 16): relation-major transform + scatter, then per-row segment sum"""
+    _req(X, "features"); _req(W, "weights"); _req(bias, "bias")
+    Wp = pack_w16(W)
+    Y = torch.empty((max(int(csr.rowptr[-1].item()) if csr.n_messages is None else csr.n_messages, 1), 16),
+                    device=X.device, dtype=torch.float32)
+    out = torch.empty((csr.n_rows, 16), device=X.device, dtype=torch.float32)
+    p = scatter_plan
+    with torch.cuda.device(X.device), _timed("spmm_scatter"):
+        _check(lib().rgcn_spmm_scatter_f32(_dp(X), _dp(Wp), _dp(Y), _dp(p.src), _dp(p.val), _dp(p.aux), _dp(p.chunk_rel),
+                                           _dp(p.items), c_i64(p.n_items), c_i32(16), _stream(X.device)), "spmm_scatter")
+    with torch.cuda.device(X.device), _timed("segment_sum"):
+        _check(lib().rgcn_segment_sum_f32(_dp(Y), _dp(csr.rowptr), _dp(bias), _dp(out), c_i64(csr.n_rows), c_i32(16),
+                                          c_i32(F_RELU if relu else 0), _stream(X.device)), "segment_sum")
     return out
 
 

@@ -15,13 +15,30 @@ import torch
 from . import _native
 
 
+def _sparse_buckets(graph, W):
+    """hidden 16 and (tile, relation) buckets so small that the 16-slot chunks are mostly padding"""
+    if W.shape[1] != 16 or W.shape[2] != 16 or getattr(graph, "_dev", None) is None:
+        return False
+    mode = os.environ.get("RGCN_SPARSE_PATH", "auto")
+    if mode != "auto":
+        return mode == "1"
+    fp = graph.fwd_plan(16)
+    if not (fp.m_pad > 0 and fp.n_messages < 0.5 * fp.m_pad):
+        return False
+    # pass 2 walks a destination's messages with 4 lanes: keep mega-hubs on the tile path (which splits them)
+    return graph.max_degree() <= 4096
+
+
 class _RelationalMP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, W, bias, graph):
         X = X.contiguous()
         W = W.contiguous()
         b = None if bias is None else bias.contiguous()
-        out = _native.spmm(X, W, b, graph.fwd_plan(W.shape[2]))
+        if _sparse_buckets(graph, W):
+            out = _native.spmm_two_pass(X, W, b, graph.scatter_plan("fwd"), graph.csr("fwd"))
+        else:
+            out = _native.spmm(X, W, b, graph.fwd_plan(W.shape[2]))
         ctx.graph = graph
         ctx.has_bias = bias is not None
         ctx.save_for_backward(X, W)
@@ -35,7 +52,10 @@ class _RelationalMP(torch.autograd.Function):
         dX = dW = db = None
         if ctx.needs_input_grad[0]:
             Wt = W.transpose(1, 2).contiguous()
-            dX = _native.spmm(g, Wt, None, graph.bwd_plan(W.shape[1]))
+            if _sparse_buckets(graph, W):
+                dX = _native.spmm_two_pass(g, Wt, None, graph.scatter_plan("bwd"), graph.csr("bwd"))
+            else:
+                dX = _native.spmm(g, Wt, None, graph.bwd_plan(W.shape[1]))
         if ctx.needs_input_grad[1]:
             fp = graph.fwd_plan(W.shape[2])
             # tile-major walk (one random gather per message) unless a (tile, relation) run is so long that

@@ -104,6 +104,32 @@ class RelGraph:
             self._plans[key] = _native.build_csr_device(dst, src, p, val, alive, self.num_nodes)
         return self._plans[key]
 
+    def max_degree(self):
+        """largest number of messages received or sent by one node (cached; device graphs only)"""
+        if "maxdeg" not in self._plans:
+            m = 0
+            for kind in ("fwd", "bwd"):
+                rp = self.csr(kind).rowptr
+                m = max(m, int((rp[1:] - rp[:-1]).max().item()) if rp.numel() > 1 else 0)
+            self._plans["maxdeg"] = m
+        return self._plans["maxdeg"]
+
+    def scatter_plan(self, kind):
+        """relation-major plan whose slots know their position in the destination-major CSR (sparse-bucket path)"""
+        key = ("scatter", kind)
+        if key not in self._plans:
+            if self._dev is None:
+                raise RuntimeError("the sparse-bucket path needs the device-side graph build")
+            s, p, o, val, alive = self._dev
+            dst, src = (s, o) if kind == "fwd" else (o, s)
+            csr = self.csr(kind)
+            if csr.n_messages is None:
+                csr.n_messages = int(csr.rowptr[-1].item())
+            N, R = self.num_nodes, self.num_rels
+            self._plans[key] = _native.build_plan_device(dst, src, p, val, alive, N, N, R, max(N, 1), self.num_messages,
+                                                         64, aux=csr.msg_slot)
+        return self._plans[key]
+
     def selfloop_edges(self, self_rel):
         """(s, o, val) device tensors of the messages of one relation (used by the LP block-dropout branch)."""
         if self._dev is not None:
