@@ -21,15 +21,19 @@ from . import _native
 _LDS_WAVE_FLOATS = 2048  # 8 KiB of LDS per wave-owned destination tile (4 waves per workgroup)
 
 
-def pick_tile_rows(width):
+def pick_tile_rows(width, n_rows=None):
     """Rows of a (wave-owned) destination tile for an output width in floats.  Padding of the
     (tile, relation) buckets is measured to be free in the gather kernels, so small tiles
-    (more waves in flight) win; the LDS row stride is the width rounded up to 4 floats."""
+    (more waves in flight) win; the LDS row stride is the width rounded up to 4 floats.
+    Small graphs get smaller tiles still: a tile is one wave, and a few dozen waves cannot fill 256 CUs."""
     ld = (max(1, width) + 3) & ~3
     env = os.environ.get("RGCN_TILE_ROWS")
     if env:
         return max(1, min(int(env), 4096 // ld))
-    return int(max(4, min(128, _LDS_WAVE_FLOATS // ld)))
+    rows = max(1, min(128, _LDS_WAVE_FLOATS // ld))        # widths up to 4096 floats fit the 64 KiB workgroup budget
+    if n_rows is not None and n_rows < rows * 2048:
+        rows = max(min(rows, 8), min(rows, n_rows // 2048))
+    return int(rows)
 
 
 class RelGraph:
@@ -84,10 +88,10 @@ class RelGraph:
         return self._plans[key]
 
     def fwd_plan(self, d_out):
-        return self._plan("fwd", pick_tile_rows(d_out))
+        return self._plan("fwd", pick_tile_rows(d_out, self.num_nodes))
 
     def bwd_plan(self, d_in):
-        return self._plan("bwd", pick_tile_rows(d_in))
+        return self._plan("bwd", pick_tile_rows(d_in, self.num_nodes))
 
     def wgt_plan(self):
         """relation-major (single tile): long runs per relation for the weight gradient"""
