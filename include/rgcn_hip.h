@@ -106,6 +106,12 @@ RGCN_API int rgcn_plan_units_host(const int32_t *tile_ptr, int64_t n_tiles, int3
  * consecutive stream values per triple.  Same stream as oracle.synthetic_triples. */
 RGCN_API int rgcn_synthetic_triples_host(int64_t N, int64_t R0, int64_t E, uint64_t seed, int64_t *out);
 
+/* Edge-neighbourhood sampler of the link-prediction experiments (utils/misc.py:125-172):
+ * picked_edges[i] = index of the i-th sampled triple, sample_size <= E distinct edges.  Same sampling distribution
+ * as the reference, O(log N) per draw (Fenwick trees) instead of O(N); its own splitmix64 stream from `seed`. */
+RGCN_API int rgcn_edge_neighborhood_host(const int64_t *triples, int64_t E, int64_t N, int64_t sample_size,
+                                         uint64_t seed, int64_t *picked_edges);
+
 /* ------------------------------------------------------------------ graph preparation (device)
  * The same work as the *_host functions above without leaving the GPU (the LP layer builds its graph on
  * every call, layers.py:481-516).  Dense counting: workspaces are one int per (tile, relation, row) cell.
@@ -240,6 +246,26 @@ RGCN_API int rgcn_distmult_fwd_f32(const int64_t *triples, int64_t T, const floa
 RGCN_API int rgcn_distmult_bwd_f32(const int64_t *triples, int64_t T, const float *nodes, const float *rel,
                                    const float *gs, float *dnodes, float *drel, float *dsbias, float *dpbias,
                                    float *dobias, int64_t n_nodes, int32_t n_rel, int32_t d, void *stream);
+
+/* Ranking evaluator (utils/misc.py:60-110 + torch_rgcn/layers.py:87-98 on the expanded
+ * [bn, N, 3] candidate tensor, which is never built here).  For each of the Q test triples in `batch` (int64
+ * [Q,3], device) every entity n is scored as its head (head != 0: (n, p, o)) or tail ((s, p, n)):
+ *   scores[q, n] = sum_k (nodes[fixed_q,k] * rel[p_q,k]) * nodes[n,k]  (+ sbias + pbias + obias as layers.py:96)
+ * fp32 MFMA NT product.  qvec [Q,d] and qbias [2Q] (only with biases) are caller-provided scratch; scores is
+ * [Q, n_nodes] row-major.  Indices are NOT range-checked on the device (the Python wrapper asserts). */
+RGCN_API int rgcn_distmult_score_all_f32(const int64_t *batch, int64_t Q, int32_t head, const float *nodes,
+                                         const float *rel, const float *sbias, const float *pbias,
+                                         const float *obias, float *qvec, float *qbias, float *scores,
+                                         int64_t n_nodes, int32_t n_rel, int32_t d, void *stream);
+/* filter_scores (utils/misc.py:40-58): scores[filt_q[e], filt_n[e]] = -inf for the F known true completions that
+ * are not the target (list built by the caller; duplicates allowed). */
+RGCN_API int rgcn_rank_filter_f32(float *scores, int64_t Q, int64_t n_nodes, const int32_t *filt_q,
+                                  const int32_t *filt_n, int64_t F, void *stream);
+/* utils/misc.py:93-96: per query, greater[q] = #{n : scores[q,n] > scores[q,target_q]} and
+ * ties[q] = #{n : scores[q,n] == scores[q,target_q]} (the target included); target = batch[q,0] (head) or
+ * batch[q,2].  rank = greater + (ties - 1) / 2 + 1 is left to the caller (misc.py:99-101). */
+RGCN_API int rgcn_rank_count_f32(const float *scores, const int64_t *batch, int64_t Q, int32_t head,
+                                 int64_t n_nodes, int64_t *greater, int64_t *ties, void *stream);
 
 #ifdef __cplusplus
 }

@@ -286,6 +286,91 @@ def distmult_backward(triples, nodes, relations, gscores, with_bias=False):
     return dn, dr, dsb, dpb, dob
 
 
+# --------------------------------------------------------------------------- ranking evaluator
+# Restatement of the reference's utils/misc.py:29-110.  `score_fn(toscore)` stands for `model(graph, toscore)[0]`:
+# it receives the expanded [bn, N, 3] candidate tensor exactly as the reference builds it (misc.py:78-83).
+
+def generate_true_dict(all_triples):
+    """misc.py:29-38: (p, o) -> list of heads, (s, p) -> list of tails, duplicates kept, input order"""
+    heads, tails = {}, {}
+    for s, p, o in np.asarray(all_triples).tolist():
+        heads.setdefault((p, o), []).append(s)
+        tails.setdefault((s, p), []).append(o)
+    return heads, tails
+
+
+def filter_indices(batch, true_triples, head=True):
+    """misc.py:46-54: (row, entity) pairs of known true completions other than the target"""
+    heads, tails = true_triples
+    idx = []
+    for i, (s, p, o) in enumerate(np.asarray(batch).tolist()):
+        if head:
+            idx.extend((i, si) for si in heads.get((p, o), []) if si != s)
+        else:
+            idx.extend((i, oi) for oi in tails.get((s, p), []) if oi != o)
+    return np.asarray(idx, np.int64).reshape(-1, 2)
+
+
+def rank_batch(scores, targets):
+    """misc.py:93-101: optimistic rank + half of the other ties, 1-based"""
+    scores = np.asarray(scores)
+    true = scores[np.arange(len(scores)), targets][:, None]
+    raw = (scores > true).sum(1)
+    ties = (scores == true).sum(1)
+    return raw + (ties - 1) // 2 + 1
+
+
+def evaluate(score_fn, test_set, true_triples, num_nodes, batch_size=16, hits_at_k=(1, 3, 10), filter_candidates=True):
+    """misc.py:60-110 -> (mrr, hits tuple, ranks list); head queries for the whole test set first, then tails"""
+    test_set = _i64(test_set)
+    ranks = []
+    for head in (True, False):
+        for fr in range(0, len(test_set), batch_size):
+            batch = test_set[fr:fr + batch_size]
+            bn = len(batch)
+            toscore = np.repeat(batch[:, None, :], num_nodes, axis=1)
+            toscore[:, :, 0 if head else 2] = np.arange(num_nodes)[None, :]
+            scores = np.array(score_fn(toscore), np.float32).reshape(bn, num_nodes)
+            if filter_candidates:
+                idx = filter_indices(batch, true_triples, head)
+                scores[idx[:, 0], idx[:, 1]] = -np.inf     # misc.py:58 (raises on an empty list in the reference)
+            ranks.extend(rank_batch(scores, batch[:, 0] if head else batch[:, 2]).tolist())
+    mrr = sum(1.0 / r for r in ranks) / len(ranks)
+    hits = tuple(sum(1.0 if r <= k else 0.0 for r in ranks) / len(ranks) for k in hits_at_k)
+    return mrr, hits, ranks
+
+
+# --------------------------------------------------------------------------- edge-neighbourhood sampler
+def edge_neighborhood(train_triples, sample_size, num_nodes, rng=np.random):
+    """misc.py:125-172, the same sequence of `rng.choice` calls (so the reference's np.random.seed stream reproduces
+    its picks); returns the indices of the sampled triples."""
+    tr = np.asarray(train_triples)
+    ends = [[] for _ in range(num_nodes)]                     # (edge, other vertex) per edge end
+    for i, (s, _, o) in enumerate(tr.tolist()):
+        ends[s].append((i, o))
+        ends[o].append((i, s))
+    left = np.array([len(a) for a in ends])                   # sample_counts
+    seen = np.zeros(num_nodes, bool)
+    picked = np.zeros(len(tr), bool)
+    out = np.zeros(sample_size, np.int64)
+    for i in range(sample_size):
+        w = left * seen
+        if w.sum() == 0:
+            w = np.ones_like(w)
+            w[left == 0] = 0
+        v = rng.choice(np.arange(num_nodes), p=w / w.sum())
+        seen[v] = True
+        e, other = ends[v][rng.choice(np.arange(len(ends[v])))]
+        while picked[e]:
+            e, other = ends[v][rng.choice(np.arange(len(ends[v])))]
+        out[i] = e
+        picked[e] = True
+        left[v] -= 1
+        left[other] -= 1
+        seen[other] = True
+    return out
+
+
 # --------------------------------------------------------------------------- deterministic graph generator
 
 _MASK = (1 << 64) - 1

@@ -14,6 +14,9 @@ Sets:
   g4_model_* NodeClassifier / EmbeddingNodeClassifier: logits, loss, grads, 3 Adam steps
   g5_distmult DistMult.forward (2-D, 3-D, +-bias) and s_penalty
   g6_mid     N=2000, R0=10, E=20000, d=16 NC layer pair (int32 triples, fp32 tensors)
+  g7_eval_*  utils/misc.py evaluate(): filtered and raw ranks (ties included) of an LP encoder + DistMult model
+  g8_sampler utils/misc.py edge_neighborhood(): picks under two np.random seeds
+  g9_lp_loader utils/data.py load_link_prediction_data() on a tiny text dataset
 """
 import os
 import sys
@@ -258,7 +261,146 @@ def g6():
          grad_w2=l2.weights.grad.numpy(), grad_b2=l2.bias.grad.numpy())
 
 
+def _reference_misc():
+    """utils/misc.py imports sacred (absent here) at module level only for create_experiment; stub it."""
+    import types
+    for name in ("sacred", "sacred.observers"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["sacred"].Experiment = object
+    sys.modules["sacred.observers"].MongoObserver = object
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_utils_misc", os.path.join(REF, "utils", "misc.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def g7():
+    misc = _reference_misc()
+    gen = torch.Generator().manual_seed(7)
+    # (a) LP encoder (basis) + DistMult without biases, float embeddings
+    N, R0, d = 30, 4, 8
+    def rand_triples(n):
+        return torch.stack([torch.randint(0, N, (n,), generator=gen), torch.randint(0, R0, (n,), generator=gen),
+                            torch.randint(0, N, (n,), generator=gen)], dim=1)
+    train, valid, test = rand_triples(90), rand_triples(15), rand_triples(20)
+    test[5] = train[3]                     # a test triple that is also a training triple
+    test[6, :2] = test[7, :2]              # two test triples sharing (s, p): each filters the other's tail
+    all_triples = torch.cat([train, valid, test]).tolist()
+    true_triples = misc.generate_true_dict(all_triples)
+    layer = RelationalGraphConvolutionLP(num_nodes=N, num_relations=2 * R0 + 1, in_features=d, out_features=d,
+                                         edge_dropout={"general": 0.5, "self_loop": 0.2, "self_loop_type": "schlichtkrull-dropout"},
+                                         decomposition={"type": "basis", "num_bases": 2}, w_init="glorot-normal",
+                                         b_init="zeros")
+    dm = DistMult(R0, d, N, R0, w_init="standard-normal")
+    seeded_params(layer, gen)
+    seeded_params(dm, gen)
+    emb = torch.randn(N, d, generator=gen)
+    layer.eval()
+
+    class Model(torch.nn.Module):
+        def forward(self, graph, triples):
+            return dm(triples, layer(graph, torch.relu(emb))), 0
+    res = {}
+    with torch.no_grad():
+        for tag, filt in (("filtered", True), ("raw", False)):
+            mrr, hits, ranks = misc.evaluate(Model(), train, test, true_triples, N, batch_size=7, hits_at_k=[1, 3, 10],
+                                             filter_candidates=filt, verbose=False)
+            res.update({f"mrr_{tag}": mrr, f"hits_{tag}": np.asarray(hits), f"ranks_{tag}": np.asarray(ranks)})
+        x = layer(train, torch.relu(emb))
+    save("g7_eval_lp", num_nodes=N, num_rels=R0, train=train.numpy(), valid=valid.numpy(), test=test.numpy(),
+         emb=emb.numpy(), nodes=x.numpy(), relations=dm.relations.detach().numpy(), batch_size=7,
+         **{f"layer_{k}": v for k, v in params_np(layer).items()}, **res)
+
+    # (b) ties: small-integer embeddings with repeated rows (all arithmetic exact in fp32), DistMult with biases
+    N, R0, d = 24, 3, 6
+    emb = torch.randint(-2, 3, (N, d), generator=gen).float()
+    emb[8:16] = emb[0:8]                   # entity n+8 ties with entity n wherever their biases agree
+    dm = DistMult(R0, d, N, R0, w_init="standard-normal", b_init="ones")
+    with torch.no_grad():
+        dm.relations.copy_(torch.randint(-2, 3, (R0, d), generator=gen).float())
+        dm.sbias.copy_(torch.randint(0, 2, (N,), generator=gen).float())
+        dm.obias.copy_(torch.randint(0, 2, (N,), generator=gen).float())
+        dm.pbias.copy_(torch.randint(-1, 2, (R0,), generator=gen).float())
+    def rand_triples(n):
+        return torch.stack([torch.randint(0, N, (n,), generator=gen), torch.randint(0, R0, (n,), generator=gen),
+                            torch.randint(0, N, (n,), generator=gen)], dim=1)
+    known, test = rand_triples(60), rand_triples(25)
+    true_triples = misc.generate_true_dict(torch.cat([known, known[:10], test]).tolist())   # duplicated entries too
+
+    class Model2(torch.nn.Module):
+        def forward(self, graph, triples):
+            return dm(triples, emb), 0
+    res = {}
+    with torch.no_grad():
+        for tag, filt in (("filtered", True), ("raw", False)):
+            mrr, hits, ranks = misc.evaluate(Model2(), known, test, true_triples, N, batch_size=25, hits_at_k=[1, 3, 10],
+                                             filter_candidates=filt, verbose=False)
+            res.update({f"mrr_{tag}": mrr, f"hits_{tag}": np.asarray(hits), f"ranks_{tag}": np.asarray(ranks)})
+        toscore = torch.cat([torch.arange(N).view(1, N, 1).expand(25, N, 1), test[:, 1:].view(25, 1, 2).expand(25, N, 2)], dim=2)
+        head_scores = dm(toscore, emb)
+    save("g7_eval_ties", num_nodes=N, num_rels=R0, known=known.numpy(), test=test.numpy(), nodes=emb.numpy(),
+         relations=dm.relations.detach().numpy(), sbias=dm.sbias.detach().numpy(), pbias=dm.pbias.detach().numpy(),
+         obias=dm.obias.detach().numpy(), head_scores=head_scores.numpy(), batch_size=25, **res)
+
+
+def g8():
+    """utils/misc.py edge_neighborhood under np.random.seed: the picks the oracle restatement must reproduce"""
+    misc = _reference_misc()
+    gen = torch.Generator().manual_seed(8)
+    N, E = 14, 40
+    T = torch.stack([torch.randint(0, N - 2, (E,), generator=gen), torch.randint(0, 3, (E,), generator=gen),
+                     torch.randint(0, N - 2, (E,), generator=gen)], dim=1)     # nodes 12, 13 isolated
+    T[3, 2] = T[3, 0]            # a self loop
+    T[5] = T[4]                  # a duplicated edge
+    T[30:36, 0] = N - 3          # a component that the sampler has to jump to
+    T[30:36, 2] = N - 3
+    entities = {f"e{i}": i for i in range(N)}
+    res = {}
+    for seed, size in ((123, 25), (7, 40)):
+        np.random.seed(seed)
+        picked = misc.edge_neighborhood(T.tolist(), sample_size=size, entities=entities)
+        res[f"picked_seed{seed}"] = np.asarray(picked)
+    save("g8_sampler", triples=T.numpy(), num_nodes=N, **res)
+
+
+def g9():
+    """utils/data.py load_link_prediction_data on a tiny text dataset (rdflib stubbed: only the module import needs it).
+    The reference numbers nodes in set-iteration order, so the fixture stores label-level facts: the decoded train /
+    test triples, the label sets and the number of distinct triples."""
+    import importlib.util
+    import tempfile
+    import types
+    sys.modules.setdefault("rdflib", types.ModuleType("rdflib"))
+    sys.modules["rdflib"].URIRef = str
+    spec = importlib.util.spec_from_file_location("ref_utils_data", os.path.join(REF, "utils", "data.py"))
+    data = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(data)
+    files = {
+        "train": "a likes b\nb likes c\nc hates a\na likes b\nd  knows\ta\ne knows d\n",
+        "valid": "a hates c\nb knows e\n",
+        "test": "c likes d\nf knows a\nb likes c\n",
+    }
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "data", "wn18"))
+        for part, text in files.items():
+            with open(os.path.join(tmp, "data", "wn18", part + ".txt"), "w") as f:
+                f.write(text)
+        data.locate_file = lambda rel: os.path.join(tmp, rel)
+        for tag, kw in (("valid", {}), ("test", {"use_test_set": True}), ("limit", {"limit": 4})):
+            (n2i, n), (r2i, r), train, test, all_triples = data.load_link_prediction_data("WN18", **kw)
+            dec = lambda ts: np.asarray([[n[s_], r[p_], n[o_]] for s_, p_, o_ in ts])  # noqa: E731
+            res.update({f"{tag}_train": dec(train), f"{tag}_test": dec(test), f"{tag}_nodes": np.asarray(sorted(n)),
+                        f"{tag}_rels": np.asarray(sorted(r)), f"{tag}_all": np.asarray(sorted(dec(all_triples).tolist()))})
+            assert sorted(n2i, key=n2i.get) == n and sorted(r2i, key=r2i.get) == r
+    save("g9_lp_loader", **{f"file_{k}": np.asarray(v) for k, v in files.items()}, **res)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    for fn in (g1, g2, g3, g4, g5, g6):
+    only = sys.argv[1:]
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
+        if only and fn.__name__ not in only:
+            continue
         fn()

@@ -29,14 +29,34 @@ def test_classify_nodes_mutag_shaped_basis():
     assert hist[-1][0] < hist[0][0]
 
 
+def test_classify_nodes_e_rgcn_config_runs():
+    sys.path.insert(0, os.path.join(PKG, "experiments"))
+    import classify_nodes
+    c = yaml.safe_load(open(os.path.join(PKG, "configs", "e-rgcn", "nc-AIFB.yaml")))
+    hist = classify_nodes.run(c, epochs=10, quiet=True)
+    assert hist[-1][0] < hist[0][0]
+
+
 def test_predict_links_small_graph_trains_and_ranks():
     sys.path.insert(0, os.path.join(PKG, "experiments"))
     import predict_links
-    c = cfg("lp-WN18.yaml")
+    c = cfg("lp-WN18.yaml")                              # reference schema: edge-neighbourhood sampling, 10 negatives, basis 2
     c["dataset"]["name"] = "fb-toy"
     c["encoder"].update(node_embedding=32, hidden1_size=32)
     c["training"].update(graph_batch_size=2000)
-    c["evaluation"] = {"batch_size": 32, "max_test": 100}
-    hist, metrics = predict_links.run(c, epochs=30, quiet=True)
+    c["evaluation"].update(check_every=20, batch_size=32, verbose=False)
+    hist, metrics = predict_links.run(c, epochs=30, quiet=True, max_test=100)
     assert hist[-1] < hist[0]
     assert 0.0 < metrics["mrr"] <= 1.0 and metrics["hits@10"] >= metrics["hits@1"]
+
+
+def test_predict_links_block_config_pads_nodes_and_c_rgcn_runs():
+    sys.path.insert(0, os.path.join(PKG, "experiments"))
+    import predict_links
+    c = cfg("lp-FB-toy.yaml")                            # block decomposition: 280 nodes padded to a multiple of 500 / 100
+    c["training"].update(graph_batch_size=300)
+    hist, metrics = predict_links.run(c, epochs=3, quiet=True, max_test=20)
+    assert len(hist) == 3 and 0.0 < metrics["mrr"] <= 1.0
+    c = yaml.safe_load(open(os.path.join(PKG, "configs", "c-rgcn", "lp-FB-toy.yaml")))   # no graph_batch_size: whole graph
+    hist, metrics = predict_links.run(c, epochs=3, quiet=True, max_test=20)
+    assert len(hist) == 3 and 0.0 < metrics["mrr"] <= 1.0

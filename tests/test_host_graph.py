@@ -188,3 +188,52 @@ def test_slab_bounds_are_rank_independent():
             t = hp.units[u0:u1, 0]
             assert np.all(t * T >= r0) and np.all(t * T < r1)
     assert rows[0] == rows[1] == rows[2] and rows[0][0][0] == 0 and rows[0][-1][1] == N
+
+
+# ------------------------------------------------------------------ edge-neighbourhood sampler (utils/misc.py:125-172)
+def _walk_is_legal(T, N, picked):
+    """every pick comes from a touched vertex whenever some touched vertex still has an unpicked edge"""
+    seen = np.zeros(N, bool)
+    left = np.bincount(np.concatenate([T[:, 0], T[:, 2]]), minlength=N)
+    for e in picked:
+        s, o = T[e, 0], T[e, 2]
+        if (left * seen).sum() > 0:
+            assert seen[s] or seen[o]
+        left[s] -= 1
+        left[o] -= 1
+        seen[s] = seen[o] = True
+
+
+def test_edge_neighborhood_native_properties():
+    d = load_golden("g8_sampler")
+    T, N = d["triples"], int(d["num_nodes"])
+    for size in (0, 1, 25, len(T)):
+        picked = nat.edge_neighborhood_host(T, N, size, seed=size + 3)
+        assert len(picked) == size and len(set(picked.tolist())) == size
+        assert picked.size == 0 or (picked.min() >= 0 and picked.max() < len(T))
+        _walk_is_legal(T, N, picked)
+    assert np.array_equal(nat.edge_neighborhood_host(T, N, 20, seed=5), nat.edge_neighborhood_host(T, N, 20, seed=5))
+    big = nat.synthetic_triples_host(40_943, 18, 141_442, 1)          # WN18-sized: milliseconds, not minutes
+    picked = nat.edge_neighborhood_host(big, 40_943, 30_000, seed=11)
+    assert len(set(picked.tolist())) == 30_000
+    _walk_is_legal(big, 40_943, picked[:2000])
+    with pytest.raises(AssertionError):
+        nat.edge_neighborhood_host(T, N, len(T) + 1, seed=0)          # the reference would spin forever here
+    with pytest.raises(AssertionError):
+        nat.edge_neighborhood_host(T, 3, 5, seed=0)                    # node index out of range
+
+
+def test_edge_neighborhood_native_distribution_matches_oracle():
+    """same sampling distribution as the restated reference algorithm: frequency of every edge as first pick, as second
+    pick and anywhere in the sample, over 3000 runs each (tolerance ~5 sigma)."""
+    T = np.array([[0, 0, 1], [1, 0, 2], [2, 0, 0], [3, 0, 4], [4, 0, 5], [1, 0, 3], [2, 0, 2], [0, 0, 1]], np.int64)
+    N, size, runs = 6, 3, 3000
+    rng = np.random.RandomState(0)
+    freq = np.zeros((2, 3, len(T)))
+    for r in range(runs):
+        for k, picked in enumerate((oracle.edge_neighborhood(T, size, N, rng), nat.edge_neighborhood_host(T, N, size, seed=1000 + r))):
+            freq[k, 0, picked[0]] += 1
+            freq[k, 1, picked[1]] += 1
+            freq[k, 2, picked] += 1
+    freq /= runs
+    assert np.abs(freq[0] - freq[1]).max() < 0.05, freq

@@ -198,3 +198,35 @@ def test_g5_distmult():
                 assert rel_err(dsb, d[f"{tag}_grad_sbias{nm}"]) < TOL
                 assert rel_err(dpb, d[f"{tag}_grad_pbias{nm}"]) < TOL
                 assert rel_err(dob, d[f"{tag}_grad_obias{nm}"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["g7_eval_lp", "g7_eval_ties"])
+def test_g7_ranking_evaluator(name):
+    """oracle.evaluate (utils/misc.py:60-110 restated) on the encoder output the reference produced"""
+    d = load_golden(name)
+    N = int(d["num_nodes"])
+    bias = [d[k] for k in ("sbias", "pbias", "obias")] if "sbias" in d else [None] * 3
+    if name == "g7_eval_lp":
+        known = np.concatenate([d["train"], d["valid"], d["test"]])
+    else:
+        known = np.concatenate([d["known"], d["known"][:10], d["test"]])
+    true_triples = oracle.generate_true_dict(known)
+    score = lambda toscore: oracle.distmult_forward(toscore, d["nodes"], d["relations"], *bias)  # noqa: E731
+    for tag, filt in (("filtered", True), ("raw", False)):
+        mrr, hits, ranks = oracle.evaluate(score, d["test"], true_triples, N, batch_size=int(d["batch_size"]),
+                                           filter_candidates=filt)
+        assert ranks == d[f"ranks_{tag}"].tolist(), tag
+        assert abs(mrr - float(d[f"mrr_{tag}"])) < 1e-12 and np.allclose(hits, d[f"hits_{tag}"], atol=1e-12)
+    if "head_scores" in d:   # integer data: the score matrix itself is exact
+        toscore = np.repeat(d["test"][:, None, :], N, axis=1)
+        toscore[:, :, 0] = np.arange(N)[None, :]
+        assert np.array_equal(score(toscore), d["head_scores"])
+
+
+def test_g8_edge_neighborhood_sampler_reproduces_reference_picks():
+    d = load_golden("g8_sampler")
+    T, N = d["triples"], int(d["num_nodes"])
+    for seed in (123, 7):
+        want = d[f"picked_seed{seed}"]
+        idx = oracle.edge_neighborhood(T, len(want), N, np.random.RandomState(seed))
+        assert len(set(idx.tolist())) == len(want) and np.array_equal(T[idx], want)

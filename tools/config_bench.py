@@ -97,12 +97,11 @@ def s2_featureless_basis():
                       "N": N, "R0": R0, "E": E, "ms_per_fwd_bwd": round(ms, 3), "edges_per_s": round(E / ms * 1e3)}), flush=True)
 
 
-def am_block_layers():
-    N, R0, E, d = 1_666_764, 133, 5_988_321, 16
-    T = _native.synthetic_triples_host(N, R0, E, 2)
+def featured_layers(title, N, R0, E, d, decomposition, seed):
+    T = _native.synthetic_triples_host(N, R0, E, seed)
     tp = torch.from_numpy(_native.add_inverse_and_self_host(T, N, R0))
     kw = dict(triples=tp, num_nodes=N, num_relations=2 * R0 + 1, in_features=d, out_features=d,
-              decomposition={"type": "block", "num_blocks": 4})
+              decomposition=decomposition)
     l1 = RelationalGraphConvolutionNC(vertical_stacking=False, **kw).to(DEV)
     l2 = RelationalGraphConvolutionNC(vertical_stacking=True, **kw).to(DEV)
     X = torch.randn(N, d, device=DEV, requires_grad=True)
@@ -112,7 +111,7 @@ def am_block_layers():
             p.grad = None
         l2(torch.relu(l1(X))).pow(2).mean().backward()
     ms = timed(step)
-    print(json.dumps({"config": "AM-shaped, block-diagonal (nb=4), 2 featured layers d=16", "N": N, "R0": R0, "E": E,
+    print(json.dumps({"config": title, "N": N, "R0": R0, "E": E,
                       "ms_per_fwd_bwd": round(ms, 3), "edges_per_s": round(E / ms * 1e3)}), flush=True)
 
 
@@ -150,7 +149,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     a = ap.parse_args()
-    todo = a.only.split(",") if a.only else ["aifb", "mutag", "am", "wn18", "s2"]
+    todo = a.only.split(",") if a.only else ["aifb", "mutag", "am", "wn18", "s2", "s1"]
     if "s2" in todo:
         s2_featureless_basis()
     if "aifb" in todo:
@@ -159,7 +158,12 @@ if __name__ == "__main__":
         nc_model("MUTAG-shaped NodeClassifier (basis 30, hidden 16, 2 classes)", 23644, 23, 74227, 16, 2,
                  {"type": "basis", "num_bases": 30}, 340)
     if "am" in todo:
-        am_block_layers()
+        featured_layers("AM-shaped, block-diagonal (nb=4), 2 featured layers d=16", 1_666_764, 133, 5_988_321, 16,
+                        {"type": "block", "num_blocks": 4}, 2)
+    if "s1" in todo:   # SURVEY.md 8(d) S1 variants (i)-(iii); (i) is what bench.py times
+        featured_layers("S1(i): no decomposition, W 101x16x16", 1_000_000, 50, 10_000_000, 16, None, 0)
+        featured_layers("S1(ii): basis B=10", 1_000_000, 50, 10_000_000, 16, {"type": "basis", "num_bases": 10}, 0)
+        featured_layers("S1(iii): block nb=4", 1_000_000, 50, 10_000_000, 16, {"type": "block", "num_blocks": 4}, 0)
     if "amreal" in todo:
         nc_model("AM-shaped NodeClassifier as shipped (featureless L1, basis 40, hidden 10, 11 classes)", 1666764, 133,
                  5988321, 10, 11, {"type": "basis", "num_bases": 40}, 802)

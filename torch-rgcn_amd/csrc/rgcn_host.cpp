@@ -334,3 +334,79 @@ extern "C" int rgcn_synthetic_triples_host(int64_t N, int64_t R0, int64_t E, uin
   }
   return RGCN_OK;
 }
+
+// ------------------------------------------------------------------ edge-neighbourhood sampler
+// utils/misc.py:125-172 draws sample_size edges; every draw picks a vertex with probability proportional to
+// (#unpicked incident edge ends) x (vertex already touched), falling back to "any vertex that still has an unpicked
+// edge" when no touched vertex has one, then one of that vertex's unpicked edge ends uniformly.  The reference
+// rebuilds the N-long probability vector per draw; here both weight vectors live in Fenwick trees.
+namespace {
+struct Fenwick {
+  std::vector<int64_t> t;
+  int64_t n, top, total = 0;
+  explicit Fenwick(int64_t n_) : t(size_t(n_) + 1, 0), n(n_), top(1) { while (top * 2 <= n) top *= 2; }
+  void add(int64_t i, int64_t d) { total += d; for (++i; i <= n; i += i & -i) t[size_t(i)] += d; }
+  int64_t find(int64_t u) const {   // smallest i with prefix_sum(i) > u, 0 <= u < total
+    int64_t pos = 0;
+    for (int64_t step = top; step; step >>= 1)
+      if (pos + step <= n && t[size_t(pos + step)] <= u) { pos += step; u -= t[size_t(pos)]; }
+    return pos;
+  }
+};
+}  // namespace
+
+extern "C" int rgcn_edge_neighborhood_host(const int64_t *triples, int64_t E, int64_t N, int64_t sample_size,
+                                           uint64_t seed, int64_t *picked_edges) {
+  if (E < 0 || N <= 0 || sample_size < 0 || (E && !triples) || (sample_size && !picked_edges)) {
+    rgcn_set_error("edge_neighborhood: bad argument");
+    return RGCN_EINVAL;
+  }
+  if (sample_size > E) { rgcn_set_error("edge_neighborhood: sample_size %lld exceeds the %lld edges", (long long)sample_size, (long long)E); return RGCN_EINVAL; }
+  for (int64_t e = 0; e < E; ++e)
+    if (triples[3 * e] < 0 || triples[3 * e] >= N || triples[3 * e + 2] < 0 || triples[3 * e + 2] >= N) {
+      rgcn_set_error("edge_neighborhood: node index out of range at triple %lld", (long long)e);
+      return RGCN_ERANGE;
+    }
+  uint64_t x = seed;
+  auto below = [&x](uint64_t n) {   // uniform in [0, n): splitmix64 + multiply-shift
+    uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return uint64_t(((unsigned __int128)z * n) >> 64);
+  };
+  // edge ends per vertex (CSR): a self loop contributes two ends to its vertex, as in the reference's adj_list
+  std::vector<int64_t> ptr((size_t)N + 1, 0);
+  for (int64_t e = 0; e < E; ++e) { ++ptr[size_t(triples[3 * e]) + 1]; ++ptr[size_t(triples[3 * e + 2]) + 1]; }
+  for (int64_t v = 0; v < N; ++v) ptr[size_t(v) + 1] += ptr[size_t(v)];
+  std::vector<int64_t> end_edge((size_t)(2 * E), 0), end_other((size_t)(2 * E), 0), fill(ptr.begin(), ptr.end() - 1);
+  for (int64_t e = 0; e < E; ++e) {
+    const int64_t s = triples[3 * e], o = triples[3 * e + 2];
+    end_edge[size_t(fill[size_t(s)])] = e; end_other[size_t(fill[size_t(s)]++)] = o;
+    end_edge[size_t(fill[size_t(o)])] = e; end_other[size_t(fill[size_t(o)]++)] = s;
+  }
+  std::vector<int64_t> left((size_t)N, 0);             // unpicked edge ends per vertex (the reference's sample_counts)
+  std::vector<char> seen((size_t)N, 0), picked((size_t)E, 0);
+  Fenwick touched(N), any(N);
+  for (int64_t v = 0; v < N; ++v) { left[size_t(v)] = ptr[size_t(v) + 1] - ptr[size_t(v)]; if (left[size_t(v)]) any.add(v, 1); }
+  auto touch = [&](int64_t v) { if (!seen[size_t(v)]) { seen[size_t(v)] = 1; touched.add(v, left[size_t(v)]); } };
+  auto drop_end = [&](int64_t v) {
+    if (seen[size_t(v)]) touched.add(v, -1);
+    if (--left[size_t(v)] == 0) any.add(v, -1);
+  };
+  for (int64_t i = 0; i < sample_size; ++i) {
+    const int64_t v = touched.total > 0 ? touched.find(int64_t(below(uint64_t(touched.total))))
+                                        : any.find(int64_t(below(uint64_t(any.total))));
+    touch(v);
+    const int64_t b = ptr[size_t(v)], deg = ptr[size_t(v) + 1] - b;
+    int64_t j = b + int64_t(below(uint64_t(deg)));
+    while (picked[size_t(end_edge[size_t(j)])]) j = b + int64_t(below(uint64_t(deg)));   // misc.py:156-159
+    const int64_t e = end_edge[size_t(j)], other = end_other[size_t(j)];
+    picked[size_t(e)] = 1;
+    picked_edges[i] = e;
+    drop_end(v);
+    drop_end(other);
+    touch(other);
+  }
+  return RGCN_OK;
+}

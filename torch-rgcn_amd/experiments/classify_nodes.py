@@ -1,12 +1,17 @@
 #!/usr/bin/env python3
-"""Node classification with R-GCN on MI355X -- counterpart of the reference's experiments/classify_nodes.py
-(:20-160) without sacred: `python experiments/classify_nodes.py configs/rgcn/nc-AIFB.yaml [--data DIR] [--epochs N]`.
-Config keys follow the reference's YAML files (dataset.name, training.{epochs,learn_rate,weight_decay,optimiser},
-rgcn.{node_embedding,hidden_size,num_layers,decomposition,edge_dropout}, l2 penalty on the first layer)."""
+"""Node classification with R-GCN on MI355X -- counterpart of the reference's experiments/classify_nodes.py (:19-175)
+without sacred.  Reads the reference's config schema unchanged:
+
+    python experiments/classify_nodes.py configs/rgcn/nc-AIFB.yaml [--data DIR] [--epochs N] [--repeats K]
+
+dataset.{name,prune}  training.{epochs,optimiser.{algorithm,learn_rate,weight_decay},use_cuda}
+rgcn.{model,hidden_size,num_layers,decomposition,layer1_l2_penalty,node_embeddings,node_embedding_l2_penalty}
+evaluation.final_run.   The HIP layers have no CPU path, so a GPU is required whatever `use_cuda` says."""
 import argparse
 import os
 import sys
 import time
+from statistics import stdev
 
 import torch
 import yaml
@@ -15,52 +20,97 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from torch_rgcn.models import EmbeddingNodeClassifier, NodeClassifier  # noqa: E402
 from utils.data import load_node_classification_data  # noqa: E402
 
+OPTIMISERS = {"adam": torch.optim.Adam, "adamw": torch.optim.AdamW, "adagrad": torch.optim.Adagrad}
+
+
+def _first_layer_l2(model, decomposition):
+    kind = decomposition["type"] if decomposition is not None else None
+    if kind == "basis":
+        return model.rgc1.bases.pow(2).sum() + model.rgc1.comps.pow(2).sum()
+    if kind == "block":
+        return model.rgc1.blocks.pow(2).sum()
+    return model.rgc1.weights.pow(2).sum()
+
 
 def run(cfg, data_dir=None, epochs=None, quiet=False):
-    ds, tr, enc = cfg["dataset"], cfg["training"], cfg.get("rgcn", cfg.get("encoder", {}))
-    triples, (n, r, c), tr_idx, tr_y, te_idx, te_y = load_node_classification_data(ds["name"], data_dir)
-    dev = torch.device("cuda")
-    kind = EmbeddingNodeClassifier if enc.get("model", "rgcn") == "e-rgcn" else NodeClassifier
-    model = kind(triples=triples, nnodes=n, nrel=r, nfeat=None, nhid=enc.get("hidden_size", 16),
-                 nlayers=enc.get("num_layers", 2), nclass=c, edge_dropout=enc.get("edge_dropout"),
-                 decomposition=enc.get("decomposition"), nemb=enc.get("node_embedding")).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=tr.get("learn_rate", 0.01), weight_decay=tr.get("weight_decay", 0.0))
-    tr_idx_t, te_idx_t = torch.as_tensor(tr_idx, device=dev), torch.as_tensor(te_idx, device=dev)
-    tr_y_t, te_y_t = torch.as_tensor(tr_y, device=dev), torch.as_tensor(te_y, device=dev)
-    l2 = tr.get("l2_penalty", enc.get("l2_penalty", 0.0))
-    hist = []
-    for epoch in range(epochs or tr.get("epochs", 50)):
-        t0 = time.time()
-        model.train()
-        opt.zero_grad(set_to_none=True)
-        logits = model()
-        loss = torch.nn.functional.cross_entropy(logits[tr_idx_t], tr_y_t)
-        if l2:   # reference classify_nodes.py:111-118: penalty on the first layer's (decomposed) weights
-            first = model.rgc1
-            for name in ("weights", "bases", "comps", "blocks"):
-                if hasattr(first, name):
-                    loss = loss + l2 * getattr(first, name).pow(2).sum()
+    """one training run -> [(loss, train accuracy, test accuracy) per epoch] (accuracies in [0, 1])"""
+    dataset, training, rgcn, evaluation = cfg["dataset"], cfg["training"], cfg["rgcn"], cfg.get("evaluation", {})
+    assert training is not None, "Training configuration is not specified!"
+    epochs = epochs or training.get("epochs", 50)
+    decomposition = rgcn.get("decomposition")
+    l2_first, l2_emb = rgcn.get("layer1_l2_penalty", 0.0), rgcn.get("node_embedding_l2_penalty", 0.0)
+
+    # the validation split is the test set unless this is a final run (classify_nodes.py:40-43)
+    triples, (n2i, i2n), (r2i, i2r), train, test = load_node_classification_data(
+        dataset["name"], use_test_set=evaluation.get("final_run", False), prune=dataset.get("prune", False),
+        directory=data_dir)
+    device = torch.device("cuda")
+    train_idx = torch.tensor([n2i[name] for name in train], dtype=torch.long, device=device)
+    train_lbl = torch.tensor(list(train.values()), dtype=torch.long, device=device)
+    test_idx = torch.tensor([n2i[name] for name in test], dtype=torch.long, device=device)
+    test_lbl = torch.tensor(list(test.values()), dtype=torch.long, device=device)
+    num_classes = len(set(train.values()) | set(test.values()))
+
+    if rgcn.get("model", "rgcn") == "rgcn":
+        kind = NodeClassifier
+    elif rgcn["model"] == "e-rgcn":
+        kind = EmbeddingNodeClassifier
+    else:
+        raise NotImplementedError(f"'{rgcn['model']}' model has not been implemented!")
+    model = kind(triples=triples, nnodes=len(n2i), nrel=len(r2i), nclass=num_classes, nhid=rgcn.get("hidden_size", 16),
+                 nlayers=rgcn.get("num_layers", 2), decomposition=decomposition,
+                 nemb=rgcn.get("node_embeddings", 10)).to(device)
+
+    opt_cfg = training.get("optimiser", {"algorithm": "adam", "learn_rate": 0.01, "weight_decay": 0.0})
+    if opt_cfg["algorithm"] not in OPTIMISERS:
+        raise NotImplementedError(f"'{opt_cfg['algorithm']}' optimiser has not been implemented!")
+    optimiser = OPTIMISERS[opt_cfg["algorithm"]](model.parameters(), lr=opt_cfg["learn_rate"], weight_decay=opt_cfg["weight_decay"])
+    criterion = torch.nn.CrossEntropyLoss()
+
+    history = []
+    for epoch in range(1, epochs + 1):
         t1 = time.time()
-        loss.backward()
-        opt.step()
-        torch.cuda.synchronize()
+        model.train()
+        optimiser.zero_grad()
+        loss = criterion(model()[train_idx, :], train_lbl)
+        if l2_first > 0.0:
+            loss = loss + l2_first * _first_layer_l2(model, decomposition)
+        if l2_emb > 0.0:
+            if rgcn.get("model") != "e-rgcn":
+                raise ValueError(f"Cannot apply L2-regularisation on node embeddings for {rgcn.get('model')} model")
+            loss = loss + l2_emb * model.node_embeddings.pow(2).sum()
         t2 = time.time()
+        loss.backward()
+        optimiser.step()
+        torch.cuda.synchronize()
+        t3 = time.time()
         with torch.no_grad():
             model.eval()
             out = model()
-            acc_tr = (out[tr_idx_t].argmax(1) == tr_y_t).float().mean().item()
-            acc_te = (out[te_idx_t].argmax(1) == te_y_t).float().mean().item()
-        hist.append((loss.item(), acc_tr, acc_te))
+            train_acc = (out[train_idx].argmax(dim=-1) == train_lbl).float().mean().item()
+            test_acc = (out[test_idx].argmax(dim=-1) == test_lbl).float().mean().item()
+        history.append((loss.item(), train_acc, test_acc))
         if not quiet:
-            print(f"[Epoch {epoch + 1}] loss {loss.item():.5f} forward {t1 - t0:.4f}s backward {t2 - t1:.4f}s "
-                  f"train acc {acc_tr:.3f} test acc {acc_te:.3f}")
-    return hist
+            print(f"[Epoch {epoch}] Loss: {loss.item():.5f} Forward: {t2 - t1:.3f}s Backward: {t3 - t2:.3f}s "
+                  f"Train Accuracy: {100 * train_acc:.2f} Test Accuracy: {100 * test_acc:.2f}")
+    if not quiet:
+        print(f"[Evaluation] Test Accuracy: {100 * history[-1][2]:.2f}")
+    return history
+
+
+def repeat(cfg, repeats=1, **kw):
+    """average test accuracy (percent) and its standard error over `repeats` runs (classify_nodes.py:156-175)"""
+    accs = [100 * run(cfg, **kw)[-1][2] for _ in range(repeats)]
+    std = stdev(accs) if len(accs) != 1 else 0
+    return round(sum(accs) / len(accs), 2), round(std / len(accs) ** 0.5, 2)
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("config")
-    ap.add_argument("--data", default=None)
+    ap.add_argument("--data", default=None, help="directory holding data/<name>/... (default: synthetic dataset-shaped graph)")
     ap.add_argument("--epochs", type=int, default=None)
+    ap.add_argument("--repeats", type=int, default=1)
     a = ap.parse_args()
-    run(yaml.safe_load(open(a.config)), a.data, a.epochs)
+    avg, ste = repeat(yaml.safe_load(open(a.config)), a.repeats, data_dir=a.data, epochs=a.epochs)
+    print(f"test accuracy {avg} +- {ste}")

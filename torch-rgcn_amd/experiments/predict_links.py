@@ -1,62 +1,138 @@
 #!/usr/bin/env python3
 """Link prediction with an R-GCN encoder + DistMult decoder on MI355X -- counterpart of the reference's
-experiments/predict_links.py (:19-228) without sacred:
-`python experiments/predict_links.py configs/rgcn/lp-WN18.yaml [--data DIR] [--epochs N]`."""
+experiments/predict_links.py (:19-228) without sacred.  Reads the reference's config schema unchanged:
+
+    python experiments/predict_links.py configs/rgcn/lp-WN18.yaml [--data DIR] [--epochs N]
+
+training.{epochs,graph_batch_size,sampling_method,negative_sampling.{sampling_rate,head_prob},optimiser.*}
+encoder.{model,...,edge_dropout.general}  decoder.l2_penalty  evaluation.{final_run,filtered,check_every,batch_size,verbose}.
+Differences: the positives are sampled by the native edge-neighbourhood sampler (milliseconds instead of minutes per
+epoch), negatives are drawn on the GPU, and evaluation encodes the training graph once (utils/misc.py)."""
 import argparse
 import os
 import sys
 import time
 
-import numpy as np
 import torch
+import torch.nn.functional as F
 import yaml
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from torch_rgcn.models import CompressionRelationPredictor, LinkPredictor  # noqa: E402
 from utils.data import load_link_prediction_data  # noqa: E402
-from utils.misc import evaluate, generate_true_dict, negative_sampling, sample_edges  # noqa: E402
+from utils.misc import evaluate, generate_true_dict, negative_sampling, select_sampling  # noqa: E402
+
+OPTIMISERS = {"adam": torch.optim.Adam, "adamw": torch.optim.AdamW, "adagrad": torch.optim.Adagrad, "sgd": torch.optim.SGD}
 
 
-def run(cfg, data_dir=None, epochs=None, quiet=False, seed=0):
-    ds, tr, enc, dec = cfg["dataset"], cfg["training"], cfg["encoder"], cfg.get("decoder", {})
-    (n, r), train, valid, test = load_link_prediction_data(ds["name"], data_dir)
-    heads, tails = generate_true_dict(np.concatenate([train, valid, test]))
-    dev = torch.device("cuda")
-    rng = np.random.default_rng(seed)
-    kind = CompressionRelationPredictor if enc.get("model") == "c-rgcn" else LinkPredictor
-    model = kind(nnodes=n, nrel=r, encoder_config=enc, decoder_config=dec).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=tr.get("learn_rate", 0.01), weight_decay=tr.get("weight_decay", 0.0))
-    drop = (enc.get("edge_dropout") or {}).get("general", 0.0)
-    hist = []
-    for epoch in range(epochs or tr.get("epochs", 10)):
-        t0 = time.time()
-        model.train()
-        positives = sample_edges(train, tr.get("graph_batch_size", 30000), rng)
-        batch, labels = negative_sampling(positives, n, tr.get("negative_sampling", {}).get("sampling_rate", 10), rng)
-        keep = rng.random(len(positives)) >= drop          # general edge dropout on the message graph
-        graph = torch.as_tensor(positives[keep])
-        opt.zero_grad(set_to_none=True)
-        scores, penalty = model(graph, torch.as_tensor(batch, device=dev))
-        loss = torch.nn.functional.binary_cross_entropy_with_logits(scores, torch.as_tensor(labels, device=dev))
-        loss = loss + (dec.get("l2_penalty", 0.0) or 0.0) * penalty
-        t1 = time.time()
-        loss.backward()
-        opt.step()
-        torch.cuda.synchronize()
-        hist.append(loss.item())
+def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None):
+    """-> (loss per epoch, {"mrr", "hits@1", "hits@3", "hits@10"} of the final evaluation)"""
+    dataset, training, encoder = cfg["dataset"], cfg["training"], cfg["encoder"]
+    decoder, evaluation = cfg.get("decoder", {}), cfg.get("evaluation", {})
+    max_epochs = epochs or training.get("epochs", 5000)
+    graph_batch_size = training.get("graph_batch_size")
+    sampling_function = select_sampling(training.get("sampling_method", "uniform"))
+    neg_sample_rate = training.get("negative_sampling", {}).get("sampling_rate")
+    head_corrupt_prob = training.get("negative_sampling", {}).get("head_prob")
+    edge_dropout = encoder.get("edge_dropout", {}).get("general", 0.0) if encoder.get("edge_dropout") else 0.0
+    decoder_l2_penalty = decoder.get("l2_penalty", 0.0)
+    filtered = evaluation.get("filtered", False)
+    eval_every = evaluation.get("check_every", 2000)
+    eval_kw = dict(batch_size=evaluation.get("batch_size", 16), verbose=evaluation.get("verbose", False) and not quiet,
+                   filter_candidates=filtered)
+
+    (n2i, nodes), (r2i, relations), train, test, all_triples = load_link_prediction_data(
+        dataset["name"], use_test_set=evaluation.get("final_run", False), directory=data_dir)
+    true_triples = generate_true_dict(all_triples)
+    if max_test:
+        test = test[:max_test]
+
+    # block decomposition: pad the node list to a multiple of the block size (predict_links.py:54-67)
+    if encoder.get("decomposition") and encoder["decomposition"]["type"] == "block":
+        if "node_embedding" not in encoder:
+            raise ValueError()
+        block_size = encoder["node_embedding"] / encoder["decomposition"]["num_blocks"]
+        added = 0
+        while len(nodes) % block_size != 0:
+            label = "null" + str(added)
+            nodes.append(label)
+            n2i[label] = len(nodes) - 1
+            added += 1
         if not quiet:
-            print(f"[Epoch {epoch + 1}] loss {loss.item():.5f} forward {t1 - t0:.4f}s backward {time.time() - t1:.4f}s")
-    metrics = evaluate(model, torch.as_tensor(train), test[: cfg.get("evaluation", {}).get("max_test", 2000)], heads, tails, n,
-                       batch_size=cfg.get("evaluation", {}).get("batch_size", 64))
+            print(f"nodes padded to {len(nodes)} to make it divisible by {block_size} (added {added} null nodes).")
+
+    device = torch.device("cuda")
+    num_nodes, num_relations = len(n2i), len(r2i)
+    test = torch.tensor(test, dtype=torch.long)
+    train_graph = torch.tensor(train, dtype=torch.long)
+    if encoder["model"] == "rgcn":
+        kind = LinkPredictor
+    elif encoder["model"] == "c-rgcn":
+        kind = CompressionRelationPredictor
+    else:
+        raise NotImplementedError(f"'{encoder['model']}' encoder has not been implemented!")
+    model = kind(nnodes=num_nodes, nrel=num_relations, encoder_config=encoder, decoder_config=decoder).to(device)
+    opt_cfg = training.get("optimiser", {"algorithm": "adam", "learn_rate": 0.01, "weight_decay": 0.0})
+    if opt_cfg["algorithm"] not in OPTIMISERS:
+        raise NotImplementedError(f"'{opt_cfg['algorithm']}' optimiser has not been implemented!")
+    optimiser = OPTIMISERS[opt_cfg["algorithm"]](model.parameters(), lr=opt_cfg["learn_rate"], weight_decay=opt_cfg["weight_decay"])
+
+    def report(tag, mrr, hits):
+        kind_ = "filtered" if filtered else "raw"
+        print(f"{tag} MRR({kind_}): {mrr:.4f} \tHits@1({kind_}): {hits[0]:.4f} \tHits@3({kind_}): {hits[1]:.4f} \t"
+              f"Hits@10({kind_}): {hits[2]:.4f}")
+
+    losses = []
+    for epoch in range(1, max_epochs + 1):
+        t1 = time.time()
+        optimiser.zero_grad()
+        model.train()
+        with torch.no_grad():
+            if graph_batch_size is None:          # the whole graph
+                positives, graph_batch_size = train, len(train)
+            else:
+                positives = sampling_function(train, sample_size=graph_batch_size, entities=n2i)
+            positives = torch.as_tensor(positives, dtype=torch.long).to(device)
+            negatives = positives[:, None, :].expand(graph_batch_size, neg_sample_rate, 3).contiguous()
+            negatives = negative_sampling(negatives, num_nodes, head_corrupt_prob, device=device)
+            batch_idx = torch.cat([positives, negatives], dim=0)
+            train_lbl = torch.cat([torch.ones(graph_batch_size, device=device),
+                                   torch.zeros(graph_batch_size * neg_sample_rate, device=device)])
+            graph = positives
+            if edge_dropout > 0.0:                # self-loop dropout happens inside the layer
+                graph = graph[torch.randperm(graph.size(0), device=device)]
+                graph = graph[round((1 - edge_dropout) * graph.size(0)):, :]     # (keeps the edge_dropout share, as upstream)
+        predictions, penalty = model(graph, batch_idx)
+        loss = F.binary_cross_entropy_with_logits(predictions, train_lbl) + decoder_l2_penalty * penalty
+        t2 = time.time()
+        loss.backward()
+        optimiser.step()
+        torch.cuda.synchronize()
+        t3 = time.time()
+        losses.append(loss.item())
+        if not quiet:
+            print(f"[Epoch {epoch}] Loss: {loss.item():.5f} Forward: {t2 - t1:.3f}s Backward: {t3 - t2:.3f}s ")
+        if epoch % eval_every == 0 and epoch != max_epochs:
+            model.eval()
+            mrr, hits, _ = evaluate(model=model, graph=train_graph, test_set=test, true_triples=true_triples,
+                                    num_nodes=num_nodes, **eval_kw)
+            if not quiet:
+                report(f"[Epoch {epoch}]", mrr, hits)
+
+    model.eval()
+    t0 = time.time()
+    mrr, hits, ranks = evaluate(model=model, graph=train_graph, test_set=test, true_triples=true_triples,
+                                num_nodes=num_nodes, **eval_kw)
     if not quiet:
-        print("test:", {k: round(v, 4) for k, v in metrics.items()})
-    return hist, metrics
+        report(f"[Final Scores] Total Epoch {max_epochs} ({len(test)} test triples ranked in {time.time() - t0:.2f}s)", mrr, hits)
+    return losses, {"mrr": mrr, "hits@1": hits[0], "hits@3": hits[1], "hits@10": hits[2]}
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("config")
-    ap.add_argument("--data", default=None)
+    ap.add_argument("--data", default=None, help="directory holding data/<name>/{train,valid,test}.txt (default: synthetic)")
     ap.add_argument("--epochs", type=int, default=None)
+    ap.add_argument("--max-test", type=int, default=None)
     a = ap.parse_args()
-    run(yaml.safe_load(open(a.config)), a.data, a.epochs)
+    run(yaml.safe_load(open(a.config)), a.data, a.epochs, max_test=a.max_test)

@@ -143,6 +143,15 @@ def synthetic_triples_host(num_nodes, num_rels, num_edges, seed=0):
     return out
 
 
+def edge_neighborhood_host(triples, num_nodes, sample_size, seed):
+    """indices of `sample_size` triples drawn by edge-neighbourhood sampling (utils/misc.py:125-172)"""
+    triples = np.ascontiguousarray(triples, np.int64)
+    out = np.empty(sample_size, np.int64)
+    _check(lib().rgcn_edge_neighborhood_host(_hp(triples), c_i64(triples.shape[0]), c_i64(num_nodes),
+                                             c_i64(sample_size), ctypes.c_uint64(seed), _hp(out)), "edge_neighborhood")
+    return out
+
+
 class HostPlan:
     """Relation-tile plan as numpy arrays (see rgcn_plan_fill_host)."""
     __slots__ = ("src", "dst", "val", "perm", "chunk_rel", "tile_ptr", "items", "run_ptr", "pack", "units", "units_host", "_cache", "n_units", "n_split", "max_run_chunks", "n_dst", "n_src", "num_rels",
@@ -568,6 +577,55 @@ def distmult_fwd(triples, nodes, rel, sbias, pbias, obias):
                                            _dp(obias), _dp(scores), c_i64(nodes.shape[0]), c_i32(rel.shape[0]),
                                            c_i32(nodes.shape[1]), _stream(nodes.device)), "distmult_fwd")
     return scores
+
+
+def distmult_score_all(batch, head, nodes, rel, sbias=None, pbias=None, obias=None, out=None):
+    """scores [Q, N] of every entity as head (head=True) or tail of each triple of `batch` (int64 [Q,3], device);
+    utils/misc.py:71-88 without the [bn, N, 3] candidate tensor."""
+    _req(nodes, "nodes"); _req(rel, "relations"); _req(batch, "batch", torch.int64)
+    for b, n in ((sbias, "sbias"), (pbias, "pbias"), (obias, "obias")):
+        _req(b, n)
+    Q, (N, d) = batch.shape[0], nodes.shape
+    assert batch.dim() == 2 and batch.shape[1] == 3, "batch must be [Q, 3]"
+    assert rel.shape[1] == d, "relation and node embeddings differ in width"
+    if Q:
+        lo, hi = batch.amin(0), batch.amax(0)
+        assert int(lo.min()) >= 0 and int(hi[0]) < N and int(hi[2]) < N and int(hi[1]) < rel.shape[0], \
+            "triple index out of range"
+    scores = out if out is not None else torch.empty(Q, N, device=nodes.device, dtype=torch.float32)
+    assert scores.shape == (Q, N) and scores.is_contiguous() and scores.dtype == torch.float32
+    qvec = torch.empty(Q, d, device=nodes.device, dtype=torch.float32)
+    qb = torch.empty(2 * Q, device=nodes.device, dtype=torch.float32) if sbias is not None else None
+    with torch.cuda.device(nodes.device), _timed("score_all"):
+        _check(lib().rgcn_distmult_score_all_f32(_dp(batch), c_i64(Q), c_i32(1 if head else 0), _dp(nodes), _dp(rel),
+                                                 _dp(sbias), _dp(pbias), _dp(obias), _dp(qvec), _dp(qb), _dp(scores),
+                                                 c_i64(N), c_i32(rel.shape[0]), c_i32(d), _stream(nodes.device)),
+               "distmult_score_all")
+    return scores
+
+
+def rank_filter(scores, filt_q, filt_n):
+    """scores[filt_q[e], filt_n[e]] = -inf (utils/misc.py:40-58); int32 device index lists"""
+    _req(scores, "scores"); _req(filt_q, "filt_q", torch.int32); _req(filt_n, "filt_n", torch.int32)
+    assert filt_q.shape == filt_n.shape and filt_q.dim() == 1
+    with torch.cuda.device(scores.device):
+        _check(lib().rgcn_rank_filter_f32(_dp(scores), c_i64(scores.shape[0]), c_i64(scores.shape[1]), _dp(filt_q),
+                                          _dp(filt_n), c_i64(filt_q.shape[0]), _stream(scores.device)), "rank_filter")
+    return scores
+
+
+def rank_count(scores, batch, head):
+    """(#scores > target score, #scores == target score) per query, int64 (utils/misc.py:93-96)"""
+    _req(scores, "scores"); _req(batch, "batch", torch.int64)
+    Q = scores.shape[0]
+    assert batch.shape == (Q, 3)
+    greater = torch.empty(Q, device=scores.device, dtype=torch.int64)
+    ties = torch.empty(Q, device=scores.device, dtype=torch.int64)
+    with torch.cuda.device(scores.device), _timed("rank_count"):
+        _check(lib().rgcn_rank_count_f32(_dp(scores), _dp(batch), c_i64(Q), c_i32(1 if head else 0),
+                                         c_i64(scores.shape[1]), _dp(greater), _dp(ties), _stream(scores.device)),
+               "rank_count")
+    return greater, ties
 
 
 def distmult_bwd(triples, nodes, rel, gs, with_bias):

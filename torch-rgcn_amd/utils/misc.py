@@ -1,66 +1,131 @@
-"""Sampling and ranking evaluation for link prediction (counterpart of the reference's utils/misc.py:60-189).
+"""Sampling and ranking evaluation for link prediction -- counterpart of the reference's utils/misc.py:29-189,
+same function names, arguments and return values (sacred's create_experiment is out of scope).
 
-evaluate(): the reference re-runs the whole encoder for every batch of 32 test triples (misc.py:86); here the graph is
-encoded ONCE and every (s, p, ?) / (?, p, o) query is scored against all entities with the DistMult kernel
-("encode once, score many").  Filtered ranks as in the reference: known true triples are
-removed from the candidate list before ranking.
+evaluate(): the reference expands every batch of test triples to a [bn, N, 3] candidate tensor and calls the whole
+model on it, which re-runs the encoder for each of the ~2 * len(test) / batch_size batches (misc.py:78-85).  Here the
+graph is encoded ONCE and the candidates are scored by the MFMA kernel behind `_native.distmult_score_all`
+("encode once, score many"); filtering and rank counting are HIP kernels too.  Ranks are defined
+exactly as in the reference: known true completions other than the target are set to -inf (misc.py:40-58), and the
+target sits halfway down its ties (misc.py:93-101).
 """
+import random
+
 import numpy as np
 import torch
 
+from torch_rgcn import _native
+from torch_rgcn.layers import DistMult
 
-def negative_sampling(positive, num_nodes, neg_sample_rate, rng=None):
-    """corrupt head or tail of each positive `neg_sample_rate` times -> (triples [B*(1+rate), 3], labels)"""
-    rng = rng or np.random.default_rng()
-    b = len(positive)
-    neg = np.tile(positive, (neg_sample_rate, 1))
-    corrupt = rng.integers(0, num_nodes, size=len(neg))
-    head = rng.random(len(neg)) < 0.5
-    neg[head, 0] = corrupt[head]
-    neg[~head, 2] = corrupt[~head]
-    labels = np.concatenate([np.ones(b, np.float32), np.zeros(len(neg), np.float32)])
-    return np.concatenate([positive, neg]), labels
-
-
-def sample_edges(train, batch_size, rng=None):
-    """uniform edge sample (the reference's default; its neighbourhood sampler is O(batch * N) numpy)"""
-    rng = rng or np.random.default_rng()
-    return train[rng.choice(len(train), size=min(batch_size, len(train)), replace=False)]
+_SCORE_BYTES = 1 << 30     # score-matrix budget per chunk of queries
 
 
 def generate_true_dict(all_triples):
+    """(p, o) -> known heads and (s, p) -> known tails, duplicates kept (misc.py:29-38)"""
     heads, tails = {}, {}
-    for s, p, o in np.asarray(all_triples).tolist():
+    for s, p, o in (all_triples.tolist() if hasattr(all_triples, "tolist") else all_triples):
         heads.setdefault((p, o), []).append(s)
         tails.setdefault((s, p), []).append(o)
     return heads, tails
 
 
+def _filter_lists(batch, true_triples, head):
+    heads, tails = true_triples
+    rows, cols = [], []
+    for i, (s, p, o) in enumerate(batch):
+        known = [si for si in heads.get((p, o), ()) if si != s] if head else [oi for oi in tails.get((s, p), ()) if oi != o]
+        rows.extend([i] * len(known))
+        cols.extend(known)
+    return rows, cols
+
+
+def filter_scores(scores, batch, true_triples, head=True):
+    """scores of known true triples that are not the target -> -inf, in place (misc.py:40-58)"""
+    rows, cols = _filter_lists(batch.tolist(), true_triples, head)
+    if rows:   # (the reference indexes an empty tensor and raises here)
+        _native.rank_filter(scores, torch.tensor(rows, dtype=torch.int32, device=scores.device),
+                            torch.tensor(cols, dtype=torch.int32, device=scores.device))
+
+
+def _rank_chunk(scores, batch, true_triples, head, filter_candidates):
+    if filter_candidates:
+        filter_scores(scores, batch, true_triples, head=head)
+    raw, ties = _native.rank_count(scores, batch, head)
+    return (raw + (ties - 1) // 2 + 1).tolist()
+
+
 @torch.no_grad()
-def evaluate(model, graph, test, true_heads, true_tails, num_nodes, batch_size=64, hits_at=(1, 3, 10), filtered=True):
-    """MRR and hits@k over head and tail queries; one encoder pass."""
-    model.eval()
+def evaluate(model, graph, test_set, true_triples, num_nodes, batch_size=16, hits_at_k=[1, 3, 10],
+             filter_candidates=True, verbose=True):
+    """(mrr, hits tuple, ranks): head queries for the whole test set first, then tail queries (misc.py:60-110).
+
+    `batch_size` only bounds the score matrix of models without an `encode`/DistMult pair; the fast path scores as many
+    queries at once as fit in 1 GiB -- ranks do not depend on the batching."""
     device = next(model.parameters()).device
-    x = model.encode(graph)
-    test = np.asarray(test)
+    test_set = torch.as_tensor(test_set, dtype=torch.long)
+    decoder = getattr(model, "scoring_function", None)
+    fast = hasattr(model, "encode") and isinstance(decoder, DistMult)
+    if fast:
+        x = model.encode(graph).contiguous()
+        assert x.shape[0] == num_nodes, "num_nodes differs from the encoder output"
+        batch_size = max(batch_size, min(len(test_set), max(64, _SCORE_BYTES // (4 * num_nodes))))
     ranks = []
-    cand = torch.arange(num_nodes, device=device)
-    for head_query in (True, False):
-        for a in range(0, len(test), batch_size):
-            b = torch.as_tensor(test[a:a + batch_size], device=device)
-            q = b[:, None, :].expand(len(b), num_nodes, 3).clone()
-            q[:, :, 0 if head_query else 2] = cand[None, :]
-            scores = model.scoring_function(q, x)                       # [batch, N] via the DistMult kernel
-            target = b[:, 0 if head_query else 2]
-            true_score = scores.gather(1, target[:, None])
-            if filtered:
-                for i, (s, p, o) in enumerate(b.tolist()):
-                    known = true_heads.get((p, o), []) if head_query else true_tails.get((s, p), [])
-                    if known:
-                        scores[i, torch.as_tensor(known, device=device)] = float("-inf")
-            ranks.append(((scores > true_score).sum(1) + 1).cpu())
-    ranks = torch.cat(ranks).float()
-    out = {"mrr": (1.0 / ranks).mean().item()}
-    for k in hits_at:
-        out[f"hits@{k}"] = (ranks <= k).float().mean().item()
-    return out
+    for head in (True, False):
+        for fr in range(0, len(test_set), batch_size):
+            batch = test_set[fr:fr + batch_size].to(device).contiguous()
+            bn = batch.shape[0]
+            if fast:
+                scores = _native.distmult_score_all(batch, head, x, decoder.relations.detach(),
+                                                    *((decoder.sbias.detach(), decoder.pbias.detach(), decoder.obias.detach())
+                                                      if decoder.b_init else ()))
+            else:
+                ar = torch.arange(num_nodes, device=device).view(1, num_nodes, 1).expand(bn, num_nodes, 1)
+                bexp = (batch[:, 1:] if head else batch[:, :2]).view(bn, 1, 2).expand(bn, num_nodes, 2)
+                scores, _ = model(graph, torch.cat([ar, bexp] if head else [bexp, ar], dim=2))
+                scores = scores.float().contiguous()
+            assert scores.shape == (bn, num_nodes)
+            ranks.extend(_rank_chunk(scores, batch, true_triples, head, filter_candidates))
+        if verbose:
+            print(f"  ranked {len(test_set)} {'head' if head else 'tail'} queries")
+    mrr = sum(1.0 / r for r in ranks) / len(ranks)
+    hits = tuple(sum(1.0 if r <= k else 0.0 for r in ranks) / len(ranks) for k in hits_at_k)
+    return mrr, hits, ranks
+
+
+def select_sampling(method):
+    method = method.lower()
+    if method == 'uniform':
+        return uniform_sampling
+    if method == 'edge-neighborhood':
+        return edge_neighborhood
+    raise NotImplementedError(f'{method} sampling method has not been implemented!')
+
+
+def uniform_sampling(graph, sample_size=30000, entities=None, train_triplets=None):
+    """sample_size triples without replacement (misc.py:120-122)"""
+    return random.sample(list(graph) if not isinstance(graph, list) else graph, sample_size)
+
+
+def edge_neighborhood(train_triples, sample_size=30000, entities=None, seed=None):
+    """Edge-neighbourhood sampling (misc.py:125-172): grow the sample along edges of already-visited vertices, a vertex
+    drawn with probability proportional to its number of still-unpicked incident edges.
+
+    The reference rebuilds an O(N) probability vector and calls np.random.choice for every one of the sample_size
+    draws (O(sample_size * N)); the native sampler keeps the weights in a Fenwick tree (O(log N) per draw).  Same
+    distribution, its own random stream (`seed`; drawn from Python's `random` when None)."""
+    triples = np.ascontiguousarray(np.asarray(train_triples, dtype=np.int64).reshape(-1, 3))
+    num_nodes = len(entities) if entities is not None else int(max(triples[:, 0].max(), triples[:, 2].max())) + 1
+    if seed is None:
+        seed = random.getrandbits(63)
+    picked = _native.edge_neighborhood_host(triples, num_nodes, sample_size, seed)
+    rows = triples[picked]
+    return [train_triples[e] for e in picked.tolist()] if isinstance(train_triples, list) else rows
+
+
+def negative_sampling(batch, num_nodes, head_corrupt_prob, device='cpu'):
+    """Corrupt the head (probability head_corrupt_prob) or else the tail of every triple of `batch` [bs, ns, 3], in
+    place; returns the [bs * ns, 3] view (misc.py:174-189)."""
+    bs, ns, _ = batch.size()
+    rows = batch.view(bs * ns, 3)
+    column = torch.where(torch.rand(bs * ns, device=device) < head_corrupt_prob, 0, 2)     # 0: head, 2: tail
+    rows[torch.arange(bs * ns, device=device), column] = torch.randint(0, num_nodes, (bs * ns,), device=device)
+    return rows
