@@ -31,6 +31,7 @@ for p in (ROOT, os.path.join(ROOT, "torch-rgcn_amd")):
 # down, i.e. after our result line.  The contract is "rank 0 prints ONE JSON line": keep it the last line.
 if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
     del os.environ["NCCL_DEBUG"]
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL across processes)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

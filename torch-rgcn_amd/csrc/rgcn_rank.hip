@@ -94,6 +94,10 @@ __global__ __launch_bounds__(WG) void score_all_kernel(
 #pragma unroll
     for (int b = 0; b < TB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 a0[TA], b0[TB], a1[TA], b1[TB];
+  if (ablate & 4) {
+    for (int a = 0; a < TA; ++a) a1[a] = f32x4{1.f, 2.f, 3.f, 4.f};
+    for (int b = 0; b < TB; ++b) b1[b] = f32x4{1.f, 2.f, 3.f, 4.f};
+  }
   auto fetch = [&](f32x4 (&av)[TA], f32x4 (&bv)[TB], int k) {
 #pragma unroll
     for (int a = 0; a < TA; ++a) av[a] = load_k4<VEC>(ap[a], k, d);
@@ -114,11 +118,11 @@ __global__ __launch_bounds__(WG) void score_all_kernel(
     fetch(a0, b0, k0);
     int t = 0;
     for (; t + 2 <= full; t += 2) {
-      fetch(a1, b1, (ablate & 1) ? k0 : 16 * (t + 1) + k0);
+      if (!(ablate & 4)) fetch(a1, b1, (ablate & 1) ? k0 : 16 * (t + 1) + k0);
       __builtin_amdgcn_sched_barrier(0);   // loads stay above the MFMAs (hipcc would sink them to their first use)
       multiply(a0, b0);
       __builtin_amdgcn_sched_barrier(0);
-      fetch(a0, b0, (ablate & 1) ? k0 : 16 * min(t + 2, full - 1) + k0);
+      if (!(ablate & 4)) fetch(a0, b0, (ablate & 1) ? k0 : 16 * min(t + 2, full - 1) + k0);
       __builtin_amdgcn_sched_barrier(0);
       multiply(a1, b1);
       __builtin_amdgcn_sched_barrier(0);

@@ -143,3 +143,8 @@ def block_diag(m):
     idx = torch.arange(nb, device=m.device)
     out[..., idx, :, idx, :] = m.movedim(-3, 0)
     return out.reshape(*lead, nb * bi, nb * bo)
+
+
+def attach_dim(v, n_dim_to_prepend=0, n_dim_to_append=0):
+    """view of `v` with singleton dimensions added in front / at the back (utils.py:198-199)"""
+    return v.reshape((1,) * n_dim_to_prepend + tuple(v.shape) + (1,) * n_dim_to_append)
