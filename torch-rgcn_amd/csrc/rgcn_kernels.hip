@@ -245,112 +245,6 @@ __global__ __launch_bounds__(WG) void pack_w16_kernel(const float *__restrict__ 
   Wp[i] = W[r * 256 + (4 * kk + c) * 16 + o];
 }
 
-// ---- variant: slot indices of block b+1 are fetched while block b is gathered and multiplied
-// (issue early / write late through a 1 KiB LDS double buffer).  The early loads are inline asm so that
-// hipcc can neither sink them to their use nor wait for them before the matrix work; they are older than
-// every compiler-visible load of the iteration, so the compiler's own counted vmcnt waits stay valid.
-__device__ __forceinline__ void asm_load_b32(int &dst, const void *p) {
-  asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
-}
-
-__global__ __launch_bounds__(WG) void spmm_d16_staged_kernel(
-    const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias,
-    float *__restrict__ out, const int *__restrict__ p_src, const int *__restrict__ p_dst,
-    const float *__restrict__ p_val, const int *__restrict__ chunk_rel, const int4 *__restrict__ units,
-    int n_units, int tile_rows, int n_dst, int relu_out) {
-  constexpr int U = 4;                       // 4 chunks = 64 slots = one slot per lane
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int uu = blockIdx.x * SPMM_WAVES + wave;
-  if (uu >= n_units) return;
-  const int4 unit = units[uu];
-  if (unit.w) return;   // experimental variant: whole-tile units only
-  const int t = unit.x;
-  const int stride = tile_rows * 16 + 2 * 256;                     // tile | 2 x (src,val,dst,rel) x 64
-  float *tile = lds + (size_t)wave * stride;
-  int *stage = reinterpret_cast<int *>(tile + tile_rows * 16);
-  const int row0 = t * tile_rows;
-  const int nrows = min(tile_rows, n_dst - row0);
-  for (int i = lane; i < nrows * 4; i += 64) reinterpret_cast<float4 *>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  const int my0 = unit.y, my1 = unit.z;
-  const int m = lane & 15, k = lane >> 4;
-  const int woff = (4 * k) * 16 + m;
-  if (my0 < my1) {
-    const int last_slot = my1 * RGCN_CHUNK - 1;
-    const int last = my1 - 1;
-    int ts, td, tv, tr;
-    auto issue = [&](int c) {   // lane l <- slot c*16 + l  (clamped; slots past the end get val = 0 when staged)
-      const int e = min(c * RGCN_CHUNK + lane, last_slot);
-      asm_load_b32(ts, p_src + e);
-      asm_load_b32(tv, p_val + e);
-      asm_load_b32(td, p_dst + e);
-      asm_load_b32(tr, chunk_rel + min(c + k, last));
-    };
-    auto land = [&](int c, int buf) {
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(ts), "+v"(tv), "+v"(td), "+v"(tr)::"memory");
-      int *sb = stage + buf * 256;
-      sb[lane] = ts;
-      sb[64 + lane] = (c * RGCN_CHUNK + lane <= last_slot) ? tv : 0;
-      sb[128 + lane] = td;
-      sb[192 + lane] = tr;
-      asm volatile("" ::: "memory");
-    };
-    issue(my0);
-    land(my0, 0);
-    int buf = 0;
-    for (int c = my0; c < my1; c += U, buf ^= 1) {
-      issue(c + U);                                        // next block's indices: in flight during this block
-      const int *sb = stage + buf * 256;
-      int s[U], d[U], r[U];
-      float v[U];
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        s[j] = sb[j * 16 + m];
-        v[j] = __builtin_bit_cast(float, sb[64 + j * 16 + m]);
-        d[j] = sb[128 + j * 16 + m];
-        r[j] = sb[192 + j * 16];
-      }
-      float4 x[U], w[U];
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        x[j] = *reinterpret_cast<const float4 *>(X + (size_t)s[j] * 16 + 4 * k);
-        const float *wr = W + (size_t)r[j] * 256 + woff;
-        w[j] = make_float4(wr[0], wr[16], wr[32], wr[48]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        const float vv = v[j];
-        const bool live = vv != 0.f;
-        f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].x, live ? x[j].x * vv : 0.f, acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].y, live ? x[j].y * vv : 0.f, acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].z, live ? x[j].z * vv : 0.f, acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].w, live ? x[j].w * vv : 0.f, acc[0], 0, 0, 0);
-        const bool tail = fold_segments<1>(acc, d[j]);
-        if (tail) {
-          f32x4 *p = reinterpret_cast<f32x4 *>(tile + (d[j] - row0) * 16 + 4 * k);
-          *p += acc[0];
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      land(c + U, buf ^ 1);
-    }
-  }
-  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (bias) bv = reinterpret_cast<const float4 *>(bias)[lane & 3];
-  float4 *o4 = reinterpret_cast<float4 *>(out + (size_t)row0 * 16);
-  asm volatile("" ::: "memory");
-  for (int i = lane; i < nrows * 4; i += 64) {
-    float4 a = reinterpret_cast<const float4 *>(tile)[i];
-    a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
-    if (relu_out) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-    o4[i] = a;
-  }
-}
-
 // ---- sparse-bucket path, pass 1: relation-major chunks (dense), transformed messages scattered to their slot in
 // destination-major order.  One wave per work item (<= 64 chunks of ONE relation): the W fragment is loaded once.
 template <int U>
@@ -1014,12 +908,7 @@ extern "C" int rgcn_spmm_f32(const float *X, const float *W, const float *bias, 
 #define RGCN_LAUNCH_D16(U, P)                                                                                      \
   hipLaunchKernelGGL((spmm_d16_kernel<U, P>), grid, block, lds, st, X, W, bias, out, p_src, p_dst, p_val, pk,      \
                      chunk_rel, tile_ptr, nt, tile_rows, (int)n_dst, relu_out, ABL)
-  static const int STAGED = getenv("RGCN_SPMM_STAGE") ? atoi(getenv("RGCN_SPMM_STAGE")) : 0;
-  if (d_in == 16 && d_out == 16 && STAGED && !packed) {
-    const size_t lds2 = (size_t)SPMM_WAVES * (tile_rows * 16 + 512) * sizeof(float);
-    hipLaunchKernelGGL(spmm_d16_staged_kernel, grid, block, lds2, st, X, W, bias, out, p_src, p_dst, p_val, chunk_rel,
-                       tile_ptr, nt, tile_rows, (int)n_dst, relu_out);
-  } else if (d_in == 16 && d_out == 16) {
+  if (d_in == 16 && d_out == 16) {
     static const int U = getenv("RGCN_SPMM_U") ? atoi(getenv("RGCN_SPMM_U")) : 4;
     static const int ABL = getenv("RGCN_ABLATE") ? atoi(getenv("RGCN_ABLATE")) : 0;  // diagnosis only
     if (packed) {
