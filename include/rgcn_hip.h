@@ -235,6 +235,28 @@ RGCN_API int rgcn_featureless_wgrad_f32(const float *G, float *dtable, const int
 /* db[j] = sum_n G[n, j]  (bias gradient; deterministic two-stage reduction). */
 RGCN_API int rgcn_colsum_f32(const float *G, float *db, int64_t n, int32_t d, void *stream);
 
+/* Featureless layer with basis decomposition, source-major (layers.py:241-242 + :286-288 without the R x N x d_out
+ * table): out[s,:] = sum_{e=(s,r,o)} val_e sum_b comps[r,b] bases[b,o,:].  `bases` / `dbases` here are NODE-major
+ * copies [N, B, d] (the caller transposes the [B, N, d] parameter: one streaming pass), comps [R, B].  Messages in SOURCE-major CSR order: e_dst / e_rel / e_val [M]; `units` = int32 [n_units][4]
+ * {row, first entry, end entry, flags (RGCN_U_SHARED | RGCN_U_FIRST)}: one unit per source node, long rows cut into
+ * several (n_split = number of shared units; their results merge with fp32 atomics into a zeroed output).
+ *   rgcn_fbasis_fwd_f32:  Y[e,:] = val_e * comps[r_e,:] . bases[o,:,:]            (d <= 64, ceil(B / (64/pow2(d))) <= 16)
+ *   rgcn_fbasis_bwd_f32:  dbases[o,:,:] = sum_e val_e comps[r_e,:]^T (x) G[s_e,:];  T[e,b] = val_e <bases[o,b,:], G[s_e,:]>
+ *                         (B <= 64, d <= 16; dbases or T may be NULL)
+ *   rgcn_gather_rows_sum_f32: out[row,:] = (bias) + sum_{j in unit ranges of row} Y[perm[j],:]   (perm NULL = identity; w <= 64)
+ *     -- rows of Y by destination give the layer output, rows of T by relation give dcomps.
+ * RGCN_EUNSUPPORTED outside the stated limits (the caller falls back to rgcn_basis_aggregate_f32). */
+RGCN_API int rgcn_fbasis_fwd_f32(const float *bases, const float *comps, float *Y, const int32_t *e_rel,
+                                 const float *e_val, const int32_t *units, int64_t n_units, int64_t n_nodes,
+                                 int32_t R, int32_t B, int32_t d, void *stream);
+RGCN_API int rgcn_fbasis_bwd_f32(const float *bases, const float *comps, const float *G, float *dbases, float *T,
+                                 const int32_t *e_dst, const int32_t *e_rel, const float *e_val,
+                                 const int32_t *units, int64_t n_units, int64_t n_split, int64_t n_nodes, int32_t R,
+                                 int32_t B, int32_t d, void *stream);
+RGCN_API int rgcn_gather_rows_sum_f32(const float *Y, const int32_t *perm, const int32_t *units, int64_t n_units,
+                                      int64_t n_split, const float *bias, float *out, int64_t n_rows, int32_t w,
+                                      void *stream);
+
 /* DistMult decoder (torch_rgcn/layers.py:86-98):
  * scores[t] = sum_k nodes[s,k] rel[p,k] nodes[o,k] (+ sbias[s] + pbias[p] + obias[o]);
  * triples int64 [T,3] on the device.  Biases may all be NULL. */

@@ -360,7 +360,7 @@ def build_csr_device(dst, src, rel, val, alive, n_rows):
     p.n_rows = n_rows
     p.rowptr = cells.clone()                      # exclusive offsets; the fill pass advances `cells` itself
     p.rowptr[n_rows] = bucket_cnt[0]
-    p.msg_slot = _i32(M, dev)                     # CSR position of every input message
+    p.msg_slot = torch.full((max(M, 1),), -1, dtype=torch.int32, device=dev)[:M]   # CSR position of every live input message
     p.n_messages = None
     p.src, pdst, p.rel = _i32(m_pad, dev), _i32(m_pad, dev), _i32(m_pad, dev)
     p.val = torch.empty(max(m_pad, 1), dtype=torch.float32, device=dev)
@@ -372,6 +372,106 @@ def build_csr_device(dst, src, rel, val, alive, n_rows):
                                     _dp(rel), _dp(p.rel), _dp(p.msg_slot), c_i64(m_pad // CHUNK), _stream(dev)),
                "dev_plan_fill")
     return p
+
+
+def row_units(rowptr, n_rows, max_len):
+    """work units {row, first entry, end entry, flags} over a CSR: one per row, rows longer than max_len cut into pieces
+    (flags RGCN_U_SHARED, first piece also RGCN_U_FIRST).  -> (units int32 [n_units, 4] on the device, n_units, n_split)"""
+    dev = rowptr.device
+    rp = rowptr[: n_rows + 1].to(torch.int64)
+    deg = rp[1:] - rp[:-1]
+    pieces = torch.clamp((deg + max_len - 1) // max_len, min=1)
+    n_units = int(pieces.sum().item())
+    row = torch.repeat_interleave(torch.arange(n_rows, device=dev), pieces, output_size=n_units)
+    first = torch.cumsum(pieces, 0) - pieces
+    k = torch.arange(n_units, device=dev) - first[row]
+    begin = rp[row] + k * max_len
+    end = torch.minimum(begin + max_len, rp[row + 1])
+    shared = pieces[row] > 1
+    flags = shared.to(torch.int64) * 1 + (shared & (k == 0)).to(torch.int64) * 2
+    units = torch.stack([row, begin, end, flags], dim=1).to(torch.int32).contiguous()
+    return units, n_units, int(shared.sum().item())
+
+
+class FBasisPlan:
+    """source-major view of a graph for the featureless basis layer (see csrc/rgcn_fbasis.hip)"""
+    __slots__ = ("e_dst", "e_rel", "e_val", "n_messages", "units_src", "perm_dst", "units_dst", "perm_rel", "units_rel",
+                 "n_nodes", "num_rels")
+
+
+def build_fbasis_plan(csr_src, csr_dst, n_nodes, num_rels, max_len=1024):
+    """csr_src: rows = source nodes (entries: destination, relation, val); csr_dst: rows = destinations.  Both were
+    built from the same message list, so their msg_slot arrays link the two orders."""
+    p = FBasisPlan()
+    M = int(csr_src.rowptr[n_nodes].item())
+    p.n_messages, p.n_nodes, p.num_rels = M, n_nodes, num_rels
+    p.e_dst, p.e_rel, p.e_val = csr_src.src, csr_src.rel, csr_src.val
+    p.units_src = row_units(csr_src.rowptr, n_nodes, max_len)
+    live = csr_src.msg_slot >= 0
+    perm = torch.zeros(max(M, 1), dtype=torch.int32, device=csr_src.rowptr.device)
+    perm[csr_dst.msg_slot[live].long()] = csr_src.msg_slot[live]
+    p.perm_dst = perm                                         # destination-major position -> source-major position
+    p.units_dst = row_units(csr_dst.rowptr, n_nodes, max_len)
+    rel = csr_src.rel[:M].long()
+    p.perm_rel = torch.argsort(rel, stable=True).to(torch.int32)     # relation-major order of source-major positions
+    rel_ptr = torch.zeros(num_rels + 1, dtype=torch.int64, device=rel.device)
+    rel_ptr[1:] = torch.cumsum(torch.bincount(rel, minlength=num_rels), 0)
+    # a relation holds M / R messages: cut it into enough pieces (>= ~16 k units overall) to fill the chip
+    p.units_rel = row_units(rel_ptr, num_rels, int(min(2 * max_len, max(64, M // 16384))))
+    return p
+
+
+def fbasis_supported(B, d):
+    """source-major kernels: within their register limits, and worth it only when a node's B x d block is big enough
+    that re-reading it per message (destination-major fallback) costs more than the Y / T round trip (measured: B >= 4)"""
+    if B < 4:
+        return False
+    dp = 4
+    while dp < d and dp < 64:
+        dp <<= 1
+    ngrp = 64 // dp
+    return d <= 16 and B <= 64 and 4 * ((B + 4 * ngrp - 1) // (4 * ngrp)) <= 16
+
+
+def fbasis_fwd(table, comps, bias, plan):
+    """table: node-major [N, B, d] copy of the bases"""
+    bases = table
+    _req(bases, "bases"); _req(comps, "comps"); _req(bias, "bias")
+    N, B, d = bases.shape
+    dev = bases.device
+    Y = torch.empty(max(plan.n_messages, 1), d, device=dev, dtype=torch.float32)
+    out = torch.empty(N, d, device=dev, dtype=torch.float32)
+    units, n_units, _ = plan.units_src
+    with torch.cuda.device(dev), _timed("fbasis_fwd"):
+        _check(lib().rgcn_fbasis_fwd_f32(_dp(bases), _dp(comps), _dp(Y), _dp(plan.e_rel), _dp(plan.e_val), _dp(units),
+                                         c_i64(n_units), c_i64(N), c_i32(comps.shape[0]), c_i32(B), c_i32(d), _stream(dev)),
+               "fbasis_fwd")
+        units, n_units, n_split = plan.units_dst
+        _check(lib().rgcn_gather_rows_sum_f32(_dp(Y), _dp(plan.perm_dst), _dp(units), c_i64(n_units), c_i64(n_split),
+                                              _dp(bias), _dp(out), c_i64(N), c_i32(d), _stream(dev)), "gather_rows_sum")
+    return out
+
+
+def fbasis_bwd(table, comps, g, plan, need_bases=True, need_comps=True):
+    """-> (d table [N, B, d] node-major, dcomps [R, B])"""
+    bases = table
+    _req(bases, "bases"); _req(comps, "comps"); _req(g, "grad")
+    N, B, d = bases.shape
+    R = comps.shape[0]
+    dev = bases.device
+    dB = torch.empty_like(bases) if need_bases else None
+    T = torch.empty(max(plan.n_messages, 1), B, device=dev, dtype=torch.float32) if need_comps else None
+    dC = torch.empty(R, B, device=dev, dtype=torch.float32) if need_comps else None
+    units, n_units, n_split = plan.units_src
+    with torch.cuda.device(dev), _timed("fbasis_bwd"):
+        _check(lib().rgcn_fbasis_bwd_f32(_dp(bases), _dp(comps), _dp(g), _dp(dB), _dp(T), _dp(plan.e_dst), _dp(plan.e_rel),
+                                         _dp(plan.e_val), _dp(units), c_i64(n_units), c_i64(n_split), c_i64(N), c_i32(R),
+                                         c_i32(B), c_i32(d), _stream(dev)), "fbasis_bwd")
+        if need_comps:
+            units, n_units, n_split = plan.units_rel
+            _check(lib().rgcn_gather_rows_sum_f32(_dp(T), _dp(plan.perm_rel), _dp(units), c_i64(n_units), c_i64(n_split),
+                                                  None, _dp(dC), c_i64(R), c_i32(B), _stream(dev)), "gather_rows_sum")
+    return dB, dC
 
 
 def basis_aggregate(X, comps, csr, B, d, n_b_in):

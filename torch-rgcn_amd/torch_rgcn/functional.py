@@ -187,7 +187,13 @@ class _FeaturelessBasisMP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, bases, comps, bias, graph):
         B, N, d = bases.shape
-        table = bases.permute(1, 0, 2).contiguous()                   # [N, B, d]: one row per source node
+        ctx.src_major = _native.fbasis_supported(B, d) and os.environ.get("RGCN_FBASIS", "src") == "src"
+        table = bases.permute(1, 0, 2).contiguous()                   # [N, B, d]: one contiguous block per source node
+        if ctx.src_major:   # every node's B x d block is read once
+            comps = comps.contiguous()
+            ctx.graph, ctx.has_bias = graph, bias is not None
+            ctx.save_for_backward(table, comps)
+            return _native.fbasis_fwd(table, comps, bias, graph.fbasis_plan())
         comps = comps.contiguous()
         out = _native.basis_aggregate(table.view(N, B * d), comps, graph.csr("fwd"), B, d, B)
         if bias is not None:
@@ -198,9 +204,17 @@ class _FeaturelessBasisMP(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        g = g.contiguous()
+        if ctx.src_major:
+            table, comps = ctx.saved_tensors
+            dB, dC = _native.fbasis_bwd(table, comps, g, ctx.graph.fbasis_plan(), ctx.needs_input_grad[0],
+                                        ctx.needs_input_grad[1])
+            if dB is not None:
+                dB = dB.permute(1, 0, 2)      # a view: autograd accumulates it into the [B, N, d] parameter gradient
+            db = _native.colsum(g) if ctx.has_bias and ctx.needs_input_grad[2] else None
+            return dB, dC, db, None
         table, comps = ctx.saved_tensors
         N, B, d = table.shape
-        g = g.contiguous()
         dB = dC = db = None
         if ctx.needs_input_grad[0]:
             dB = _native.basis_aggregate(g, comps, ctx.graph.csr("bwd"), B, d, 1).view(N, B, d).permute(1, 0, 2)

@@ -108,6 +108,12 @@ class RelGraph:
             self._plans[key] = _native.build_csr_device(dst, src, p, val, alive, self.num_nodes)
         return self._plans[key]
 
+    def fbasis_plan(self):
+        """source-major message list + the permutations back to destination / relation order (featureless basis layer)"""
+        if "fbasis" not in self._plans:
+            self._plans["fbasis"] = _native.build_fbasis_plan(self.csr("bwd"), self.csr("fwd"), self.num_nodes, self.num_rels)
+        return self._plans["fbasis"]
+
     def max_degree(self):
         """largest number of messages received or sent by one node (cached; device graphs only)"""
         if "maxdeg" not in self._plans:
