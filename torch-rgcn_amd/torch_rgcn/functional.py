@@ -29,9 +29,31 @@ def _sparse_buckets(graph, W):
     return graph.max_degree() <= 4096
 
 
+def _pad16(X, W, bias):
+    """Widths below 16 (the classifier's output layer: 16 -> 4, 10 -> 11, 16 -> 2 ...) run on the hidden-16 kernels with
+    zero-padded operands: a 40-byte row costs the same 128-byte fabric request as a 64-byte one, and the d16 kernels
+    (packed slots, tiled / two-pass variants) are ~3x faster than the generic-width ones (AM: 2.9 -> 0.9 ms per launch).
+    -> (X16, W16, bias16, (d_in, d_out)) or the inputs unchanged and None."""
+    d_in, d_out = W.shape[1], W.shape[2]
+    if d_in > 16 or d_out > 16 or (d_in == 16 and d_out == 16) or os.environ.get("RGCN_PAD16", "1") == "0":
+        return X, W, bias, None
+    pad = torch.nn.functional.pad
+    return (X if d_in == 16 else pad(X, (0, 16 - d_in)), pad(W, (0, 16 - d_out, 0, 16 - d_in)),
+            None if bias is None else pad(bias, (0, 16 - d_out)), (d_in, d_out))
+
+
+def _unpad16(dims, dX, dW, db):
+    if dims is None:
+        return dX, dW, db
+    d_in, d_out = dims
+    return (None if dX is None else dX[:, :d_in], None if dW is None else dW[:, :d_in, :d_out],
+            None if db is None else db[:d_out])
+
+
 class _RelationalMP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, W, bias, graph):
+        X, W, bias, ctx.dims = _pad16(X, W, bias)
         X = X.contiguous()
         W = W.contiguous()
         b = None if bias is None else bias.contiguous()
@@ -42,13 +64,13 @@ class _RelationalMP(torch.autograd.Function):
         ctx.graph = graph
         ctx.has_bias = bias is not None
         ctx.save_for_backward(X, W)
-        return out
+        return out if ctx.dims is None else out[:, :ctx.dims[1]]
 
     @staticmethod
     def backward(ctx, g):
         X, W = ctx.saved_tensors
         graph = ctx.graph
-        g = g.contiguous()
+        g = g.contiguous() if ctx.dims is None else torch.nn.functional.pad(g, (0, 16 - ctx.dims[1]))
         dX = dW = db = None
         if ctx.needs_input_grad[0]:
             Wt = W.transpose(1, 2).contiguous()
@@ -69,7 +91,7 @@ class _RelationalMP(torch.autograd.Function):
                 dW = _native.wgrad(X, g, graph.wgt_plan(), W.shape[0])
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _native.colsum(g)
-        return dX, dW, db, None
+        return (*_unpad16(ctx.dims, dX, dW, db), None)
 
 
 class _ShardedRelationalMP(torch.autograd.Function):
@@ -81,6 +103,7 @@ class _ShardedRelationalMP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, W, bias, graph, group, n_slabs):
         import torch.distributed as dist
+        X, W, bias, ctx.dims = _pad16(X, W, bias)
         X, W = X.contiguous(), W.contiguous()
         rank = dist.get_rank(group)
         b = bias.contiguous() if (bias is not None and rank == 0) else None
@@ -91,14 +114,14 @@ class _ShardedRelationalMP(torch.autograd.Function):
             w.wait()
         ctx.graph, ctx.group, ctx.n_slabs, ctx.has_bias = graph, group, n_slabs, bias is not None
         ctx.save_for_backward(X, W)
-        return out
+        return out if ctx.dims is None else out[:, :ctx.dims[1]]
 
     @staticmethod
     def backward(ctx, g):
         import torch.distributed as dist
         X, W = ctx.saved_tensors
         graph = ctx.graph
-        g = g.contiguous()
+        g = g.contiguous() if ctx.dims is None else torch.nn.functional.pad(g, (0, 16 - ctx.dims[1]))
         dX = dW = db = None
         works = []
         if ctx.needs_input_grad[0]:
@@ -116,7 +139,7 @@ class _ShardedRelationalMP(torch.autograd.Function):
             db = _native.colsum(g)
         for w in works:
             w.wait()
-        return dX, dW, db, None, None, None
+        return (*_unpad16(ctx.dims, dX, dW, db), None, None, None)
 
 
 def sharded_relational_mp(features, weights, bias, graph, group, n_slabs=4):
