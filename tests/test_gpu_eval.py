@@ -207,3 +207,23 @@ def test_negative_sampling_and_samplers_on_device():
     assert len(sub) == 100 and all(t in triples for t in sub)
     sub = misc.edge_neighborhood(triples, sample_size=100, entities={str(i): i for i in range(50)}, seed=3)
     assert len(sub) == 100 and all(t in triples for t in sub)
+
+
+def test_s_penalty_value_and_gradients_match_the_gather_formulation():
+    """layers.py:77-85 literally (three gathers, autograd scatters) against the histogram form used here"""
+    from torch_rgcn.layers import DistMult
+    N, R0, dim, T = 500, 7, 24, 4000
+    g = torch.Generator().manual_seed(3)
+    dm = DistMult(R0, dim, N, R0).to(DEV)
+    nodes = torch.randn(N, dim, generator=g).to(DEV).requires_grad_(True)
+    for shape in ((T, 3), (40, 100, 3)):
+        tr = torch.stack([torch.randint(0, N, (T,), generator=g), torch.randint(0, R0, (T,), generator=g),
+                          torch.randint(0, N, (T,), generator=g)], dim=1).reshape(shape).to(DEV)
+        pen = dm.s_penalty(tr, nodes)
+        gn, gr = torch.autograd.grad(pen, [nodes, dm.relations])
+        s, p, o = tr[..., 0], tr[..., 1], tr[..., 2]
+        ref = nodes[s, :].pow(2).mean() + dm.relations[p, :].pow(2).mean() + nodes[o, :].pow(2).mean()
+        rn, rr = torch.autograd.grad(ref, [nodes, dm.relations])
+        assert abs(pen.item() - ref.item()) < 1e-5 * abs(ref.item())
+        assert (gn - rn).abs().max().item() < 1e-5 * rn.abs().max().item()
+        assert (gr - rr).abs().max().item() < 1e-5 * rr.abs().max().item()

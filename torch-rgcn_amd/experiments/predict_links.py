@@ -13,6 +13,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 import yaml
@@ -64,7 +65,8 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None):
     device = torch.device("cuda")
     num_nodes, num_relations = len(n2i), len(r2i)
     test = torch.tensor(test, dtype=torch.long)
-    train_graph = torch.tensor(train, dtype=torch.long)
+    train = np.asarray(train, dtype=np.int64)          # sampled from every epoch: keep it an array
+    train_graph = torch.from_numpy(train)
     if encoder["model"] == "rgcn":
         kind = LinkPredictor
     elif encoder["model"] == "c-rgcn":

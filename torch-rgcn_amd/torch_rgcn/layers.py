@@ -67,9 +67,21 @@ class DistMult(Module):
                 fill_b(b)
 
     def s_penalty(self, triples, nodes):
-        """Schlichtkrull L2 penalty: mean squares of the gathered s / p / o embeddings."""
+        """Schlichtkrull L2 penalty: mean squares of the gathered s / p / o embeddings (layers.py:77-85).
+
+        The reference gathers three T x d operands and lets autograd scatter their gradients back (index_put with
+        accumulation: 15 ms of a 20 ms WN18 training step here).  The same number is sum_n count(n) * |row_n|^2 / (T d):
+        count the occurrences once (integer histogram), square-sum every row once -- the gradient is then a plain
+        elementwise product and nothing is gathered or scattered."""
         s, p, o = split_spo(triples)
-        return nodes[s, :].pow(2).mean() + self.relations[p, :].pow(2).mean() + nodes[o, :].pow(2).mean()
+        s, p, o = s.reshape(-1), p.reshape(-1), o.reshape(-1)
+        scale = 1.0 / (s.numel() * nodes.shape[-1])
+        node_sq = nodes.pow(2).sum(dim=-1)
+        rel_sq = self.relations.pow(2).sum(dim=-1)
+        count = lambda idx, n: torch.bincount(idx.to(nodes.device), minlength=n).to(nodes.dtype)  # noqa: E731
+        n_nodes, n_rel = nodes.shape[0], self.relations.shape[0]
+        return (((count(s, n_nodes) * node_sq).sum() + (count(o, n_nodes) * node_sq).sum()) * scale
+                + (count(p, n_rel) * rel_sq).sum() * (1.0 / (p.numel() * self.relations.shape[-1])))
 
     def forward(self, triples, nodes):
         _require_gpu(nodes, "DistMult node embeddings")

@@ -101,8 +101,10 @@ def select_sampling(method):
 
 
 def uniform_sampling(graph, sample_size=30000, entities=None, train_triplets=None):
-    """sample_size triples without replacement (misc.py:120-122)"""
-    return random.sample(list(graph) if not isinstance(graph, list) else graph, sample_size)
+    """sample_size triples without replacement (misc.py:120-122); an ndarray / tensor of triples is indexed, not copied"""
+    if isinstance(graph, list):
+        return random.sample(graph, sample_size)
+    return graph[random.sample(range(len(graph)), sample_size)]
 
 
 def edge_neighborhood(train_triples, sample_size=30000, entities=None, seed=None):
@@ -112,7 +114,9 @@ def edge_neighborhood(train_triples, sample_size=30000, entities=None, seed=None
     The reference rebuilds an O(N) probability vector and calls np.random.choice for every one of the sample_size
     draws (O(sample_size * N)); the native sampler keeps the weights in a Fenwick tree (O(log N) per draw).  Same
     distribution, its own random stream (`seed`; drawn from Python's `random` when None)."""
-    triples = np.ascontiguousarray(np.asarray(train_triples, dtype=np.int64).reshape(-1, 3))
+    triples = train_triples if isinstance(train_triples, np.ndarray) and train_triples.dtype == np.int64 else \
+        np.asarray(train_triples, dtype=np.int64)
+    triples = np.ascontiguousarray(triples.reshape(-1, 3))
     num_nodes = len(entities) if entities is not None else int(max(triples[:, 0].max(), triples[:, 2].max())) + 1
     if seed is None:
         seed = random.getrandbits(63)
