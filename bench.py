@@ -141,16 +141,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    if os.environ.get("RGCN_BENCH_ONE_DEVICE"):   # test hook: every rank on cuda:0 (with RGCN_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    backend = os.environ.get("RGCN_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
     group = None
     if world > 1 or os.environ.get("RGCN_FORCE_DIST"):   # RGCN_FORCE_DIST=1: exercise the RCCL path on one GPU
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        extra = {"device_id": device} if backend == "nccl" else {}
         if "RANK" not in os.environ:
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+            dist.init_process_group(backend, rank=0, world_size=1, **extra)
         else:
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group(backend, **extra)
         group = dist.group.WORLD
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -194,16 +198,25 @@ def main():
     if rank == 0:
         kern = prof.get("spmm", [])
         spmm_ms = float(np.mean(kern)) if kern else None
+        slabbed = False
+        if spmm_ms is None and prof.get("spmm_slab"):
+            # relation-sharded path: every spmm is launched in slabs of whole tiles (the all-reduce of slab k overlaps the
+            # kernels of slab k+1); one launch = the slabs of one spmm, 4 spmm per step (2 forward, 2 feature-gradient)
+            kern = prof["spmm_slab"]
+            spmm_ms = float(np.sum(kern)) / (4 * args.steps)
+            slabbed = True
         alg = algorithmic_bytes(M, N, d, d)
         roof = None
         traffic = pmc_traffic("spmm_d16_kernel")
         if spmm_ms:
             ach = alg / (spmm_ms * 1e-3) / 1e9
-            roof = {"kernel": "spmm_d16_kernel (forward and feature-gradient launches)", "bound": "hbm",
+            roof = {"kernel": "spmm_d16_kernel (forward and feature-gradient launches)" +
+                              (f", each launched in {len(kern) // (4 * args.steps)} slabs on rank 0" if slabbed else ""),
+                    "bound": "hbm",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "traffic_if_64B_requests": pmc_traffic("spmm_d16_kernel", doubled=False),
                     "traffic_rate_GBs": round(traffic / (spmm_ms * 1e-3) / 1e9, 1) if traffic else None,
-                    "traffic_source": PMC_NOTE if traffic else None, "pmc": pmc_detail("spmm"), "avg_launch_ms": round(spmm_ms, 4), "launches_per_step": len(kern) / args.steps,
+                    "traffic_source": PMC_NOTE if traffic else None, "pmc": pmc_detail("spmm"), "avg_launch_ms": round(spmm_ms, 4), "launches_per_step": 4.0 if slabbed else len(kern) / args.steps,
                     "algorithmic_bytes_per_launch": alg,
                     "other_kernels_ms": {k: round(float(np.mean(v)), 4) for k, v in prof.items() if k != "spmm"}}
         res = {"metric": METRIC, "value": world * E / (ms * 1e-3), "unit": "edges/s", "n_gpus": world,
