@@ -233,6 +233,7 @@ def g5():
 
 # ------------------------------------------------------------------ G6
 def g6():
+    torch.manual_seed(606)              # the layers keep their own xavier init: make it independent of what ran before
     gen = torch.Generator().manual_seed(606)
     N, R0, E, d = 2000, 10, 20000, 16
     s = torch.randint(0, N, (E,), generator=gen)
