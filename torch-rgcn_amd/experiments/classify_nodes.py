@@ -81,9 +81,11 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, hipgraph=False):
     opt_cfg = training.get("optimiser", {"algorithm": "adam", "learn_rate": 0.01, "weight_decay": 0.0})
     if opt_cfg["algorithm"] not in OPTIMISERS:
         raise NotImplementedError(f"'{opt_cfg['algorithm']}' optimiser has not been implemented!")
-    extra = {"capturable": True} if hipgraph and opt_cfg["algorithm"] in ("adam", "adamw") else {}
-    if hipgraph and not extra:
+    adam_like = opt_cfg["algorithm"] in ("adam", "adamw")
+    if hipgraph and not adam_like:
         raise NotImplementedError("hipgraph=True needs a capturable optimiser (adam / adamw)")
+    # one fused multi-tensor kernel per step instead of ~10 elementwise passes over every parameter (AM: 667 M of them)
+    extra = {"fused": True, **({"capturable": True} if hipgraph else {})} if adam_like else {}
     optimiser = OPTIMISERS[opt_cfg["algorithm"]](model.parameters(), lr=opt_cfg["learn_rate"],
                                                   weight_decay=opt_cfg["weight_decay"], **extra)
     criterion = torch.nn.CrossEntropyLoss()

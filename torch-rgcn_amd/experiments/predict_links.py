@@ -77,7 +77,9 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None):
     opt_cfg = training.get("optimiser", {"algorithm": "adam", "learn_rate": 0.01, "weight_decay": 0.0})
     if opt_cfg["algorithm"] not in OPTIMISERS:
         raise NotImplementedError(f"'{opt_cfg['algorithm']}' optimiser has not been implemented!")
-    optimiser = OPTIMISERS[opt_cfg["algorithm"]](model.parameters(), lr=opt_cfg["learn_rate"], weight_decay=opt_cfg["weight_decay"])
+    extra = {"fused": True} if opt_cfg["algorithm"] in ("adam", "adamw") else {}
+    optimiser = OPTIMISERS[opt_cfg["algorithm"]](model.parameters(), lr=opt_cfg["learn_rate"],
+                                                  weight_decay=opt_cfg["weight_decay"], **extra)
 
     def report(tag, mrr, hits):
         kind_ = "filtered" if filtered else "raw"
