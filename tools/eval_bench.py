@@ -75,7 +75,7 @@ def main():
     res = {"workload": f"WN18-sized ranking: N={N}, d={d}, {Q} test triples -> {2 * Q} queries x {N} candidates, filtered",
            "evaluate_wall_s": round(wall, 4), "queries_per_s": round(2 * Q / wall), "true_dict_build_s": round(t_dict, 3),
            "mrr": mrr, "kernels_ms_in_evaluate": {k: round(float(np.sum(v)), 3) for k, v in prof.items()},
-           "roofline": {"kernel": "score_all_kernel<true> (+ rank_query_kernel)", "bound": "mfma", "achieved": round(flops / (k_ms * 1e-3) / 1e12, 2),
+           "roofline": {"kernel": "score_all_lds_kernel<true> (+ rank_query_kernel)", "bound": "mfma", "achieved": round(flops / (k_ms * 1e-3) / 1e12, 2),
                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / (k_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                         "avg_launch_ms": round(k_ms, 4), "flops_per_launch": flops, "traffic": None}}
     if not a.no_cpu:

@@ -161,6 +161,100 @@ __global__ __launch_bounds__(WG) void score_all_kernel(
     }
 }
 
+// Same product with the operands staged through LDS: a workgroup owns 128 queries x 128 candidates (a 64 x 64 block
+// per wave), every K step's two 128 x 16 operand slabs are fetched from L2 ONCE per workgroup (the register-only kernel
+// fetches each slab twice, and 16 rows x 64 B per instruction is a poor shape for the L1), written to a double-buffered
+// LDS tile (row stride 20 floats: the ds_read_b128 of 16 rows x 4 column groups is conflict-free) and read back as MFMA
+// operands.  The loads of step t+1 are issued before the 64 MFMAs of step t and land in LDS after them.
+constexpr int LDS_LD = 20;
+template <bool VEC>
+__global__ __launch_bounds__(WG) void score_all_lds_kernel(
+    const float *__restrict__ qvec, const float *__restrict__ qb, const float *__restrict__ nodes,
+    const float *__restrict__ cbias, float *__restrict__ scores, int Q, long long N, int d, int head, int q_blocks) {
+  __shared__ __attribute__((aligned(16))) float sA[2][128 * LDS_LD], sB[2][128 * LDS_LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, kq = lane >> 4;
+  const int qt = (blockIdx.x % q_blocks) * 128;
+  const long long ct = (long long)(blockIdx.x / q_blocks) * 128;
+  const int q0 = qt + (wave >> 1) * 64;
+  const long long c0 = ct + (wave & 1) * 64;
+  // staging: thread -> rows (tid >> 2) and (tid >> 2) + 64 of both slabs, 16-byte column group tid & 3
+  const int sr = tid >> 2, sc = 4 * (tid & 3);
+  const float *ga[2], *gb[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    ga[h] = qvec + (size_t)min(qt + sr + 64 * h, Q - 1) * d;
+    gb[h] = nodes + (size_t)min(ct + sr + 64 * h, N - 1) * d;
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int steps = (d + 15) / 16;
+  f32x4 sa[2], sb[2];
+  auto fetch = [&](int t) {
+    const int k = 16 * t + sc;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      sa[h] = load_k4<VEC>(ga[h], k, d);
+      sb[h] = load_k4<VEC>(gb[h], k, d);
+    }
+  };
+  auto stash = [&](int buf, int t) {         // zero the K tail here, so the compute loop never masks
+    const int k = 16 * t + sc;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<f32x4 *>(&sA[buf][(sr + 64 * h) * LDS_LD + sc]) = mask_k4<VEC>(sa[h], k, d);
+      *reinterpret_cast<f32x4 *>(&sB[buf][(sr + 64 * h) * LDS_LD + sc]) = mask_k4<VEC>(sb[h], k, d);
+    }
+  };
+  fetch(0);
+  stash(0, 0);
+  __syncthreads();
+  for (int t = 0; t < steps; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < steps) fetch(t + 1);
+    f32x4 av[4], bv[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      av[a] = *reinterpret_cast<const f32x4 *>(&sA[cur][((wave >> 1) * 64 + 16 * a + i) * LDS_LD + 4 * kq]);
+      bv[a] = *reinterpret_cast<const f32x4 *>(&sB[cur][((wave & 1) * 64 + 16 * a + i) * LDS_LD + 4 * kq]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][c], bv[b][c], acc[a][b], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < steps) stash(cur ^ 1, t + 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qrow = q0 + 16 * a + 4 * kq + r;
+      if (qrow >= Q) continue;
+      float s1 = 0.f, s2 = 0.f;
+      if (qb) { s1 = qb[2 * qrow]; s2 = qb[2 * qrow + 1]; }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const long long col = c0 + 16 * b + i;
+        if (col >= N) continue;
+        float sc_ = acc[a][b][r];
+        if (qb) {
+          const float cb = cbias[col];
+          sc_ += head ? ((cb + s1) + s2) : ((s2 + s1) + cb);
+        }
+        scores[(size_t)qrow * N + col] = sc_;
+      }
+    }
+}
+
 __global__ void rank_filter_kernel(float *__restrict__ scores, long long N, const int *__restrict__ fq,
                                    const int *__restrict__ fn, long long F) {
   for (long long e = (long long)blockIdx.x * WG + threadIdx.x; e < F; e += (long long)gridDim.x * WG)
@@ -217,8 +311,22 @@ extern "C" int rgcn_distmult_score_all_f32(const int64_t *batch, int64_t Q, int3
                      reinterpret_cast<const long long *>(batch), (int)Q, head, nodes, rel, sbias, pbias, obias, qvec,
                      qbias, d);
   static const int ablate = getenv("RGCN_RANK_ABLATE") ? atoi(getenv("RGCN_RANK_ABLATE")) : 0;   // measurement only
-  static const int tile_env = getenv("RGCN_RANK_TILE") ? atoi(getenv("RGCN_RANK_TILE")) : 44;   // TA*10 + TB
-  const int tile = (tile_env == 22 || tile_env == 24 || tile_env == 42) ? tile_env : 44;    // 4 x 4 measured fastest
+  static const int tile_env = getenv("RGCN_RANK_TILE") ? atoi(getenv("RGCN_RANK_TILE")) : 1;   // 1 = LDS-staged (default); TA*10 + TB = register-only variant
+  const int tile = (tile_env == 22 || tile_env == 24 || tile_env == 42 || tile_env == 44) ? tile_env : 1;
+  if (tile == 1) {
+    const int qbl = (int)((Q + 127) / 128);
+    const int64_t nwg = ((n_nodes + 127) / 128) * qbl;
+    if (nwg > INT32_MAX) { rgcn_set_error("distmult_score_all: too many scores in one call; split the batch"); return RGCN_EUNSUPPORTED; }
+    const float *qb1 = sbias ? qbias : nullptr, *cb1 = sbias ? (head ? sbias : obias) : nullptr;
+    if (d % 4 == 0)
+      hipLaunchKernelGGL(score_all_lds_kernel<true>, dim3((unsigned)nwg), dim3(WG), 0, st, qvec, qb1, nodes, cb1, scores,
+                         (int)Q, (long long)n_nodes, d, head, qbl);
+    else
+      hipLaunchKernelGGL(score_all_lds_kernel<false>, dim3((unsigned)nwg), dim3(WG), 0, st, qvec, qb1, nodes, cb1, scores,
+                         (int)Q, (long long)n_nodes, d, head, qbl);
+    HIP_TRY(hipGetLastError());
+    return RGCN_OK;
+  }
   const int TAv = tile / 10, TBv = tile % 10;
   const int q_blocks = (int)((Q + 32 * TAv - 1) / (32 * TAv));
   const int64_t n_wg = ((n_nodes + 32 * TBv - 1) / (32 * TBv)) * q_blocks;
