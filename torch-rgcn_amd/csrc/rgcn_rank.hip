@@ -7,8 +7,9 @@
 // Here the [bn, N, 3] index tensor is never built.  For a batch of Q queries
 //     scores[q, n] = sum_k (nodes[fixed_q, k] * rel[p_q, k]) * nodes[n, k]  (+ biases)
 // is an NT product of the Q x d query vectors with the N x d entity table: fp32 MFMA (v_mfma_f32_16x16x4_f32,
-// exact fp32 products and accumulation), one 64 x 64 score tile per workgroup, operands straight from L2 into
-// registers (no LDS: each lane's float4 feeds four MFMAs of each of the two tiles that share it).
+// exact fp32 products and accumulation).  Default kernel: 128 x 128 scores per workgroup, operand slabs staged through
+// double-buffered LDS (score_all_lds_kernel); the register-only variant (operands straight from L2, each lane's float4
+// feeding four MFMAs of each tile that shares it) is kept selectable for comparison (RGCN_RANK_TILE=44).
 // The K index is permuted -- lane group kq carries k = 16t + 4kq + c at MFMA c of step t -- which is legal
 // because both operands use the same permutation and the sum over k does not care.
 #include <hip/hip_runtime.h>
