@@ -176,7 +176,7 @@ RGCN_API int rgcn_basis_dcomps_f32(const float *X, const float *D, float *dcomps
  * p_pack (may be NULL): packed slots from rgcn_plan_fill_host; with d_in = d_out = 16 the kernel then
  * reads 8 bytes of index data per message instead of 12. */
 #define RGCN_F_RELU 1
-#define RGCN_F_WPACKED 2   /* W is in MFMA fragment order (rgcn_pack_w16_f32); d_in = d_out = 16 only */
+#define RGCN_F_WPACKED 2   /* W is in MFMA fragment order (rgcn_pack_w16_f32 / rgcn_pack_w_blocks_f32); widths multiples of 16, <= 64 */
 RGCN_API int rgcn_spmm_f32(const float *X, const float *W, const float *bias, float *out, const int32_t *p_src,
                            const int32_t *p_dst, const float *p_val, const int32_t *p_pack,
                            const int32_t *chunk_rel, const int32_t *units, int64_t n_units, int64_t n_split,
@@ -186,6 +186,9 @@ RGCN_API int rgcn_spmm_f32(const float *X, const float *W, const float *bias, fl
 /* Wp[r][16k+o][c] = W[r][4k+c][o]: the per-lane float4 the hidden-16 kernel feeds to the matrix cores
  * (weight assembly step of layers.py:239-244, device side).  W, Wp: [R,16,16]. */
 RGCN_API int rgcn_pack_w16_f32(const float *W, float *Wp, int32_t R, void *stream);
+/* The same for widths that are multiples of 16 (d_in, d_out <= 64; rgcn_spmm_f32 with RGCN_F_WPACKED):
+ * Wp[r][ib][jb][16k+o][c] = W[r][16 ib + 4k + c][16 jb + o].  W, Wp: [R, d_in, d_out]. */
+RGCN_API int rgcn_pack_w_blocks_f32(const float *W, float *Wp, int32_t R, int32_t d_in, int32_t d_out, void *stream);
 
 /* Sparse-bucket variant of rgcn_spmm_f32 for d_in = d_out = 16 (graphs with many relations per tile, e.g. AM:
  * (tile, relation) buckets of a few messages would leave the 16-slot chunks mostly empty).  Two passes:

@@ -245,6 +245,113 @@ __global__ __launch_bounds__(WG) void pack_w16_kernel(const float *__restrict__ 
   Wp[i] = W[r * 256 + (4 * kk + c) * 16 + o];
 }
 
+// ---- d_in = 16 NI, d_out = 16 NJ (NI, NJ <= 4): the hidden-16 scheme over blocks of 16 features.  A lane gathers NI
+// quarters of its slot's source row (one float4 per 16-feature block; at d_in = 32 the row is a full 128-byte line), the
+// W_rel fragments come pre-swizzled per (input block, output block), the NJ accumulators are folded together and a
+// segment updates NJ float4 of its LDS row.  Packed slots only.
+// Wp[r][ib][jb][lane = 16k+o][c] = W[r][16 ib + 4k + c][16 jb + o]
+__global__ __launch_bounds__(WG) void pack_w_blocks_kernel(const float *__restrict__ W, float *__restrict__ Wp, int n,
+                                                           int NI, int NJ) {
+  const int i = blockIdx.x * WG + threadIdx.x;   // index into Wp
+  if (i >= n) return;
+  const int c = i & 3, o = (i >> 2) & 15, kk = (i >> 6) & 3;
+  const int blk = i >> 8, jb = blk % NJ, ib = (blk / NJ) % NI, r = blk / (NI * NJ);
+  Wp[i] = W[((size_t)r * 16 * NI + 16 * ib + 4 * kk + c) * (16 * NJ) + 16 * jb + o];
+}
+
+template <int NI, int NJ, int U>
+__global__ __launch_bounds__(WG) void spmm_wide_kernel(
+    const float *__restrict__ X, const float *__restrict__ Wp, const float *__restrict__ bias,
+    float *__restrict__ out, const int2 *__restrict__ p_pack, const int *__restrict__ chunk_rel,
+    const int4 *__restrict__ units, int n_units, int tile_rows, int n_dst, int relu_out) {
+  constexpr int DI = 16 * NI, DO = 16 * NJ;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int u = blockIdx.x * SPMM_WAVES + wave;
+  if (u >= n_units) return;
+  const int4 unit = units[u];
+  float *tile = lds + wave * tile_rows * DO;
+  const int row0 = unit.x * tile_rows;
+  const int nrows = min(tile_rows, n_dst - row0);
+  for (int i = lane; i < nrows * (DO / 4); i += 64) reinterpret_cast<float4 *>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int my0 = unit.y, my1 = unit.z;
+  const int m = lane & 15, k = lane >> 4;
+  if (my0 < my1) {
+    const int last = my1 - 1;
+    for (int c0 = my0; c0 < my1; c0 += U) {
+      int s[U], d[U], r[U];
+      float v[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const int cc = min(c0 + j, last);
+        const int2 pk = p_pack[cc * RGCN_CHUNK + m];
+        s[j] = pk.x & 0xFFFFFF;
+        const int dl = (int)((unsigned)pk.x >> 24);
+        d[j] = dl == 0xFF ? -1 : row0 + dl;
+        v[j] = (c0 + j <= last) ? __builtin_bit_cast(float, pk.y) : 0.f;
+        r[j] = chunk_rel[cc];
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) asm volatile("" : "+v"(d[j]), "+v"(v[j]));   // keep the index loads up here
+      __builtin_amdgcn_sched_barrier(0);
+      float4 x[U][NI], w[U][NI][NJ];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+#pragma unroll
+        for (int ib = 0; ib < NI; ++ib) x[j][ib] = *reinterpret_cast<const float4 *>(X + (size_t)s[j] * DI + 16 * ib + 4 * k);
+        const float4 *wr = reinterpret_cast<const float4 *>(Wp) + (size_t)r[j] * (NI * NJ * 64) + lane;
+#pragma unroll
+        for (int ib = 0; ib < NI; ++ib)
+#pragma unroll
+          for (int jb = 0; jb < NJ; ++jb) w[j][ib][jb] = wr[(ib * NJ + jb) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const bool live = v[j] != 0.f;
+        f32x4 acc[NJ];
+#pragma unroll
+        for (int jb = 0; jb < NJ; ++jb) acc[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ib = 0; ib < NI; ++ib) {
+          const float bx = live ? x[j][ib].x * v[j] : 0.f, by = live ? x[j][ib].y * v[j] : 0.f;
+          const float bz = live ? x[j][ib].z * v[j] : 0.f, bw = live ? x[j][ib].w * v[j] : 0.f;
+#pragma unroll
+          for (int jb = 0; jb < NJ; ++jb) {
+            acc[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j][ib][jb].x, bx, acc[jb], 0, 0, 0);
+            acc[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j][ib][jb].y, by, acc[jb], 0, 0, 0);
+            acc[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j][ib][jb].z, bz, acc[jb], 0, 0, 0);
+            acc[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j][ib][jb].w, bw, acc[jb], 0, 0, 0);
+          }
+        }
+        if (fold_segments<NJ>(acc, d[j])) {
+          float *row = tile + (d[j] - row0) * DO + 4 * k;
+#pragma unroll
+          for (int jb = 0; jb < NJ; ++jb) *reinterpret_cast<f32x4 *>(row + 16 * jb) += acc[jb];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const bool shared = (unit.w & RGCN_U_SHARED) != 0, add_bias = bias && (!shared || (unit.w & RGCN_U_FIRST));
+  float4 *o4 = reinterpret_cast<float4 *>(out + (size_t)row0 * DO);
+  for (int i = lane; i < nrows * (DO / 4); i += 64) {
+    float4 a = reinterpret_cast<const float4 *>(tile)[i];
+    if (add_bias) {
+      const float4 bv = reinterpret_cast<const float4 *>(bias)[i % (DO / 4)];
+      a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
+    }
+    if (shared) {   // piece of a hub tile: out was zeroed by the launcher, pieces are summed atomically
+      float *o = reinterpret_cast<float *>(o4 + i);
+      atomicAdd(o, a.x); atomicAdd(o + 1, a.y); atomicAdd(o + 2, a.z); atomicAdd(o + 3, a.w);
+    } else {
+      if (relu_out) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+      o4[i] = a;
+    }
+  }
+}
+
 // ---- sparse-bucket path, pass 1: relation-major chunks (dense), transformed messages scattered to their slot in
 // destination-major order.  One wave per work item (<= 64 chunks of ONE relation): the W fragment is loaded once.
 template <int U>
@@ -868,6 +975,16 @@ extern "C" int rgcn_pack_w16_f32(const float *W, float *Wp, int32_t R, void *str
   return RGCN_OK;
 }
 
+extern "C" int rgcn_pack_w_blocks_f32(const float *W, float *Wp, int32_t R, int32_t d_in, int32_t d_out, void *stream) {
+  if (!W || !Wp || R <= 0 || d_in <= 0 || d_out <= 0 || d_in % 16 || d_out % 16) { rgcn_set_error("pack_w_blocks: widths must be multiples of 16"); return RGCN_EINVAL; }
+  const int64_t n = (int64_t)R * d_in * d_out;
+  if (n > INT32_MAX) { rgcn_set_error("pack_w_blocks: weight tensor too large"); return RGCN_EUNSUPPORTED; }
+  hipLaunchKernelGGL(pack_w_blocks_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, (hipStream_t)stream, W, Wp,
+                     (int)n, d_in / 16, d_out / 16);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
 extern "C" int rgcn_spmm_f32(const float *X, const float *W, const float *bias, float *out, const int32_t *p_src,
                              const int32_t *p_dst, const float *p_val, const int32_t *p_pack,
                              const int32_t *chunk_rel, const int32_t *units, int64_t n_units, int64_t n_split,
@@ -884,8 +1001,9 @@ extern "C" int rgcn_spmm_f32(const float *X, const float *W, const float *bias, 
   }
   const int relu_out = flags & RGCN_F_RELU;
   const bool packed = (flags & RGCN_F_WPACKED) != 0;
-  if (packed && (d_in != 16 || d_out != 16 || !p_pack)) {
-    rgcn_set_error("spmm: RGCN_F_WPACKED needs d_in = d_out = 16 and packed slots");
+  const bool blocks = d_in % 16 == 0 && d_out % 16 == 0 && d_in <= 64 && d_out <= 64;
+  if (packed && (!blocks || !p_pack)) {
+    rgcn_set_error("spmm: RGCN_F_WPACKED needs widths that are multiples of 16 (<= 64) and packed slots");
     return RGCN_EINVAL;
   }
   if (n_tiles == 0) return RGCN_OK;
@@ -922,6 +1040,25 @@ extern "C" int rgcn_spmm_f32(const float *X, const float *W, const float *bias, 
       else if (U >= 2) RGCN_LAUNCH_D16(2, false);
       else RGCN_LAUNCH_D16(1, false);
     }
+  } else if (packed) {   // blocks of 16 features, fragments pre-swizzled by rgcn_pack_w_blocks_f32
+#define RGCN_LAUNCH_WIDE(NIC, NJC, UC)                                                                              \
+  hipLaunchKernelGGL((spmm_wide_kernel<NIC, NJC, UC>), grid, block, lds, st, X, W, bias, out, pk, chunk_rel, tile_ptr, \
+                     nt, tile_rows, (int)n_dst, relu_out)
+#define RGCN_WIDE_ROW(NIC)                                                                       \
+  switch (d_out / 16) {                                                                          \
+    case 1: RGCN_LAUNCH_WIDE(NIC, 1, 2); break;                                                  \
+    case 2: RGCN_LAUNCH_WIDE(NIC, 2, (NIC <= 2 ? 2 : 1)); break;                                 \
+    case 3: RGCN_LAUNCH_WIDE(NIC, 3, 1); break;                                                  \
+    default: RGCN_LAUNCH_WIDE(NIC, 4, 1); break;                                                 \
+  }
+    switch (d_in / 16) {
+      case 1: RGCN_WIDE_ROW(1) break;
+      case 2: RGCN_WIDE_ROW(2) break;
+      case 3: RGCN_WIDE_ROW(3) break;
+      default: RGCN_WIDE_ROW(4) break;
+    }
+#undef RGCN_WIDE_ROW
+#undef RGCN_LAUNCH_WIDE
   } else if (d_out <= 16) {
     RGCN_LAUNCH_GENERIC(1);
   } else if (d_out <= 32) {

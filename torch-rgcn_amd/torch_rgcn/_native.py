@@ -530,15 +530,28 @@ def _spmm_launch(X, W, bias, plan, out, flags, u0, u1, n_split, tag):
                                    c_i32(d_out), c_i32(flags), _stream(X.device)), "spmm")
 
 
+def pack_w_blocks(W):
+    """[R, 16 NI, 16 NJ] weights -> per-(input block, output block) MFMA fragments for the wide spmm kernel"""
+    Wp = torch.empty_like(W)
+    with torch.cuda.device(W.device):
+        _check(lib().rgcn_pack_w_blocks_f32(_dp(W), _dp(Wp), c_i32(W.shape[0]), c_i32(W.shape[1]), c_i32(W.shape[2]),
+                                            _stream(W.device)), "pack_w_blocks")
+    return Wp
+
+
 def _spmm_prepare(X, W, bias, plan):
     _req(X, "features"); _req(W, "weights"); _req(bias, "bias")
     R, d_in, d_out = W.shape
     assert X.shape == (plan.n_src, d_in), f"features {tuple(X.shape)} vs ({plan.n_src}, {d_in})"
     assert R == plan.num_rels
     flags = 0
-    if d_in == 16 and d_out == 16 and plan.pack is not None and not os.environ.get("RGCN_NO_PACK"):
-        W = pack_w16(W)
-        flags |= F_WPACKED
+    if plan.pack is not None and not os.environ.get("RGCN_NO_PACK"):
+        if d_in == 16 and d_out == 16:
+            W = pack_w16(W)
+            flags |= F_WPACKED
+        elif d_in % 16 == 0 and d_out % 16 == 0 and d_in <= 64 and d_out <= 64:
+            W = pack_w_blocks(W)
+            flags |= F_WPACKED
     return W, flags
 
 

@@ -30,16 +30,18 @@ def _sparse_buckets(graph, W):
 
 
 def _pad16(X, W, bias):
-    """Widths below 16 (the classifier's output layer: 16 -> 4, 10 -> 11, 16 -> 2 ...) run on the hidden-16 kernels with
-    zero-padded operands: a 40-byte row costs the same 128-byte fabric request as a 64-byte one, and the d16 kernels
-    (packed slots, tiled / two-pass variants) are ~3x faster than the generic-width ones (AM: 2.9 -> 0.9 ms per launch).
-    -> (X16, W16, bias16, (d_in, d_out)) or the inputs unchanged and None."""
+    """Widths up to 64 run on the MFMA block kernels (hidden-16 scheme over blocks of 16 features) with operands
+    zero-padded to multiples of 16: a 40-byte row costs the same 128-byte fabric request as a 64-byte one, and these
+    kernels (packed slots, pre-swizzled weight fragments, DPP folds) are several times faster than the generic-width
+    one (AM: 10 -> 11 layer 2.9 -> 0.9 ms per launch, 32 -> 32 layer 7.5 -> ~1 ms).
+    -> (X', W', bias', (d_in, d_out)) or the inputs unchanged and None."""
     d_in, d_out = W.shape[1], W.shape[2]
-    if d_in > 16 or d_out > 16 or (d_in == 16 and d_out == 16) or os.environ.get("RGCN_PAD16", "1") == "0":
+    pi, po = -d_in % 16, -d_out % 16
+    if d_in > 64 or d_out > 64 or (pi == 0 and po == 0) or os.environ.get("RGCN_PAD16", "1") == "0":
         return X, W, bias, None
     pad = torch.nn.functional.pad
-    return (X if d_in == 16 else pad(X, (0, 16 - d_in)), pad(W, (0, 16 - d_out, 0, 16 - d_in)),
-            None if bias is None else pad(bias, (0, 16 - d_out)), (d_in, d_out))
+    return (X if pi == 0 else pad(X, (0, pi)), pad(W, (0, po, 0, pi)), None if bias is None else pad(bias, (0, po)),
+            (d_in, d_out))
 
 
 def _unpad16(dims, dX, dW, db):
@@ -70,7 +72,7 @@ class _RelationalMP(torch.autograd.Function):
     def backward(ctx, g):
         X, W = ctx.saved_tensors
         graph = ctx.graph
-        g = g.contiguous() if ctx.dims is None else torch.nn.functional.pad(g, (0, 16 - ctx.dims[1]))
+        g = g.contiguous() if ctx.dims is None else torch.nn.functional.pad(g, (0, -ctx.dims[1] % 16))
         dX = dW = db = None
         if ctx.needs_input_grad[0]:
             Wt = W.transpose(1, 2).contiguous()
@@ -121,7 +123,7 @@ class _ShardedRelationalMP(torch.autograd.Function):
         import torch.distributed as dist
         X, W = ctx.saved_tensors
         graph = ctx.graph
-        g = g.contiguous() if ctx.dims is None else torch.nn.functional.pad(g, (0, 16 - ctx.dims[1]))
+        g = g.contiguous() if ctx.dims is None else torch.nn.functional.pad(g, (0, -ctx.dims[1] % 16))
         dX = dW = db = None
         works = []
         if ctx.needs_input_grad[0]:
