@@ -644,10 +644,12 @@ __global__ __launch_bounds__(WG) void wgrad_tiled_d16_kernel(
     int n_groups, int n_items) {
   __shared__ __attribute__((aligned(16))) float lds_all[(WG / 64) * (512 + 64)];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int item = blockIdx.x * (WG / 64) + wave;
-  if (item >= n_items) return;
-  const int grp = item % n_groups, tb = item / n_groups;
+  // XCD-aware work mapping (workgroup b runs on XCD b % 8, each XCD has its own L2): all the relation items of one
+  // tile block read the same G rows, so they go to ONE XCD -- the rows are fetched into one L2 instead of eight.
+  const int xcd = blockIdx.x & 7, local = (blockIdx.x >> 3) * (WG / 64) + wave;
+  const int grp = local % n_groups, tb = (local / n_groups) * 8 + xcd;
   const int t0 = tb * tiles_per_item, t1 = min(n_tiles, t0 + tiles_per_item);
+  if (t0 >= n_tiles) return;
   const int r0 = grp * RG, r1 = min(R, r0 + RG);
   float *xs = lds_all + wave * (512 + 64);                          // 2 x scratch 16x16 | dst rows of U chunks
   int *dl = reinterpret_cast<int *>(xs + 512);
@@ -1148,8 +1150,11 @@ extern "C" int rgcn_wgrad_tiled_f32(const float *X, const float *G, float *dW, c
   const int RGv = RGSEL <= 1 ? 1 : RGSEL <= 2 ? 2 : RGSEL <= 4 ? 4 : RGSEL <= 8 ? 8 : 16;
   const int n_groups = (R + RGv - 1) / RGv;
   tiles_per_item = std::min(tiles_per_item, 8);   // the kernel keeps the run bounds of one item in registers
-  const int64_t n_items = ((n_tiles + tiles_per_item - 1) / tiles_per_item) * n_groups;
-  const unsigned gx = (unsigned)((n_items + WG / 64 - 1) / (WG / 64));
+  const int64_t n_blocks = (n_tiles + tiles_per_item - 1) / tiles_per_item;
+  const int64_t n_items = n_blocks * n_groups;
+  // 8 interleaved work lists (one per XCD): list x holds the items of tile blocks x, x + 8, x + 16, ...
+  const int64_t per_xcd = ((n_blocks + 7) / 8) * n_groups;
+  const unsigned gx = (unsigned)(8 * ((per_xcd + WG / 64 - 1) / (WG / 64)));
 #define RGCN_LAUNCH_WT(RGC, UC)                                                                                    \
   hipLaunchKernelGGL((wgrad_tiled_d16_kernel<RGC, UC>), dim3(gx), dim3(WG), 0, st, X, G, dW, p_src, p_dst, p_val, \
                      chunk_rel, run_ptr, (int)n_tiles, R, tiles_per_item, n_groups, (int)n_items)

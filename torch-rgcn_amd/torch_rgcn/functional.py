@@ -15,6 +15,13 @@ import torch
 from . import _native
 
 
+def _wgrad_tiles(plan):
+    """destination tiles per work item of the tile-major weight gradient: more tiles amortise the item's set-up and its
+    256 atomics (8 measured best at S1), fewer keep small graphs parallel"""
+    env = os.environ.get("RGCN_WGRAD_TILES")
+    return int(env) if env else (8 if plan.n_tiles >= 4096 else 4)
+
+
 def _sparse_buckets(graph, W):
     """hidden 16 and (tile, relation) buckets so small that the 16-slot chunks are mostly padding"""
     if W.shape[1] != 16 or W.shape[2] != 16 or getattr(graph, "_dev", None) is None:
@@ -88,7 +95,7 @@ class _RelationalMP(torch.autograd.Function):
             dense = fp.m_pad > 0 and fp.n_messages >= 0.5 * fp.m_pad
             tiled_ok = W.shape[1] == 16 and W.shape[2] == 16 and fp.max_run_chunks <= 64 and dense
             if tiled_ok and os.environ.get("RGCN_WGRAD", "tiled") == "tiled":
-                dW = _native.wgrad_tiled(X, g, fp, W.shape[0], int(os.environ.get("RGCN_WGRAD_TILES", "4")))
+                dW = _native.wgrad_tiled(X, g, fp, W.shape[0], _wgrad_tiles(fp))
             else:
                 dW = _native.wgrad(X, g, graph.wgt_plan(), W.shape[0])
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -134,7 +141,7 @@ class _ShardedRelationalMP(torch.autograd.Function):
             fp = graph.fwd_plan(W.shape[2])
             dense = fp.m_pad > 0 and fp.n_messages >= 0.5 * fp.m_pad
             if W.shape[1] == 16 and W.shape[2] == 16 and fp.max_run_chunks <= 64 and dense:
-                dW = _native.wgrad_tiled(X, g, fp, W.shape[0], int(os.environ.get("RGCN_WGRAD_TILES", "4")))
+                dW = _native.wgrad_tiled(X, g, fp, W.shape[0], _wgrad_tiles(fp))
             else:
                 dW = _native.wgrad(X, g, graph.wgt_plan(), W.shape[0])
         if ctx.has_bias and ctx.needs_input_grad[2]:
