@@ -23,6 +23,8 @@ ap.add_argument("--d", type=int, default=16)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--what", default="spmm,wgrad")
 ap.add_argument("--skew", type=float, default=0.0, help="Zipf exponent for subjects/objects/relations (0 = uniform S1 graph)")
+ap.add_argument("--local", type=int, default=0, help="objects within +-LOCAL rows of their subject (0 = uniform S1 graph): shows "
+                "what the same kernels do when the graph has node locality")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 N, R0, E, d = a.nodes, a.rels, a.edges, a.d
@@ -35,6 +37,11 @@ if a.skew > 0:
         return rng.choice(n, size=size, p=w / w.sum())
     T = np.stack([zipf(N, E), zipf(R0, E), rng.permutation(N)[zipf(N, E)]], axis=1).astype(np.int64)
     print("skewed graph: max in-degree", np.bincount(T[:, 0]).max(), "largest relation", np.bincount(T[:, 1]).max(), flush=True)
+elif a.local > 0:
+    T = _native.synthetic_triples_host(N, R0, E, 0)
+    rng = np.random.default_rng(0)
+    T[:, 2] = (T[:, 0] + rng.integers(-a.local, a.local + 1, size=E)) % N
+    print(f"local graph: |subject - object| <= {a.local}", flush=True)
 else:
     T = _native.synthetic_triples_host(N, R0, E, 0)
 tp = _native.add_inverse_and_self_host(T, N, R0)
