@@ -40,7 +40,7 @@ def _pad16(X, W, bias):
     """Widths up to 64 run on the MFMA block kernels (hidden-16 scheme over blocks of 16 features) with operands
     zero-padded to multiples of 16: a 40-byte row costs the same 128-byte fabric request as a 64-byte one, and these
     kernels (packed slots, pre-swizzled weight fragments, DPP folds) are several times faster than the generic-width
-    one (AM: 10 -> 11 layer 2.9 -> 0.9 ms per launch, 32 -> 32 layer 7.5 -> ~1 ms).
+    one (AM: 10 -> 11 layer 2.9 -> 0.9 ms per launch, 32 -> 32 layer 7.5 -> 2.2 ms).
     -> (X', W', bias', (d_in, d_out)) or the inputs unchanged and None."""
     d_in, d_out = W.shape[1], W.shape[2]
     pi, po = -d_in % 16, -d_out % 16
