@@ -1,3 +1,5 @@
+"""More than 2^24 nodes (the packed 8-byte slot holds a 24-bit source id): the unpacked slot arrays against the oracle
+at N = 17 M (python tools/big_n_check.py; ~20 s of oracle time)."""
 import sys, os, time
 ROOT=os.environ.get("GRAFT_REPO_ROOT","/root/repo")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT,"torch-rgcn_amd"))

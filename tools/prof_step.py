@@ -1,3 +1,5 @@
+"""cProfile of the eager AIFB-shaped training step: where the host time goes when the kernels are short
+(python tools/prof_step.py)."""
 import cProfile, pstats, sys, os, io
 ROOT=os.environ.get("GRAFT_REPO_ROOT","/root/repo")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT,"torch-rgcn_amd"))

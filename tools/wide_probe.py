@@ -1,3 +1,5 @@
+"""Undecomposed weights at widths above 16: per-message kernels vs transform-then-aggregate through the R x N x d message
+table, fwd+bwd, three graph shapes (python tools/wide_probe.py)."""
 import sys, os, time
 ROOT=os.environ.get("GRAFT_REPO_ROOT","/root/repo")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT,"torch-rgcn_amd"))
