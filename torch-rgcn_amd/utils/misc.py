@@ -28,22 +28,59 @@ def generate_true_dict(all_triples):
     return heads, tails
 
 
-def _filter_lists(batch, true_triples, head):
-    heads, tails = true_triples
-    rows, cols = [], []
-    for i, (s, p, o) in enumerate(batch):
-        known = [si for si in heads.get((p, o), ()) if si != s] if head else [oi for oi in tails.get((s, p), ()) if oi != o]
-        rows.extend([i] * len(known))
-        cols.extend(known)
-    return rows, cols
+class _FilterIndex:
+    """The true-triple dictionaries flattened once into two sorted key -> candidates tables (numpy), so that the filter
+    lists of a whole batch of queries are a searchsorted + repeat instead of a Python loop over the queries."""
+
+    def __init__(self, true_triples, num_nodes):
+        self.n = int(num_nodes)
+        self.tables = []
+        for table, key_of in ((true_triples[0], lambda k: k[0] * self.n + k[1]),      # heads: (p, o) -> [s]
+                              (true_triples[1], lambda k: k[1] * self.n + k[0])):     # tails: (s, p) -> [o]
+            keys = np.fromiter((key_of(k) for k in table), np.int64, len(table))
+            lens = np.fromiter((len(v) for v in table.values()), np.int64, len(table))
+            vals = np.fromiter((x for v in table.values() for x in v), np.int64, int(lens.sum()))
+            order = np.argsort(keys, kind="stable")
+            ptr = np.zeros(len(keys) + 1, np.int64)
+            np.cumsum(lens[order], out=ptr[1:])
+            starts = np.concatenate([[0], np.cumsum(lens)])[:-1][order]
+            gather = np.repeat(starts - ptr[:-1], lens[order]) + np.arange(int(lens.sum()))
+            self.tables.append((keys[order], ptr, vals[gather]))
+
+    def lists(self, batch, head):
+        """-> (rows, cols) int32 arrays: for query i every known completion except its own target"""
+        b = np.asarray(batch, np.int64)
+        keys, ptr, vals = self.tables[0 if head else 1]
+        q = b[:, 1] * self.n + (b[:, 2] if head else b[:, 0])
+        pos = np.searchsorted(keys, q)
+        pos_c = np.minimum(pos, max(len(keys) - 1, 0))
+        hit = (pos < len(keys)) & (keys[pos_c] == q) if len(keys) else np.zeros(len(q), bool)
+        lo = np.where(hit, ptr[pos_c], 0)
+        cnt = np.where(hit, ptr[pos_c + 1] - ptr[pos_c], 0) if len(keys) else np.zeros(len(q), np.int64)
+        rows = np.repeat(np.arange(len(q)), cnt)
+        cols = vals[np.repeat(lo - np.concatenate([[0], np.cumsum(cnt)])[:-1], cnt) + np.arange(int(cnt.sum()))]
+        keep = cols != (b[:, 0] if head else b[:, 2])[rows]
+        return rows[keep].astype(np.int32), cols[keep].astype(np.int32)
+
+
+_FILTER_CACHE = []      # [(true_triples object, num_nodes, _FilterIndex)]: one entry per experiment in practice
+
+
+def _filter_index(true_triples, num_nodes):
+    for obj, n, idx in _FILTER_CACHE:
+        if obj is true_triples and n == num_nodes:
+            return idx
+    idx = _FilterIndex(true_triples, num_nodes)
+    del _FILTER_CACHE[:-3]
+    _FILTER_CACHE.append((true_triples, num_nodes, idx))
+    return idx
 
 
 def filter_scores(scores, batch, true_triples, head=True):
     """scores of known true triples that are not the target -> -inf, in place (misc.py:40-58)"""
-    rows, cols = _filter_lists(batch.tolist(), true_triples, head)
-    if rows:   # (the reference indexes an empty tensor and raises here)
-        _native.rank_filter(scores, torch.tensor(rows, dtype=torch.int32, device=scores.device),
-                            torch.tensor(cols, dtype=torch.int32, device=scores.device))
+    rows, cols = _filter_index(true_triples, scores.shape[1]).lists(batch.cpu().numpy(), head)
+    if len(rows):   # (the reference indexes an empty tensor and raises here)
+        _native.rank_filter(scores, torch.from_numpy(rows).to(scores.device), torch.from_numpy(cols).to(scores.device))
 
 
 def _rank_chunk(scores, batch, true_triples, head, filter_candidates):
