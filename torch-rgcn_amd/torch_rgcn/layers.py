@@ -136,7 +136,7 @@ def _block_messages(features, blocks):
     kernels; expanding the blocks to dense R x d x d weights (1 MB per relation at d = 500) and multiplying per message
     is what it replaces (FB-toy, d = 500, 100 blocks: 23 ms -> well under 1 ms per layer call)."""
     n, (r, nb, bi, bo) = features.shape[0], blocks.shape
-    return torch.einsum('nbi,rbio->rnbo', features.view(n, nb, bi), blocks).reshape(r, n, nb * bo)
+    return torch.einsum('nbi,rbio->rnbo', features.reshape(n, nb, bi), blocks).reshape(r, n, nb * bo)
 
 
 def _wide_block(weight_decomp, in_dim, out_dim, num_relations, num_nodes):
