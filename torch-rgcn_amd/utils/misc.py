@@ -1,5 +1,5 @@
 """Sampling and ranking evaluation for link prediction -- counterpart of the reference's utils/misc.py:29-189,
-same function names, arguments and return values (sacred's create_experiment is out of scope).
+same function names, arguments and return values.
 
 evaluate(): the reference expands every batch of test triples to a [bn, N, 3] candidate tensor and calls the whole
 model on it, which re-runs the encoder for each of the ~2 * len(test) / batch_size batches (misc.py:78-85).  Here the
@@ -17,6 +17,23 @@ from torch_rgcn import _native
 from torch_rgcn.layers import DistMult
 
 _SCORE_BYTES = 1 << 30     # score-matrix budget per chunk of queries
+
+
+def create_experiment(name='exp', database=None):
+    """sacred Experiment for the REFERENCE's own experiment scripts (misc.py:10-24), so that they keep running with this
+    package first on the path; sacred is imported here, not at module level -- this package's experiments/ do not use it.
+    A MongoDB observer is attached only when MONGO_DB_USER / MONGO_DB_PASS / MONGO_DB_HOST are all set."""
+    try:
+        from sacred import Experiment
+    except ImportError as exc:
+        raise ImportError("sacred is not installed: run this package's experiments/*.py (argparse + YAML) instead") from exc
+    import os
+    ex = Experiment(name)
+    user, password, host = (os.environ.get(k) for k in ("MONGO_DB_USER", "MONGO_DB_PASS", "MONGO_DB_HOST"))
+    if user and password and host:
+        from sacred.observers import MongoObserver
+        ex.observers.append(MongoObserver(url=f"mongodb+srv://{user}:{password}@{host}", db_name=database))
+    return ex
 
 
 def generate_true_dict(all_triples):
