@@ -36,7 +36,7 @@ def _sparse_buckets(graph, W):
     return graph.max_degree() <= 4096
 
 
-def _pad16(X, W, bias):
+def _pad_blocks(X, W, bias):
     """Widths up to 64 run on the MFMA block kernels (hidden-16 scheme over blocks of 16 features) with operands
     zero-padded to multiples of 16: a 40-byte row costs the same 128-byte fabric request as a 64-byte one, and these
     kernels (packed slots, pre-swizzled weight fragments, DPP folds) are several times faster than the generic-width
@@ -51,7 +51,7 @@ def _pad16(X, W, bias):
             (d_in, d_out))
 
 
-def _unpad16(dims, dX, dW, db):
+def _unpad_blocks(dims, dX, dW, db):
     if dims is None:
         return dX, dW, db
     d_in, d_out = dims
@@ -62,7 +62,7 @@ def _unpad16(dims, dX, dW, db):
 class _RelationalMP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, W, bias, graph):
-        X, W, bias, ctx.dims = _pad16(X, W, bias)
+        X, W, bias, ctx.dims = _pad_blocks(X, W, bias)
         X = X.contiguous()
         W = W.contiguous()
         b = None if bias is None else bias.contiguous()
@@ -100,7 +100,7 @@ class _RelationalMP(torch.autograd.Function):
                 dW = _native.wgrad(X, g, graph.wgt_plan(), W.shape[0])
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _native.colsum(g)
-        return (*_unpad16(ctx.dims, dX, dW, db), None)
+        return (*_unpad_blocks(ctx.dims, dX, dW, db), None)
 
 
 class _ShardedRelationalMP(torch.autograd.Function):
@@ -112,7 +112,7 @@ class _ShardedRelationalMP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, W, bias, graph, group, n_slabs):
         import torch.distributed as dist
-        X, W, bias, ctx.dims = _pad16(X, W, bias)
+        X, W, bias, ctx.dims = _pad_blocks(X, W, bias)
         X, W = X.contiguous(), W.contiguous()
         rank = dist.get_rank(group)
         b = bias.contiguous() if (bias is not None and rank == 0) else None
@@ -148,7 +148,7 @@ class _ShardedRelationalMP(torch.autograd.Function):
             db = _native.colsum(g)
         for w in works:
             w.wait()
-        return (*_unpad16(ctx.dims, dX, dW, db), None, None, None)
+        return (*_unpad_blocks(ctx.dims, dX, dW, db), None, None, None)
 
 
 def sharded_relational_mp(features, weights, bias, graph, group, n_slabs=4):
