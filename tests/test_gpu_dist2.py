@@ -19,7 +19,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, backend="gloo"):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "torch-rgcn_amd")):
@@ -28,9 +28,11 @@ def _worker(rank, world, port, outdir):
     from oracle import oracle
     from torch_rgcn.dist import shard_layer
     from torch_rgcn.layers import RelationalGraphConvolutionNC
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda:0")
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    index = rank if backend == "nccl" else 0            # RCCL: one GPU per rank; gloo: both ranks share cuda:0
+    torch.cuda.set_device(index)
+    dev = torch.device("cuda", index)
+    extra = {"device_id": dev} if backend == "nccl" else {}
+    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, **extra)
     try:
         N, R0, E = 5000, 6, 90_000
         T = oracle.synthetic_triples(N, R0, E, seed=17)
@@ -68,6 +70,19 @@ def test_two_ranks_one_gpu_sharded_layer_matches_unsharded(tmp_path):
     import torch.multiprocessing as mp
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    z = np.load(os.path.join(str(tmp_path), "res.npz"))
+    for d_in, d_out in ((16, 16), (16, 4)):
+        for i, name in enumerate(("out", "dX", "dW", "db")):
+            a, b = z[f"{d_in}_{d_out}_1_{i}"], z[f"{d_in}_{d_out}_0_{i}"]
+            assert np.abs(a - b).max() <= 3e-5 * np.abs(b).max(), (d_in, d_out, name)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the single-GPU boxes run the gloo variant above)")
+def test_two_ranks_two_gpus_rccl_sharded_layer_matches_unsharded(tmp_path):
+    """the same check over RCCL / xGMI when the box has two GPUs"""
+    import torch.multiprocessing as mp
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "nccl"), nprocs=2, join=True)
     z = np.load(os.path.join(str(tmp_path), "res.npz"))
     for d_in, d_out in ((16, 16), (16, 4)):
         for i, name in enumerate(("out", "dX", "dW", "db")):
