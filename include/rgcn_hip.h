@@ -201,6 +201,10 @@ RGCN_API int rgcn_spmm_scatter_f32(const float *X, const float *Wp, float *Y, co
                                    const int32_t *items, int64_t n_items, int32_t d, void *stream);
 RGCN_API int rgcn_segment_sum_f32(const float *Y, const int32_t *rowptr, const float *bias, float *out,
                                   int64_t n_rows, int32_t d, int32_t flags, void *stream);
+/* Variant: pass 1 called with p_pos = NULL leaves Y in relation-major SLOT order (sequential writes); pass 2 then
+ * gathers a destination's rows through perm[destination-major position] = slot. */
+RGCN_API int rgcn_segment_gather_sum_f32(const float *Y, const int32_t *perm, const int32_t *rowptr, const float *bias,
+                                         float *out, int64_t n_rows, int32_t d, int32_t flags, void *stream);
 
 /* dW[rel] += sum over slots val * X[src,:]^T G[dst,:]  for every work item; dW
  * ([R, d_in, d_out]) is zeroed first.  Autograd dual of the einsum / sparse mm pair

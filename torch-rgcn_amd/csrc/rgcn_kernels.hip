@@ -375,7 +375,7 @@ __global__ __launch_bounds__(WG) void spmm_scatter_d16_kernel(
       const int cc = min(c + j, last);
       const int e = cc * RGCN_CHUNK + m;
       s[j] = p_src[e];
-      pos[j] = p_pos[e];
+      pos[j] = p_pos ? p_pos[e] : e;            // no position list: rows stay in relation-major slot order (sequential writes)
       const float vv = p_val[e];
       v[j] = (c + j <= last) ? vv : 0.f;
     }
@@ -415,6 +415,35 @@ __global__ __launch_bounds__(WG) void segment_sum_d16_kernel(const float *__rest
       const float4 y = *reinterpret_cast<const float4 *>(Y + (size_t)e * 16 + 4 * q);
       a.x += y.x; a.y += y.y; a.z += y.z; a.w += y.w;
     }
+    if (relu_out) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+    *reinterpret_cast<float4 *>(out + (size_t)row * 16 + 4 * q) = a;
+  }
+}
+
+// ---- pass 2 when pass 1 wrote its rows in slot order: the rows of a destination are gathered through `perm`
+// (destination-major position -> slot).  4 lanes per row, 4 row reads in flight.
+__global__ __launch_bounds__(WG) void segment_gather_sum_d16_kernel(const float *__restrict__ Y, const int *__restrict__ perm,
+                                                                    const int *__restrict__ rowptr, const float *__restrict__ bias,
+                                                                    float *__restrict__ out, long long n_rows, int relu_out) {
+  const int q = threadIdx.x & 3;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) bv = reinterpret_cast<const float4 *>(bias)[q];
+  for (long long row = ((long long)blockIdx.x * WG + threadIdx.x) >> 2; row < n_rows; row += ((long long)gridDim.x * WG) >> 2) {
+    const int e0 = rowptr[row], e1 = rowptr[row + 1];
+    float4 a = bv, b = make_float4(0.f, 0.f, 0.f, 0.f);
+    int e = e0;
+    for (; e + 1 < e1; e += 2) {
+      const int p0 = perm[e], p1 = perm[e + 1];
+      const float4 y0 = *reinterpret_cast<const float4 *>(Y + (size_t)p0 * 16 + 4 * q);
+      const float4 y1 = *reinterpret_cast<const float4 *>(Y + (size_t)p1 * 16 + 4 * q);
+      a.x += y0.x; a.y += y0.y; a.z += y0.z; a.w += y0.w;
+      b.x += y1.x; b.y += y1.y; b.z += y1.z; b.w += y1.w;
+    }
+    if (e < e1) {
+      const float4 y0 = *reinterpret_cast<const float4 *>(Y + (size_t)perm[e] * 16 + 4 * q);
+      a.x += y0.x; a.y += y0.y; a.z += y0.z; a.w += y0.w;
+    }
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     if (relu_out) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
     *reinterpret_cast<float4 *>(out + (size_t)row * 16 + 4 * q) = a;
   }
@@ -1079,7 +1108,7 @@ extern "C" int rgcn_spmm_f32(const float *X, const float *W, const float *bias, 
 extern "C" int rgcn_spmm_scatter_f32(const float *X, const float *Wp, float *Y, const int32_t *p_src, const float *p_val,
                                      const int32_t *p_pos, const int32_t *chunk_rel, const int32_t *items,
                                      int64_t n_items, int32_t d, void *stream) {
-  if (!X || !Wp || !Y || n_items < 0 || (n_items && (!p_src || !p_val || !p_pos || !chunk_rel || !items))) { rgcn_set_error("spmm_scatter: bad argument"); return RGCN_EINVAL; }
+  if (!X || !Wp || !Y || n_items < 0 || (n_items && (!p_src || !p_val || !chunk_rel || !items))) { rgcn_set_error("spmm_scatter: bad argument"); return RGCN_EINVAL; }
   if (d != 16) { rgcn_set_error("spmm_scatter: only d = 16"); return RGCN_EUNSUPPORTED; }
   if (!n_items) return RGCN_OK;
   hipLaunchKernelGGL(spmm_scatter_d16_kernel<4>, dim3((unsigned)((n_items + WG / 64 - 1) / (WG / 64))), dim3(WG), 0,
@@ -1096,6 +1125,18 @@ extern "C" int rgcn_segment_sum_f32(const float *Y, const int32_t *rowptr, const
   if (!n_rows) return RGCN_OK;
   const unsigned gx = (unsigned)std::min<int64_t>((n_rows * 4 + WG - 1) / WG, 256 * 64);
   hipLaunchKernelGGL(segment_sum_d16_kernel, dim3(gx), dim3(WG), 0, (hipStream_t)stream, Y, rowptr, bias, out,
+                     (long long)n_rows, flags & RGCN_F_RELU);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_segment_gather_sum_f32(const float *Y, const int32_t *perm, const int32_t *rowptr, const float *bias,
+                                           float *out, int64_t n_rows, int32_t d, int32_t flags, void *stream) {
+  if (!Y || !perm || !rowptr || !out || n_rows < 0) { rgcn_set_error("segment_gather_sum: bad argument"); return RGCN_EINVAL; }
+  if (d != 16) { rgcn_set_error("segment_gather_sum: only d = 16"); return RGCN_EUNSUPPORTED; }
+  if (!n_rows) return RGCN_OK;
+  const unsigned gx = (unsigned)std::min<int64_t>((n_rows * 4 + WG - 1) / WG, 256 * 64);
+  hipLaunchKernelGGL(segment_gather_sum_d16_kernel, dim3(gx), dim3(WG), 0, (hipStream_t)stream, Y, perm, rowptr, bias, out,
                      (long long)n_rows, flags & RGCN_F_RELU);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;

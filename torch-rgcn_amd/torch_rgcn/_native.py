@@ -599,19 +599,36 @@ def spmm_slabs(X, W, bias, plan, n_slabs, after_slab):
 
 
 def spmm_two_pass(X, W, bias, scatter_plan, csr, relu=False):
-    """sparse-bucket path (d = 16): relation-major transform + scatter, then per-row segment sum"""
+    """sparse-bucket path (d = 16): relation-major transform, then per-destination sum.  Default: pass 1 writes its rows
+    in slot order (sequential, full lines) and pass 2 gathers them through a permutation; RGCN_TWOPASS=scatter: pass 1
+    scatters the rows to destination-major positions and pass 2 streams them."""
     _req(X, "features"); _req(W, "weights"); _req(bias, "bias")
     Wp = pack_w16(W)
-    Y = torch.empty((max(int(csr.rowptr[-1].item()) if csr.n_messages is None else csr.n_messages, 1), 16),
-                    device=X.device, dtype=torch.float32)
-    out = torch.empty((csr.n_rows, 16), device=X.device, dtype=torch.float32)
     p = scatter_plan
+    n_msg = int(csr.rowptr[-1].item()) if csr.n_messages is None else csr.n_messages
+    out = torch.empty((csr.n_rows, 16), device=X.device, dtype=torch.float32)
+    gather = os.environ.get("RGCN_TWOPASS", "gather") == "gather"
+    if gather:
+        if getattr(p, "_inv", None) is None:     # destination-major position -> slot of the relation-major plan
+            live = p.dst >= 0
+            inv = torch.zeros(max(n_msg, 1), dtype=torch.int32, device=X.device)
+            inv[p.aux[live].long()] = torch.arange(p.dst.shape[0], device=X.device, dtype=torch.int32)[live]
+            p._inv = inv
+        Y = torch.empty((max(p.dst.shape[0], 1), 16), device=X.device, dtype=torch.float32)
+    else:
+        Y = torch.empty((max(n_msg, 1), 16), device=X.device, dtype=torch.float32)
     with torch.cuda.device(X.device), _timed("spmm_scatter"):
-        _check(lib().rgcn_spmm_scatter_f32(_dp(X), _dp(Wp), _dp(Y), _dp(p.src), _dp(p.val), _dp(p.aux), _dp(p.chunk_rel),
-                                           _dp(p.items), c_i64(p.n_items), c_i32(16), _stream(X.device)), "spmm_scatter")
+        _check(lib().rgcn_spmm_scatter_f32(_dp(X), _dp(Wp), _dp(Y), _dp(p.src), _dp(p.val), None if gather else _dp(p.aux),
+                                           _dp(p.chunk_rel), _dp(p.items), c_i64(p.n_items), c_i32(16), _stream(X.device)),
+               "spmm_scatter")
     with torch.cuda.device(X.device), _timed("segment_sum"):
-        _check(lib().rgcn_segment_sum_f32(_dp(Y), _dp(csr.rowptr), _dp(bias), _dp(out), c_i64(csr.n_rows), c_i32(16),
-                                          c_i32(F_RELU if relu else 0), _stream(X.device)), "segment_sum")
+        if gather:
+            _check(lib().rgcn_segment_gather_sum_f32(_dp(Y), _dp(p._inv), _dp(csr.rowptr), _dp(bias), _dp(out),
+                                                     c_i64(csr.n_rows), c_i32(16), c_i32(F_RELU if relu else 0),
+                                                     _stream(X.device)), "segment_gather_sum")
+        else:
+            _check(lib().rgcn_segment_sum_f32(_dp(Y), _dp(csr.rowptr), _dp(bias), _dp(out), c_i64(csr.n_rows), c_i32(16),
+                                              c_i32(F_RELU if relu else 0), _stream(X.device)), "segment_sum")
     return out
 
 
