@@ -46,9 +46,9 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane) {   // src_la
 // ---------------------------------------------------------------- forward, pass 1
 // lane = (bg, i): feature i = lane % dp, basis group bg = lane / dp; the lane keeps block[bg*NREG + k][i], k < NREG, so
 // that its NREG coefficients are contiguous: the coefficient table sits in LDS as [R][Bp = NREG * ngrp] (zero padded)
-// and a lane reads its coefficients of one message with NREG/4 ds_read_b128.  512-thread persistent workgroups: the
-// table is staged once per workgroup and 3 workgroups (24 waves) fit a CU next to a 51 KB table.
-constexpr int FWD_WG = 512;
+// and a lane reads its coefficients of one message with NREG/4 ds_read_b128.  1024-thread persistent workgroups: the
+// table is staged once per workgroup and 2 workgroups (32 waves) fit a CU next to a 51 KB table.
+constexpr int FWD_WG = 1024;
 
 template <int NREG, bool TAB_LDS>
 __global__ __launch_bounds__(FWD_WG) void fbasis_fwd_kernel(
@@ -223,7 +223,7 @@ extern "C" int rgcn_fbasis_fwd_f32(const float *bases, const float *comps, float
   const size_t tab_bytes = (size_t)R * nreg * ngrp * sizeof(float);
   const bool in_lds = tab_bytes <= 52 * 1024;
   const int waves = FWD_WG / 64;
-  const dim3 grid((unsigned)std::min<int64_t>((n_units + waves - 1) / waves, 256 * 3));
+  const dim3 grid((unsigned)std::min<int64_t>((n_units + waves - 1) / waves, 256 * 2));
   const int4 *un = reinterpret_cast<const int4 *>(units);
 #define RGCN_FB_FWD(NR)                                                                                                  \
   {                                                                                                                      \
