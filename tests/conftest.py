@@ -14,6 +14,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built artefacts (they are git-ignored): build the HIP library and the C oracle once
+    lib = os.path.join(PKG, "torch_rgcn", "lib", "librgcn_hip.so")
+    ora = os.path.join(ROOT, "oracle", "_build")
+    if not os.path.isfile(lib) or not os.path.isdir(ora):
+        import subprocess
+        if not os.path.isfile(lib):
+            subprocess.check_call(["make", "-C", os.path.join(PKG, "csrc")])
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
 
 
 @pytest.fixture(scope="session")
