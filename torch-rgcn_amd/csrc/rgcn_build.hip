@@ -402,17 +402,35 @@ __global__ __launch_bounds__(TB) void basis_aggregate_kernel(
     const int e0 = rowptr[row], e1 = rowptr[row + 1];
     for (int i0 = 0; i0 < d; i0 += lpr) {
       const int i = i0 + il;
+      constexpr int MB = 4;   // messages whose index / row / coefficient loads fly together (the row loop is latency bound)
       if (n_b_in == 1) {
         for (int b0 = 0; b0 < B; b0 += 4) {           // up to 4 bases per pass in registers
           float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-          for (int e = e0 + sub; e < e1; e += ngrp) {
-            const float x = i < d ? X[(size_t)p_src[e] * d + i] : 0.f;
-            const float v = p_val[e] * x;
-            const float *c = comps + (size_t)p_rel[e] * B + b0;
-            a0 += c[0] * v;
-            if (b0 + 1 < B) a1 += c[1] * v;
-            if (b0 + 2 < B) a2 += c[2] * v;
-            if (b0 + 3 < B) a3 += c[3] * v;
+          for (int eb = e0 + sub; eb < e1; eb += ngrp * MB) {
+            int src[MB], rel[MB];
+            float val[MB];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+              const int e = min(eb + m * ngrp, e1 - 1);
+              src[m] = p_src[e];
+              rel[m] = p_rel[e];
+              val[m] = (eb + m * ngrp < e1) ? p_val[e] : 0.f;
+            }
+            float x[MB], c[MB][4];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+              x[m] = i < d ? X[(size_t)src[m] * d + i] : 0.f;
+              const float *cp = comps + (size_t)rel[m] * B + b0;
+              c[m][0] = cp[0];
+              c[m][1] = b0 + 1 < B ? cp[1] : 0.f;
+              c[m][2] = b0 + 2 < B ? cp[2] : 0.f;
+              c[m][3] = b0 + 3 < B ? cp[3] : 0.f;
+            }
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+              const float v = val[m] * x[m];
+              a0 += c[m][0] * v; a1 += c[m][1] * v; a2 += c[m][2] * v; a3 += c[m][3] * v;
+            }
           }
           a0 = group_sum(a0, lpr); a1 = group_sum(a1, lpr); a2 = group_sum(a2, lpr); a3 = group_sum(a3, lpr);
           if (sub == 0 && i < d) {
@@ -425,13 +443,27 @@ __global__ __launch_bounds__(TB) void basis_aggregate_kernel(
         }
       } else {
         float a = 0.f;
-        for (int e = e0 + sub; e < e1; e += ngrp) {
-          const float *c = comps + (size_t)p_rel[e] * B;
-          const float *x = X + (size_t)p_src[e] * B * d + i;
-          float t = 0.f;
+        for (int eb = e0 + sub; eb < e1; eb += ngrp * MB) {
+          int src[MB], rel[MB];
+          float val[MB];
+#pragma unroll
+          for (int m = 0; m < MB; ++m) {
+            const int e = min(eb + m * ngrp, e1 - 1);
+            src[m] = p_src[e];
+            rel[m] = p_rel[e];
+            val[m] = (eb + m * ngrp < e1) ? p_val[e] : 0.f;
+          }
+          float t[MB];
+#pragma unroll
+          for (int m = 0; m < MB; ++m) t[m] = 0.f;
           if (i < d)
-            for (int b = 0; b < B; ++b) t += c[b] * x[(size_t)b * d];
-          a += p_val[e] * t;
+            for (int b = 0; b < B; ++b) {
+#pragma unroll
+              for (int m = 0; m < MB; ++m)
+                t[m] += comps[(size_t)rel[m] * B + b] * X[((size_t)src[m] * B + b) * d + i];
+            }
+#pragma unroll
+          for (int m = 0; m < MB; ++m) a += val[m] * t[m];
         }
         a = group_sum(a, lpr);
         if (sub == 0 && i < d) out[(size_t)row * d + i] = a;
