@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Featureless basis layer at AM scale (N = 1,666,764, R = 267, M = 13.6 M messages, B = 40, d = 10): kernel times of the
-source-major path (csrc/rgcn_fbasis.hip) and of the destination-major fallback.   python tools/fbasis_bench.py"""
+source-major path (csrc/rgcn_basis.hip) and of the destination-major fallback.   python tools/fbasis_bench.py"""
 import json
 import os
 import sys

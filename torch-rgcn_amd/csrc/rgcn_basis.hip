@@ -1,4 +1,5 @@
-// Featureless layer with basis decomposition, source-major (the NodeClassifier's first layer
+// Basis decomposition (layers.py:241-242, :468-469) without the R x ... weight tensors.
+// Part 1 -- featureless layer with basis decomposition, source-major (the NodeClassifier's first layer
 // on MUTAG / BGS / AM; reference layers.py:241-242 materialises weights = einsum('rb,bio->rio') -- R x N x d_out
 // floats, 17.8 GB on AM -- and :286-288 multiplies the stacked adjacency with it).
 //
@@ -277,6 +278,187 @@ extern "C" int rgcn_gather_rows_sum_f32(const float *Y, const int32_t *perm, con
   if (n_units == 0) return RGCN_OK;
   hipLaunchKernelGGL(gather_rows_sum_kernel, dim3((unsigned)((n_units + WAVES - 1) / WAVES)), dim3(WG), 0, st, Y, perm,
                      reinterpret_cast<const int4 *>(units), (int)n_units, bias, out, w, pow2_at_least(w, 4));
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+// ==================================================================== destination-major kernels
+// (featured layers with basis decomposition at large width, and the fallback of the featureless layer outside the
+//  source-major kernels' limits)
+// ------------------------------------------------------------------ basis decomposition, aggregate-then-contract
+namespace {
+
+constexpr int TB = 256;
+inline unsigned blocks_for(int64_t n, int per = TB) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + per - 1) / per, 1 << 20)); }
+
+// One wave per destination row; the wave is split into 64/lpr groups of lpr = min(64, pow2 >= d) lanes and every
+// group takes every (64/lpr)-th message of the row (narrow rows keep all lanes busy), reduced across groups at the end.
+// NB_IN = 1: out[row][b][:] = sum_e comps[rel_e][b] * val_e * X[src_e][:]
+// NB_IN = B: out[row][:]    = sum_e sum_b comps[rel_e][b] * val_e * X[src_e][b][:]
+__device__ __forceinline__ float group_sum(float a, int lpr) {   // sum over the lane groups; result valid in group 0
+  for (int off = lpr; off < 64; off <<= 1) a += __shfl_xor(a, off, 64);
+  return a;
+}
+
+__global__ __launch_bounds__(TB) void basis_aggregate_kernel(
+    const float *__restrict__ X, const float *__restrict__ comps, float *__restrict__ out,
+    const int *__restrict__ rowptr, const int *__restrict__ p_src, const int *__restrict__ p_rel,
+    const float *__restrict__ p_val, long long n_rows, int B, int d, int n_b_in, int lpr) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / lpr, il = lane % lpr, ngrp = 64 / lpr;
+  const long long wave0 = ((long long)blockIdx.x * TB + threadIdx.x) >> 6, nw = ((long long)gridDim.x * TB) >> 6;
+  for (long long row = wave0; row < n_rows; row += nw) {
+    const int e0 = rowptr[row], e1 = rowptr[row + 1];
+    for (int i0 = 0; i0 < d; i0 += lpr) {
+      const int i = i0 + il;
+      constexpr int MB = 4;   // messages whose index / row / coefficient loads fly together (the row loop is latency bound)
+      if (n_b_in == 1) {
+        for (int b0 = 0; b0 < B; b0 += 4) {           // up to 4 bases per pass in registers
+          float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+          for (int eb = e0 + sub; eb < e1; eb += ngrp * MB) {
+            int src[MB], rel[MB];
+            float val[MB];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+              const int e = min(eb + m * ngrp, e1 - 1);
+              src[m] = p_src[e];
+              rel[m] = p_rel[e];
+              val[m] = (eb + m * ngrp < e1) ? p_val[e] : 0.f;
+            }
+            float x[MB], c[MB][4];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+              x[m] = i < d ? X[(size_t)src[m] * d + i] : 0.f;
+              const float *cp = comps + (size_t)rel[m] * B + b0;
+              c[m][0] = cp[0];
+              c[m][1] = b0 + 1 < B ? cp[1] : 0.f;
+              c[m][2] = b0 + 2 < B ? cp[2] : 0.f;
+              c[m][3] = b0 + 3 < B ? cp[3] : 0.f;
+            }
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+              const float v = val[m] * x[m];
+              a0 += c[m][0] * v; a1 += c[m][1] * v; a2 += c[m][2] * v; a3 += c[m][3] * v;
+            }
+          }
+          a0 = group_sum(a0, lpr); a1 = group_sum(a1, lpr); a2 = group_sum(a2, lpr); a3 = group_sum(a3, lpr);
+          if (sub == 0 && i < d) {
+            float *o = out + ((size_t)row * B + b0) * d + i;
+            o[0] = a0;
+            if (b0 + 1 < B) o[d] = a1;
+            if (b0 + 2 < B) o[2 * (size_t)d] = a2;
+            if (b0 + 3 < B) o[3 * (size_t)d] = a3;
+          }
+        }
+      } else {
+        float a = 0.f;
+        for (int eb = e0 + sub; eb < e1; eb += ngrp * MB) {
+          int src[MB], rel[MB];
+          float val[MB];
+#pragma unroll
+          for (int m = 0; m < MB; ++m) {
+            const int e = min(eb + m * ngrp, e1 - 1);
+            src[m] = p_src[e];
+            rel[m] = p_rel[e];
+            val[m] = (eb + m * ngrp < e1) ? p_val[e] : 0.f;
+          }
+          float t[MB];
+#pragma unroll
+          for (int m = 0; m < MB; ++m) t[m] = 0.f;
+          if (i < d)
+            for (int b = 0; b < B; ++b) {
+#pragma unroll
+              for (int m = 0; m < MB; ++m)
+                t[m] += comps[(size_t)rel[m] * B + b] * X[((size_t)src[m] * B + b) * d + i];
+            }
+#pragma unroll
+          for (int m = 0; m < MB; ++m) a += val[m] * t[m];
+        }
+        a = group_sum(a, lpr);
+        if (sub == 0 && i < d) out[(size_t)row * d + i] = a;
+      }
+    }
+  }
+}
+
+// Relation-major work items (chunk ranges of one relation, relation-major plan): per-lane partial sums over the
+// whole item, ONE wave reduction and one atomic per (item piece, basis) -- not per message.  Lane groups of lpr
+// lanes take alternate slots so that narrow rows keep all 64 lanes busy.
+__global__ __launch_bounds__(TB) void basis_dcomps_kernel(
+    const float *__restrict__ X, const float *__restrict__ D, float *__restrict__ dcomps,
+    const int *__restrict__ p_src, const int *__restrict__ p_dst, const float *__restrict__ p_val,
+    const int *__restrict__ chunk_rel, const int2 *__restrict__ items, int n_items, int B, int d, int lpr) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / lpr, il = lane % lpr, ngrp = 64 / lpr;
+  const int item = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
+  if (item >= n_items) return;
+  const int2 whole = items[item];
+  const int r = chunk_rel[whole.x];
+  // blockIdx.y = piece of the item (an item of the shared work list can hold 1024 messages: too long for one wave)
+  const int per = (whole.y - whole.x + (int)gridDim.y - 1) / (int)gridDim.y;
+  int2 range;
+  range.x = whole.x + (int)blockIdx.y * per;
+  range.y = min(whole.y, range.x + per);
+  if (range.x >= range.y) return;
+  for (int b0 = 0; b0 < B; b0 += 4) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int e = range.x * RGCN_CHUNK + sub; e < range.y * RGCN_CHUNK; e += ngrp) {
+      const float v = p_val[e];
+      if (v == 0.f) continue;                    // pad
+      const float *x = X + (size_t)p_src[e] * d;
+      const float *dd = D + ((size_t)p_dst[e] * B + b0) * d;
+      for (int i = il; i < d; i += lpr) {
+        const float xv = v * x[i];
+        a0 += xv * dd[i];
+        if (b0 + 1 < B) a1 += xv * dd[(size_t)d + i];
+        if (b0 + 2 < B) a2 += xv * dd[2 * (size_t)d + i];
+        if (b0 + 3 < B) a3 += xv * dd[3 * (size_t)d + i];
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64);
+      a2 += __shfl_xor(a2, off, 64); a3 += __shfl_xor(a3, off, 64);
+    }
+    if (lane == 0) {
+      atomicAdd(&dcomps[(size_t)r * B + b0], a0);
+      if (b0 + 1 < B) atomicAdd(&dcomps[(size_t)r * B + b0 + 1], a1);
+      if (b0 + 2 < B) atomicAdd(&dcomps[(size_t)r * B + b0 + 2], a2);
+      if (b0 + 3 < B) atomicAdd(&dcomps[(size_t)r * B + b0 + 3], a3);
+    }
+  }
+}
+
+int lanes_per_row(int d) {
+  int l = 1;
+  while (l < d && l < 64) l <<= 1;
+  return l;
+}
+
+}  // namespace
+
+extern "C" int rgcn_basis_aggregate_f32(const float *X, const float *comps, float *out, const int32_t *rowptr,
+                                        const int32_t *p_src, const int32_t *p_rel, const float *p_val, int64_t n_rows,
+                                        int32_t R, int32_t B, int32_t d, int32_t n_b_in, void *stream) {
+  (void)R;
+  if (!X || !comps || !out || !rowptr || n_rows < 0 || B <= 0 || d <= 0 || (n_b_in != 1 && n_b_in != B)) { rgcn_set_error("basis_aggregate: bad argument"); return RGCN_EINVAL; }
+  if (!n_rows) return RGCN_OK;
+  hipLaunchKernelGGL(basis_aggregate_kernel, dim3(blocks_for(n_rows * 64)), dim3(TB), 0, (hipStream_t)stream, X, comps, out,
+                     rowptr, p_src, p_rel, p_val, (long long)n_rows, B, d, n_b_in, lanes_per_row(d));
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_basis_dcomps_f32(const float *X, const float *D, float *dcomps, const int32_t *p_src,
+                                     const int32_t *p_dst, const float *p_val, const int32_t *chunk_rel,
+                                     const int32_t *items, int64_t n_items, int32_t R, int32_t B, int32_t d,
+                                     void *stream) {
+  if (!X || !D || !dcomps || n_items < 0 || R <= 0 || B <= 0 || d <= 0) { rgcn_set_error("basis_dcomps: bad argument"); return RGCN_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(dcomps, 0, (size_t)R * B * sizeof(float), st));
+  if (!n_items) return RGCN_OK;
+  hipLaunchKernelGGL(basis_dcomps_kernel, dim3((unsigned)((n_items + TB / 64 - 1) / (TB / 64)), 16), dim3(TB), 0, st, X, D, dcomps,
+                     p_src, p_dst, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), (int)n_items, B, d, lanes_per_row(d));
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

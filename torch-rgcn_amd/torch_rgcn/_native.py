@@ -394,7 +394,7 @@ def row_units(rowptr, n_rows, max_len):
 
 
 class FBasisPlan:
-    """source-major view of a graph for the featureless basis layer (see csrc/rgcn_fbasis.hip)"""
+    """source-major view of a graph for the featureless basis layer (see csrc/rgcn_basis.hip)"""
     __slots__ = ("e_dst", "e_rel", "e_val", "n_messages", "units_src", "perm_dst", "units_dst", "perm_rel", "units_rel",
                  "n_nodes", "num_rels")
 
