@@ -44,11 +44,36 @@ def _pad_blocks(X, W, bias):
     -> (X', W', bias', (d_in, d_out)) or the inputs unchanged and None."""
     d_in, d_out = W.shape[1], W.shape[2]
     pi, po = -d_in % 16, -d_out % 16
-    if d_in > 64 or d_out > 64 or (pi == 0 and po == 0) or os.environ.get("RGCN_PAD16", "1") == "0":
+    if max(d_in, d_out) > _BLOCKED_MAX or (pi == 0 and po == 0) or os.environ.get("RGCN_PAD16", "1") == "0":
         return X, W, bias, None
     pad = torch.nn.functional.pad
     return (X if pi == 0 else pad(X, (0, pi)), pad(W, (0, po, 0, pi)), None if bias is None else pad(bias, (0, po)),
             (d_in, d_out))
+
+
+_BLOCKED_MAX = 512     # widest layer that is cut into 64-wide blocks of the MFMA block kernel
+
+
+def _spmm_blocked(X, W, bias, plan_of):
+    """spmm for any width.  Up to 64 x 64 it is one launch; above (undecomposed weights at d = 100, 200, ...) W is cut into
+    64-wide row / column blocks and every block pair is one launch of the block kernel on a contiguous 64-column slice of
+    X -- (d_in / 64) x (d_out / 64) launches that re-gather X once per column block, against a generic-width kernel that is
+    ~8x slower per launch at these widths."""
+    d_in, d_out = W.shape[1], W.shape[2]
+    if max(d_in, d_out) <= 64 or d_in % 16 or d_out % 16 or max(d_in, d_out) > _BLOCKED_MAX or \
+            os.environ.get("RGCN_PAD16", "1") == "0":
+        return _native.spmm(X, W, bias, plan_of(d_out))
+    xs = [X[:, i:i + 64].contiguous() for i in range(0, d_in, 64)]
+    cols = []
+    for j in range(0, d_out, 64):
+        wj = min(64, d_out - j)
+        acc = None
+        for bi, i in enumerate(range(0, d_in, 64)):
+            part = _native.spmm(xs[bi], W[:, i:i + 64, j:j + wj].contiguous(),
+                                bias[j:j + wj].contiguous() if (bias is not None and bi == 0) else None, plan_of(wj))
+            acc = part if acc is None else acc.add_(part)
+        cols.append(acc)
+    return torch.cat(cols, dim=1)
 
 
 def _unpad_blocks(dims, dX, dW, db):
@@ -69,7 +94,7 @@ class _RelationalMP(torch.autograd.Function):
         if _sparse_buckets(graph, W):
             out = _native.spmm_two_pass(X, W, b, graph.scatter_plan("fwd"), graph.csr("fwd"))
         else:
-            out = _native.spmm(X, W, b, graph.fwd_plan(W.shape[2]))
+            out = _spmm_blocked(X, W, b, graph.fwd_plan)
         ctx.graph = graph
         ctx.has_bias = bias is not None
         ctx.save_for_backward(X, W)
@@ -86,9 +111,9 @@ class _RelationalMP(torch.autograd.Function):
             if _sparse_buckets(graph, W):
                 dX = _native.spmm_two_pass(g, Wt, None, graph.scatter_plan("bwd"), graph.csr("bwd"))
             else:
-                dX = _native.spmm(g, Wt, None, graph.bwd_plan(W.shape[1]))
+                dX = _spmm_blocked(g, Wt, None, graph.bwd_plan)
         if ctx.needs_input_grad[1]:
-            fp = graph.fwd_plan(W.shape[2])
+            fp = graph.fwd_plan(min(W.shape[2], 64))
             # tile-major walk (one random gather per message) unless a (tile, relation) run is so long that
             # one wave would serialise it (hub nodes): then the relation-major kernel with bounded work items
             # and unless the (tile, relation) buckets are so sparse that a work item is a fraction of a chunk
