@@ -3,7 +3,7 @@
 import cProfile, pstats, sys, os, io
 ROOT=os.environ.get("GRAFT_REPO_ROOT","/root/repo")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT,"torch-rgcn_amd"))
-import torch, numpy as np
+import torch
 from torch_rgcn import _native
 from torch_rgcn.models import NodeClassifier
 N,R0,E=8285,45,29043

@@ -3,7 +3,7 @@ table, fwd+bwd, three graph shapes (python tools/wide_probe.py)."""
 import sys, os, time
 ROOT=os.environ.get("GRAFT_REPO_ROOT","/root/repo")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT,"torch-rgcn_amd"))
-import torch, numpy as np
+import torch
 from torch_rgcn import _native, functional as F_
 from torch_rgcn.layers import RelationalGraphConvolutionNC
 def timed(fn, it=5):
