@@ -182,12 +182,16 @@ def main():
         step()
     fence()
     _native.profile_start()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        marks[k].record()                 # HIP events on the launch stream: per-step GPU time (median / min below)
         step()
+    marks[args.steps].record()
     fence()
     elapsed = time.perf_counter() - t0
     prof = _native.profile_stop()
+    per_step = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)]
 
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if group is not None:
@@ -223,6 +227,7 @@ def main():
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "per_gpu_edges_per_s": E / (ms * 1e-3),
+               "step_ms_median": round(float(np.median(per_step)), 4), "step_ms_min": round(float(np.min(per_step)), 4),
                "config": {"workload": f"S1: N={N} nodes, E={E} base triples/GPU, R0={R0} relations/GPU "
                                       f"(layer R={2 * R0 + 1}), M={M} messages/layer, hidden={d}, 2 NC layers "
                                       "(horizontal, vertical), fwd+bwd, learnable X",
