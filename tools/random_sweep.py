@@ -1,0 +1,29 @@
+"""One-off randomised parity sweep (400 NC layer configurations per seed against the oracle): python tools/random_sweep.py SEED"""
+import sys, os
+ROOT=os.environ.get("GRAFT_REPO_ROOT","/root/repo")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT,"torch-rgcn_amd")); sys.path.insert(0, os.path.join(ROOT,"tests"))
+import numpy as np
+import test_gpu_parity as T
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv)>1 else 1)
+widths = [1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 15, 16, 17, 20, 24, 31, 32, 33, 40, 47, 48, 49, 63, 64, 65, 72, 80, 96, 100, 128, 130, 200]
+fails=0
+for case in range(400):
+    N = int(rng.choice([1, 2, 3, 5, 8, 17, 63, 64, 65, 127, 128, 129, 300, 777, 2049]))
+    R0 = int(rng.integers(1, 9))
+    E = int(rng.choice([0, 1, 2, 3, 15, 16, 17, 50, 400, 2500, 9000]))
+    mode = str(rng.choice(["none", "none", "basis", "block", "diag"]))
+    featureless = bool(rng.random() < 0.25) and mode != "diag"
+    vertical = bool(rng.random() < 0.5) and not featureless
+    d_in, d_out = int(rng.choice(widths)), int(rng.choice(widths))
+    if featureless and N*d_out > 400000: d_out = 16
+    if mode == "block":
+        d_in, d_out = 2 * max(1, d_in // 2), 2 * max(1, d_out // 2)
+        if featureless and N % 2: N += 1
+    if mode == "diag": d_out = d_in
+    try:
+        T.run_layer_vs_oracle(N=N, R0=R0, E=E, d_in=d_in, d_out=d_out, mode=mode, featureless=featureless, vertical=vertical,
+                              seed=5000 + case, hub=bool(rng.random() < 0.3) and N > 1, num_bases=int(rng.integers(1, 70)))
+    except Exception as exc:
+        fails+=1
+        print(f"FAIL case {case}: N={N} R0={R0} E={E} mode={mode} fl={featureless} vert={vertical} d=({d_in},{d_out}): {type(exc).__name__}: {str(exc)[:200]}", flush=True)
+print("done, failures:", fails)
