@@ -178,6 +178,26 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    slabs = None
+    if group is not None and "RGCN_DIST_SLABS" not in os.environ:
+        # Untimed set-up: how many slabs should a sharded spmm be cut into so that the all-reduce of slab k hides behind
+        # the kernels of slab k+1?  That depends on the link (xGMI ring vs one rank vs gloo), so it is measured here, once:
+        # 3 steps per candidate, max over ranks, the same choice on every rank.
+        best = None
+        for cand in ("0", "2", "4"):
+            os.environ["RGCN_DIST_SLABS"] = cand
+            step()
+            fence()
+            t_c = time.perf_counter()
+            for _ in range(3):
+                step()
+            fence()
+            tc = torch.tensor([time.perf_counter() - t_c], device=device, dtype=torch.float64)
+            dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+            if best is None or tc.item() < best[0]:
+                best = (tc.item(), cand)
+        slabs = best[1]
+        os.environ["RGCN_DIST_SLABS"] = slabs
     for _ in range(args.warmup):
         step()
     fence()
@@ -231,7 +251,8 @@ def main():
                "config": {"workload": f"S1: N={N} nodes, E={E} base triples/GPU, R0={R0} relations/GPU "
                                       f"(layer R={2 * R0 + 1}), M={M} messages/layer, hidden={d}, 2 NC layers "
                                       "(horizontal, vertical), fwd+bwd, learnable X",
-                          "sharding": "single GPU" if world == 1 else f"relation-sharded x{world}, all-reduce N x {d} fp32"},
+                          "sharding": "single GPU" if world == 1 else f"relation-sharded x{world}, all-reduce N x {d} fp32"
+                                      + (f", {slabs} slabs per spmm (picked in the untimed set-up)" if slabs else "")},
                "step_hbm_algorithmic_GBs": round(4 * (alg + 0) / (ms * 1e-3) / 1e9, 1),
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
