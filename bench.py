@@ -8,11 +8,15 @@ Workload S1 (SURVEY.md 8d / BASELINE.md): N = 1,000,000 nodes, R0 = 50 relations
 E = 10,000,000 base triples from a splitmix64 stream (seed 0), augmented with inverses and self loops
 (M = 21,000,000 messages per layer); layer 1 16->16 (horizontal normalisation), ReLU, layer 2 16->16
 (vertical), learnable input features, loss = mean(out^2); fp32.  One step = forward + backward of
-both layers (optimiser excluded, graph preprocessing excluded: the NC graph is static).
+both layers (optimiser excluded, graph preprocessing excluded: the NC graph is static; its one-off
+cost is reported as graph_build_ms).
 
-N > 1: relation-sharded, weak scaling -- every rank owns its own 50 relations / 10 M triples over the
-SAME 1 M nodes (rank r uses seed r), and the partial N x 16 outputs / feature gradients are summed with
-an RCCL all-reduce between layers.  value = edges of all ranks / max-over-ranks time.
+N > 1 (BASELINE.json configs[4]): STRONG scaling of that ONE graph -- every rank generates the same
+seed-0 S1 graph, normalises it on the full graph, keeps the relations the LPT packer assigns to it
+(torch_rgcn.dist.shard_layer(keep="lpt")) and the partial N x 16 outputs / feature gradients are summed
+over RCCL between layers.  value = E / max-over-ranks step time (whole job).
+`--weak` keeps round 1's weak-scaling mode (every rank its own 50 relations / 10 M triples over the
+same 1 M nodes, seed = rank; value = N_gpus * E / time).
 
 Prints ONE JSON line on rank 0.
 """
@@ -39,51 +43,58 @@ import torch.distributed as dist  # noqa: E402
 
 METRIC = "edges/s/GPU (fwd+bwd) 2-layer RGCN, 1M nodes/10M edges/50 rels, h=16"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PROFILE_ROUND = "r02"
 
 
-def algorithmic_bytes(M, N, d_in, d_out):
+def fwd_bytes(M, N, d_in, d_out):
     """forward of one layer = M*(4*d_in + 8) + N*4*d_out."""
     return M * (4 * d_in + 8) + N * 4 * d_out
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_kernels.json")
-PMC_NOTE = ("profiles/r01_pmc_kernels.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/kbench.py "
-            "on the same S1 launch; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE tallies 128-B requests "
-            "at 64 B, MI355X_MICROARCH.md HBM section). Calibration on a known random-64B-row pattern "
-            "(profiles/r01_pmc_gather_probe_calibration.json) reads 1.0x: if the row gathers are 64-B requests the "
-            "HBM-side bytes are (FETCH_SIZE + WRITE_SIZE)*1024 (see traffic_if_64B_requests).")
+def bwd_bytes(M, N, d_in, d_out, x_needs_grad=True):
+    """backward of one layer = M*(4*d_out + 8) + N*4*d_in*(1 + [X needs grad])."""
+    return M * (4 * d_out + 8) + N * 4 * d_in * (2 if x_needs_grad else 1)
+
+
+def _profile_json(name):
+    for rnd in (PROFILE_ROUND, "r01"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")) as f:
+                return json.load(f), f"profiles/{rnd}_{name}.json"
+        except OSError:
+            continue
+    return None, None
 
 
 def pmc_traffic(kernel_substr, doubled=True):
     """HBM-side bytes per launch of a kernel from the committed PMC summary (None when absent)."""
-    try:
-        with open(PMC_FILE) as f:
-            data = json.load(f)
-    except OSError:
-        return None
+    data, src = _profile_json("pmc_kernels")
+    if data is None:
+        return None, None
     for name, c in data.items():
         if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            return int(((2.0 if doubled else 1.0) * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024)
-    return None
+            return int(((2.0 if doubled else 1.0) * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024), src
+    return None, None
 
 
 def pmc_detail(kernel_key):
-    """fabric request counters / MFMA busy of a kernel from profiles/r01_pmc_detail.json (None when absent)"""
+    """fabric request counters / MFMA busy / LDS conflicts of a kernel from the committed PMC detail file"""
+    data, src = _profile_json("pmc_detail")
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_detail.json")) as f:
-            c = json.load(f)[kernel_key]
-        return {"fabric_read_requests": int(c["TCC_EA0_RDREQ_sum"]),
-                "share_of_128B_requests": round(c["TCC_EA0_RDREQ_128B_sum"] / c["TCC_EA0_RDREQ_sum"], 4),
-                "l2_hit_rate": round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3),
-                "mfma_busy_frac": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * 1024), 4),
-                "note": "profiles/r01_pmc_detail.json (tools/pmc_passes.sh): every 64-B row gather is a 128-B fabric request "
-                        "(profiles/r01_gather_probe2.txt), so traffic ~ 1.75x the algorithmic bytes is the floor of this "
-                        "access pattern, not re-reads"}
-    except (OSError, KeyError, ZeroDivisionError):
+        c = data[kernel_key]
+        out = {"fabric_read_requests": int(c["TCC_EA0_RDREQ_sum"]),
+               "share_of_128B_requests": round(c["TCC_EA0_RDREQ_128B_sum"] / c["TCC_EA0_RDREQ_sum"], 4),
+               "l2_hit_rate": round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3),
+               "mfma_busy_frac": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * 1024), 4),
+               "source": src}
+        if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE"):
+            out["lds_bank_conflict_frac"] = round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 3)
+        return out
+    except (TypeError, KeyError, ZeroDivisionError):
         return None
 
 
-def build_layers(N, R0, E, d, seed, device, group):
+def build_layers(N, R0, E, d, seed, device, group, keep):
     from torch_rgcn import _native
     from torch_rgcn.dist import shard_layer
     from torch_rgcn.layers import RelationalGraphConvolutionNC
@@ -95,34 +106,54 @@ def build_layers(N, R0, E, d, seed, device, group):
     l1 = RelationalGraphConvolutionNC(vertical_stacking=False, **kw).to(device)
     l2 = RelationalGraphConvolutionNC(vertical_stacking=True, **kw).to(device)
     if group is not None:
-        shard_layer(l1, group)
-        shard_layer(l2, group)
+        shard_layer(l1, group, keep=keep)
+        shard_layer(l2, group, keep=keep)
     return l1, l2, tp.size(0)
 
 
-def cpu_baseline(steps=2):
-    """The reference's op sequence (oracle/torch_cpu_port.py) on the host cores, 1/10-scale S1."""
+def cpu_baseline(full_scale):
+    """The reference's op sequence (oracle/torch_cpu_port.py) on the host cores: S1 at 1/10 scale (3 timed steps) and,
+    when the host has the memory for the dense R x N x d intermediates (~15 GB), S1 itself (1 warm-up + 2 timed)."""
     from oracle import oracle, torch_cpu_port
-    N, R0, E, d = 100_000, 50, 1_000_000, 16
     # ATen's sparse kernels stop scaling (and then regress) long before 256 host threads: 13.1 s/step at
     # 256 threads vs the figures below; the baseline gets the best thread count we measured, not the worst.
     threads = int(os.environ.get("RGCN_CPU_THREADS", min(os.cpu_count() or 1, 32)))
     torch.set_num_threads(threads)
-    tp = torch.from_numpy(oracle.add_inverse_and_self(oracle.synthetic_triples(N, R0, E, 0), N, R0))
-    R = 2 * R0 + 1
-    g = torch.Generator().manual_seed(0)
-    base = [torch.randn(N, d, generator=g), torch.randn(R, d, d, generator=g) * 0.2, torch.zeros(d),
-            torch.randn(R, d, d, generator=g) * 0.2, torch.zeros(d)]
-    times = []
-    for it in range(steps + 1):
-        ts = [t.clone().requires_grad_(True) for t in base]
-        t0 = time.perf_counter()
-        torch_cpu_port.two_layer_step(tp, N, R, *ts)
-        times.append(time.perf_counter() - t0)
-    best = min(times[1:])
-    return {"value": E / best, "unit": "edges/s", "cores": threads, "kind": "port",
-            "sample": f"S1 at 1/10 scale (N={N}, E={E}, R0={R0}, d={d}), 1 warm-up + {steps} timed steps, best; "
-                      f"{best:.2f} s/step"}
+
+    def leg(N, R0, E, d, steps):
+        tp = torch.from_numpy(oracle.add_inverse_and_self(oracle.synthetic_triples(N, R0, E, 0), N, R0))
+        R = 2 * R0 + 1
+        g = torch.Generator().manual_seed(0)
+        base = [torch.randn(N, d, generator=g), torch.randn(R, d, d, generator=g) * 0.2, torch.zeros(d),
+                torch.randn(R, d, d, generator=g) * 0.2, torch.zeros(d)]
+        times = []
+        for _ in range(steps + 1):
+            ts = [t.clone().requires_grad_(True) for t in base]
+            t0 = time.perf_counter()
+            torch_cpu_port.two_layer_step(tp, N, R, *ts)
+            times.append(time.perf_counter() - t0)
+        return E / min(times[1:]), min(times[1:])
+
+    small_v, small_t = leg(100_000, 50, 1_000_000, 16, 3)
+    res = {"value": small_v, "unit": "edges/s", "cores": threads, "kind": "port",
+           "sample": f"S1 at 1/10 scale (N=100000, E=1000000, R0=50, d=16), 1 warm-up + 3 timed steps, best; {small_t:.2f} s/step",
+           "port_vs_reference": "profiles/r02_port_vs_reference.json (tools/port_vs_reference.py, build container)"}
+    if full_scale:
+        v, t = leg(1_000_000, 50, 10_000_000, 16, 2)
+        res.update({"value": v, "sample": f"S1 itself (N=1000000, E=10000000, R0=50, d=16), 1 warm-up + 2 timed steps, best; "
+                                          f"{t:.2f} s/step", "tenth_scale": {"value": small_v, "s_per_step": round(small_t, 3)}})
+    return res
+
+
+def host_ram_gb():
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
 
 
 def main():
@@ -134,7 +165,10 @@ def main():
     ap.add_argument("--rels", type=int, default=50)
     ap.add_argument("--edges", type=int, default=10_000_000)
     ap.add_argument("--hidden", type=int, default=16)
+    ap.add_argument("--weak", action="store_true", help="N > 1: every rank its own relations/triples (round 1's mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-s1", action="store_true", help="CPU baseline at 1/10 scale only")
+    ap.add_argument("--no-configs", action="store_true", help="skip the secondary lines for BASELINE configs 1-4")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -157,17 +191,30 @@ def main():
             dist.init_process_group(backend, **extra)
         group = dist.group.WORLD
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    mode = "single" if group is None else ("weak" if args.weak else "strong")
 
     from torch_rgcn import _native
     N, R0, E, d = args.nodes, args.rels, args.edges, args.hidden
-    l1, l2, M = build_layers(N, R0, E, d, seed=rank, device=device, group=group)
+    l1, l2, M = build_layers(N, R0, E, d, seed=rank if mode == "weak" else 0, device=device, group=group,
+                             keep="all" if mode == "weak" else "lpt")
     torch.manual_seed(99)
     X = torch.randn(N, d, device=device, requires_grad=True)
+
+    # one-off graph preprocessing (NC graphs are static): normalisation + the plans one step needs, both layers
+    torch.cuda.synchronize()
+    t_b = time.perf_counter()
+    for layer in (l1, l2):
+        g = layer._graph_on(device)
+        g.fwd_plan(d)
+        g.bwd_plan(d)
+    torch.cuda.synchronize()
+    graph_build_ms = 1e3 * (time.perf_counter() - t_b)
+    my_messages = l1._graph.num_messages
 
     def step():
         for p in (X, l1.weights, l1.bias, l2.weights, l2.bias):
             p.grad = None
-        out = l2(torch.relu(l1(X)))
+        out = l2(l1.forward_activated(X, "relu"))
         loss = out.pow(2).mean()
         loss.backward()
         return loss
@@ -178,26 +225,33 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    slabs = None
-    if group is not None and "RGCN_DIST_SLABS" not in os.environ:
-        # Untimed set-up: how many slabs should a sharded spmm be cut into so that the all-reduce of slab k hides behind
-        # the kernels of slab k+1?  That depends on the link (xGMI ring vs one rank vs gloo), so it is measured here, once:
-        # 3 steps per candidate, max over ranks, the same choice on every rank.
-        best = None
-        for cand in ("0", "2", "4"):
-            os.environ["RGCN_DIST_SLABS"] = cand
+    def timed_steps(k):
+        step()
+        fence()
+        t_c = time.perf_counter()
+        for _ in range(k):
             step()
-            fence()
-            t_c = time.perf_counter()
-            for _ in range(3):
-                step()
-            fence()
-            tc = torch.tensor([time.perf_counter() - t_c], device=device, dtype=torch.float64)
+        fence()
+        tc = torch.tensor([time.perf_counter() - t_c], device=device, dtype=torch.float64)
+        if group is not None:
             dist.all_reduce(tc, op=dist.ReduceOp.MAX)
-            if best is None or tc.item() < best[0]:
-                best = (tc.item(), cand)
-        slabs = best[1]
-        os.environ["RGCN_DIST_SLABS"] = slabs
+        return 1e3 * tc.item() / k
+
+    comm = None
+    if group is not None:
+        # Untimed set-up: which form of the collective is fastest on THIS link (xGMI ring / direct, one rank, gloo)?
+        # 3 steps per candidate, max over ranks, the same choice on every rank.
+        cands = [("allreduce", "0"), ("rs_ag", "0"), ("allreduce", "2")] + ([("allreduce", "4")] if mode == "weak" else [])
+        if "RGCN_DIST_COMM" in os.environ or "RGCN_DIST_SLABS" in os.environ:
+            cands = [(os.environ.get("RGCN_DIST_COMM", "allreduce"), os.environ.get("RGCN_DIST_SLABS", "0"))]
+        tried = {}
+        for c, s in cands:
+            os.environ["RGCN_DIST_COMM"], os.environ["RGCN_DIST_SLABS"] = c, s
+            tried[f"{c}/slabs={s}"] = round(timed_steps(3), 4)
+        best = min(tried, key=tried.get)
+        os.environ["RGCN_DIST_COMM"], os.environ["RGCN_DIST_SLABS"] = best.split("/slabs=")
+        comm = {"collective": best, "candidates_ms_per_step": tried}
+
     for _ in range(args.warmup):
         step()
     fence()
@@ -219,44 +273,114 @@ def main():
     elapsed = t.item()
     ms = 1e3 * elapsed / args.steps
 
+    if group is not None:
+        # what the collectives cost: (a) the step without them (RGCN_DIST_COMM=none: same kernels, wrong numbers),
+        # (b) the four N x d collectives of one step on their own
+        chosen = os.environ["RGCN_DIST_COMM"]
+        os.environ["RGCN_DIST_COMM"] = "none"
+        compute_ms = timed_steps(3)
+        os.environ["RGCN_DIST_COMM"] = chosen
+        from torch_rgcn.functional import _join_shards
+        buf = torch.zeros(N, d, device=device)
+        fence()
+        t_c = time.perf_counter()
+        for _ in range(3 * 4):
+            _join_shards(buf, group)
+        fence()
+        comm_ms = 1e3 * (time.perf_counter() - t_c) / 3
+        counts = torch.zeros(world, device=device, dtype=torch.float64)
+        counts[rank] = my_messages
+        dist.all_reduce(counts)
+        bytes_per_coll = N * d * 4
+        comm.update({"collectives_per_step": 4, "bytes_per_collective": bytes_per_coll,
+                     "compute_alone_ms_per_step": round(compute_ms, 4),
+                     "collectives_alone_ms_per_step": round(comm_ms, 4),
+                     "exposed_ms_per_step": round(ms - compute_ms, 4),
+                     "allreduce_algbw_GBs": round(4 * bytes_per_coll / (comm_ms * 1e-3) / 1e9, 1) if comm_ms > 0 else None,
+                     "messages_per_rank": [int(c) for c in counts.tolist()],
+                     "model": "per step 4 x all-reduce of N x d fp32 (2 forward outputs, 2 feature gradients); a ring moves "
+                              "2(G-1)/G x 64 MB over each rank's slowest link, a direct reduce-scatter + all-gather "
+                              "2(G-1)/G x 64 MB spread over G-1 links (DESIGN.md section 6)"})
+
     if rank == 0:
-        kern = prof.get("spmm", [])
-        spmm_ms = float(np.mean(kern)) if kern else None
-        slabbed = False
-        if spmm_ms is None and prof.get("spmm_slab"):
-            # relation-sharded path: every spmm is launched in slabs of whole tiles (the all-reduce of slab k overlaps the
-            # kernels of slab k+1); one launch = the slabs of one spmm, 4 spmm per step (2 forward, 2 feature-gradient)
-            kern = prof["spmm_slab"]
-            spmm_ms = float(np.sum(kern)) / (4 * args.steps)
-            slabbed = True
-        alg = algorithmic_bytes(M, N, d, d)
+        total_edges = E * (world if mode == "weak" else 1)
+        value = total_edges / (ms * 1e-3)
+        alg = fwd_bytes(M, N, d, d)
+        launches = {k: (float(np.mean(v)), len(v) / args.steps) for k, v in prof.items()}
+        spmm_key = "spmm" if "spmm" in launches else ("spmm_slab" if "spmm_slab" in launches else None)
         roof = None
-        traffic = pmc_traffic("spmm_d16_kernel")
-        if spmm_ms:
+        if spmm_key and mode != "strong":
+            spmm_ms = launches[spmm_key][0]
+            slabbed = spmm_key == "spmm_slab"
+            if slabbed:   # one spmm = the slabs of one launch group; 4 spmm per step unless the backward is fused
+                n_spmm = 2 if "bwd_fused" in launches else 4
+                spmm_ms = float(np.sum(prof[spmm_key])) / (n_spmm * args.steps)
             ach = alg / (spmm_ms * 1e-3) / 1e9
-            roof = {"kernel": "spmm_d16_kernel (forward and feature-gradient launches)" +
-                              (f", each launched in {len(kern) // (4 * args.steps)} slabs on rank 0" if slabbed else ""),
-                    "bound": "hbm",
-                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "traffic_if_64B_requests": pmc_traffic("spmm_d16_kernel", doubled=False),
+            traffic, tsrc = pmc_traffic("spmm_d16_kernel")
+            traffic64, _ = pmc_traffic("spmm_d16_kernel", doubled=False)
+            roof = {"kernel": "spmm_d16_kernel (forward launches" + ("" if "bwd_fused" in launches else " and feature-gradient launches") + ")",
+                    "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_if_64B_requests": traffic64,
                     "traffic_rate_GBs": round(traffic / (spmm_ms * 1e-3) / 1e9, 1) if traffic else None,
-                    "traffic_source": PMC_NOTE if traffic else None, "pmc": pmc_detail("spmm"), "avg_launch_ms": round(spmm_ms, 4), "launches_per_step": 4.0 if slabbed else len(kern) / args.steps,
-                    "algorithmic_bytes_per_launch": alg,
-                    "other_kernels_ms": {k: round(float(np.mean(v)), 4) for k, v in prof.items() if k != "spmm"}}
-        res = {"metric": METRIC, "value": world * E / (ms * 1e-3), "unit": "edges/s", "n_gpus": world,
+                    "traffic_source": (f"{tsrc}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on the same S1 launch; "
+                                       "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B, "
+                                       "MI355X_MICROARCH.md HBM section)") if traffic else None,
+                    "pmc": pmc_detail("spmm"), "avg_launch_ms": round(spmm_ms, 4),
+                    "launches_per_step": launches[spmm_key][1] if not slabbed else None,
+                    "algorithmic_bytes_per_launch": alg}
+            # the backward of one layer, whatever kernels it is made of (SURVEY 8d backward bytes)
+            balg = bwd_bytes(M, N, d, d)
+            if "bwd_fused" in launches:
+                bms = launches["bwd_fused"][0] + launches.get("dw_reduce", (0.0, 0))[0]
+                roof["backward"] = {"kernels": "bwd_fused_d16_kernel (+ dw_reduce)", "avg_ms_per_layer": round(bms, 4),
+                                    "algorithmic_bytes_per_layer": balg, "achieved": round(balg / (bms * 1e-3) / 1e9, 1),
+                                    "frac": round(balg / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "unit": "GB/s",
+                                    "pmc": pmc_detail("bwd_fused")}
+            elif "wgrad" in launches and not slabbed:
+                bms = spmm_ms + launches["wgrad"][0]
+                roof["backward"] = {"kernels": "spmm_d16_kernel (dX) + wgrad_tiled_d16_kernel (dW)", "avg_ms_per_layer": round(bms, 4),
+                                    "algorithmic_bytes_per_layer": balg, "achieved": round(balg / (bms * 1e-3) / 1e9, 1),
+                                    "frac": round(balg / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "unit": "GB/s"}
+            roof["other_kernels_ms"] = {k: round(v[0], 4) for k, v in launches.items() if k != spmm_key}
+        elif spmm_key:   # strong scaling: a rank's launch covers its share of the messages only
+            spmm_ms = launches[spmm_key][0]
+            m_local = my_messages
+            ach = fwd_bytes(m_local, N, d, d) / (spmm_ms * 1e-3) / 1e9
+            roof = {"kernel": "spmm_d16_kernel on rank 0's relation shard", "bound": "hbm", "achieved": round(ach, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_ms": round(spmm_ms, 4), "algorithmic_bytes_per_launch": fwd_bytes(m_local, N, d, d),
+                    "other_kernels_ms": {k: round(v[0], 4) for k, v in launches.items() if k != spmm_key}}
+        step_alg = 2 * (fwd_bytes(M, N, d, d) + bwd_bytes(M, N, d, d))
+        res = {"metric": METRIC, "value": value, "unit": "edges/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "per_gpu_edges_per_s": E / (ms * 1e-3),
+               "scaling": "weak" if mode == "weak" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "per_gpu_edges_per_s": value / world,
                "step_ms_median": round(float(np.median(per_step)), 4), "step_ms_min": round(float(np.min(per_step)), 4),
-               "config": {"workload": f"S1: N={N} nodes, E={E} base triples/GPU, R0={R0} relations/GPU "
-                                      f"(layer R={2 * R0 + 1}), M={M} messages/layer, hidden={d}, 2 NC layers "
-                                      "(horizontal, vertical), fwd+bwd, learnable X",
-                          "sharding": "single GPU" if world == 1 else f"relation-sharded x{world}, all-reduce N x {d} fp32"
-                                      + (f", {slabs} slabs per spmm (picked in the untimed set-up)" if slabs else "")},
-               "step_hbm_algorithmic_GBs": round(4 * (alg + 0) / (ms * 1e-3) / 1e9, 1),
+               "graph_build_ms": round(graph_build_ms, 2),
+               "config": {"workload": (f"S1: N={N} nodes, E={E} base triples" + ("/GPU" if mode == "weak" else "") +
+                                       f", R0={R0} relations" + ("/GPU" if mode == "weak" else "") +
+                                       f" (layer R={2 * R0 + 1}), M={M} messages/layer, hidden={d}, 2 NC layers "
+                                       "(horizontal, vertical), fwd+bwd, learnable X"),
+                          "sharding": "single GPU" if world == 1 and group is None else
+                                      (f"relation-sharded x{world} (LPT on message counts, ONE seed-0 graph), "
+                                       if mode == "strong" else f"relation-sharded x{world} (each rank its own relations), ")
+                                      + f"N x {d} fp32 partials joined by {comm['collective']}"},
+               "step_hbm_algorithmic_GBs": round((step_alg if mode != "weak" else step_alg) / (ms * 1e-3) / 1e9, 1),
                "roofline": roof}
+        if comm is not None:
+            res["comm"] = comm
+        if world == 1 and group is None and not args.no_configs:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import config_bench
+                res["configs"] = config_bench.secondary_lines()
+            except Exception as exc:  # noqa: BLE001  (secondary lines must never cost the headline number)
+                res["configs"] = f"failed: {type(exc).__name__}: {exc}"[:300]
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
+            del l1, l2, X
+            torch.cuda.empty_cache()
+            res["cpu_baseline"] = cpu_baseline(full_scale=not args.no_cpu_s1 and host_ram_gb() >= 32.0 and
+                                               (N, R0, E, d) == (1_000_000, 50, 10_000_000, 16))
     else:
         res = None
     if group is not None:

@@ -106,3 +106,43 @@ def test_partition_relations_lpt():
     assert partition_relations(counts, 1).tolist() == [0] * 7
     o8 = partition_relations(np.full(101, 1000), 8)
     assert np.bincount(o8, minlength=8).max() - np.bincount(o8, minlength=8).min() <= 1
+
+
+def _join_worker(rank, world, port, q):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from torch_rgcn.functional import _join_shards
+    out = {}
+    for mode in ("allreduce", "rs_ag", "none"):
+        os.environ["RGCN_DIST_COMM"] = mode
+        for n in (10, 11):                                   # 11 rows: not divisible by the world size (padded blocks)
+            part = torch.arange(n * 3, dtype=torch.float32).view(n, 3) * (rank + 1)
+            out[(mode, n)] = _join_shards(part.clone(), dist.group.WORLD).numpy()
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_join_shards_collective_variants_agree():
+    """the three transports of the partial-sum join (torch_rgcn.functional._join_shards): all-reduce and
+    reduce-scatter + all-gather give the sum over ranks, "none" (bench.py's compute-alone timing leg) leaves the partial"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_join_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for n in (10, 11):
+        base = np.arange(n * 3, dtype=np.float32).reshape(n, 3)
+        assert np.array_equal(out[("allreduce", n)], 3 * base)
+        assert np.array_equal(out[("rs_ag", n)], 3 * base) and out[("rs_ag", n)].shape == (n, 3)
+        assert np.array_equal(out[("none", n)], base)

@@ -90,23 +90,161 @@ def test_two_ranks_two_gpus_rccl_sharded_layer_matches_unsharded(tmp_path):
             assert np.abs(a - b).max() <= 3e-5 * np.abs(b).max(), (d_in, d_out, name)
 
 
-def test_bench_contract_with_two_ranks_on_one_gpu():
-    """`torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` exactly as the driver launches it, both ranks on
-    cuda:0 over gloo, reduced workload: ONE JSON line, on rank 0, whole-job aggregate, weak scaling."""
+def _bench_path_worker(rank, world, port, outdir, backend="gloo"):
+    """bench.py's own strong-scaling path (build_layers(keep="lpt") + the step) at 1/10 of S1, every collective variant,
+    plus the unsharded run of the same graph on the same device."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "torch-rgcn_amd")):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    import bench
+    from torch_rgcn.dist import gather_owned_parameters
+    index = rank if backend == "nccl" else 0
+    torch.cuda.set_device(index)
+    dev = torch.device("cuda", index)
+    extra = {"device_id": dev} if backend == "nccl" else {}
+    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, **extra)
+    try:
+        N, R0, E, d = 100_000, 50, 1_000_000, 16
+        res = {}
+
+        def run(tag, group, comm=None, slabs=None):
+            if comm is not None:
+                os.environ["RGCN_DIST_COMM"], os.environ["RGCN_DIST_SLABS"] = comm, slabs
+            l1, l2, _ = bench.build_layers(N, R0, E, d, seed=0, device=dev, group=group, keep="lpt")
+            with torch.no_grad():
+                l1.bias.normal_()
+                l2.bias.normal_()
+            torch.manual_seed(99)
+            X = torch.randn(N, d, device=dev, requires_grad=True)
+            out = l2(l1.forward_activated(X, "relu"))
+            loss = out.pow(2).mean()
+            loss.backward()
+            grads = [l1.weights.grad.clone(), l2.weights.grad.clone()]
+            if group is not None:     # relation rows live on their owners: sum the (disjoint) rows for the comparison
+                for gte in grads:
+                    dist.all_reduce(gte)
+                full = gather_owned_parameters(l1)["weights"]
+                assert torch.equal(full, l1.weights.detach())   # same seed on every rank and no optimiser step yet
+                assert 0 < len(l1._graph.owned_relations) < 2 * R0 + 1
+            res[tag] = [t.detach().cpu().numpy() for t in (out, X.grad, grads[0], grads[1], l1.bias.grad, l2.bias.grad)]
+
+        run("ref", None)
+        for comm, slabs in (("allreduce", "0"), ("rs_ag", "0"), ("allreduce", "2")):
+            run(f"{comm}{slabs}", dist.group.WORLD, comm, slabs)
+        if rank == 0:
+            np.savez(os.path.join(outdir, "bench_path.npz"), **{f"{k}_{i}": a for k, v in res.items() for i, a in enumerate(v)})
+    finally:
+        dist.destroy_process_group()
+
+
+def _check_bench_path(tmp_path):
+    z = np.load(os.path.join(str(tmp_path), "bench_path.npz"))
+    for tag in ("allreduce0", "rs_ag0", "allreduce2"):
+        for i, name in enumerate(("out", "dX", "dW1", "dW2", "db1", "db2")):
+            a, b = z[f"{tag}_{i}"], z[f"ref_{i}"]
+            assert np.abs(a - b).max() <= 3e-5 * np.abs(b).max(), (tag, name)
+
+
+def test_bench_strong_scaling_path_matches_unsharded_two_ranks_one_gpu(tmp_path):
+    """the sharded == unsharded check on bench.py's OWN strong-scaling path (1/10 of S1, LPT shards),
+    for every collective variant bench.py may pick; gloo, both ranks on cuda:0."""
+    import torch.multiprocessing as mp
+    mp.spawn(_bench_path_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    _check_bench_path(tmp_path)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the single-GPU boxes run the gloo variant above)")
+def test_bench_strong_scaling_path_matches_unsharded_rccl(tmp_path):
+    import torch.multiprocessing as mp
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    mp.spawn(_bench_path_worker, args=(2, _free_port(), str(tmp_path), "nccl"), nprocs=2, join=True)
+    _check_bench_path(tmp_path)
+
+
+def _basis_worker(rank, world, port, outdir):
+    """relation-sharded layers with basis decomposition -- `bases` gets gradient from every relation, so the
+    shard hook must all-reduce it; `comps` rows live on the owners."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "torch-rgcn_amd")):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    from oracle import oracle
+    from torch_rgcn.dist import gather_owned_parameters, shard_layer
+    from torch_rgcn.layers import RelationalGraphConvolutionNC
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        N, R0, E, d = 4000, 5, 60_000, 16
+        tp = torch.from_numpy(oracle.add_inverse_and_self(oracle.synthetic_triples(N, R0, E, seed=5), N, R0))
+        res = {}
+        for sharded in (False, True):
+            torch.manual_seed(0)
+            layer = RelationalGraphConvolutionNC(triples=tp, num_nodes=N, num_relations=2 * R0 + 1, in_features=d,
+                                                 out_features=d, decomposition={"type": "basis", "num_bases": 3}).to(dev)
+            if sharded:
+                shard_layer(layer, dist.group.WORLD, keep="lpt")
+            opt = torch.optim.SGD(layer.parameters(), lr=0.5)
+            X = torch.randn(N, d, device=dev)
+            for _ in range(3):                      # replicas of `bases` must stay in step over optimiser steps
+                opt.zero_grad()
+                layer(X).pow(2).mean().backward()
+                opt.step()
+            comps = gather_owned_parameters(layer)["comps"] if sharded else layer.comps.detach()
+            res[sharded] = [layer.bases.detach().cpu().numpy(), comps.cpu().numpy(), layer.bias.detach().cpu().numpy()]
+            if sharded:
+                b = layer.bases.detach().clone()
+                dist.all_reduce(b)
+                assert torch.allclose(b / world, layer.bases.detach(), rtol=0, atol=0), "bases replicas diverged"
+        if rank == 0:
+            np.savez(os.path.join(outdir, "basis.npz"), **{f"{int(k)}_{i}": a for k, v in res.items() for i, a in enumerate(v)})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_basis_layer_trains_like_unsharded(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_basis_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    z = np.load(os.path.join(str(tmp_path), "basis.npz"))
+    for i, name in enumerate(("bases", "comps", "bias")):
+        a, b = z[f"1_{i}"], z[f"0_{i}"]
+        assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max(), name
+
+
+def _run_bench(extra_args, env_extra=None):
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, RGCN_BENCH_ONE_DEVICE="1", RGCN_DIST_BACKEND="gloo")
+    env = dict(os.environ, RGCN_BENCH_ONE_DEVICE="1", RGCN_DIST_BACKEND="gloo", **(env_extra or {}))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--nodes", "200000", "--edges", "1000000", "--rels", "20"]
+           "--nodes", "200000", "--edges", "1000000", "--rels", "20"] + extra_args
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
-    res = json.loads(lines[0])
-    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["warmup"] == 1 and res["scaling"] == "weak"
+    return json.loads(lines[0])
+
+
+def test_bench_contract_with_two_ranks_on_one_gpu():
+    """`torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` exactly as the driver launches it, both ranks on
+    cuda:0 over gloo, reduced workload: ONE JSON line, on rank 0; default = STRONG scaling of one graph (BASELINE
+    configs[4]): value = E / t, LPT shards, collective timings reported."""
+    res = _run_bench([])
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["warmup"] == 1 and res["scaling"] == "strong"
     assert res["unit"] == "edges/s" and res["higher_is_better"] is True and res["dtype"] == "f32"
-    assert abs(res["value"] - 2 * 1_000_000 / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]
+    assert abs(res["value"] - 1_000_000 / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]
     assert "cpu_baseline" not in res and res["roofline"]["bound"] == "hbm" and "relation-sharded x2" in res["config"]["sharding"]
+    comm = res["comm"]
+    assert sum(comm["messages_per_rank"]) == 2 * 1_000_000 + 200_000 and min(comm["messages_per_rank"]) > 0
+    assert comm["collectives_per_step"] == 4 and comm["compute_alone_ms_per_step"] > 0 and comm["collectives_alone_ms_per_step"] > 0
+    assert comm["collective"] in comm["candidates_ms_per_step"] and res["graph_build_ms"] > 0
+
+
+def test_bench_weak_mode_still_available():
+    res = _run_bench(["--weak"])
+    assert res["scaling"] == "weak" and abs(res["value"] - 2 * 1_000_000 / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]

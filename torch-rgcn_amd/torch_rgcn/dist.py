@@ -63,6 +63,20 @@ def partition_relations(message_counts, world_size):
     return owner
 
 
+def _sum_over_group(group):
+    def hook(grad):
+        g = grad.contiguous().clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+        return g
+    return hook
+
+
+# parameters whose gradient is a SUM over relations (every rank holds a partial sum) vs. parameters with one row per
+# relation (the gradient of a relation's row lives on the rank that owns the relation)
+_SUMMED_PARAMS = ("bases",)
+_PER_RELATION_PARAMS = ("weights", "comps", "blocks")
+
+
 def shard_layer(layer, group=None, keep="all"):
     """Turn a RelationalGraphConvolutionNC into one shard of a relation-sharded layer.
 
@@ -70,12 +84,43 @@ def shard_layer(layer, group=None, keep="all"):
                   was built on its own relation bucket); only the collectives are added.
     keep="lpt"  : the layer holds the FULL graph; this rank keeps the relations LPT-assigned to it
                   (normalisation is computed on the full graph first, then messages are filtered).
+
+    Parameter gradients: `bias` is computed from the replicated upstream gradient (identical on every rank);
+    `bases` (basis decomposition: W_r = sum_b comps[r,b] bases[b]) receives contributions from every relation, so its
+    gradient is all-reduced here (a hook; B x d_in x d_out floats) and the replicas stay in step; `weights` / `comps` /
+    `blocks` have one row per relation and the row's gradient exists on the owner only -- rows of relations a rank does
+    not own keep their values there, `gather_owned_parameters()` assembles the complete tensors (checkpoints).
     """
     group = group if group is not None else dist.group.WORLD
     layer._shard_group = group
     layer._shard_keep = keep
     layer._graph = None  # rebuild with the filter
+    if keep == "lpt" and not getattr(layer, "_shard_hooks", None):
+        layer._shard_hooks = [getattr(layer, n).register_hook(_sum_over_group(group))
+                              for n in _SUMMED_PARAMS if getattr(layer, n, None) is not None]
     return layer
+
+
+@torch.no_grad()
+def gather_owned_parameters(layer):
+    """{name: complete tensor} of the per-relation parameters of a keep="lpt" shard: every relation's row is taken from
+    its owner (sum all-reduce of the rows masked by ownership).  Collective: call it on every rank."""
+    group = layer._shard_group
+    graph = layer._graph
+    assert graph is not None and getattr(graph, "owned_relations", None) is not None, \
+        "run one forward (the shard's graph is built lazily) before gathering parameters"
+    out = {}
+    for name in _PER_RELATION_PARAMS:
+        p = getattr(layer, name, None)
+        if p is None:
+            continue
+        mask = torch.zeros(p.shape[0], dtype=p.dtype, device=p.device)
+        owned = torch.as_tensor(graph.owned_relations, device=p.device, dtype=torch.long)
+        mask[owned[owned < p.shape[0]]] = 1        # LP-style `blocks` has R-1 rows (the self-loop relation is separate)
+        full = p.detach() * mask.view(-1, *([1] * (p.dim() - 1)))
+        dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
+        out[name] = full
+    return out
 
 
 def filter_graph_for_rank(graph, group):

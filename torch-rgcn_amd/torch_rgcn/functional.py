@@ -54,7 +54,7 @@ def _pad_blocks(X, W, bias):
 _BLOCKED_MAX = 512     # widest layer that is cut into 64-wide blocks of the MFMA block kernel
 
 
-def _spmm_blocked(X, W, bias, plan_of):
+def _spmm_blocked(X, W, bias, plan_of, relu=False):
     """spmm for any width.  Up to 64 x 64 it is one launch; above (undecomposed weights at d = 100, 200, ...) W is cut into
     64-wide row / column blocks and every block pair is one launch of the block kernel on a contiguous 64-column slice of
     X -- (d_in / 64) x (d_out / 64) launches that re-gather X once per column block, against a generic-width kernel that is
@@ -62,7 +62,7 @@ def _spmm_blocked(X, W, bias, plan_of):
     d_in, d_out = W.shape[1], W.shape[2]
     if max(d_in, d_out) <= 64 or d_in % 16 or d_out % 16 or max(d_in, d_out) > _BLOCKED_MAX or \
             os.environ.get("RGCN_PAD16", "1") == "0":
-        return _native.spmm(X, W, bias, plan_of(d_out))
+        return _native.spmm(X, W, bias, plan_of(d_out), relu=relu and max(d_in, d_out) <= 64)
     xs = [X[:, i:i + 64].contiguous() for i in range(0, d_in, 64)]
     cols = []
     for j in range(0, d_out, 64):
@@ -86,25 +86,36 @@ def _unpad_blocks(dims, dX, dW, db):
 
 class _RelationalMP(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, X, W, bias, graph):
+    def forward(ctx, X, W, bias, graph, relu=False):
         X, W, bias, ctx.dims = _pad_blocks(X, W, bias)
         X = X.contiguous()
         W = W.contiguous()
         b = None if bias is None else bias.contiguous()
+        fused_relu = relu and max(W.shape[1], W.shape[2]) <= 64     # the kernels' own epilogue (RGCN_F_RELU)
         if _sparse_buckets(graph, W):
-            out = _native.spmm_two_pass(X, W, b, graph.scatter_plan("fwd"), graph.csr("fwd"))
+            out = _native.spmm_two_pass(X, W, b, graph.scatter_plan("fwd"), graph.csr("fwd"), relu=fused_relu)
         else:
-            out = _spmm_blocked(X, W, b, graph.fwd_plan)
+            out = _spmm_blocked(X, W, b, graph.fwd_plan, relu=fused_relu)
+        if relu and not fused_relu:
+            out = torch.relu_(out)
         ctx.graph = graph
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(X, W)
+        ctx.relu = relu
+        if relu:
+            ctx.save_for_backward(X, W, out)
+        else:
+            ctx.save_for_backward(X, W)
         return out if ctx.dims is None else out[:, :ctx.dims[1]]
 
     @staticmethod
     def backward(ctx, g):
-        X, W = ctx.saved_tensors
+        X, W = ctx.saved_tensors[:2]
         graph = ctx.graph
-        g = g.contiguous() if ctx.dims is None else torch.nn.functional.pad(g, (0, -ctx.dims[1] % 16))
+        if ctx.dims is not None and ctx.dims[1] % 16:
+            g = torch.nn.functional.pad(g, (0, -ctx.dims[1] % 16))
+        g = g.contiguous()   # after the pad: a zero-width pad keeps the strides of a non-contiguous upstream gradient
+        if ctx.relu:         # out = relu(pre): the gradient passes where the stored output is positive
+            g = torch.ops.aten.threshold_backward(g, ctx.saved_tensors[2], 0.0)
         dX = dW = db = None
         if ctx.needs_input_grad[0]:
             Wt = W.transpose(1, 2).contiguous()
@@ -125,14 +136,39 @@ class _RelationalMP(torch.autograd.Function):
                 dW = _native.wgrad(X, g, graph.wgt_plan(), W.shape[0])
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _native.colsum(g)
-        return (*_unpad_blocks(ctx.dims, dX, dW, db), None)
+        return (*_unpad_blocks(ctx.dims, dX, dW, db), None, None)
+
+
+def _join_shards(partial, group, works=None):
+    """Sum the ranks' partial N x d matrices (in place; returns the tensor to use).  RGCN_DIST_COMM:
+      allreduce (default)  one RCCL all-reduce of the whole matrix
+      rs_ag                reduce-scatter of row blocks + all-gather (the two halves of an all-reduce as separate
+                           collectives: lets RCCL pick its direct algorithms per half; same bytes on every link)
+      none                 no collective at all -- TIMING ONLY (bench.py's compute-alone leg); results are wrong"""
+    import torch.distributed as dist
+    mode = os.environ.get("RGCN_DIST_COMM", "allreduce")
+    if mode == "none":
+        return partial
+    if mode == "rs_ag":
+        world = dist.get_world_size(group)
+        n, d = partial.shape
+        rows = -(-n // world)
+        buf = partial if rows * world == n else torch.nn.functional.pad(partial, (0, 0, 0, rows * world - n))
+        shard = torch.empty((rows, d), device=partial.device, dtype=partial.dtype)
+        dist.reduce_scatter_tensor(shard, buf, group=group)
+        dist.all_gather_into_tensor(buf, shard, group=group)
+        return buf if rows * world == n else buf[:n].contiguous()
+    dist.all_reduce(partial, group=group)
+    return partial
 
 
 class _ShardedRelationalMP(torch.autograd.Function):
-    """Relation shard of the featured layer with the collective overlapped: the output (and, in backward, the
-    feature gradient) is produced slab by slab and every finished slab is all-reduced asynchronously (RCCL
-    on its own stream) while the next slab's kernels run.  Features and upstream gradient are replicated;
-    rank 0 alone adds the bias (it is summed once)."""
+    """Relation shard of the featured layer.  Features and upstream gradient are replicated; every rank computes the
+    partial output (and, in backward, the partial feature gradient) of ITS relations and the partials are summed over
+    the group; rank 0 alone adds the bias (it is summed once).  n_slabs > 0: the partial is produced slab by slab and
+    every finished slab is all-reduced asynchronously (RCCL on its own stream) while the next slab's kernels run --
+    pays when the kernels are long against the collective (weak scaling); n_slabs = 0: one collective after the kernel
+    (strong scaling at 8 GPUs: the kernel is ~8x shorter than the collective, nothing to hide behind)."""
 
     @staticmethod
     def forward(ctx, X, W, bias, graph, group, n_slabs):
@@ -141,11 +177,14 @@ class _ShardedRelationalMP(torch.autograd.Function):
         X, W = X.contiguous(), W.contiguous()
         rank = dist.get_rank(group)
         b = bias.contiguous() if (bias is not None and rank == 0) else None
-        works = []
-        out = _native.spmm_slabs(X, W, b, graph.fwd_plan(W.shape[2]), n_slabs,
-                                 lambda o, r0, r1: works.append(dist.all_reduce(o[r0:r1], group=group, async_op=True)))
-        for w in works:
-            w.wait()
+        if n_slabs > 0 and os.environ.get("RGCN_DIST_COMM", "allreduce") == "allreduce":
+            works = []
+            out = _native.spmm_slabs(X, W, b, graph.fwd_plan(W.shape[2]), n_slabs,
+                                     lambda o, r0, r1: works.append(dist.all_reduce(o[r0:r1], group=group, async_op=True)))
+            for w in works:
+                w.wait()
+        else:
+            out = _join_shards(_native.spmm(X, W, b, graph.fwd_plan(W.shape[2])), group)
         ctx.graph, ctx.group, ctx.n_slabs, ctx.has_bias = graph, group, n_slabs, bias is not None
         ctx.save_for_backward(X, W)
         return out if ctx.dims is None else out[:, :ctx.dims[1]]
@@ -155,13 +194,19 @@ class _ShardedRelationalMP(torch.autograd.Function):
         import torch.distributed as dist
         X, W = ctx.saved_tensors
         graph = ctx.graph
-        g = g.contiguous() if ctx.dims is None else torch.nn.functional.pad(g, (0, -ctx.dims[1] % 16))
+        if ctx.dims is not None and ctx.dims[1] % 16:
+            g = torch.nn.functional.pad(g, (0, -ctx.dims[1] % 16))
+        g = g.contiguous()   # after the pad: a zero-width pad keeps the strides of a non-contiguous upstream gradient
         dX = dW = db = None
         works = []
+        slabbed = ctx.n_slabs > 0 and os.environ.get("RGCN_DIST_COMM", "allreduce") == "allreduce"
         if ctx.needs_input_grad[0]:
             Wt = W.transpose(1, 2).contiguous()
-            dX = _native.spmm_slabs(g, Wt, None, graph.bwd_plan(W.shape[1]), ctx.n_slabs,
-                                    lambda o, r0, r1: works.append(dist.all_reduce(o[r0:r1], group=ctx.group, async_op=True)))
+            if slabbed:
+                dX = _native.spmm_slabs(g, Wt, None, graph.bwd_plan(W.shape[1]), ctx.n_slabs,
+                                        lambda o, r0, r1: works.append(dist.all_reduce(o[r0:r1], group=ctx.group, async_op=True)))
+            else:
+                dX = _native.spmm(g, Wt, None, graph.bwd_plan(W.shape[1]))
         if ctx.needs_input_grad[1]:   # owner-local: runs while the last slabs are still being reduced
             fp = graph.fwd_plan(W.shape[2])
             dense = fp.m_pad > 0 and fp.n_messages >= 0.5 * fp.m_pad
@@ -171,6 +216,8 @@ class _ShardedRelationalMP(torch.autograd.Function):
                 dW = _native.wgrad(X, g, graph.wgt_plan(), W.shape[0])
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _native.colsum(g)
+        if dX is not None and not slabbed:
+            dX = _join_shards(dX, ctx.group)
         for w in works:
             w.wait()
         return (*_unpad_blocks(ctx.dims, dX, dW, db), None, None, None)
@@ -297,9 +344,10 @@ def use_basis_path(num_bases, d_in, d_out, graph):
     return d_in * d_out >= 64 * 64 and num_bases <= 8
 
 
-def relational_mp(features, weights, bias, graph):
-    """features [N, d_in], weights [R, d_in, d_out] (dense), bias [d_out] or None -> [N, d_out]"""
-    return _RelationalMP.apply(features, weights, bias, graph)
+def relational_mp(features, weights, bias, graph, relu=False):
+    """features [N, d_in], weights [R, d_in, d_out] (dense), bias [d_out] or None -> [N, d_out]; relu=True applies the
+    activation in the kernel's epilogue (the backward masks the upstream gradient with the stored output)"""
+    return _RelationalMP.apply(features, weights, bias, graph, relu)
 
 
 def featureless_mp(table, bias, graph):

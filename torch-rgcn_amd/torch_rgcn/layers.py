@@ -210,7 +210,14 @@ class RelationalGraphConvolutionNC(_RGCBase):
         return self._graph
 
     def forward(self, features=None):
+        return self.forward_activated(features, None)
+
+    def forward_activated(self, features=None, activation=None):
+        """forward() plus the activation the models apply right after this layer (reference models.py:194,235,290
+        `F.relu(self.rgc1(...))`), run in the kernel's epilogue.  activation: None or "relu".  A separate method so that
+        forward() keeps the reference's exact signature."""
         assert (features is None) == (self.in_features is None), "in_features not provided!"
+        assert activation in (None, "relu"), f"unknown activation {activation!r}"
         any_param = self.weights if (self.diag_weight_matrix or self.weight_decomp is None) else \
             (self.bases if self.weight_decomp == 'basis' else self.blocks)
         _require_gpu(any_param, "RelationalGraphConvolutionNC parameters")
@@ -251,22 +258,25 @@ class RelationalGraphConvolutionNC(_RGCBase):
             elif block_table:
                 local = lambda x, b: F_.featureless_mp(_block_messages(x, self.blocks), b, graph)
             else:
-                local = lambda x, b: F_.relational_mp(x, weights, b, graph)
+                fuse_act = activation == "relu" and getattr(self, "_shard_group", None) is None
+                local = lambda x, b: F_.relational_mp(x, weights, b, graph, relu=fuse_act)
+                if fuse_act:
+                    activation = None
         group = getattr(self, "_shard_group", None)
         if group is None:
             output = local(features, self.bias)
-        elif self.in_features is not None and os.environ.get("RGCN_DIST_SLABS", "2") != "0" and not block_table and not (
+        elif self.in_features is not None and not block_table and not (
                 self.weight_decomp == 'basis' and F_.use_basis_path(self.num_bases, in_dim, out_dim, graph)):
-            # relation-sharded, collective overlapped with the kernels slab by slab
+            # relation-sharded: partial sums joined by the collective picked with RGCN_DIST_COMM / RGCN_DIST_SLABS
             output = F_.sharded_relational_mp(features, weights, self.bias, graph, group,
-                                              int(os.environ.get("RGCN_DIST_SLABS", "2")))
+                                              int(os.environ.get("RGCN_DIST_SLABS", "0")))
         else:  # relation-sharded: partial sums joined by an all-reduce, bias added once afterwards
             from .dist import sharded_apply
             output = sharded_apply(lambda x: local(x, None), features, group)
             if self.bias is not None:
                 output = output + self.bias
         assert output.size() == (N, out_dim)
-        return output
+        return torch.relu(output) if activation == "relu" else output
 
 
 class RelationalGraphConvolutionLP(_RGCBase):

@@ -40,10 +40,9 @@ class NodeClassifier(nn.Module):
                                                      **common)
 
     def forward(self):
-        x = self.rgc1()
-        if self.nlayers == 2:
-            x = self.rgc2(features=F.relu(x))
-        return x
+        if self.nlayers == 2:      # ReLU in the first layer's epilogue where its kernel has one (reference: F.relu(self.rgc1()))
+            return self.rgc2(features=self.rgc1.forward_activated(None, "relu"))
+        return self.rgc1()
 
 
 class EmbeddingNodeClassifier(NodeClassifier):
@@ -62,8 +61,7 @@ class EmbeddingNodeClassifier(NodeClassifier):
         nn.init.kaiming_normal_(self.node_embeddings, mode='fan_in')
 
     def forward(self):
-        x = self.rgcn_no_hidden(self.node_embeddings)
-        return self.rgc1(features=F.relu(x))
+        return self.rgc1(features=self.rgcn_no_hidden.forward_activated(self.node_embeddings, "relu"))
 
 
 def _init_embedding(tensor, name, gain=1.0):
