@@ -225,6 +225,26 @@ RGCN_API int rgcn_wgrad_tiled_f32(const float *X, const float *G, float *dW, con
                                   int64_t n_src, int32_t R, int32_t d_in, int32_t d_out,
                                   int32_t tiles_per_item, void *stream);
 
+/* Fused backward of the hidden-16 layer: dX AND dW from ONE walk of the transposed plan (destination tile = tile of
+ * source rows of the forward: the rows X[o]), i.e. one random row gather (G[s]) per message instead of two.  Autograd
+ * duals of layers.py:293-301: dX[o] += val G[s] W_r^T, dW_r += val X[o]^T G[s].
+ *   G            upstream gradient [n_rows, 16] (gathered);  X  layer input [n_rows, 16] (tile-local reads)
+ *   Wt_packed    W^T in fragment order (rgcn_pack_w16t_f32)
+ *   dX [n_rows,16], dW [R,16,16] outputs (both fully written)
+ *   p_pack / chunk_rel / run_ptr / tile_rows: the transposed relation-tile plan, built with run pointers and packed
+ *   slots (tile_rows <= 255), NO hub-split tiles (one work unit per tile)
+ *   scratch      rgcn_bwd_fused_scratch_floats(n_tiles, R) floats: per-workgroup dW partials, summed in a fixed order
+ *                by two small kernels (bit-reproducible); with RGCN_F_DW_ATOMIC the partials are added to dW with
+ *                fp32 atomics instead and scratch may be NULL. */
+#define RGCN_F_DW_ATOMIC 4
+RGCN_API int64_t rgcn_bwd_fused_scratch_floats(int64_t n_tiles, int32_t R);
+RGCN_API int rgcn_bwd_fused_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW,
+                                float *scratch, const int32_t *p_pack, const int32_t *chunk_rel,
+                                const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R,
+                                int32_t flags, void *stream);
+/* Wp[r][16k+f][c] = W[r][f][4k+c]: fragments of W_r^T straight from W (the feature-gradient kernels multiply by W^T). */
+RGCN_API int rgcn_pack_w16t_f32(const float *W, float *Wp, int32_t R, void *stream);
+
 /* Featureless layer (X = I, d_in = N): out[dst,:] = bias + sum val * table[rel*n_src + src, :].
  * Replaces torch.mm(adj, weights.view(R*N, d_out)) of layers.py:286-288 / :518-523. */
 RGCN_API int rgcn_featureless_fwd_f32(const float *table, const float *bias, float *out, const int32_t *p_src,
@@ -239,8 +259,10 @@ RGCN_API int rgcn_featureless_wgrad_f32(const float *G, float *dtable, const int
                                         int64_t n_chunks, int64_t n_dst, int64_t n_src, int32_t R,
                                         int32_t d_out, void *stream);
 
-/* db[j] = sum_n G[n, j]  (bias gradient; deterministic two-stage reduction). */
-RGCN_API int rgcn_colsum_f32(const float *G, float *db, int64_t n, int32_t d, void *stream);
+/* db[j] = sum_n G[n, j]  (bias gradient: autograd dual of the `+ bias` of layers.py:305-306).  Two stages through
+ * `scratch` (rgcn_colsum_scratch_floats(n, d) floats), no atomics, fixed summation order: bit-reproducible. */
+RGCN_API int64_t rgcn_colsum_scratch_floats(int64_t n, int32_t d);
+RGCN_API int rgcn_colsum_f32(const float *G, float *db, float *scratch, int64_t n, int32_t d, void *stream);
 
 /* Featureless layer with basis decomposition, source-major (layers.py:241-242 + :286-288 without the R x N x d_out
  * table): out[s,:] = sum_{e=(s,r,o)} val_e sum_b comps[r,b] bases[b,o,:].  `bases` / `dbases` here are NODE-major

@@ -98,4 +98,22 @@ if "wtiled" in a.what:
     err = ((got - ref).abs().max() / ref.abs().max()).item()
     med, mn = timeit(lambda: _native.wgrad_tiled(X, G, plan, R, tpi), a.iters)
     print(f"[{tag}] wgrad_tiled tiles/item={tpi} relerr_vs_relmajor={err:.2e} med {med:.3f} ms min {mn:.3f} ms", flush=True)
+if "bwd" in a.what:
+    bp, fp = g.bwd_plan(d), g.fwd_plan(d)
+    Wt = W.transpose(1, 2).contiguous()
+    ref_dx = _native.spmm(G, Wt, None, bp)
+    ref_dw = _native.wgrad_tiled(X, G, fp, R, 8)
+    for atomic in (False, True):
+        dx, dw = _native.bwd_fused(G, X, W, bp, atomic=atomic)
+        e1 = ((dx - ref_dx).abs().max() / ref_dx.abs().max()).item()
+        e2 = ((dw - ref_dw).abs().max() / ref_dw.abs().max()).item()
+        _native.profile_start()
+        med, mn = timeit(lambda: _native.bwd_fused(G, X, W, bp, atomic=atomic), a.iters)
+        _native.profile_stop()
+        balg = M * (4 * d + 8) + 2 * N * 4 * d
+        print(f"[{tag} BU={os.environ.get('RGCN_BWD_U', '-')}] bwd_fused {'atomic' if atomic else 'partial'} tile={bp.tile_rows} relerr dX {e1:.2e} dW {e2:.2e} "
+              f"med {med:.3f} ms min {mn:.3f} ms -> {balg / med / 1e6:.0f} GB/s algorithmic (backward bytes)", flush=True)
+    d2 = _native.bwd_fused(G, X, W, bp)
+    d3 = _native.bwd_fused(G, X, W, bp)
+    print("bwd_fused (partial) bitwise reproducible:", bool(torch.equal(d2[0], d3[0]) and torch.equal(d2[1], d3[1])), flush=True)
 print(f"setup {time.time() - t0:.1f}s", flush=True)

@@ -1,0 +1,101 @@
+// Device-side helpers shared by the message-passing kernels (rgcn_kernels.hip, rgcn_bwd.hip): DPP primitives and the
+// segmented fold over the 16 slots of a chunk.  gfx950 only, 64-wide wavefronts: lane = 16*k + m.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rgcn_hip.h"
+
+extern "C" void rgcn_set_error(const char *fmt, ...);
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      rgcn_set_error("%s failed: %s", #expr, hipGetErrorString(e_));                    \
+      return RGCN_EHIP;                                                                 \
+    }                                                                                   \
+  } while (0)
+
+namespace {
+
+constexpr int WG = 256;            // 4 wavefronts
+constexpr int LDS_TILE_BYTES = 64 * 1024;
+
+// ------------------------------------------------------------------ spmm
+// One WAVE per destination tile (a workgroup = 4 independent waves = 4 tiles).  The wave is the
+// only writer of its tile's rows, so the LDS accumulation is a plain read-modify-write
+// (ds_read_b128 / ds_write_b128): LDS float atomics measured ~160 cycles per wave-instruction on
+// gfx950 and were 80% of the first version of this kernel; the RMW form is free and deterministic.
+//
+// Per chunk of 16 messages (one relation):   D^T[o][slot] = sum_f W_rel[f][o] * (val * X[src_slot][f])
+//   A operand = W fragment  (lane 16k+o, step c : W[f(c,k)][o])
+//   B operand = gathered rows (lane 16k+m, step c : val_m * X[src_m][f(c,k)])
+//   D         : lane 16q+m holds output features 4q..4q+3 of slot m  -> ONE 16-byte LDS update per lane
+// Slots are sorted by destination, so messages that share a destination sit in adjacent lanes of a
+// 16-lane DPP row: a 4-step segmented scan (v_*_dpp row_shr) folds them and only the last lane of
+// each segment touches LDS -- no two lanes of one instruction ever update the same address.
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float old, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                              CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int old, int src) {
+  return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, 0xF, false);
+}
+// The wave-owned LDS tile of the hidden-16 kernels is XOR-swizzled: float4 column q of row r is stored at column
+// q ^ ((r >> 2) & 3).  With the plain layout (row stride 16 floats) rows r and r + 4 share their banks and the 8 lanes of a
+// ds_read/write_b128 group that carry the same column collide 2-3 ways (round 1: SQ_LDS_BANK_CONFLICT = 70 % of
+// SQ_LDS_IDX_ACTIVE in spmm_d16_kernel); swizzled, 16 consecutive rows cover all 64 banks.  i = float4 index (4 row + q).
+__device__ __forceinline__ int tile_swz(int i) { return i ^ ((i >> 4) & 3); }
+
+constexpr int ROW_SHR = 0x110;  // + n : lane m reads lane m-n of its 16-lane row
+constexpr int ROW_SHL = 0x100;  // + n : lane m reads lane m+n
+
+// In-place inclusive segmented sum over the slots (lanes m = 0..15 of a DPP row) of NV accumulators.
+// Branch-free: lane m adds lane m-N's value times a 0/1 mask (same destination), N = 1, 2, 4, 8; the
+// DPP shift is foldable into the multiply-add.  Returns true in the last lane of every run of equal `dst`.
+template <int N>
+__device__ __forceinline__ float dpp_shr0(float src) {   // lane m <- lane m-N of the 16-lane row, 0 when m < N
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), ROW_SHR + N, 0xF, 0xF, true));
+}
+
+template <int NV>
+__device__ __forceinline__ bool fold_segments(f32x4 (&acc)[NV], int dst) {
+#define RGCN_FOLD_STEP(N, SAME)                                                \
+  {                                                                            \
+    const float sf = (SAME) ? 1.f : 0.f;                                       \
+    _Pragma("unroll") for (int v = 0; v < NV; ++v) {                           \
+      acc[v][0] = fmaf(dpp_shr0<N>(acc[v][0]), sf, acc[v][0]);                 \
+      acc[v][1] = fmaf(dpp_shr0<N>(acc[v][1]), sf, acc[v][1]);                 \
+      acc[v][2] = fmaf(dpp_shr0<N>(acc[v][2]), sf, acc[v][2]);                 \
+      acc[v][3] = fmaf(dpp_shr0<N>(acc[v][3]), sf, acc[v][3]);                 \
+    }                                                                          \
+  }
+  // runs of equal destinations are contiguous (slots are sorted): a step of distance N is needed only if some
+  // run is longer than N -- most chunks stop after step 1 or need no step at all (wave-uniform early exits)
+  // pads carry dst = -1 and never join a run
+  const bool s1 = dpp_i<ROW_SHR + 1>(-1, dst) == dst && dst >= 0;
+  if (__builtin_amdgcn_ballot_w64(s1)) {
+    RGCN_FOLD_STEP(1, s1)
+    const bool s2 = dpp_i<ROW_SHR + 2>(-1, dst) == dst && dst >= 0;
+    if (__builtin_amdgcn_ballot_w64(s2)) {
+      RGCN_FOLD_STEP(2, s2)
+      const bool s4 = dpp_i<ROW_SHR + 4>(-1, dst) == dst && dst >= 0;
+      if (__builtin_amdgcn_ballot_w64(s4)) {
+        RGCN_FOLD_STEP(4, s4)
+        const bool s8 = dpp_i<ROW_SHR + 8>(-1, dst) == dst && dst >= 0;
+        RGCN_FOLD_STEP(8, s8)
+      }
+    }
+  }
+#undef RGCN_FOLD_STEP
+  return dpp_i<ROW_SHL + 1>(-2, dst) != dst && dst >= 0;   // last lane of a run of real slots
+}
+
+
+}  // namespace

@@ -17,96 +17,11 @@
 //
 // 64-wide wavefronts throughout: lane = 16*k + m addresses MFMA operand element
 // (row m, k-slot k) -- see cdna_hip_programming.md section 3.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
 #include <stdlib.h>
 
-#include "rgcn_hip.h"
-
-extern "C" void rgcn_set_error(const char *fmt, ...);
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define HIP_TRY(expr)                                                                   \
-  do {                                                                                  \
-    hipError_t e_ = (expr);                                                             \
-    if (e_ != hipSuccess) {                                                             \
-      rgcn_set_error("%s failed: %s", #expr, hipGetErrorString(e_));                    \
-      return RGCN_EHIP;                                                                 \
-    }                                                                                   \
-  } while (0)
+#include "rgcn_device.h"
 
 namespace {
-
-constexpr int WG = 256;            // 4 wavefronts
-constexpr int LDS_TILE_BYTES = 64 * 1024;
-
-// ------------------------------------------------------------------ spmm
-// One WAVE per destination tile (a workgroup = 4 independent waves = 4 tiles).  The wave is the
-// only writer of its tile's rows, so the LDS accumulation is a plain read-modify-write
-// (ds_read_b128 / ds_write_b128): LDS float atomics measured ~160 cycles per wave-instruction on
-// gfx950 and were 80% of the first version of this kernel; the RMW form is free and deterministic.
-//
-// Per chunk of 16 messages (one relation):   D^T[o][slot] = sum_f W_rel[f][o] * (val * X[src_slot][f])
-//   A operand = W fragment  (lane 16k+o, step c : W[f(c,k)][o])
-//   B operand = gathered rows (lane 16k+m, step c : val_m * X[src_m][f(c,k)])
-//   D         : lane 16q+m holds output features 4q..4q+3 of slot m  -> ONE 16-byte LDS update per lane
-// Slots are sorted by destination, so messages that share a destination sit in adjacent lanes of a
-// 16-lane DPP row: a 4-step segmented scan (v_*_dpp row_shr) folds them and only the last lane of
-// each segment touches LDS -- no two lanes of one instruction ever update the same address.
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float old, float src) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
-                                                              CTRL, 0xF, 0xF, false));
-}
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int old, int src) {
-  return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, 0xF, false);
-}
-constexpr int ROW_SHR = 0x110;  // + n : lane m reads lane m-n of its 16-lane row
-constexpr int ROW_SHL = 0x100;  // + n : lane m reads lane m+n
-
-// In-place inclusive segmented sum over the slots (lanes m = 0..15 of a DPP row) of NV accumulators.
-// Branch-free: lane m adds lane m-N's value times a 0/1 mask (same destination), N = 1, 2, 4, 8; the
-// DPP shift is foldable into the multiply-add.  Returns true in the last lane of every run of equal `dst`.
-template <int N>
-__device__ __forceinline__ float dpp_shr0(float src) {   // lane m <- lane m-N of the 16-lane row, 0 when m < N
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), ROW_SHR + N, 0xF, 0xF, true));
-}
-
-template <int NV>
-__device__ __forceinline__ bool fold_segments(f32x4 (&acc)[NV], int dst) {
-#define RGCN_FOLD_STEP(N, SAME)                                                \
-  {                                                                            \
-    const float sf = (SAME) ? 1.f : 0.f;                                       \
-    _Pragma("unroll") for (int v = 0; v < NV; ++v) {                           \
-      acc[v][0] = fmaf(dpp_shr0<N>(acc[v][0]), sf, acc[v][0]);                 \
-      acc[v][1] = fmaf(dpp_shr0<N>(acc[v][1]), sf, acc[v][1]);                 \
-      acc[v][2] = fmaf(dpp_shr0<N>(acc[v][2]), sf, acc[v][2]);                 \
-      acc[v][3] = fmaf(dpp_shr0<N>(acc[v][3]), sf, acc[v][3]);                 \
-    }                                                                          \
-  }
-  // runs of equal destinations are contiguous (slots are sorted): a step of distance N is needed only if some
-  // run is longer than N -- most chunks stop after step 1 or need no step at all (wave-uniform early exits)
-  // pads carry dst = -1 and never join a run
-  const bool s1 = dpp_i<ROW_SHR + 1>(-1, dst) == dst && dst >= 0;
-  if (__builtin_amdgcn_ballot_w64(s1)) {
-    RGCN_FOLD_STEP(1, s1)
-    const bool s2 = dpp_i<ROW_SHR + 2>(-1, dst) == dst && dst >= 0;
-    if (__builtin_amdgcn_ballot_w64(s2)) {
-      RGCN_FOLD_STEP(2, s2)
-      const bool s4 = dpp_i<ROW_SHR + 4>(-1, dst) == dst && dst >= 0;
-      if (__builtin_amdgcn_ballot_w64(s4)) {
-        RGCN_FOLD_STEP(4, s4)
-        const bool s8 = dpp_i<ROW_SHR + 8>(-1, dst) == dst && dst >= 0;
-        RGCN_FOLD_STEP(8, s8)
-      }
-    }
-  }
-#undef RGCN_FOLD_STEP
-  return dpp_i<ROW_SHL + 1>(-2, dst) != dst && dst >= 0;   // last lane of a run of real slots
-}
 
 constexpr int SPMM_WAVES = WG / 64;
 
@@ -200,7 +115,8 @@ __global__ __launch_bounds__(WG) void spmm_d16_kernel(
         }
         const bool tail = fold_segments<1>(acc, g.d[j]);
         if (tail) {
-          f32x4 *p = reinterpret_cast<f32x4 *>(tile + (g.d[j] - row0) * 16 + 4 * k);
+          const int dl = g.d[j] - row0;
+          f32x4 *p = reinterpret_cast<f32x4 *>(tile + dl * 16 + 4 * (k ^ ((dl >> 2) & 3)));   // swizzled: see tile_swz
           *p += acc[0];
         }
       }
@@ -223,14 +139,14 @@ __global__ __launch_bounds__(WG) void spmm_d16_kernel(
   float4 *o4 = reinterpret_cast<float4 *>(out + (size_t)row0 * 16);
   if (unit.w & RGCN_U_SHARED) {   // piece of a hub tile: out was zeroed by the launcher, pieces are summed atomically
     for (int i = lane; i < nrows * 4; i += 64) {
-      const float4 a = reinterpret_cast<const float4 *>(tile)[i];
+      const float4 a = reinterpret_cast<const float4 *>(tile)[tile_swz(i)];
       float *o = reinterpret_cast<float *>(o4 + i);
       atomicAdd(o, a.x + bv.x); atomicAdd(o + 1, a.y + bv.y); atomicAdd(o + 2, a.z + bv.z); atomicAdd(o + 3, a.w + bv.w);
     }
     return;
   }
   for (int i = lane; i < nrows * 4; i += 64) {  // (i & 3) == (lane & 3)
-    float4 a = reinterpret_cast<const float4 *>(tile)[i];
+    float4 a = reinterpret_cast<const float4 *>(tile)[tile_swz(i)];
     a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
     if (relu_out) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
     o4[i] = a;
@@ -890,25 +806,59 @@ __global__ __launch_bounds__(WG) void featureless_wgrad_kernel(
 }
 
 // ------------------------------------------------------------------ column sum (bias gradient)
-__global__ __launch_bounds__(WG) void colsum_kernel(const float *__restrict__ G, float *__restrict__ db,
-                                                    long long n, int d) {
-  // thread -> column (tid % d) when d <= 256; rows strided by WG / d groups
+// Two stages, no atomics, fixed summation order (bit-reproducible): stage A -- every workgroup streams its rows (float4 per
+// thread when d % 4 == 0) and leaves one partial row in `partial[block][d]`; stage B -- one workgroup sums the partial rows.
+template <bool VEC4>
+__global__ __launch_bounds__(WG) void colsum_a_kernel(const float *__restrict__ G, float *__restrict__ partial, long long n, int d) {
+  __shared__ float part[WG * 4];
+  const int tid = threadIdx.x;
+  const int lanes = VEC4 ? d / 4 : d;                 // threads per row
+  const int groups = max(1, WG / lanes);
+  const int c = tid % lanes, grp = tid / lanes;
+  for (int cb = 0; cb < lanes; cb += WG) {            // column blocks when a row needs more than 256 threads
+    const int cc = cb + c;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (grp < groups && cc < lanes)
+      for (long long row = (long long)blockIdx.x * groups + grp; row < n; row += (long long)gridDim.x * groups) {
+        if (VEC4) {
+          const float4 x = *reinterpret_cast<const float4 *>(G + (size_t)row * d + 4 * cc);
+          a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+        } else {
+          a.x += G[(size_t)row * d + cc];
+        }
+      }
+    reinterpret_cast<float4 *>(part)[tid] = a;
+    __syncthreads();
+    if (grp == 0 && cc < lanes) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int g2 = 0; g2 < groups; ++g2) {
+        const float4 x = reinterpret_cast<const float4 *>(part)[g2 * lanes + c];
+        t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w;
+      }
+      float *o = partial + (size_t)blockIdx.x * d;
+      if (VEC4) *reinterpret_cast<float4 *>(o + 4 * cc) = t;
+      else o[cc] = t.x;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(WG) void colsum_b_kernel(const float *__restrict__ partial, float *__restrict__ db, int n_part, int d) {
   __shared__ float part[WG];
   const int tid = threadIdx.x;
   const int groups = max(1, WG / d);
-  const int col = tid % d, grp = tid / d;
-  for (int cb = 0; cb < d; cb += WG) {  // column blocks when d > 256
-    const int cc = cb + col;
+  const int c = tid % d, grp = tid / d;
+  for (int cb = 0; cb < d; cb += WG) {
+    const int cc = cb + c;
     float a = 0.f;
     if (grp < groups && cc < d)
-      for (long long row = (long long)blockIdx.x * groups + grp; row < n; row += (long long)gridDim.x * groups)
-        a += G[(size_t)row * d + cc];
+      for (int p = grp; p < n_part; p += groups) a += partial[(size_t)p * d + cc];
     part[tid] = a;
     __syncthreads();
     if (grp == 0 && cc < d) {
-      float s = 0.f;
-      for (int g2 = 0; g2 < groups; ++g2) s += part[g2 * d + col];
-      atomicAdd(&db[cc], s);
+      float t = 0.f;
+      for (int g2 = 0; g2 < groups; ++g2) t += part[g2 * d + c];
+      db[cc] = t;
     }
     __syncthreads();
   }
@@ -1252,14 +1202,22 @@ extern "C" int rgcn_featureless_wgrad_f32(const float *G, float *dtable, const i
   return RGCN_OK;
 }
 
-extern "C" int rgcn_colsum_f32(const float *G, float *db, int64_t n, int32_t d, void *stream) {
-  if (!G || !db || n < 0 || d <= 0) { rgcn_set_error("colsum: bad argument"); return RGCN_EINVAL; }
+extern "C" int64_t rgcn_colsum_scratch_floats(int64_t n, int32_t d) {
+  (void)n;
+  return (int64_t)1024 * d;
+}
+
+extern "C" int rgcn_colsum_f32(const float *G, float *db, float *scratch, int64_t n, int32_t d, void *stream) {
+  if (!G || !db || !scratch || n < 0 || d <= 0) { rgcn_set_error("colsum: bad argument"); return RGCN_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(db, 0, (size_t)d * sizeof(float), st));
-  if (n == 0) return RGCN_OK;
-  const int groups = std::max(1, WG / d);
+  if (n == 0) { HIP_TRY(hipMemsetAsync(db, 0, (size_t)d * sizeof(float), st)); return RGCN_OK; }
+  const bool vec4 = d % 4 == 0;
+  const int lanes = vec4 ? d / 4 : d;
+  const int groups = std::max(1, WG / lanes);
   const unsigned gx = (unsigned)std::min<int64_t>((n + groups - 1) / groups, 1024);
-  hipLaunchKernelGGL(colsum_kernel, dim3(gx), dim3(WG), 0, st, G, db, (long long)n, d);
+  if (vec4) hipLaunchKernelGGL(colsum_a_kernel<true>, dim3(gx), dim3(WG), 0, st, G, scratch, (long long)n, d);
+  else hipLaunchKernelGGL(colsum_a_kernel<false>, dim3(gx), dim3(WG), 0, st, G, scratch, (long long)n, d);
+  hipLaunchKernelGGL(colsum_b_kernel, dim3(1), dim3(WG), 0, st, scratch, db, (int)gx, d);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

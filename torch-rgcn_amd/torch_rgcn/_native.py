@@ -32,6 +32,8 @@ def lib():
                 "(hipcc --offload-arch=gfx950). torch_rgcn has no CPU/eager fallback.")
         L = ctypes.CDLL(_LIB_PATH)
         L.rgcn_version.restype = ctypes.c_char_p
+        L.rgcn_bwd_fused_scratch_floats.restype = ctypes.c_int64
+        L.rgcn_colsum_scratch_floats.restype = ctypes.c_int64
         L.rgcn_last_error.restype = ctypes.c_char_p
         _lib = L
     return _lib
@@ -660,6 +662,44 @@ def wgrad_tiled(X, G, plan, num_rels, tiles_per_item=4):
     return dW
 
 
+F_DW_ATOMIC = 4
+
+
+def pack_w16t(W):
+    """[R,16,16] weights -> fragments of W^T (what the feature-gradient kernels multiply by), see rgcn_pack_w16t_f32"""
+    Wp = torch.empty_like(W)
+    with torch.cuda.device(W.device):
+        _check(lib().rgcn_pack_w16t_f32(_dp(W), _dp(Wp), c_i32(W.shape[0]), _stream(W.device)), "pack_w16t")
+    return Wp
+
+
+def bwd_fused_ok(plan):
+    """the fused backward kernel walks the transposed plan tile by tile: packed slots, run pointers, no hub-split tiles"""
+    return (plan.pack is not None and plan.run_ptr is not None and plan.n_split == 0 and plan.n_units == plan.n_tiles
+            and plan.tile_rows <= 255 and plan.n_tiles > 0)
+
+
+def bwd_fused(G, X, W, plan, atomic=False):
+    """(dX [n, 16], dW [R, 16, 16]) of the hidden-16 layer from one walk of the transposed plan (rgcn_bwd_fused_f32):
+    G upstream gradient, X the layer's input, W [R, 16, 16]."""
+    _req(G, "grad_output"); _req(X, "features"); _req(W, "weights")
+    assert W.shape[1:] == (16, 16) and G.shape == (plan.n_src, 16) and X.shape == (plan.n_dst, 16)
+    dev = G.device
+    Wtp = pack_w16t(W)
+    dX = torch.empty((plan.n_dst, 16), device=dev, dtype=torch.float32)
+    dW = torch.empty_like(W)
+    scratch = None
+    if not atomic:
+        n = int(lib().rgcn_bwd_fused_scratch_floats(c_i64(plan.n_tiles), c_i32(W.shape[0])))
+        scratch = torch.empty(n, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev), _timed("bwd_fused"):
+        _check(lib().rgcn_bwd_fused_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(scratch), _dp(plan.pack),
+                                        _dp(plan.chunk_rel), _dp(plan.run_ptr), c_i64(plan.n_tiles), c_i32(plan.tile_rows),
+                                        c_i64(plan.n_dst), c_i32(W.shape[0]), c_i32(F_DW_ATOMIC if atomic else 0),
+                                        _stream(dev)), "bwd_fused")
+    return dX, dW
+
+
 def featureless_fwd(table, bias, plan):
     """out[n_dst, d] = bias + sum_slots val * table[rel, src, :]   (table: [R, n_src, d])"""
     _req(table, "weights"); _req(bias, "bias")
@@ -690,9 +730,11 @@ def featureless_wgrad(G, plan, num_rels):
 def colsum(G):
     _req(G, "grad_output")
     db = torch.empty(G.shape[1], device=G.device, dtype=torch.float32)
+    scratch = torch.empty(int(lib().rgcn_colsum_scratch_floats(c_i64(G.shape[0]), c_i32(G.shape[1]))), device=G.device,
+                          dtype=torch.float32)
     with torch.cuda.device(G.device), _timed("colsum"):
-        _check(lib().rgcn_colsum_f32(_dp(G), _dp(db), c_i64(G.shape[0]), c_i32(G.shape[1]), _stream(G.device)),
-               "colsum")
+        _check(lib().rgcn_colsum_f32(_dp(G), _dp(db), _dp(scratch), c_i64(G.shape[0]), c_i32(G.shape[1]),
+                                     _stream(G.device)), "colsum")
     return db
 
 

@@ -84,6 +84,40 @@ def _unpad_blocks(dims, dX, dW, db):
             None if db is None else db[:d_out])
 
 
+def deterministic():
+    """RGCN_DETERMINISTIC=1: bit-reproducible gradients.  The fused hidden-16 backward then writes its per-workgroup dW
+    partials with plain stores and two small kernels sum them in a fixed order (+0.11 ms per layer at S1) instead of
+    adding them to dW with fp32 atomics.  Outputs, feature gradients and bias gradients are reproducible either way."""
+    return os.environ.get("RGCN_DETERMINISTIC", "0") == "1"
+
+
+def _dense_buckets(plan):
+    return plan.m_pad > 0 and plan.n_messages >= 0.5 * plan.m_pad
+
+
+def _fused_backward(X, W, g, graph):
+    """hidden 16, both gradients wanted: ONE walk of the transposed plan gathers G[s] once per message and produces dX
+    and dW together (csrc/rgcn_bwd.hip).  None when the plan does not qualify (hub-split tiles, unpacked slots) or
+    RGCN_BWD=split asks for round 1's two-pass backward."""
+    if W.shape[1] != 16 or W.shape[2] != 16 or os.environ.get("RGCN_BWD", "fused") == "split":
+        return None
+    bp = graph.bwd_plan(16)
+    if not _native.bwd_fused_ok(bp):
+        return None
+    return _native.bwd_fused(g, X, W, bp, atomic=not deterministic())
+
+
+def _weight_gradient(X, W, g, graph):
+    fp = graph.fwd_plan(min(W.shape[2], 64))
+    # tile-major walk (one random gather per message) unless a (tile, relation) run is so long that
+    # one wave would serialise it (hub nodes): then the relation-major kernel with bounded work items
+    # and unless the (tile, relation) buckets are so sparse that a work item is a fraction of a chunk
+    tiled_ok = W.shape[1] == 16 and W.shape[2] == 16 and fp.max_run_chunks <= 64 and _dense_buckets(fp)
+    if tiled_ok and os.environ.get("RGCN_WGRAD", "tiled") == "tiled":
+        return _native.wgrad_tiled(X, g, fp, W.shape[0], _wgrad_tiles(fp))
+    return _native.wgrad(X, g, graph.wgt_plan(), W.shape[0])
+
+
 class _RelationalMP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, W, bias, graph, relu=False):
@@ -117,23 +151,21 @@ class _RelationalMP(torch.autograd.Function):
         if ctx.relu:         # out = relu(pre): the gradient passes where the stored output is positive
             g = torch.ops.aten.threshold_backward(g, ctx.saved_tensors[2], 0.0)
         dX = dW = db = None
-        if ctx.needs_input_grad[0]:
-            Wt = W.transpose(1, 2).contiguous()
-            if _sparse_buckets(graph, W):
-                dX = _native.spmm_two_pass(g, Wt, None, graph.scatter_plan("bwd"), graph.csr("bwd"))
-            else:
-                dX = _spmm_blocked(g, Wt, None, graph.bwd_plan)
-        if ctx.needs_input_grad[1]:
-            fp = graph.fwd_plan(min(W.shape[2], 64))
-            # tile-major walk (one random gather per message) unless a (tile, relation) run is so long that
-            # one wave would serialise it (hub nodes): then the relation-major kernel with bounded work items
-            # and unless the (tile, relation) buckets are so sparse that a work item is a fraction of a chunk
-            dense = fp.m_pad > 0 and fp.n_messages >= 0.5 * fp.m_pad
-            tiled_ok = W.shape[1] == 16 and W.shape[2] == 16 and fp.max_run_chunks <= 64 and dense
-            if tiled_ok and os.environ.get("RGCN_WGRAD", "tiled") == "tiled":
-                dW = _native.wgrad_tiled(X, g, fp, W.shape[0], _wgrad_tiles(fp))
-            else:
-                dW = _native.wgrad(X, g, graph.wgt_plan(), W.shape[0])
+        sparse = _sparse_buckets(graph, W)
+        both = None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not sparse:
+            both = _fused_backward(X, W, g, graph)
+        if both is not None:
+            dX, dW = both
+        else:
+            if ctx.needs_input_grad[0]:
+                Wt = W.transpose(1, 2).contiguous()
+                if sparse:
+                    dX = _native.spmm_two_pass(g, Wt, None, graph.scatter_plan("bwd"), graph.csr("bwd"))
+                else:
+                    dX = _spmm_blocked(g, Wt, None, graph.bwd_plan)
+            if ctx.needs_input_grad[1]:
+                dW = _weight_gradient(X, W, g, graph)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _native.colsum(g)
         return (*_unpad_blocks(ctx.dims, dX, dW, db), None, None)
@@ -200,20 +232,21 @@ class _ShardedRelationalMP(torch.autograd.Function):
         dX = dW = db = None
         works = []
         slabbed = ctx.n_slabs > 0 and os.environ.get("RGCN_DIST_COMM", "allreduce") == "allreduce"
-        if ctx.needs_input_grad[0]:
-            Wt = W.transpose(1, 2).contiguous()
-            if slabbed:
-                dX = _native.spmm_slabs(g, Wt, None, graph.bwd_plan(W.shape[1]), ctx.n_slabs,
-                                        lambda o, r0, r1: works.append(dist.all_reduce(o[r0:r1], group=ctx.group, async_op=True)))
-            else:
-                dX = _native.spmm(g, Wt, None, graph.bwd_plan(W.shape[1]))
-        if ctx.needs_input_grad[1]:   # owner-local: runs while the last slabs are still being reduced
-            fp = graph.fwd_plan(W.shape[2])
-            dense = fp.m_pad > 0 and fp.n_messages >= 0.5 * fp.m_pad
-            if W.shape[1] == 16 and W.shape[2] == 16 and fp.max_run_chunks <= 64 and dense:
-                dW = _native.wgrad_tiled(X, g, fp, W.shape[0], _wgrad_tiles(fp))
-            else:
-                dW = _native.wgrad(X, g, graph.wgt_plan(), W.shape[0])
+        both = None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not slabbed:
+            both = _fused_backward(X, W, g, graph)
+        if both is not None:
+            dX, dW = both
+        else:
+            if ctx.needs_input_grad[0]:
+                Wt = W.transpose(1, 2).contiguous()
+                if slabbed:
+                    dX = _native.spmm_slabs(g, Wt, None, graph.bwd_plan(W.shape[1]), ctx.n_slabs,
+                                            lambda o, r0, r1: works.append(dist.all_reduce(o[r0:r1], group=ctx.group, async_op=True)))
+                else:
+                    dX = _native.spmm(g, Wt, None, graph.bwd_plan(W.shape[1]))
+            if ctx.needs_input_grad[1]:   # owner-local: runs while the last slabs are still being reduced
+                dW = _weight_gradient(X, W, g, graph)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _native.colsum(g)
         if dX is not None and not slabbed:

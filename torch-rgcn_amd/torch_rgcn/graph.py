@@ -73,7 +73,7 @@ class RelGraph:
             s, p, o, val, alive = self._dev
             dst, src = (s, o) if kind == "fwd" else (o, s)
             self._plans[key] = _native.build_plan_device(dst, src, p, val, alive, N, N, R, tile_rows, self.num_messages,
-                                                         max_item_chunks, want_runs=(kind == "fwd"), want_pack=True)
+                                                         max_item_chunks, want_runs=True, want_pack=True)
         if key not in self._plans:
             N, R = self.num_nodes, self.num_rels
             if kind == "fwd":
@@ -81,7 +81,7 @@ class RelGraph:
                                              want_runs=True, want_pack=True)
             elif kind == "bwd":
                 hp = _native.build_plan_host(self._o, self._s, self._p, self._val, N, N, R, tile_rows, max_item_chunks,
-                                             want_pack=True)
+                                             want_runs=True, want_pack=True)
             else:
                 raise KeyError(kind)
             self._plans[key] = _native.DevicePlan(hp, self.device)
@@ -91,7 +91,12 @@ class RelGraph:
         return self._plan("fwd", pick_tile_rows(d_out, self.num_nodes))
 
     def bwd_plan(self, d_in):
-        return self._plan("bwd", pick_tile_rows(d_in, self.num_nodes))
+        rows = pick_tile_rows(d_in, self.num_nodes)
+        if d_in == 16 and "RGCN_TILE_ROWS" not in os.environ:
+            # hidden 16: the fused backward kernel (dX + dW in one walk) keeps a dX tile, a transposition scratch and the
+            # dW staging slots in LDS; 64-row tiles keep 4 workgroups per CU resident (measured: 0.71 ms at 64 rows, 0.80 at 128)
+            rows = min(rows, int(os.environ.get("RGCN_BWD_TILE_ROWS", "64")))
+        return self._plan("bwd", rows)
 
     def wgt_plan(self):
         """relation-major (single tile): long runs per relation for the weight gradient"""
