@@ -94,6 +94,22 @@ def pmc_detail(kernel_key):
         return None
 
 
+class _MeanSquare(torch.autograd.Function):
+    """loss = mean(out^2) as two kernels (a dot product; one scaled copy in backward) instead of the five elementwise /
+    reduction kernels of out.pow(2).mean() -- the loss is part of the timed step but not the thing measured."""
+
+    @staticmethod
+    def forward(ctx, out):
+        flat = out.reshape(-1)
+        ctx.save_for_backward(out)
+        return torch.dot(flat, flat) / flat.numel()
+
+    @staticmethod
+    def backward(ctx, g):
+        out, = ctx.saved_tensors
+        return out * (g * (2.0 / out.numel()))
+
+
 def build_layers(N, R0, E, d, seed, device, group, keep):
     from torch_rgcn import _native
     from torch_rgcn.dist import shard_layer
@@ -215,7 +231,7 @@ def main():
         for p in (X, l1.weights, l1.bias, l2.weights, l2.bias):
             p.grad = None
         out = l2(l1.forward_activated(X, "relu"))
-        loss = out.pow(2).mean()
+        loss = _MeanSquare.apply(out)
         loss.backward()
         return loss
 

@@ -288,12 +288,14 @@ RGCN_API int rgcn_gather_rows_sum_f32(const float *Y, const int32_t *perm, const
 
 /* DistMult decoder (torch_rgcn/layers.py:86-98):
  * scores[t] = sum_k nodes[s,k] rel[p,k] nodes[o,k] (+ sbias[s] + pbias[p] + obias[o]);
- * triples int64 [T,3] on the device.  Biases may all be NULL. */
+ * triples int64 [T,3] on the device.  Biases may all be NULL.  Triples whose s / o are outside [0, n_nodes) or whose p
+ * is outside [0, n_rel) are NOT touched (the reference's fancy indexing raises IndexError): their score is 0 and
+ * *err_flag (device int32, may be NULL) is set to 1 -- the caller turns it into the exception. */
 RGCN_API int rgcn_distmult_fwd_f32(const int64_t *triples, int64_t T, const float *nodes, const float *rel,
                                    const float *sbias, const float *pbias, const float *obias, float *scores,
-                                   int64_t n_nodes, int32_t n_rel, int32_t d, void *stream);
+                                   int64_t n_nodes, int32_t n_rel, int32_t d, int32_t *err_flag, void *stream);
 /* Gradients of sum_t gs[t] * scores[t]; dnodes / drel (and the bias grads when
- * non-NULL) are zeroed first and accumulated with fp32 atomics. */
+ * non-NULL) are zeroed first and accumulated with fp32 atomics.  Out-of-range triples are skipped. */
 RGCN_API int rgcn_distmult_bwd_f32(const int64_t *triples, int64_t T, const float *nodes, const float *rel,
                                    const float *gs, float *dnodes, float *drel, float *dsbias, float *dpbias,
                                    float *dobias, int64_t n_nodes, int32_t n_rel, int32_t d, void *stream);

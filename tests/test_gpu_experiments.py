@@ -17,7 +17,7 @@ def cfg(name):
 def test_classify_nodes_aifb_shaped_learns():
     sys.path.insert(0, os.path.join(PKG, "experiments"))
     import classify_nodes
-    hist = classify_nodes.run(cfg("nc-AIFB.yaml"), epochs=25, quiet=True)
+    hist = classify_nodes.run(cfg("nc-AIFB.yaml"), epochs=25, quiet=True, synthetic=True)
     assert hist[-1][0] < 0.6 * hist[0][0]          # loss goes down
     assert hist[-1][1] > 0.9                         # and the (featureless, 12 M parameter) model fits the train labels
 
@@ -30,7 +30,7 @@ def test_classify_nodes_hipgraph_replay_matches_eager():
     hist = {}
     for mode in (False, True):
         torch.manual_seed(0)
-        hist[mode] = classify_nodes.run(cfg("nc-MUTAG.yaml"), epochs=8, quiet=True, hipgraph=mode)
+        hist[mode] = classify_nodes.run(cfg("nc-MUTAG.yaml"), epochs=8, quiet=True, hipgraph=mode, synthetic=True)
     # the capture warms up with 3 extra optimiser steps: epoch k of the replay is eager epoch k + 3... compare shapes and trend
     assert len(hist[True]) == 8 and hist[True][-1][0] < hist[True][0][0]
     # (fp32 atomics in the featureless weight gradient make the two trajectories drift apart in the last digits)
@@ -40,7 +40,7 @@ def test_classify_nodes_hipgraph_replay_matches_eager():
 def test_classify_nodes_mutag_shaped_basis():
     sys.path.insert(0, os.path.join(PKG, "experiments"))
     import classify_nodes
-    hist = classify_nodes.run(cfg("nc-MUTAG.yaml"), epochs=15, quiet=True)
+    hist = classify_nodes.run(cfg("nc-MUTAG.yaml"), epochs=15, quiet=True, synthetic=True)
     assert hist[-1][0] < hist[0][0]
 
 
@@ -48,7 +48,7 @@ def test_classify_nodes_e_rgcn_config_runs():
     sys.path.insert(0, os.path.join(PKG, "experiments"))
     import classify_nodes
     c = yaml.safe_load(open(os.path.join(PKG, "configs", "e-rgcn", "nc-AIFB.yaml")))
-    hist = classify_nodes.run(c, epochs=10, quiet=True)
+    hist = classify_nodes.run(c, epochs=10, quiet=True, synthetic=True)
     assert hist[-1][0] < hist[0][0]
 
 
@@ -60,7 +60,7 @@ def test_predict_links_small_graph_trains_and_ranks():
     c["encoder"].update(node_embedding=32, hidden1_size=32)
     c["training"].update(graph_batch_size=2000)
     c["evaluation"].update(check_every=20, batch_size=32, verbose=False)
-    hist, metrics = predict_links.run(c, epochs=30, quiet=True, max_test=100)
+    hist, metrics = predict_links.run(c, epochs=30, quiet=True, max_test=100, synthetic=True)
     assert hist[-1] < hist[0]
     assert 0.0 < metrics["mrr"] <= 1.0 and metrics["hits@10"] >= metrics["hits@1"]
 
@@ -70,8 +70,8 @@ def test_predict_links_block_config_pads_nodes_and_c_rgcn_runs():
     import predict_links
     c = cfg("lp-FB-toy.yaml")                            # block decomposition: 280 nodes padded to a multiple of 500 / 100
     c["training"].update(graph_batch_size=300)
-    hist, metrics = predict_links.run(c, epochs=3, quiet=True, max_test=20)
+    hist, metrics = predict_links.run(c, epochs=3, quiet=True, max_test=20, synthetic=True)
     assert len(hist) == 3 and 0.0 < metrics["mrr"] <= 1.0
     c = yaml.safe_load(open(os.path.join(PKG, "configs", "c-rgcn", "lp-FB-toy.yaml")))   # no graph_batch_size: whole graph
-    hist, metrics = predict_links.run(c, epochs=3, quiet=True, max_test=20)
+    hist, metrics = predict_links.run(c, epochs=3, quiet=True, max_test=20, synthetic=True)
     assert len(hist) == 3 and 0.0 < metrics["mrr"] <= 1.0

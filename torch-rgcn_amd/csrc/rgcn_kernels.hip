@@ -851,8 +851,18 @@ __global__ __launch_bounds__(WG) void colsum_b_kernel(const float *__restrict__ 
   for (int cb = 0; cb < d; cb += WG) {
     const int cc = cb + c;
     float a = 0.f;
-    if (grp < groups && cc < d)
-      for (int p = grp; p < n_part; p += groups) a += partial[(size_t)p * d + cc];
+    if (grp < groups && cc < d) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;      // four independent chains: the loads of one thread overlap
+      int p = grp;
+      for (; p + 3 * groups < n_part; p += 4 * groups) {
+        a0 += partial[(size_t)p * d + cc];
+        a1 += partial[(size_t)(p + groups) * d + cc];
+        a2 += partial[(size_t)(p + 2 * groups) * d + cc];
+        a3 += partial[(size_t)(p + 3 * groups) * d + cc];
+      }
+      for (; p < n_part; p += groups) a0 += partial[(size_t)p * d + cc];
+      a = (a0 + a1) + (a2 + a3);
+    }
     part[tid] = a;
     __syncthreads();
     if (grp == 0 && cc < d) {
@@ -868,11 +878,15 @@ __global__ __launch_bounds__(WG) void colsum_b_kernel(const float *__restrict__ 
 __global__ __launch_bounds__(WG) void distmult_fwd_kernel(
     const long long *__restrict__ tr, long long T, const float *__restrict__ nodes, const float *__restrict__ rel,
     const float *__restrict__ sb, const float *__restrict__ pb, const float *__restrict__ ob,
-    float *__restrict__ scores, int d) {
+    float *__restrict__ scores, int d, long long n_nodes, int n_rel, int *__restrict__ err) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long long wstride = (long long)gridDim.x * (WG / 64);
   for (long long t = (long long)blockIdx.x * (WG / 64) + wave; t < T; t += wstride) {
     const long long s = tr[3 * t], p = tr[3 * t + 1], o = tr[3 * t + 2];
+    if (s < 0 || s >= n_nodes || o < 0 || o >= n_nodes || p < 0 || p >= n_rel) {   // the reference raises IndexError here
+      if (lane == 0) { if (err) atomicMax(err, 1); scores[t] = 0.f; }
+      continue;
+    }
     const float *ns = nodes + (size_t)s * d, *rp = rel + (size_t)p * d, *no = nodes + (size_t)o * d;
     float a = 0.f;
     for (int j = lane; j < d; j += 64) a += ns[j] * rp[j] * no[j];
@@ -891,7 +905,7 @@ __global__ __launch_bounds__(WG) void distmult_fwd_kernel(
 __global__ __launch_bounds__(WG) void distmult_bwd_kernel(
     const long long *__restrict__ tr, long long T, const float *__restrict__ nodes, const float *__restrict__ rel,
     const float *__restrict__ gs, float *__restrict__ dnodes, float *__restrict__ drel, float *__restrict__ dsb,
-    float *__restrict__ dpb, float *__restrict__ dob, int d) {
+    float *__restrict__ dpb, float *__restrict__ dob, int d, long long n_nodes, int n_rel) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long long wstride = (long long)gridDim.x * (WG / 64) * 64;
   for (long long t0 = ((long long)blockIdx.x * (WG / 64) + wave) * 64; t0 < T; t0 += wstride) {
@@ -901,6 +915,7 @@ __global__ __launch_bounds__(WG) void distmult_bwd_kernel(
       long long cur = -1;
       for (long long t = t0; t < t1; ++t) {
         const long long s = tr[3 * t], p = tr[3 * t + 1], o = tr[3 * t + 2];
+        if (s < 0 || s >= n_nodes || o < 0 || o >= n_nodes || p < 0 || p >= n_rel) continue;   // flagged by the forward
         if (p != cur) {
           if (cur >= 0)
 #pragma unroll
@@ -1214,7 +1229,7 @@ extern "C" int rgcn_colsum_f32(const float *G, float *db, float *scratch, int64_
   const bool vec4 = d % 4 == 0;
   const int lanes = vec4 ? d / 4 : d;
   const int groups = std::max(1, WG / lanes);
-  const unsigned gx = (unsigned)std::min<int64_t>((n + groups - 1) / groups, 1024);
+  const unsigned gx = (unsigned)std::min<int64_t>((n + groups - 1) / groups, 512);
   if (vec4) hipLaunchKernelGGL(colsum_a_kernel<true>, dim3(gx), dim3(WG), 0, st, G, scratch, (long long)n, d);
   else hipLaunchKernelGGL(colsum_a_kernel<false>, dim3(gx), dim3(WG), 0, st, G, scratch, (long long)n, d);
   hipLaunchKernelGGL(colsum_b_kernel, dim3(1), dim3(WG), 0, st, scratch, db, (int)gx, d);
@@ -1224,16 +1239,15 @@ extern "C" int rgcn_colsum_f32(const float *G, float *db, float *scratch, int64_
 
 extern "C" int rgcn_distmult_fwd_f32(const int64_t *triples, int64_t T, const float *nodes, const float *rel,
                                      const float *sbias, const float *pbias, const float *obias, float *scores,
-                                     int64_t n_nodes, int32_t n_rel, int32_t d, void *stream) {
-  (void)n_nodes;
-  (void)n_rel;
+                                     int64_t n_nodes, int32_t n_rel, int32_t d, int32_t *err_flag, void *stream) {
   if (T < 0 || d <= 0 || (T && (!triples || !nodes || !rel || !scores))) { rgcn_set_error("distmult_fwd: bad argument"); return RGCN_EINVAL; }
   if ((sbias != nullptr) != (pbias != nullptr) || (sbias != nullptr) != (obias != nullptr)) { rgcn_set_error("distmult_fwd: biases must be all set or all NULL"); return RGCN_EINVAL; }
+  if (err_flag) HIP_TRY(hipMemsetAsync(err_flag, 0, sizeof(int32_t), (hipStream_t)stream));
   if (T == 0) return RGCN_OK;
   const unsigned gx = (unsigned)std::min<int64_t>((T + 3) / 4, 256 * 32);
   hipLaunchKernelGGL(distmult_fwd_kernel, dim3(gx), dim3(WG), 0, (hipStream_t)stream,
                      reinterpret_cast<const long long *>(triples), (long long)T, nodes, rel, sbias, pbias, obias,
-                     scores, d);
+                     scores, d, (long long)n_nodes, n_rel, err_flag);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
@@ -1253,7 +1267,7 @@ extern "C" int rgcn_distmult_bwd_f32(const int64_t *triples, int64_t T, const fl
   if (T == 0) return RGCN_OK;
   const unsigned gx = (unsigned)std::min<int64_t>((T + 255) / 256, 256 * 32);
   hipLaunchKernelGGL(distmult_bwd_kernel, dim3(gx), dim3(WG), 0, st, reinterpret_cast<const long long *>(triples),
-                     (long long)T, nodes, rel, gs, dnodes, drel, dsbias, dpbias, dobias, d);
+                     (long long)T, nodes, rel, gs, dnodes, drel, dsbias, dpbias, dobias, d, (long long)n_nodes, n_rel);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

@@ -46,7 +46,7 @@ def _capture(fn, warmup=3):
     return graph, out
 
 
-def run(cfg, data_dir=None, epochs=None, quiet=False, hipgraph=False):
+def run(cfg, data_dir=None, epochs=None, quiet=False, hipgraph=False, synthetic=None):
     """one training run -> [(loss, train accuracy, test accuracy) per epoch] (accuracies in [0, 1]).
     hipgraph=True replays the whole training step (forward, loss, backward, optimiser) and the evaluation forward as
     two captured hipGraphs: full-batch node classification is the same launch sequence every epoch, and on the small
@@ -60,7 +60,7 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, hipgraph=False):
     # the validation split is the test set unless this is a final run (classify_nodes.py:40-43)
     triples, (n2i, i2n), (r2i, i2r), train, test = load_node_classification_data(
         dataset["name"], use_test_set=evaluation.get("final_run", False), prune=dataset.get("prune", False),
-        directory=data_dir)
+        directory=data_dir, synthetic=synthetic)
     device = torch.device("cuda")
     train_idx = torch.tensor([n2i[name] for name in train], dtype=torch.long, device=device)
     train_lbl = torch.tensor(list(train.values()), dtype=torch.long, device=device)
@@ -160,10 +160,13 @@ def repeat(cfg, repeats=1, **kw):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("config")
-    ap.add_argument("--data", default=None, help="directory holding data/<name>/... (default: synthetic dataset-shaped graph)")
+    ap.add_argument("--data", default=None, help="directory holding data/<name>/...")
+    ap.add_argument("--synthetic", action="store_true", help="when the dataset files are absent, train on a random graph with "
+                    "the dataset's node / relation / edge counts (timing and plumbing only: the accuracies mean nothing)")
     ap.add_argument("--epochs", type=int, default=None)
     ap.add_argument("--repeats", type=int, default=1)
     ap.add_argument("--hipgraph", action="store_true", help="replay the training step and the evaluation as captured hipGraphs")
     a = ap.parse_args()
-    avg, ste = repeat(yaml.safe_load(open(a.config)), a.repeats, data_dir=a.data, epochs=a.epochs, hipgraph=a.hipgraph)
-    print(f"test accuracy {avg} +- {ste}")
+    avg, ste = repeat(yaml.safe_load(open(a.config)), a.repeats, data_dir=a.data, epochs=a.epochs, hipgraph=a.hipgraph,
+                      synthetic=True if a.synthetic else None)
+    print(f"test accuracy {avg} +- {ste}" + (" [SYNTHETIC DATA]" if a.synthetic else ""))

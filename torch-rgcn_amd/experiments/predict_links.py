@@ -26,7 +26,7 @@ from utils.misc import evaluate, generate_true_dict, negative_sampling, select_s
 OPTIMISERS = {"adam": torch.optim.Adam, "adamw": torch.optim.AdamW, "adagrad": torch.optim.Adagrad, "sgd": torch.optim.SGD}
 
 
-def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None):
+def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None, synthetic=None):
     """-> (loss per epoch, {"mrr", "hits@1", "hits@3", "hits@10"} of the final evaluation)"""
     dataset, training, encoder = cfg["dataset"], cfg["training"], cfg["encoder"]
     decoder, evaluation = cfg.get("decoder", {}), cfg.get("evaluation", {})
@@ -43,7 +43,7 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None):
                    filter_candidates=filtered)
 
     (n2i, nodes), (r2i, relations), train, test, all_triples = load_link_prediction_data(
-        dataset["name"], use_test_set=evaluation.get("final_run", False), directory=data_dir)
+        dataset["name"], use_test_set=evaluation.get("final_run", False), directory=data_dir, synthetic=synthetic)
     true_triples = generate_true_dict(all_triples)
     if max_test:
         test = test[:max_test]
@@ -135,8 +135,10 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("config")
-    ap.add_argument("--data", default=None, help="directory holding data/<name>/{train,valid,test}.txt (default: synthetic)")
+    ap.add_argument("--data", default=None, help="directory holding data/<name>/{train,valid,test}.txt")
+    ap.add_argument("--synthetic", action="store_true", help="when the dataset files are absent, train on a random graph with "
+                    "the dataset's entity / relation / triple counts (timing and plumbing only: MRR / Hits mean nothing)")
     ap.add_argument("--epochs", type=int, default=None)
     ap.add_argument("--max-test", type=int, default=None)
     a = ap.parse_args()
-    run(yaml.safe_load(open(a.config)), a.data, a.epochs, max_test=a.max_test)
+    run(yaml.safe_load(open(a.config)), a.data, a.epochs, max_test=a.max_test, synthetic=True if a.synthetic else None)

@@ -239,9 +239,47 @@ def _i32(n, device):
     return torch.empty(max(int(n), 1), dtype=torch.int32, device=device)
 
 
-def dev_check_err(err_flag, what):
-    if int(err_flag.item()):
-        raise AssertionError(f"{what}: node or relation index out of range")
+# Device-side range checks leave a flag in device memory.  By default the flag is read back at once (one 4-byte
+# device -> host copy, i.e. a synchronisation) and a bad index raises where the reference raises.  A training loop that
+# must not synchronise (hipGraph capture, torch.cuda.set_sync_debug_mode) sets RGCN_DEFERRED_CHECKS=1: the flags are then
+# queued and looked at on later calls once the GPU has passed them (event query, no wait) or in check_deferred_errors().
+_DEFERRED = []
+
+
+def _deferred_mode():
+    return os.environ.get("RGCN_DEFERRED_CHECKS", "0") == "1"
+
+
+def dev_check_err(err_flag, what, exc=AssertionError):
+    if not _deferred_mode():
+        if int(err_flag.item()):
+            raise exc(f"{what}: node or relation index out of range")
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return                                   # inside a hipGraph capture nothing can be read back: validated before capture
+    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+    host.copy_(err_flag[:1], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _DEFERRED.append((ev, host, what, exc))
+    check_deferred_errors(wait=False)
+
+
+def check_deferred_errors(wait=True):
+    """raise for any queued device-side range check that failed; wait=False only looks at checks the GPU has finished"""
+    keep = []
+    err = None
+    for ev, host, what, exc in _DEFERRED:
+        if wait:
+            ev.synchronize()
+        if ev.query():
+            if int(host[0]) and err is None:
+                err = exc(f"{what}: node or relation index out of range")
+        else:
+            keep.append((ev, host, what, exc))
+    _DEFERRED[:] = keep
+    if err is not None:
+        raise err
 
 
 def dev_split_triples(triples_plus, num_nodes, num_rels):
@@ -744,10 +782,13 @@ def distmult_fwd(triples, nodes, rel, sbias, pbias, obias):
         _req(b, n)
     T = triples.shape[0]
     scores = torch.empty(T, device=nodes.device, dtype=torch.float32)
+    err = _i32(1, nodes.device)
     with torch.cuda.device(nodes.device), _timed("distmult_fwd"):
         _check(lib().rgcn_distmult_fwd_f32(_dp(triples), c_i64(T), _dp(nodes), _dp(rel), _dp(sbias), _dp(pbias),
                                            _dp(obias), _dp(scores), c_i64(nodes.shape[0]), c_i32(rel.shape[0]),
-                                           c_i32(nodes.shape[1]), _stream(nodes.device)), "distmult_fwd")
+                                           c_i32(nodes.shape[1]), _dp(err), _stream(nodes.device)), "distmult_fwd")
+    # the reference indexes nodes[s], relations[p], nodes[o] (layers.py:89-93) and raises IndexError on a bad index
+    dev_check_err(err, "DistMult triples (s, o < num_nodes, p < num_relations)", IndexError)
     return scores
 
 

@@ -102,8 +102,14 @@ class LinkPredictor(nn.Module):
 
     @staticmethod
     def _layer_init(name, default="glorot-normal"):
-        # the LP layer / DistMult call init(tensor, gain=...) -- schlichtkrull needs a shape there (upstream bug F4a)
-        return default if (name is None or name.lower().startswith("schlichtkrull")) else name
+        # the LP layer / DistMult call init(tensor, gain=...) -- schlichtkrull needs a shape there and upstream crashes
+        # (SURVEY F4a); every shipped LP config asks for it, so the substitution is said out loud, once
+        if name is not None and name.lower().startswith("schlichtkrull"):
+            import warnings
+            warnings.warn(f"weight_init '{name}' cannot initialise the R-GCN layer / decoder weights (upstream passes no shape and "
+                          f"fails there): using '{default}' for them; node embeddings keep '{name}'", stacklevel=3)
+            return default
+        return default if name is None else name
 
     @staticmethod
     def _rgc1_in(nemb, nhid1):

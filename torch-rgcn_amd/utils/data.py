@@ -132,8 +132,21 @@ def _label_codes(frame, label_header, nodes_header):
     return {node: int(code) for node, code in zip(frame[nodes_header].values, codes)}
 
 
+def _want_synthetic(synthetic, what, path):
+    """Dataset files are missing: a dataset-SHAPED random graph is only handed out when the caller asked for it
+    (synthetic=True / RGCN_SYNTHETIC=1 / the experiments' --synthetic); otherwise fail like the reference does."""
+    if synthetic is None:
+        synthetic = os.environ.get("RGCN_SYNTHETIC", "0") == "1"
+    if not synthetic:
+        raise FileNotFoundError(f"{what}: {path} not found (pass synthetic=True / --synthetic / RGCN_SYNTHETIC=1 to train on a "
+                                "random graph with the dataset's node, relation and edge counts instead)")
+    import warnings
+    warnings.warn(f"{what}: files not found, using a SYNTHETIC dataset-shaped random graph -- accuracies / MRR are meaningless",
+                  stacklevel=3)
+
+
 def load_node_classification_data(name, use_test_set=False, limit=None, enable_cache=True, val_prop=0.4, prune=False,
-                                  directory=None, seed=0):
+                                  directory=None, seed=0, synthetic=None):
     """-> edges [[s, p, o], ...], (n2i, i2n), (r2i, i2r), train {node label: class}, test {node label: class}
     (utils/data.py:50-200; `enable_cache` is accepted and ignored: parsing takes seconds, nothing is pickled)."""
     REST, INV = ".rest", "inv."
@@ -143,6 +156,7 @@ def load_node_classification_data(name, use_test_set=False, limit=None, enable_c
     graph_file, train_file, test_file, label_header, nodes_header = NC_FILES[key]
     graph_path = locate_file(f"data{S}{key}{S}{graph_file}", directory)
     if not os.path.isfile(graph_path):
+        _want_synthetic(synthetic, f"node classification dataset '{name}'", graph_path)
         return _synthetic_node_classification(key, use_test_set, val_prop, seed)
     import pandas as pd
     labels_train = pd.read_csv(locate_file(f"data{S}{key}{S}{train_file}", directory), sep="\t", encoding="utf8")
@@ -190,7 +204,7 @@ def _synthetic_node_classification(key, use_test_set, val_prop, seed):
 
 
 # ------------------------------------------------------------------ link prediction
-def load_link_prediction_data(name, use_test_set=False, limit=None, directory=None, seed=0):
+def load_link_prediction_data(name, use_test_set=False, limit=None, directory=None, seed=0, synthetic=None):
     """-> (n2i, nodes), (r2i, relations), train [[s, p, o], ...], test [[s, p, o], ...], all_triples {(s, p, o), ...}
     (utils/data.py:202-256: the validation file is the test set unless `use_test_set`; `limit` keeps the first triples)."""
     key = name.lower()
@@ -198,6 +212,7 @@ def load_link_prediction_data(name, use_test_set=False, limit=None, directory=No
         raise ValueError(f"Could not find '{name}' dataset")
     paths = [locate_file(f"data{S}{LP_DIRS[key]}{S}{part}.txt", directory) for part in ("train", "valid", "test")]
     if not all(os.path.isfile(p) for p in paths):
+        _want_synthetic(synthetic, f"link prediction dataset '{name}'", next(p for p in paths if not os.path.isfile(p)))
         return _synthetic_link_prediction(key, use_test_set, limit, seed)
     train, val, test = (load_strings(p) for p in paths)
     if not use_test_set:
