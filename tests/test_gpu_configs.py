@@ -1,0 +1,148 @@
+"""BASELINE.json configs 2 and 3 inside `pytest -m gpu` (`configs_untested` named AM / block-diagonal):
+
+  AM    nc-AM.yaml:3,15-20 -- N = 1,666,764, R0 = 133 (layer R = 267), E = 5,988,321; BASELINE's block-diagonal variant is
+        run at layer level (featured, d = 16, nb = 4) -- reference layers.py:243-244 + utils.py:168-196 --
+        and the shipped first layer (featureless, basis 40, hidden 10) without the 17.8 GB R x N x d table.
+  MUTAG nc-MUTAG.yaml:15-20 -- N = 23,644, R0 = 23, E = 74,227, basis 30, hidden 16, 2 classes, featureless layer 1.
+
+Dataset-shaped synthetic graphs (the files are not available offline).  1/10-AM and full MUTAG go against the
+oracle (out, dX, every parameter gradient, 1e-4); full-size AM goes through size-independent properties (linearity,
+(relation, subject) counts, checksum), both the sparse-bucket two-pass path and the tile path."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from test_gpu_parity import DEV, TOL, rel_err, run_layer_vs_oracle
+
+pytestmark = pytest.mark.gpu
+
+AM = dict(N=1_666_764, R0=133, E=5_988_321)
+MUTAG = dict(N=23_644, R0=23, E=74_227)
+
+
+@pytest.mark.parametrize("vertical", [False, True])
+@pytest.mark.parametrize("sparse_path", ["1", "0"])
+def test_am_tenth_scale_block_diagonal_layer_vs_oracle(monkeypatch, sparse_path, vertical):
+    """1/10 of AM, block-diagonal nb = 4, d = 16, both stackings, both the two-pass (sparse (tile, relation) buckets:
+    267 relations) and the tile kernels: out / dX / dblocks / db against the oracle"""
+    from torch_rgcn import _native
+    monkeypatch.setenv("RGCN_SPARSE_PATH", sparse_path)
+    _native.profile_start()
+    run_layer_vs_oracle(N=166_676, R0=133, E=598_832, d_in=16, d_out=16, mode="block", num_blocks=4, vertical=vertical,
+                        seed=301 + int(vertical))
+    prof = _native.profile_stop()
+    assert ("spmm_scatter" in prof) == (sparse_path == "1")
+
+
+def test_am_tenth_scale_default_path_is_the_sparse_one():
+    """without any switch the 267-relation graph must pick the two-pass path by itself (fill of the 16-slot chunks < 50 %)"""
+    from torch_rgcn import _native
+    _native.profile_start()
+    run_layer_vs_oracle(N=166_676, R0=133, E=598_832, d_in=16, d_out=16, mode="none", seed=303)
+    assert "spmm_scatter" in _native.profile_stop()
+
+
+def _am_graph():
+    T = oracle.synthetic_triples(AM["N"], AM["R0"], AM["E"], seed=2)
+    return oracle.add_inverse_and_self(T, AM["N"], AM["R0"])
+
+
+def test_am_full_size_block_layer_properties():
+    """full-size AM, featured block-diagonal layer: linearity in X, per-subject (relation, subject) group counts,
+    checksum -- through the counting workspace of the full graph (445 M cells) and the max_degree() guard"""
+    from torch_rgcn import _native
+    from torch_rgcn.layers import RelationalGraphConvolutionNC
+    N, R0 = AM["N"], AM["R0"]
+    tp = _am_graph()
+    layer = RelationalGraphConvolutionNC(triples=torch.from_numpy(tp), num_nodes=N, num_relations=2 * R0 + 1, in_features=16,
+                                         out_features=16, bias=False, decomposition={"type": "block", "num_blocks": 4}).to(DEV)
+    _native.profile_start()
+    with torch.no_grad():
+        a, b = torch.randn(N, 16, device=DEV), torch.randn(N, 16, device=DEV)
+        ya, yb, yab = layer(a), layer(b), layer(0.5 * a + 2.0 * b)
+        assert rel_err(yab, (0.5 * ya + 2.0 * yb).cpu().numpy()) < 1e-5
+        layer.blocks.fill_(0.0)
+        layer.blocks[:, 0, 0, 0] = 1.0                      # W_r[0, 0] = 1
+        y = layer(torch.ones(N, 16, device=DEV))[:, 0]
+        key = torch.from_numpy(tp[:, 1] * N + tp[:, 0]).to(DEV)
+        cnt = torch.bincount(torch.unique(key) % N, minlength=N).float()
+        assert torch.allclose(y, cnt, rtol=1e-5, atol=1e-5)
+        assert abs(y.sum().item() - cnt.sum().item()) < 1e-3 * cnt.sum().item()
+    prof = _native.profile_stop()
+    assert "spmm_scatter" in prof, "full-size AM should run on the sparse-bucket two-pass path"
+    # gradients at full size: dX of a constant upstream gradient with W_r[0,0] = 1 is the count of (relation, object)
+    # groups each node SENDS into, weighted by 1/c of the receiving group -- checked as a checksum: sum(dX[:,0]) = sum(out[:,0])
+    X = torch.ones(N, 16, device=DEV, requires_grad=True)
+    out = layer(X)
+    out.backward(torch.ones_like(out))
+    assert abs(X.grad[:, 0].sum().item() - out[:, 0].sum().item()) < 1e-3 * abs(out[:, 0].sum().item())
+    assert torch.isfinite(layer.blocks.grad).all()
+
+
+def test_am_full_size_featureless_basis40_properties():
+    """AM as shipped (nc-AM.yaml: featureless first layer, basis 40, hidden 10): the source-major kernels at full size.
+    With comps = 1/B and bases = 1 the output row is the number of (relation, subject) groups of the node; linear in bases."""
+    from torch_rgcn.layers import RelationalGraphConvolutionNC
+    N, R0, B, d = AM["N"], AM["R0"], 40, 10
+    tp = _am_graph()
+    layer = RelationalGraphConvolutionNC(triples=torch.from_numpy(tp), num_nodes=N, num_relations=2 * R0 + 1, in_features=None,
+                                         out_features=d, bias=False, decomposition={"type": "basis", "num_bases": B}).to(DEV)
+    with torch.no_grad():
+        layer.comps.fill_(1.0 / B)
+        layer.bases.fill_(1.0)
+        y = layer()
+        key = torch.from_numpy(tp[:, 1] * N + tp[:, 0]).to(DEV)
+        cnt = torch.bincount(torch.unique(key) % N, minlength=N).float()
+        assert torch.allclose(y[:, 0], cnt, rtol=1e-4, atol=1e-4) and torch.allclose(y[:, d - 1], cnt, rtol=1e-4, atol=1e-4)
+        layer.comps.normal_()
+        b1 = torch.randn_like(layer.bases)
+        layer.bases.copy_(b1)
+        y1 = layer()
+        layer.bases.mul_(-0.5)
+        assert rel_err(layer(), (-0.5 * y1).cpu().numpy()) < 1e-5
+    out = layer()
+    out.backward(torch.ones_like(out))
+    assert torch.isfinite(layer.bases.grad).all() and torch.isfinite(layer.comps.grad).all()
+    # d out / d bases[b, o, j] = sum over messages sent by o of val * comps[r, b]: same for every j
+    assert torch.allclose(layer.bases.grad[:, :, 0], layer.bases.grad[:, :, d - 1], rtol=1e-4, atol=1e-5)
+
+
+def test_mutag_full_shape_layers_vs_oracle():
+    """MUTAG at its full shape: the NodeClassifier's two layers (featureless basis-30 16-wide; featured basis-30 16 -> 2,
+    vertical) against the oracle"""
+    run_layer_vs_oracle(N=MUTAG["N"], R0=MUTAG["R0"], E=MUTAG["E"], d_in=None, d_out=16, mode="basis", featureless=True,
+                        num_bases=30, seed=401)
+    run_layer_vs_oracle(N=MUTAG["N"], R0=MUTAG["R0"], E=MUTAG["E"], d_in=16, d_out=2, mode="basis", vertical=True,
+                        num_bases=30, seed=402)
+
+
+def test_mutag_full_shape_node_classifier_matches_oracle_composition():
+    """the whole MUTAG-shaped NodeClassifier (featureless basis layer -> fused ReLU -> vertical basis layer): logits and
+    the gradient of every parameter against the two oracle layers chained by hand"""
+    from torch_rgcn.models import NodeClassifier
+    N, R0, E = MUTAG["N"], MUTAG["R0"], MUTAG["E"]
+    R = 2 * R0 + 1
+    T = oracle.synthetic_triples(N, R0, E, seed=403)
+    model = NodeClassifier(triples=T.tolist(), nnodes=N, nrel=R0, nfeat=None, nhid=16, nlayers=2, nclass=2,
+                           decomposition={"type": "basis", "num_bases": 30}).to(DEV)
+    rng = np.random.default_rng(5)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(torch.from_numpy(rng.standard_normal(tuple(p.shape)).astype(np.float32) * 0.2))
+    logits = model()
+    g = rng.standard_normal(tuple(logits.shape)).astype(np.float32)
+    logits.backward(torch.from_numpy(g).to(DEV))
+    tp = oracle.add_inverse_and_self(T, N, R0)
+    P = {n: p.detach().cpu().numpy() for n, p in model.named_parameters()}
+    l1 = oracle.nc_layer(tp, N, R, None, {"bases": P["rgc1.bases"], "comps": P["rgc1.comps"]}, "basis", P["rgc1.bias"], False, None)
+    a = np.maximum(l1["out"], 0)
+    l2 = oracle.nc_layer(tp, N, R, a, {"bases": P["rgc2.bases"], "comps": P["rgc2.comps"]}, "basis", P["rgc2.bias"], True, g)
+    assert rel_err(logits, l2["out"]) < TOL
+    for n, gv in l2["grads"].items():
+        assert rel_err(getattr(model.rgc2, n).grad, gv) < TOL, n
+    assert rel_err(model.rgc2.bias.grad, l2["db"]) < TOL
+    l1b = oracle.nc_layer(tp, N, R, None, {"bases": P["rgc1.bases"], "comps": P["rgc1.comps"]}, "basis", P["rgc1.bias"], False,
+                          (l2["dX"] * (l1["out"] > 0)).astype(np.float32))
+    for n, gv in l1b["grads"].items():
+        assert rel_err(getattr(model.rgc1, n).grad, gv) < TOL, n
