@@ -286,6 +286,29 @@ RGCN_API int rgcn_gather_rows_sum_f32(const float *Y, const int32_t *perm, const
                                       int64_t n_split, const float *bias, float *out, int64_t n_rows, int32_t w,
                                       void *stream);
 
+/* ------------------------------------------------------------------ dense contractions on the matrix cores
+ * Basis decomposition (layers.py:241-242, :468-469: W_r = sum_b comps[r,b] bases[b]) at large width: the layer is
+ * out = ag @ flat(bases) + bias with ag[s, b, :] = sum_e comps[r_e, b] val_e X[o_e, :].
+ * rgcn_basis_fused_fwd_f32 (opt-in; the default forward is rgcn_basis_aggregate_f32 + rgcn_gemm_f32, measured faster at
+ * WN18 size): aggregation of a 32-row destination tile into LDS, then the (B d_in) x d_out contraction with
+ * v_mfma_f32_16x16x4_f32 straight from LDS -- ag is not written to HBM unless ag_out != NULL (training keeps it for the
+ * backward's dbases = ag^T g).  CSR arguments as rgcn_basis_aggregate_f32; bases [B, d_in, d_out]; needs
+ * 32 * (B d_in + pad) floats of LDS (RGCN_EUNSUPPORTED beyond 64 KiB: callers then aggregate + rgcn_gemm_f32). */
+RGCN_API int rgcn_basis_fused_fwd_f32(const float *X, const float *comps, const float *bases, const float *bias, float *out,
+                                      float *ag_out, const int32_t *rowptr, const int32_t *p_src, const int32_t *p_rel,
+                                      const float *p_val, int64_t n_rows, int32_t R, int32_t B, int32_t d_in, int32_t d_out,
+                                      void *stream);
+/* C[M,N] = op(A) op(B) (+ bias[n]); fp32 MFMA, LDS-tiled (128 x 128 x 16).  A is [M,K] (lda) or, with RGCN_G_TRANS_A,
+ * stored [K,M]; B is [K,N] (ldb) or, with RGCN_G_TRANS_B, stored [N,K].  split_k > 1 cuts K into slices whose partial
+ * products go to `scratch` (rgcn_gemm_scratch_floats) and are summed in a fixed order.  The backward of the basis path
+ * (d_ag = g flat^T, dbases = ag^T g) and the weight assembly / wide-block products of layers.py:241-244 run on it. */
+#define RGCN_G_TRANS_A 1
+#define RGCN_G_TRANS_B 2
+RGCN_API int64_t rgcn_gemm_scratch_floats(int64_t M, int64_t N, int64_t K, int32_t split_k);
+RGCN_API int rgcn_gemm_f32(const float *A, const float *B, const float *bias, float *C, float *scratch, int64_t M,
+                           int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t flags, int32_t split_k,
+                           void *stream);
+
 /* DistMult decoder (torch_rgcn/layers.py:86-98):
  * scores[t] = sum_k nodes[s,k] rel[p,k] nodes[o,k] (+ sbias[s] + pbias[p] + obias[o]);
  * triples int64 [T,3] on the device.  Biases may all be NULL.  Triples whose s / o are outside [0, n_nodes) or whose p

@@ -145,6 +145,125 @@ def wn18_lp():
               flush=True)
 
 
+# ------------------------------------------------------------------ secondary bench lines (bench.py `configs`)
+HBM_PEAK_GBS = 8000.0
+
+
+def _dominant(step, iters=3):
+    """per-kernel launch times (HIP events on the launch stream) of `iters` steps -> (name, avg ms per launch, launches per step, all)"""
+    _native.profile_start()
+    for _ in range(iters):
+        step()
+    prof = _native.profile_stop()
+    if not prof:
+        return None, None, None, {}
+    tot = {k: float(np.sum(v)) for k, v in prof.items()}
+    name = max(tot, key=tot.get)
+    return name, float(np.mean(prof[name])), len(prof[name]) / iters, {k: round(float(np.mean(v)), 4) for k, v in prof.items()}
+
+
+def _roof(name, ms, alg_bytes, note):
+    if not name or not ms:
+        return None
+    ach = alg_bytes / (ms * 1e-3) / 1e9
+    return {"kernel": name, "bound": "hbm", "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "bytes_model": note}
+
+
+def line_node_classifier(tag, N, R0, E, nhid, ncls, decomp, labelled, baseline_config):
+    T = _native.synthetic_triples_host(N, R0, E, 1)
+    model = NodeClassifier(triples=T, nnodes=N, nrel=R0, nhid=nhid, nclass=ncls, decomposition=decomp).to(DEV)
+    idx = torch.arange(labelled, device=DEV)
+    y = torch.randint(0, ncls, (labelled,), device=DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy(model()[idx], y).backward()
+        opt.step()
+    ms = timed(step, iters=10, warm=3)
+    name, kms, per_step, allk = _dominant(step)
+    M = 2 * E + N
+    B = (decomp or {}).get("num_bases")
+    # featureless first layer: one weight-table row (basis: the node's B x d block) per message + index, one output row per node
+    row = (B or 1) * nhid * 4
+    fwd = M * (row + 8) + N * nhid * 4
+    alg = {"featureless_fwd": fwd, "fbasis_fwd": fwd, "featureless_wgrad": M * (nhid * 4 + 8) + (2 * R0 + 1) * N * nhid * 4,
+           "fbasis_bwd": M * (nhid * 4 + 8) + 2 * N * row}.get(name, fwd)
+    return {"baseline_config": baseline_config, "workload": tag, "N": N, "R0": R0, "E": E, "params": sum(p.numel() for p in model.parameters()),
+            "step": "NodeClassifier forward + cross-entropy + backward + Adam", "ms_per_step": round(ms, 3),
+            "edges_per_s": round(E / ms * 1e3), "kernels_ms": allk,
+            "roofline": _roof(name, kms, alg, "messages x (weight-table row + 8 B index) + node rows written")}
+
+
+def line_featured(tag, N, R0, E, d, decomposition, seed, baseline_config):
+    T = _native.synthetic_triples_host(N, R0, E, seed)
+    tp = torch.from_numpy(_native.add_inverse_and_self_host(T, N, R0))
+    kw = dict(triples=tp, num_nodes=N, num_relations=2 * R0 + 1, in_features=d, out_features=d, decomposition=decomposition)
+    l1 = RelationalGraphConvolutionNC(vertical_stacking=False, **kw).to(DEV)
+    l2 = RelationalGraphConvolutionNC(vertical_stacking=True, **kw).to(DEV)
+    X = torch.randn(N, d, device=DEV, requires_grad=True)
+
+    def step():
+        for p in [X] + list(l1.parameters()) + list(l2.parameters()):
+            p.grad = None
+        l2(l1.forward_activated(X, "relu")).pow(2).mean().backward()
+    ms = timed(step, iters=10, warm=3)
+    name, kms, per_step, allk = _dominant(step)
+    M = 2 * E + N
+    alg = {"spmm": M * (4 * d + 8) + N * 4 * d, "spmm_scatter": M * (4 * d + 8) + M * 4 * d, "segment_sum": M * (4 * d + 4) + N * 4 * d,
+           "bwd_fused": M * (4 * d + 8) + 2 * N * 4 * d, "wgrad": M * (4 * d + 8) + N * 4 * d}.get(name, M * (4 * d + 8) + N * 4 * d)
+    return {"baseline_config": baseline_config, "workload": tag, "N": N, "R0": R0, "E": E, "step": "2 featured layers, forward + backward",
+            "ms_per_step": round(ms, 3), "edges_per_s": round(E / ms * 1e3), "kernels_ms": allk,
+            "roofline": _roof(name, kms, alg, "SURVEY 8(d): M (4 d + 8) + N 4 d (two-pass: the transformed rows once more)")}
+
+
+def line_wn18(baseline_config):
+    N, R0, d, E, Tn = 40_943, 18, 200, 15_000, 330_000
+    ed = {"general": 0.5, "self_loop": 0.2, "self_loop_type": "schlichtkrull-dropout"}
+    layer = RelationalGraphConvolutionLP(num_nodes=N, num_relations=2 * R0 + 1, in_features=d, out_features=d, edge_dropout=ed,
+                                         decomposition={"type": "basis", "num_bases": 2}, w_init="glorot-normal",
+                                         b_init="zeros").to(DEV)
+    dm = DistMult(R0, d, N, R0).to(DEV)
+    emb = torch.randn(N, d, device=DEV, requires_grad=True)
+    graph = torch.from_numpy(_native.synthetic_triples_host(N, R0, E, 3)).to(DEV)
+    batch = torch.from_numpy(_native.synthetic_triples_host(N, R0, Tn, 4)).to(DEV)
+    y = torch.rand(Tn, device=DEV).round()
+
+    def step():
+        for p in [emb] + list(layer.parameters()) + list(dm.parameters()):
+            p.grad = None
+        x = layer(graph, torch.relu(emb))
+        torch.nn.functional.binary_cross_entropy_with_logits(dm(batch, x), y).backward()
+    ms = timed(step, iters=10, warm=3)
+    name, kms, per_step, allk = _dominant(step)
+    alg = {"distmult_bwd": Tn * (3 * d * 4 + 28) + Tn * 2 * d * 4, "distmult_fwd": Tn * (3 * d * 4 + 28)}.get(name, Tn * 3 * d * 4)
+    return {"baseline_config": baseline_config, "workload": "WN18-shaped: LP layer d=200 basis 2 (graph of 15,000 triples built per step) + "
+            "DistMult on 330,000 triples", "N": N, "R0": R0, "graph_triples": E, "scored_triples": Tn,
+            "step": "encoder + decoder forward + BCE + backward (per-step graph build included)", "ms_per_step": round(ms, 3),
+            "scored_triples_per_s": round(Tn / ms * 1e3), "kernels_ms": allk,
+            "roofline": _roof(name, kms, alg, "scored triples x (three d-wide rows + 24 B of indices [+ two gradient rows])")}
+
+
+def secondary_lines():
+    """one dict per BASELINE.json config 1-4 (dataset-shaped synthetic graphs), each with the dominant kernel's
+    roofline; bounded to a few seconds each"""
+    out = []
+    for fn in (lambda: line_node_classifier("AIFB-shaped NodeClassifier (featureless L1, hidden 16, 4 classes)", 8285, 45, 29043, 16, 4, None, 176,
+                                            "configs[0] AIFB (reference config nc-AIFB.yaml; here on the GPU, the CPU run is cpu_baseline's business)"),
+               lambda: line_node_classifier("MUTAG-shaped NodeClassifier (basis 30, hidden 16, 2 classes)", 23644, 23, 74227, 16, 2,
+                                            {"type": "basis", "num_bases": 30}, 340, "configs[1] MUTAG, basis decomposition"),
+               lambda: line_featured("AM-shaped, block-diagonal (nb=4), 2 featured layers d=16 (layer-level, SURVEY 8d)", 1_666_764, 133,
+                                     5_988_321, 16, {"type": "block", "num_blocks": 4}, 2, "configs[2] AM, block-diagonal"),
+               lambda: line_wn18("configs[3] WN18 link prediction, DistMult decoder")):
+        try:
+            out.append(fn())
+        except Exception as exc:  # noqa: BLE001
+            out.append({"failed": f"{type(exc).__name__}: {exc}"[:300]})
+        torch.cuda.empty_cache()
+    return out
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")

@@ -34,6 +34,7 @@ def lib():
         L.rgcn_version.restype = ctypes.c_char_p
         L.rgcn_bwd_fused_scratch_floats.restype = ctypes.c_int64
         L.rgcn_colsum_scratch_floats.restype = ctypes.c_int64
+        L.rgcn_gemm_scratch_floats.restype = ctypes.c_int64
         L.rgcn_last_error.restype = ctypes.c_char_p
         _lib = L
     return _lib
@@ -536,6 +537,54 @@ def basis_dcomps(X, D, plan, R, B, d, swap=False):
                                            _dp(plan.chunk_rel), _dp(plan.items), c_i64(plan.n_items), c_i32(R), c_i32(B),
                                            c_i32(d), _stream(X.device)), "basis_dcomps")
     return dc
+
+
+G_TRANS_A, G_TRANS_B = 1, 2
+
+
+def gemm(A, B, bias=None, trans_a=False, trans_b=False, split_k=1):
+    """C = op(A) @ op(B) (+ bias) on the matrix cores (rgcn_gemm_f32; fp32, exact FMA chains).  A: [M, K] or, trans_a,
+    stored [K, M]; B: [K, N] or, trans_b, stored [N, K]."""
+    _req(A, "A"); _req(B, "B"); _req(bias, "bias")
+    assert A.dim() == 2 and B.dim() == 2
+    M, K = (A.shape[1], A.shape[0]) if trans_a else A.shape
+    N = B.shape[0] if trans_b else B.shape[1]
+    assert (B.shape[1] if trans_b else B.shape[0]) == K, f"gemm: inner dimensions {tuple(A.shape)} x {tuple(B.shape)}"
+    C = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    if M == 0 or N == 0:
+        return C
+    scratch = None
+    if split_k > 1:
+        scratch = torch.empty(int(lib().rgcn_gemm_scratch_floats(c_i64(M), c_i64(N), c_i64(K), c_i32(split_k))),
+                              device=A.device, dtype=torch.float32)
+    flags = (G_TRANS_A if trans_a else 0) | (G_TRANS_B if trans_b else 0)
+    with torch.cuda.device(A.device), _timed("gemm"):
+        _check(lib().rgcn_gemm_f32(_dp(A), _dp(B), _dp(bias), _dp(C), _dp(scratch), c_i64(M), c_i64(N), c_i64(K),
+                                   c_i64(A.shape[1]), c_i64(B.shape[1]), c_i64(N), c_i32(flags), c_i32(split_k),
+                                   _stream(A.device)), "gemm")
+    return C
+
+
+def basis_fused_supported(B, d_in):
+    """the 32-row ag tile of the fused basis kernel must fit 64 KiB of LDS"""
+    ldk = (B * d_in + 15) & ~15
+    while ldk & 31 != 4:
+        ldk += 4
+    return 32 * ldk * 4 <= 64 * 1024
+
+
+def basis_fused_fwd(X, comps, bases, bias, csr, keep_ag):
+    """out = ag @ flat(bases) + bias with the aggregation tile kept in LDS (rgcn_basis_fused_fwd_f32) -> (out, ag or None)"""
+    _req(X, "features"); _req(comps, "comps"); _req(bases, "bases"); _req(bias, "bias")
+    Bn, d_in, d_out = bases.shape
+    out = torch.empty((csr.n_rows, d_out), device=X.device, dtype=torch.float32)
+    ag = torch.empty((csr.n_rows, Bn * d_in), device=X.device, dtype=torch.float32) if keep_ag else None
+    with torch.cuda.device(X.device), _timed("basis_fused_fwd"):
+        _check(lib().rgcn_basis_fused_fwd_f32(_dp(X), _dp(comps), _dp(bases), _dp(bias), _dp(out), _dp(ag), _dp(csr.rowptr),
+                                              _dp(csr.src), _dp(csr.rel), _dp(csr.val), c_i64(csr.n_rows),
+                                              c_i32(comps.shape[0]), c_i32(Bn), c_i32(d_in), c_i32(d_out), _stream(X.device)),
+               "basis_fused_fwd")
+    return out, ag
 
 
 def _req(t, name, dtype=torch.float32):

@@ -123,7 +123,11 @@ class _RGCBase(Module):
             return self.weights
         if kind == 'basis':
             B = self.bases.size(0)
-            return torch.matmul(self.comps, self.bases.reshape(B, -1)).view(self.comps.size(0), *self.bases.shape[1:])
+            flat = self.bases.reshape(B, -1)
+            # einsum('rb,bio->rio') as an [R, B] x [B, d_i d_o] product on the matrix cores (GPU); CPU tensors (parameter
+            # inspection before .cuda()) keep torch.matmul
+            W = F_.matmul_mfma(self.comps, flat) if self.comps.is_cuda else torch.matmul(self.comps, flat)
+            return W.view(self.comps.size(0), *self.bases.shape[1:])
         if kind == 'block':
             return block_diag(self.blocks)
         raise NotImplementedError(f'{kind} decomposition has not been implemented')
@@ -237,6 +241,9 @@ class RelationalGraphConvolutionNC(_RGCBase):
             assert self.bases.size() == (self.num_bases, in_dim, out_dim) and self.comps.size() == (R, self.num_bases)
         elif block_table:
             weights = None                                     # never expand the blocks to R x d x d
+        elif self.in_features is not None and self.weight_decomp == 'basis' and \
+                F_.use_basis_path(self.num_bases, in_dim, out_dim, graph):
+            weights = None                                     # aggregate per basis, then contract
         else:
             weights = self._dense_weights()
             assert weights.size() == (R, in_dim, out_dim)
@@ -252,8 +259,7 @@ class RelationalGraphConvolutionNC(_RGCBase):
         else:
             _require_gpu(features, "features")
             assert features.size() == (N, in_dim), f"features {tuple(features.size())} vs ({N}, {in_dim})"
-            if self.weight_decomp == 'basis' and not self.diag_weight_matrix and \
-                    F_.use_basis_path(self.num_bases, in_dim, out_dim, graph):
+            if self.weight_decomp == 'basis' and not self.diag_weight_matrix and weights is None:
                 local = lambda x, b: F_.basis_mp(x, self.bases, self.comps, b, graph)
             elif block_table:
                 local = lambda x, b: F_.featureless_mp(_block_messages(x, self.blocks), b, graph)
@@ -265,8 +271,7 @@ class RelationalGraphConvolutionNC(_RGCBase):
         group = getattr(self, "_shard_group", None)
         if group is None:
             output = local(features, self.bias)
-        elif self.in_features is not None and not block_table and not (
-                self.weight_decomp == 'basis' and F_.use_basis_path(self.num_bases, in_dim, out_dim, graph)):
+        elif self.in_features is not None and not block_table and weights is not None:
             # relation-sharded: partial sums joined by the collective picked with RGCN_DIST_COMM / RGCN_DIST_SLABS
             output = F_.sharded_relational_mp(features, weights, self.bias, graph, group,
                                               int(os.environ.get("RGCN_DIST_SLABS", "0")))
@@ -360,11 +365,13 @@ class RelationalGraphConvolutionLP(_RGCBase):
             else:
                 own = torch.zeros_like(self.blocks_self) if self_drop is not None else self.blocks_self
                 weights = torch.cat([block_diag(self.blocks), own[None]], dim=0)
+        elif self.weight_decomp == 'basis' and F_.use_basis_path(self.num_bases, in_dim, out_dim, graph):
+            weights = None                                     # aggregate per basis, then contract: no R x d x d tensor
         else:
             weights = self._dense_weights()
         assert weights is None or weights.size() == (R, in_dim, out_dim)
 
-        if self.weight_decomp == 'basis' and F_.use_basis_path(self.num_bases, in_dim, out_dim, graph):
+        if self.weight_decomp == 'basis' and weights is None:
             output = F_.basis_mp(features, self.bases, self.comps, self.bias, graph)
         elif block_table:
             output = F_.featureless_mp(table, self.bias, graph)
