@@ -144,6 +144,16 @@ RGCN_API int rgcn_dev_plan_fill(const int32_t *dst, const int32_t *src, const in
                                 int32_t *p_pack, int32_t *chunk_rel, int32_t *tile_ptr, int32_t *run_ptr,
                                 const int32_t *aux, int32_t *p_aux, int32_t *msg_slot, int64_t n_chunks,
                                 void *stream);
+/* Completion of a plan WITHOUT any device -> host read (per-call graphs of the link-prediction layer, layers.py:481-516,
+ * inside a training step that must not synchronise / is captured in a hipGraph): the caller sizes p_src / p_dst / p_val /
+ * p_pack / chunk_rel by the upper bound m_pad_ub >= M + 15 * min(n_buckets, M) (rounded up to 16), runs rgcn_dev_plan_count
+ * and rgcn_dev_plan_fill with n_chunks = m_pad_ub / 16, then this: slots past the real end become pads, `units` gets one
+ * work unit per tile (no hub splitting) and, for the relation-major plan (n_tiles == 1), `items` the chunk ranges of each
+ * relation cut at max_item_chunks, padded with empty items up to n_items_ub >= m_pad_ub / 16 / max_item_chunks + R. */
+RGCN_API int rgcn_dev_plan_finish_nosync(const int32_t *bucket_base, int64_t n_tiles, int32_t R, int64_t m_pad_ub,
+                                         int32_t *p_src, int32_t *p_dst, float *p_val, int32_t *p_pack, int32_t *p_aux,
+                                         const int32_t *tile_ptr, int32_t *units, int32_t *items, int64_t n_items_ub,
+                                         int32_t max_item_chunks, void *stream);
 /* (msg_slot, may be NULL: slot index of every input message.)
  * (aux / p_aux, may be NULL: one extra int32 per message carried into slot order -- with R = 1 and
  * tile_rows >= n_dst the plan degenerates to a destination-major CSR, aux = relation, and `cells` holds the

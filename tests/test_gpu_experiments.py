@@ -1,5 +1,7 @@
 """End-to-end: the experiment counterparts train on dataset-shaped synthetic graphs through the HIP layers."""
 import os
+
+import numpy as np
 import sys
 
 import pytest
@@ -75,3 +77,18 @@ def test_predict_links_block_config_pads_nodes_and_c_rgcn_runs():
     c = yaml.safe_load(open(os.path.join(PKG, "configs", "c-rgcn", "lp-FB-toy.yaml")))   # no graph_batch_size: whole graph
     hist, metrics = predict_links.run(c, epochs=3, quiet=True, max_test=20, synthetic=True)
     assert len(hist) == 3 and 0.0 < metrics["mrr"] <= 1.0
+
+
+def test_predict_links_training_step_as_hipgraph_learns():
+    """the WN18-config training step (basis 2, per-step graph build, DistMult, schlichtkrull-l2 penalty,
+    Adam) captured once in a hipGraph and replayed on freshly sampled batches"""
+    sys.path.insert(0, os.path.join(PKG, "experiments"))
+    import predict_links
+    c = cfg("lp-WN18.yaml")
+    c["dataset"]["name"] = "fb-toy"
+    c["encoder"].update(node_embedding=64, hidden1_size=64)
+    c["training"].update(graph_batch_size=2000)
+    c["evaluation"].update(check_every=1000, batch_size=32, verbose=False)
+    hist, metrics = predict_links.run(c, epochs=40, quiet=True, max_test=50, synthetic=True, hipgraph=True)
+    assert len(hist) == 40 and all(np.isfinite(hist)) and np.mean(hist[-5:]) < np.mean(hist[:5])
+    assert 0.0 < metrics["mrr"] <= 1.0

@@ -13,6 +13,7 @@
 // The order of messages inside one (relation, destination) cell is arbitrary (they are summed anyway).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -279,6 +280,56 @@ __global__ void plan_finish_kernel(long long n_buckets, int R, const int *__rest
   }
 }
 
+// ---- sync-free completion of a plan whose arrays were sized by an UPPER BOUND (the per-call graphs of the link-prediction
+// layer: nothing may be read back).  The real padded size lives in bucket_base[n_buckets] on the device.
+// slots past the real end become pads (val = 0, dst = -1): every consumer kernel may walk them
+__global__ void plan_tail_kernel(const int *__restrict__ bucket_base, long long n_buckets, long long m_pad_ub,
+                                 int *__restrict__ p_src, int *__restrict__ p_dst, float *__restrict__ p_val,
+                                 int2 *__restrict__ p_pack, int *__restrict__ p_aux) {
+  const long long real = bucket_base[n_buckets];
+  for (long long q = real + (long long)blockIdx.x * TB + threadIdx.x; q < m_pad_ub; q += (long long)gridDim.x * TB) {
+    p_src[q] = 0;
+    p_dst[q] = -1;
+    p_val[q] = 0.f;
+    if (p_pack) p_pack[q] = make_int2((int)(0xFFu << 24), 0);
+    if (p_aux) p_aux[q] = 0;
+  }
+}
+
+// one work unit per destination tile (no hub splitting: the tile sizes are not known on the host)
+__global__ void plan_units_kernel(const int *__restrict__ tile_ptr, long long n_tiles, int4 *__restrict__ units) {
+  for (long long t = (long long)blockIdx.x * TB + threadIdx.x; t < n_tiles; t += (long long)gridDim.x * TB)
+    units[t] = make_int4((int)t, tile_ptr[t], tile_ptr[t + 1], 0);
+}
+
+// relation-major plan (one tile): work items = chunk ranges of ONE relation, at most max_item_chunks long; the list is
+// padded with empty items {0, 0} up to n_items_ub (consumers return at once on an empty item).  Single workgroup.
+__global__ __launch_bounds__(TB) void plan_items_kernel(const int *__restrict__ bucket_base, int R, int max_item_chunks,
+                                                        int2 *__restrict__ items, long long n_items_ub) {
+  __shared__ int offs[TB + 1];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int r0 = 0; r0 < R; r0 += TB) {
+    const int r = r0 + threadIdx.x;
+    const int c0 = r < R ? bucket_base[r] / RGCN_CHUNK : 0, c1 = r < R ? bucket_base[r + 1] / RGCN_CHUNK : 0;
+    const int pieces = (c1 - c0 + max_item_chunks - 1) / max_item_chunks;
+    offs[threadIdx.x + 1] = pieces;
+    if (threadIdx.x == 0) offs[0] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int q = 1; q <= TB; ++q) offs[q] += offs[q - 1];      // 256 adds: the plan is built once per call
+    __syncthreads();
+    const int first = carry + offs[threadIdx.x];
+    for (int q = 0; q < pieces; ++q)
+      if (first + q < n_items_ub) items[first + q] = make_int2(c0 + q * max_item_chunks, min(c1, c0 + (q + 1) * max_item_chunks));
+    __syncthreads();
+    if (threadIdx.x == 0) carry += offs[TB];
+    __syncthreads();
+  }
+  for (long long q = carry + threadIdx.x; q < n_items_ub; q += TB) items[q] = make_int2(0, 0);
+}
+
 int exclusive_scan(const int *in, int *out, int *totals, long long n, int *grand, hipStream_t st) {
   const long long nb = (n + TB * 4 - 1) / (TB * 4);
   hipLaunchKernelGGL(scan_blocks_kernel, dim3((unsigned)nb), dim3(TB), 0, st, in, out, totals, n);
@@ -375,6 +426,30 @@ extern "C" int rgcn_dev_plan_fill(const int32_t *dst, const int32_t *src, const 
   if (n_chunks > 0)
     hipLaunchKernelGGL(chunk_rel_kernel, dim3(blocks_for(n_chunks)), dim3(TB), 0, st, bucket_base, (long long)nbk, R,
                        (long long)n_chunks, chunk_rel);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_dev_plan_finish_nosync(const int32_t *bucket_base, int64_t n_tiles, int32_t R, int64_t m_pad_ub,
+                                           int32_t *p_src, int32_t *p_dst, float *p_val, int32_t *p_pack, int32_t *p_aux,
+                                           const int32_t *tile_ptr, int32_t *units, int32_t *items, int64_t n_items_ub,
+                                           int32_t max_item_chunks, void *stream) {
+  if (!bucket_base || n_tiles <= 0 || R <= 0 || m_pad_ub < 0 || !p_src || !p_dst || !p_val || !tile_ptr ||
+      (items && (n_tiles != 1 || max_item_chunks <= 0 || n_items_ub <= 0))) {
+    rgcn_set_error("dev_plan_finish_nosync: bad argument");
+    return RGCN_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const long long nbk = (long long)n_tiles * R;
+  if (m_pad_ub)
+    hipLaunchKernelGGL(plan_tail_kernel, dim3(blocks_for(m_pad_ub)), dim3(TB), 0, st, bucket_base, nbk, (long long)m_pad_ub, p_src,
+                       p_dst, p_val, reinterpret_cast<int2 *>(p_pack), p_aux);
+  if (units)
+    hipLaunchKernelGGL(plan_units_kernel, dim3(blocks_for(n_tiles)), dim3(TB), 0, st, tile_ptr, (long long)n_tiles,
+                       reinterpret_cast<int4 *>(units));
+  if (items)
+    hipLaunchKernelGGL(plan_items_kernel, dim3(1), dim3(TB), 0, st, bucket_base, R, max_item_chunks,
+                       reinterpret_cast<int2 *>(items), (long long)n_items_ub);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

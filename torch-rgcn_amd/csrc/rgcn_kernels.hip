@@ -279,6 +279,7 @@ __global__ __launch_bounds__(WG) void spmm_scatter_d16_kernel(
   const int item = blockIdx.x * (WG / 64) + wave;
   if (item >= n_items) return;
   const int2 range = items[item];
+  if (range.x >= range.y) return;          // padding of a work list sized by an upper bound (rgcn_dev_plan_finish_nosync)
   const int r = __builtin_amdgcn_readfirstlane(chunk_rel[range.x]);
   const int m = lane & 15, k = lane >> 4;
   const float4 w = reinterpret_cast<const float4 *>(Wp)[(size_t)r * 64 + lane];
@@ -447,6 +448,7 @@ __global__ __launch_bounds__(WG) void wgrad_generic_kernel(
   const int item = blockIdx.x * (WG / 64) + wave;
   if (item >= n_items) return;
   const int2 range = items[item];
+  if (range.x >= range.y) return;          // padding of a work list sized by an upper bound (rgcn_dev_plan_finish_nosync)
   const int r = __builtin_amdgcn_readfirstlane(chunk_rel[range.x]);
   const int i0 = (blockIdx.y / n_jgroups) * 16 * NIT;
   const int j0 = (blockIdx.y % n_jgroups) * 16 * NJT;
@@ -513,6 +515,7 @@ __global__ __launch_bounds__(WG) void wgrad_d16_kernel(
   const int item = blockIdx.x * (WG / 64) + wave;
   if (item >= n_items) return;
   const int2 range = items[item];
+  if (range.x >= range.y) return;          // padding of a work list sized by an upper bound (rgcn_dev_plan_finish_nosync)
   const int r = __builtin_amdgcn_readfirstlane(chunk_rel[range.x]);
   const int b = lane >> 2, q = lane & 3;
   f32x4 acc[4][4];

@@ -26,8 +26,11 @@ from utils.misc import evaluate, generate_true_dict, negative_sampling, select_s
 OPTIMISERS = {"adam": torch.optim.Adam, "adamw": torch.optim.AdamW, "adagrad": torch.optim.Adagrad, "sgd": torch.optim.SGD}
 
 
-def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None, synthetic=None):
-    """-> (loss per epoch, {"mrr", "hits@1", "hits@3", "hits@10"} of the final evaluation)"""
+def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None, synthetic=None, hipgraph=False):
+    """-> (loss per epoch, {"mrr", "hits@1", "hits@3", "hits@10"} of the final evaluation).
+    hipgraph=True: the training step (per-step graph build, encoder, decoder, loss, backward, optimiser) is captured once in
+    a hipGraph and replayed every epoch on freshly sampled inputs copied into static buffers; needs the sync-free plan
+    builder (RGCN_DEFERRED_CHECKS=1, set here)."""
     dataset, training, encoder = cfg["dataset"], cfg["training"], cfg["encoder"]
     decoder, evaluation = cfg.get("decoder", {}), cfg.get("evaluation", {})
     max_epochs = epochs or training.get("epochs", 5000)
@@ -78,6 +81,10 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None, synthetic=N
     if opt_cfg["algorithm"] not in OPTIMISERS:
         raise NotImplementedError(f"'{opt_cfg['algorithm']}' optimiser has not been implemented!")
     extra = {"fused": True} if opt_cfg["algorithm"] in ("adam", "adamw") else {}
+    deferred_before = os.environ.get("RGCN_DEFERRED_CHECKS")
+    if hipgraph:
+        os.environ["RGCN_DEFERRED_CHECKS"] = "1"            # no device -> host reads inside the captured step
+        extra = {"capturable": True} if opt_cfg["algorithm"] in ("adam", "adamw") else {}
     optimiser = OPTIMISERS[opt_cfg["algorithm"]](model.parameters(), lr=opt_cfg["learn_rate"],
                                                   weight_decay=opt_cfg["weight_decay"], **extra)
 
@@ -86,11 +93,32 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None, synthetic=N
         print(f"{tag} MRR({kind_}): {mrr:.4f} \tHits@1({kind_}): {hits[0]:.4f} \tHits@3({kind_}): {hits[1]:.4f} \t"
               f"Hits@10({kind_}): {hits[2]:.4f}")
 
-    losses = []
-    for epoch in range(1, max_epochs + 1):
-        t1 = time.time()
-        optimiser.zero_grad()
-        model.train()
+    # hipGraph mode: between replays NOTHING but copies may run on the GPU.  On this stack (ROCm 7.2 hipcc code objects under
+    # PyTorch 2.10 + ROCm 7.0 runtime) eager kernel launches between replays of a graph that contains this library's
+    # kernels end in "write access to a read-only page" inside the replay (torch-only graphs are unaffected; bisected with
+    # tools/dbg_lp.py / dbg_lp2.py / dbg_graph_torch*.py), while host-to-device copies are fine.  So the per-epoch
+    # sampling (negatives, edge dropout permutation) is done with numpy on the host and copied into the static buffers.
+    host_rng = np.random.default_rng(int(torch.initial_seed()) & 0x7FFFFFFF) if hipgraph else None
+
+    def sample_inputs_host():
+        nonlocal graph_batch_size
+        if graph_batch_size is None:
+            positives, graph_batch_size = train, len(train)
+        else:
+            positives = np.asarray(sampling_function(train, sample_size=graph_batch_size, entities=n2i), dtype=np.int64)
+        negatives = np.repeat(positives, neg_sample_rate, axis=0)
+        corrupt_head = host_rng.random(len(negatives)) < head_corrupt_prob
+        fresh = host_rng.integers(0, num_nodes, len(negatives))
+        negatives[corrupt_head, 0] = fresh[corrupt_head]
+        negatives[~corrupt_head, 2] = fresh[~corrupt_head]
+        graph = positives
+        if edge_dropout > 0.0:
+            graph = positives[host_rng.permutation(len(positives))][round((1 - edge_dropout) * len(positives)):]
+        return torch.from_numpy(np.ascontiguousarray(graph)), torch.from_numpy(np.concatenate([positives, negatives], axis=0))
+
+    def sample_inputs():
+        """one epoch's positives / negatives / labels / message graph (all sizes are the same every epoch)"""
+        nonlocal graph_batch_size
         with torch.no_grad():
             if graph_batch_size is None:          # the whole graph
                 positives, graph_batch_size = train, len(train)
@@ -106,11 +134,51 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None, synthetic=N
             if edge_dropout > 0.0:                # self-loop dropout happens inside the layer
                 graph = graph[torch.randperm(graph.size(0), device=device)]
                 graph = graph[round((1 - edge_dropout) * graph.size(0)):, :]     # (keeps the edge_dropout share, as upstream)
+        return graph, batch_idx, train_lbl
+
+    def train_step(graph, batch_idx, train_lbl):
+        optimiser.zero_grad(set_to_none=False)
         predictions, penalty = model(graph, batch_idx)
         loss = F.binary_cross_entropy_with_logits(predictions, train_lbl) + decoder_l2_penalty * penalty
-        t2 = time.time()
         loss.backward()
         optimiser.step()
+        return loss
+
+    captured = None
+    if hipgraph:
+        model.train()
+        g0, b0 = sample_inputs_host()
+        static = [g0.to(device), b0.to(device),
+                  torch.cat([torch.ones(graph_batch_size, device=device), torch.zeros(graph_batch_size * neg_sample_rate, device=device)])]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                        # warm-up off the capture: allocator pools, lazy inits
+            for _ in range(3):
+                train_step(*static)
+        torch.cuda.current_stream().wait_stream(side)
+        captured = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(captured):
+            static_loss = train_step(*static)
+
+    losses = []
+    for epoch in range(1, max_epochs + 1):
+        t1 = time.time()
+        model.train()
+        if captured is not None:
+            g_h, b_h = sample_inputs_host()
+            static[0].copy_(g_h)
+            static[1].copy_(b_h)
+            captured.replay()
+            loss = static_loss
+            t2 = time.time()
+        else:
+            optimiser.zero_grad()
+            graph, batch_idx, train_lbl = sample_inputs()
+            predictions, penalty = model(graph, batch_idx)
+            loss = F.binary_cross_entropy_with_logits(predictions, train_lbl) + decoder_l2_penalty * penalty
+            t2 = time.time()
+            loss.backward()
+            optimiser.step()
         torch.cuda.synchronize()
         t3 = time.time()
         losses.append(loss.item())
@@ -129,6 +197,11 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None, synthetic=N
                                 num_nodes=num_nodes, **eval_kw)
     if not quiet:
         report(f"[Final Scores] Total Epoch {max_epochs} ({len(test)} test triples ranked in {time.time() - t0:.2f}s)", mrr, hits)
+    if hipgraph:
+        if deferred_before is None:
+            os.environ.pop("RGCN_DEFERRED_CHECKS", None)
+        else:
+            os.environ["RGCN_DEFERRED_CHECKS"] = deferred_before
     return losses, {"mrr": mrr, "hits@1": hits[0], "hits@3": hits[1], "hits@10": hits[2]}
 
 
@@ -140,5 +213,7 @@ if __name__ == "__main__":
                     "the dataset's entity / relation / triple counts (timing and plumbing only: MRR / Hits mean nothing)")
     ap.add_argument("--epochs", type=int, default=None)
     ap.add_argument("--max-test", type=int, default=None)
+    ap.add_argument("--hipgraph", action="store_true", help="capture the training step in a hipGraph and replay it every epoch")
     a = ap.parse_args()
-    run(yaml.safe_load(open(a.config)), a.data, a.epochs, max_test=a.max_test, synthetic=True if a.synthetic else None)
+    run(yaml.safe_load(open(a.config)), a.data, a.epochs, max_test=a.max_test, synthetic=True if a.synthetic else None,
+        hipgraph=a.hipgraph)

@@ -245,6 +245,7 @@ def _i32(n, device):
 # must not synchronise (hipGraph capture, torch.cuda.set_sync_debug_mode) sets RGCN_DEFERRED_CHECKS=1: the flags are then
 # queued and looked at on later calls once the GPU has passed them (event query, no wait) or in check_deferred_errors().
 _DEFERRED = []
+_PINNED_FREE = []        # recycled 1-int pinned host buffers (allocating pinned memory per call would stall the stream)
 
 
 def _deferred_mode():
@@ -258,7 +259,7 @@ def dev_check_err(err_flag, what, exc=AssertionError):
         return
     if torch.cuda.is_current_stream_capturing():
         return                                   # inside a hipGraph capture nothing can be read back: validated before capture
-    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+    host = _PINNED_FREE.pop() if _PINNED_FREE else torch.empty(1, dtype=torch.int32, pin_memory=True)
     host.copy_(err_flag[:1], non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
@@ -276,6 +277,7 @@ def check_deferred_errors(wait=True):
         if ev.query():
             if int(host[0]) and err is None:
                 err = exc(f"{what}: node or relation index out of range")
+            _PINNED_FREE.append(host)
         else:
             keep.append((ev, host, what, exc))
     _DEFERRED[:] = keep
@@ -324,7 +326,11 @@ class BuiltPlan:
 
 
 def build_plan_device(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_rows, n_live, max_item_chunks=64,
-                      want_runs=False, want_pack=False, max_unit_chunks=256, aux=None):
+                      want_runs=False, want_pack=False, max_unit_chunks=256, aux=None, sync_free=False):
+    """sync_free: size everything by an upper bound and finish the plan on the device (rgcn_dev_plan_finish_nosync): no
+    device -> host read at all -- for the per-call graphs of the LP layer inside a step that must not synchronise.  Costs
+    memory (up to 16 slots per message) and gives one work unit per tile (no hub splitting), so static graphs keep the
+    exact path."""
     dev = dst.device
     M = dst.shape[0]
     n_tiles = (n_dst + tile_rows - 1) // tile_rows
@@ -339,7 +345,10 @@ def build_plan_device(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_ro
         _check(L.rgcn_dev_plan_count(_dp(dst), _dp(rel), _dp(alive), c_i64(M), c_i64(n_dst), c_i32(num_rels),
                                      c_i32(tile_rows), _dp(cells), _dp(bucket_cnt), _dp(bucket_base), _dp(scan_tmp),
                                      _dp(cells_tmp), _stream(dev)), "dev_plan_count")
-    m_pad = int(bucket_base[nbk].item())        # the one host round trip: output sizes
+    if sync_free:
+        m_pad = (M + 15 * min(nbk, M) + CHUNK - 1) // CHUNK * CHUNK      # every non-empty bucket pads by < 16 slots
+    else:
+        m_pad = int(bucket_base[nbk].item())        # the one host round trip: output sizes
     p = BuiltPlan()
     p.device = dev
     p.n_dst, p.n_src, p.num_rels, p.tile_rows = n_dst, n_src, num_rels, tile_rows
@@ -358,6 +367,23 @@ def build_plan_device(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_ro
                                     _dp(bucket_base), _dp(p.src), _dp(p.dst), _dp(p.val), _dp(p.pack), _dp(p.chunk_rel),
                                     _dp(p.tile_ptr), _dp(p.run_ptr), _dp(aux), _dp(p.aux), None, c_i64(p.n_chunks),
                                     _stream(dev)), "dev_plan_fill")
+    if sync_free:
+        p.n_units, p.n_split, p.units_host = n_tiles, 0, None
+        p.units = torch.empty((max(n_tiles, 1), 4), dtype=torch.int32, device=dev)
+        p.max_run_chunks = 1 << 30                  # unknown on the host: callers must not rely on short runs
+        if n_tiles == 1:
+            p.n_items = p.n_chunks // max_item_chunks + num_rels
+            p.items = torch.empty((max(p.n_items, 1), 2), dtype=torch.int32, device=dev)
+        else:
+            p.n_items, p.items = 0, None
+        with torch.cuda.device(dev):
+            _check(L.rgcn_dev_plan_finish_nosync(_dp(bucket_base), c_i64(n_tiles), c_i32(num_rels), c_i64(m_pad), _dp(p.src),
+                                                 _dp(p.dst), _dp(p.val), _dp(p.pack), _dp(p.aux), _dp(p.tile_ptr), _dp(p.units),
+                                                 _dp(p.items), c_i64(max(p.n_items, 1)), c_i32(max_item_chunks), _stream(dev)),
+                   "dev_plan_finish_nosync")
+        if p.items is None:
+            p.items = _i32(2, dev).view(1, 2)
+        return p
     # work units (hub tiles split) and the relation-major work list are tiny: host side
     tp_host = p.tile_ptr[:n_tiles + 1].cpu().numpy()
     nu, ns = c_i64(0), c_i64(0)
@@ -385,10 +411,15 @@ class CsrPlan:
     """destination-major CSR (rowptr, src, rel, val) built on the device: the layout of the basis kernels"""
 
 
-def build_csr_device(dst, src, rel, val, alive, n_rows):
+def build_csr_device(dst, src, rel, val, alive, n_rows, sync_free=False):
     dev = dst.device
     M = dst.shape[0]
-    cells, cells_tmp = _i32(n_rows + 1, dev), _i32(n_rows + 1, dev)
+    # `cells` (one counter per row) lives at rowbuf[1:]: the count pass leaves the rows' exclusive offsets there and the fill
+    # pass advances every counter to the END of its row -- which is the start of the next one, so rowbuf (rowbuf[0] = 0)
+    # IS the CSR row pointer afterwards.  No device-to-device copy: inside a captured hipGraph such copies become memcpy
+    # nodes, and those fault on this ROCm build when pageable host-to-device copies run between replays (tools/dbg_lp.py).
+    rowbuf = torch.zeros(n_rows + 2, dtype=torch.int32, device=dev)
+    cells, cells_tmp = rowbuf[1:], _i32(n_rows + 1, dev)
     bucket_cnt, bucket_base, scan_tmp = _i32(1, dev), _i32(2, dev), _i32(n_rows // 1024 + 4, dev)
     zeros = torch.zeros(max(M, 1), dtype=torch.int32, device=dev)
     L = lib()
@@ -396,11 +427,10 @@ def build_csr_device(dst, src, rel, val, alive, n_rows):
         _check(L.rgcn_dev_plan_count(_dp(dst), _dp(zeros), _dp(alive), c_i64(M), c_i64(n_rows), c_i32(1), c_i32(n_rows),
                                      _dp(cells), _dp(bucket_cnt), _dp(bucket_base), _dp(scan_tmp), _dp(cells_tmp),
                                      _stream(dev)), "dev_plan_count")
-    m_pad = int(bucket_base[1].item())
+    # one bucket: the padded size is the live message count rounded up to 16 -- bounded by the list length (sync_free)
+    m_pad = (M + CHUNK - 1) // CHUNK * CHUNK if sync_free else int(bucket_base[1].item())
     p = CsrPlan()
     p.n_rows = n_rows
-    p.rowptr = cells.clone()                      # exclusive offsets; the fill pass advances `cells` itself
-    p.rowptr[n_rows] = bucket_cnt[0]
     p.msg_slot = torch.full((max(M, 1),), -1, dtype=torch.int32, device=dev)[:M]   # CSR position of every live input message
     p.n_messages = None
     p.src, pdst, p.rel = _i32(m_pad, dev), _i32(m_pad, dev), _i32(m_pad, dev)
@@ -412,6 +442,7 @@ def build_csr_device(dst, src, rel, val, alive, n_rows):
                                     _dp(p.src), _dp(pdst), _dp(p.val), None, _dp(chunk_rel), _dp(tile_ptr), None,
                                     _dp(rel), _dp(p.rel), _dp(p.msg_slot), c_i64(m_pad // CHUNK), _stream(dev)),
                "dev_plan_fill")
+    p.rowptr = rowbuf[: n_rows + 1]
     return p
 
 

@@ -47,6 +47,7 @@ class RelGraph:
             raise NotImplementedError("num_nodes * num_relations must stay below 2^31")
         self._dev = None
         self._plans = {}
+        self.sync_free = False      # True: plans are sized by upper bounds and finished on the device (no host read-back)
         if triples_plus is None:
             return
         tp = np.ascontiguousarray(triples_plus, dtype=np.int64).reshape(-1, 3)
@@ -73,7 +74,8 @@ class RelGraph:
             s, p, o, val, alive = self._dev
             dst, src = (s, o) if kind == "fwd" else (o, s)
             self._plans[key] = _native.build_plan_device(dst, src, p, val, alive, N, N, R, tile_rows, self.num_messages,
-                                                         max_item_chunks, want_runs=True, want_pack=True)
+                                                         max_item_chunks, want_runs=True, want_pack=True,
+                                                         sync_free=self.sync_free)
         if key not in self._plans:
             N, R = self.num_nodes, self.num_rels
             if kind == "fwd":
@@ -110,7 +112,7 @@ class RelGraph:
                 raise RuntimeError("the basis-aggregation path needs the device-side graph build")
             s, p, o, val, alive = self._dev
             dst, src = (s, o) if kind == "fwd" else (o, s)
-            self._plans[key] = _native.build_csr_device(dst, src, p, val, alive, self.num_nodes)
+            self._plans[key] = _native.build_csr_device(dst, src, p, val, alive, self.num_nodes, sync_free=self.sync_free)
         return self._plans[key]
 
     def fbasis_plan(self):
@@ -121,6 +123,8 @@ class RelGraph:
 
     def max_degree(self):
         """largest number of messages received or sent by one node (cached; device graphs only)"""
+        if self.sync_free:
+            return 0                 # unknown without a read-back; callers treat the graph as hub-free
         if "maxdeg" not in self._plans:
             m = 0
             for kind in ("fwd", "bwd"):
@@ -190,8 +194,12 @@ def graph_from_lp_triples(triples, num_nodes, num_rels, vertical, keep_mask, dev
         s, p, o, alive, err = _native.dev_lp_expand(t, num_nodes, (num_rels - 1) // 2, keep_mask)
         _native.dev_check_err(err, "stack_matrices")
         val = _native.dev_edge_norm(s, p, o, alive, num_nodes, num_rels, vertical, E)
-        n_live = 3 * E + (num_nodes if keep_mask is None else int(keep_mask.sum().item()))
-        return RelGraph.on_device(s, p, o, val, alive, n_live, num_nodes, num_rels)
+        sync_free = _native._deferred_mode()
+        # live messages: exact (one read-back) or, in a step that must not synchronise, the upper bound (all self loops kept)
+        n_live = 3 * E + (num_nodes if (keep_mask is None or sync_free) else int(keep_mask.sum().item()))
+        g = RelGraph.on_device(s, p, o, val, alive, n_live, num_nodes, num_rels)
+        g.sync_free = sync_free
+        return g
     t = triples.detach().cpu().numpy() if torch.is_tensor(triples) else np.asarray(triples)
     t = np.ascontiguousarray(t, dtype=np.int64).reshape(-1, 3)
     R0 = (num_rels - 1) // 2

@@ -78,7 +78,9 @@ class DistMult(Module):
         scale = 1.0 / (s.numel() * nodes.shape[-1])
         node_sq = nodes.pow(2).sum(dim=-1)
         rel_sq = self.relations.pow(2).sum(dim=-1)
-        count = lambda idx, n: torch.bincount(idx.to(nodes.device), minlength=n).to(nodes.dtype)  # noqa: E731
+        def count(idx, n):       # occurrence histogram without torch.bincount (which reads the maximum back: a sync)
+            return torch.zeros(n, device=nodes.device, dtype=nodes.dtype).index_add_(
+                0, idx.to(nodes.device), torch.ones(idx.numel(), device=nodes.device, dtype=nodes.dtype))
         n_nodes, n_rel = nodes.shape[0], self.relations.shape[0]
         return (((count(s, n_nodes) * node_sq).sum() + (count(o, n_nodes) * node_sq).sum()) * scale
                 + (count(p, n_rel) * rel_sq).sum() * (1.0 / (p.numel() * self.relations.shape[-1])))
@@ -348,7 +350,11 @@ class RelationalGraphConvolutionLP(_RGCBase):
                                "(block decomposition is only usable with horizontal stacking)")
 
         with torch.no_grad():
-            mask = torch.bernoulli(torch.full((N,), float(keep), dtype=torch.float, device=device)).to(torch.bool)
+            # keep == 1 (evaluation, or schlichtkrull-dropout): every self loop stays -- nothing is drawn, which also keeps
+            # torch's RNG out of a hipGraph-captured training step (eager RNG calls between replays of a graph that captured
+            # a generator fault on this ROCm build)
+            mask = None if keep == 1 else \
+                torch.bernoulli(torch.full((N,), float(keep), dtype=torch.float, device=device)).to(torch.bool)
             graph = graph_from_lp_triples(triples, N, R, self.vertical_stacking, mask, device)
 
         assert features.size() == (N, in_dim)
@@ -359,7 +365,7 @@ class RelationalGraphConvolutionLP(_RGCBase):
                 # dense dropout on the self-loop messages X @ blocks_self before aggregation (added below)
                 self_drop = self.edge_dropout["self_loop"]
             if block_table:     # messages of every relation, transformed first: [R, N, d_out]
-                own = torch.zeros(N, out_dim, device=device) if self_drop is not None else features @ self.blocks_self
+                own = torch.zeros(N, out_dim, device=device) if self_drop is not None else F_.matmul_mfma(features, self.blocks_self)
                 weights = None
                 table = torch.cat([_block_messages(features, self.blocks), own[None]], dim=0)
             else:
@@ -378,8 +384,8 @@ class RelationalGraphConvolutionLP(_RGCBase):
         else:
             output = F_.relational_mp(features, weights, self.bias, graph)
         if self_drop is not None:
-            msg = nn.functional.dropout(features @ self.blocks_self, p=self_drop, training=True)
-            s, o, v = graph.selfloop_edges(R - 1)
-            output = output.index_add(0, s, msg[o] * v[:, None])
+            # schlichtkrull-dropout keeps every self loop (keep = 1 above), each node has exactly one, and its
+            # normalisation count is 1 in both stackings: the self-loop messages are added row for row
+            output = output + nn.functional.dropout(F_.matmul_mfma(features, self.blocks_self), p=self_drop, training=True)
         assert output.size() == (N, out_dim)
         return output

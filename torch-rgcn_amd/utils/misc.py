@@ -179,11 +179,13 @@ def edge_neighborhood(train_triples, sample_size=30000, entities=None, seed=None
     return [train_triples[e] for e in picked.tolist()] if isinstance(train_triples, list) else rows
 
 
-def negative_sampling(batch, num_nodes, head_corrupt_prob, device='cpu'):
+def negative_sampling(batch, num_nodes, head_corrupt_prob, device='cpu', generator=None):
     """Corrupt the head (probability head_corrupt_prob) or else the tail of every triple of `batch` [bs, ns, 3], in
-    place; returns the [bs * ns, 3] view (misc.py:174-189)."""
+    place; returns the [bs * ns, 3] view (misc.py:174-189).  `generator` (extension): a torch.Generator to draw from
+    instead of the device's default one."""
     bs, ns, _ = batch.size()
     rows = batch.view(bs * ns, 3)
-    column = torch.where(torch.rand(bs * ns, device=device) < head_corrupt_prob, 0, 2)     # 0: head, 2: tail
-    rows[torch.arange(bs * ns, device=device), column] = torch.randint(0, num_nodes, (bs * ns,), device=device)
+    column = torch.where(torch.rand(bs * ns, device=device, generator=generator) < head_corrupt_prob, 0, 2)     # 0: head, 2: tail
+    rows[torch.arange(bs * ns, device=device), column] = torch.randint(0, num_nodes, (bs * ns,), device=device,
+                                                                       generator=generator)
     return rows
