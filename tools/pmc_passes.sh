@@ -1,17 +1,46 @@
 #!/bin/bash
-# Collect PMC counters in separate rocprofv3 passes (never combined with sys/hip traces) for the S1 kernels and the probe.
-# usage: tools/pmc_passes.sh <outdir>
+# Collect PMC counters in separate rocprofv3 passes (never combined with sys/hip traces) for the S1 kernels (forward spmm,
+# fused backward, two-pass backward for comparison) and write profiles-style summaries.
+# usage: tools/pmc_passes.sh <outdir>      -> <outdir>/pmc_detail.json, <outdir>/pmc_kernels.json
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=${1:-gpurun_out/pmc_detail}
+OUT=${1:-gpurun_out/pmc}
 mkdir -p "$OUT"
 i=0
 for SET in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
-           "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum" "GRBM_GUI_ACTIVE GRBM_TA_BUSY"; do
+           "GRBM_GUI_ACTIVE GRBM_TA_BUSY" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/k$i" -o p -- python tools/kbench.py --what spmm,wtiled --iters 3 > /dev/null 2>&1
-  timeout 100 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/g$i" -o p -- ./tools/gather_probe.bin > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/k$i" -o p -- python tools/kbench.py --what spmm,bwd,wtiled --iters 3 > "$OUT/k$i.log" 2>&1
 done
-ls "$OUT"
+python - "$OUT" <<'PY'
+import collections, csv, glob, json, sys
+out = sys.argv[1]
+per = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/k*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        per[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+keys = {"spmm": "spmm_d16_kernel", "bwd_fused": "bwd_fused_d16_kernel<4, true", "bwd_fused_deterministic": "bwd_fused_d16_kernel<4, false",
+        "wgrad_tiled": "wgrad_tiled_d16_kernel"}
+detail = {"_how": "tools/pmc_passes.sh: separate rocprofv3 --pmc passes over tools/kbench.py --what spmm,bwd,wtiled (S1 launches); means per launch. "
+                  "GRBM_GUI_ACTIVE is summed over the 8 XCDs: MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)"}
+kernels = {}
+for name, c in per.items():
+    means = {k: sum(v) / len(v) for k, v in c.items()}
+    for key, sub in keys.items():
+        if sub in name:
+            detail[key] = {k: v for k, v in means.items() if k not in ("FETCH_SIZE", "WRITE_SIZE")}
+    if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
+        kernels[name[:90]] = {k: {"launches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)} for k, v in c.items()
+                              if k in ("FETCH_SIZE", "WRITE_SIZE")}
+json.dump(detail, open(out + "/pmc_detail.json", "w"), indent=1, sort_keys=True)
+json.dump(kernels, open(out + "/pmc_kernels.json", "w"), indent=1, sort_keys=True)
+for key in keys:
+    d = detail.get(key)
+    if d and d.get("GRBM_GUI_ACTIVE"):
+        print(key, "GUI", round(d["GRBM_GUI_ACTIVE"]), "RDREQ", round(d.get("TCC_EA0_RDREQ_sum", 0)), "LDS conflict frac",
+              round(d.get("SQ_LDS_BANK_CONFLICT", 0) / max(d.get("SQ_LDS_IDX_ACTIVE", 1), 1), 3), "MFMA busy frac",
+              round(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (d["GRBM_GUI_ACTIVE"] / 8 * 1024), 3), "SALU", round(d.get("SQ_INSTS_SALU", 0)),
+              "VALU", round(d.get("SQ_INSTS_VALU", 0)))
+PY

@@ -28,8 +28,10 @@
 //   dX           D^T[o'][slot] = sum_f Wt_r[f][o'] (val G[s_slot][f])   4 x v_mfma_f32_16x16x4_f32, DPP segment fold,
 //                one ds_read/ds_write_b128 per destination segment into the wave-owned LDS tile (as the forward kernel)
 //   dW           the scaled rows go through a 1.25 KiB LDS scratch into K-over-messages operand layout
-//                (B[mu][j] = val G[s_mu][j]); A[i][mu] = X[o_mu][i] is read straight from L1/L2 (tile-local rows);
-//                4 x v_mfma_f32_16x16x4_f32 accumulate dW_r in 4 registers per lane.
+//                (B[mu][j] = val G[s_mu][j]; A[i][mu] = X[o_mu][i], the tile-local rows read as 16-byte row quarters from
+//                L1/L2 -- keeping the tile's X rows in LDS instead was measured: 0.94 ms against 0.73, fewer resident
+//                waves and LDS traffic cost more than the saved requests); 4 x v_mfma_f32_16x16x4_f32 accumulate dW_r in
+//                4 registers per lane.
 #include <stdlib.h>
 
 #include <algorithm>
@@ -54,7 +56,7 @@ struct BwdStage {
 };
 
 template <int U, bool ATOMIC, int BW_D>
-__global__ __launch_bounds__(WG, 5) void bwd_fused_d16_kernel(
+__global__ __launch_bounds__(WG, 4) void bwd_fused_d16_kernel(
     const float *__restrict__ G, const float *__restrict__ X, const float *__restrict__ Wtp, float *__restrict__ dX,
     float *__restrict__ dWout, const int2 *__restrict__ p_pack, const int *__restrict__ chunk_rel,
     const int *__restrict__ run_ptr, int n_tiles, int n_blocks, int tile_rows, int n_dst, int R, int ablate) {
@@ -110,15 +112,25 @@ __global__ __launch_bounds__(WG, 5) void bwd_fused_d16_kernel(
 
   if (my0 < my1) {
     const int last = my1 - 1;
+    // index data (packed slots + relations) of the NEXT group of U chunks is requested while the current group's gathers
+    // are in flight: a wave's iteration is then gather latency + compute, not index latency + gather latency + compute
+    // (0.77 -> 0.72 ms at S1)
+    int2 pk_n[U];
+    int relv_n;
+    auto request_idx = [&](int c) {
+      relv_n = chunk_rel[min(c + (lane & (U - 1)), last)];
+#pragma unroll
+      for (int j = 0; j < U; ++j) pk_n[j] = p_pack[min(c + j, last) * RGCN_CHUNK + m];
+    };
+    request_idx(my0);
     for (int c = my0; c < my1; c += U) {
       BwdStage<U> A;
-      // stage 1: packed slots (chunks past the range re-read the last chunk with val = 0); the U relations come from ONE
-      // vector load (a scalar load per chunk makes hipcc wait for each in turn)
-      const int relv = chunk_rel[min(c + (lane & (U - 1)), last)];
+      // stage 1: unpack the slots requested one iteration ago (chunks past the range re-read the last chunk with val = 0);
+      // the U relations come from ONE vector load (a scalar load per chunk makes hipcc wait for each in turn)
+      const int relv = relv_n;
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        const int cc = min(c + j, last);
-        const int2 pk = p_pack[cc * RGCN_CHUNK + m];
+        const int2 pk = pk_n[j];
         A.s[j] = pk.x & 0xFFFFFF;
         A.dl[j] = (int)((unsigned)pk.x >> 24);
         A.d[j] = A.dl[j] == 0xFF ? -1 : row0 + A.dl[j];
@@ -127,7 +139,7 @@ __global__ __launch_bounds__(WG, 5) void bwd_fused_d16_kernel(
 #pragma unroll
       for (int j = 0; j < U; ++j) A.r[j] = __builtin_amdgcn_readlane(relv, j);
 #pragma unroll
-      for (int j = 0; j < U; ++j) asm volatile("" : "+v"(A.d[j]), "+v"(A.v[j]));   // pin the index loads here
+      for (int j = 0; j < U; ++j) asm volatile("" : "+v"(A.d[j]), "+v"(A.v[j]));   // pin the index data here
       __builtin_amdgcn_sched_barrier(0);
       // stage 2: the random gather, the W_r^T fragment, and the tile-local X rows in operand order
 #pragma unroll
@@ -137,6 +149,8 @@ __global__ __launch_bounds__(WG, 5) void bwd_fused_d16_kernel(
         A.xn[j] = (ablate & 4) ? make_float4(1.f, 1.f, 1.f, 1.f)
                                : *reinterpret_cast<const float4 *>(X + (size_t)(row0 + (A.dl[j] == 0xFF ? 0 : A.dl[j])) * 16 + 4 * k);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      request_idx(c + U);                  // behind the gathers in the (in-order) memory pipeline; used next iteration
       __builtin_amdgcn_sched_barrier(0);
       // stage 3: matrix cores
 #pragma unroll
