@@ -85,7 +85,8 @@ def pmc_detail(kernel_key):
         out = {"fabric_read_requests": int(c["TCC_EA0_RDREQ_sum"]),
                "share_of_128B_requests": round(c["TCC_EA0_RDREQ_128B_sum"] / c["TCC_EA0_RDREQ_sum"], 4),
                "l2_hit_rate": round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3),
-               "mfma_busy_frac": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * 1024), 4),
+               # GRBM_GUI_ACTIVE is summed over the 8 XCDs (8 x 2.3 GHz x kernel time): busy SIMD-cycles / (cycles x 1024 SIMDs)
+               "mfma_busy_frac": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024), 4),
                "source": src}
         if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE"):
             out["lds_bank_conflict_frac"] = round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 3)
