@@ -252,6 +252,15 @@ RGCN_API int rgcn_bwd_fused_f32(const float *G, const float *X, const float *Wt_
                                 float *scratch, const int32_t *p_pack, const int32_t *chunk_rel,
                                 const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R,
                                 int32_t flags, void *stream);
+/* The same for graphs whose (tile, relation) buckets are sparse (AM: 267 relations), on the RELATION-major plan of the
+ * two-pass path: one wave per work item gathers G[p_src] and X[p_dst] once per message and produces
+ *   Y[slot, :] = val G[p_src] W_r^T   (slot order; pass 2 = rgcn_segment_gather_sum_f32 sums them per destination -> dX)
+ *   dW[r]    += val X[p_dst]^T G[p_src]   (one flush of 256 fp32 atomics per item; dW is zeroed first)
+ * i.e. two random row reads per message instead of the three of rgcn_spmm_scatter_f32 + rgcn_wgrad_f32.  d = 16 only. */
+RGCN_API int rgcn_bwd_scatter_dw_f32(const float *G, const float *X, const float *Wt_packed, float *Y, float *dW,
+                                     const int32_t *p_src, const int32_t *p_dst, const float *p_val,
+                                     const int32_t *chunk_rel, const int32_t *items, int64_t n_items, int32_t R, int32_t d,
+                                     void *stream);
 /* Wp[r][16k+f][c] = W[r][f][4k+c]: fragments of W_r^T straight from W (the feature-gradient kernels multiply by W^T). */
 RGCN_API int rgcn_pack_w16t_f32(const float *W, float *Wp, int32_t R, void *stream);
 

@@ -33,6 +33,8 @@ def test_am_tenth_scale_block_diagonal_layer_vs_oracle(monkeypatch, sparse_path,
                         seed=301 + int(vertical))
     prof = _native.profile_stop()
     assert ("spmm_scatter" in prof) == (sparse_path == "1")
+    # backward: relation-major fused pass (dX rows + dW from one walk) on the sparse path, tile-walk fused kernel otherwise
+    assert ("bwd_scatter_dw" in prof) == (sparse_path == "1") and ("bwd_fused" in prof) == (sparse_path == "0")
 
 
 def test_am_tenth_scale_default_path_is_the_sparse_one():

@@ -206,6 +206,85 @@ __global__ __launch_bounds__(WG, 4) void bwd_fused_d16_kernel(
   for (int i = lane; i < nrows * 4; i += 64) o4[i] = reinterpret_cast<const float4 *>(tile)[tile_swz(i)];
 }
 
+// ---- sparse (tile, relation) buckets (AM: 267 relations): backward of the two-pass path with ONE relation-major walk.
+// Round 1: pass 1 of the feature gradient gathers G[s] per message (relation-major chunks, dense), and the weight gradient
+// walks the same relation-major plan again gathering G[dst] AND X[src] -- three random row reads per message.  Here one
+// wave per work item (<= 64 chunks of ONE relation) gathers G[s] and X[o] once each and produces both the transformed rows
+// Y[slot] = val G[s] W_r^T (summed per destination by pass 2, rgcn_segment_gather_sum_f32) and the item's share of dW_r,
+// which stays in 4 accumulator registers for the whole item (runs are long in relation-major order): one flush of 256
+// atomics per item, no staging, no barriers.
+template <int U>
+__global__ __launch_bounds__(WG) void bwd_scatter_dw_d16_kernel(
+    const float *__restrict__ G, const float *__restrict__ X, const float *__restrict__ Wtp, float *__restrict__ Y,
+    float *__restrict__ dW, const int *__restrict__ p_src, const int *__restrict__ p_dst, const float *__restrict__ p_val,
+    const int *__restrict__ chunk_rel, const int2 *__restrict__ items, int n_items) {
+  __shared__ __attribute__((aligned(16))) float scr_all[(WG / 64) * BW_SCR];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int item = blockIdx.x * (WG / 64) + wave;
+  if (item >= n_items) return;
+  const int2 range = items[item];
+  if (range.x >= range.y) return;
+  const int r = __builtin_amdgcn_readfirstlane(chunk_rel[range.x]);
+  float *xs = scr_all + wave * BW_SCR;
+  const int m = lane & 15, k = lane >> 4;
+  const float4 w = reinterpret_cast<const float4 *>(Wtp)[(size_t)r * 64 + lane];
+  f32x4 acc_w = {0.f, 0.f, 0.f, 0.f};
+  const int last = range.y - 1;
+  for (int c = range.x; c < range.y; c += U) {
+    int s[U], d[U];
+    float v[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int e = min(c + j, last) * RGCN_CHUNK + m;
+      s[j] = p_src[e];
+      d[j] = p_dst[e];
+      const float vv = p_val[e];
+      v[j] = (c + j <= last) ? vv : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) asm volatile("" : "+v"(s[j]), "+v"(d[j]), "+v"(v[j]));
+    __builtin_amdgcn_sched_barrier(0);
+    float4 g[U], x[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      g[j] = *reinterpret_cast<const float4 *>(G + (size_t)s[j] * 16 + 4 * k);
+      x[j] = *reinterpret_cast<const float4 *>(X + (size_t)max(d[j], 0) * 16 + 4 * k);     // pads: dst = -1, val = 0
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const float vv = v[j];
+      const bool live = vv != 0.f;
+      const f32x4 sc = {live ? g[j].x * vv : 0.f, live ? g[j].y * vv : 0.f, live ? g[j].z * vv : 0.f, live ? g[j].w * vv : 0.f};
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, sc[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, sc[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, sc[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, sc[3], acc, 0, 0, 0);
+      if (live) *reinterpret_cast<f32x4 *>(Y + ((size_t)min(c + j, last) * RGCN_CHUNK + m) * 16 + 4 * k) = acc;
+      // dW_r += (X[o])^T (val G[s]): both operands through the LDS scratch into K-over-messages layout
+      float bv[4], av[4];
+      asm volatile("" ::: "memory");
+      *reinterpret_cast<f32x4 *>(xs + m * 20 + 4 * k) = sc;
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) bv[t4] = xs[(4 * t4 + k) * 20 + m];
+      asm volatile("" ::: "memory");
+      *reinterpret_cast<f32x4 *>(xs + m * 20 + 4 * k) = f32x4{live ? x[j].x : 0.f, live ? x[j].y : 0.f, live ? x[j].z : 0.f,
+                                                              live ? x[j].w : 0.f};
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) av[t4] = xs[(4 * t4 + k) * 20 + m];
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) acc_w = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4], bv[t4], acc_w, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float *wr = dW + (size_t)r * 256 + (4 * k) * 16 + m;       // D: lane 16q+j holds rows 4q..4q+3 (input feature), column j
+  atomicAdd(wr, acc_w[0]); atomicAdd(wr + 16, acc_w[1]); atomicAdd(wr + 32, acc_w[2]); atomicAdd(wr + 48, acc_w[3]);
+}
+
 // partial[r][block][256] (fragment order) -> tmp[r][s][256]: slice s sums blocks s, s + S, ...
 __global__ __launch_bounds__(WG) void dw_reduce_a_kernel(const float *__restrict__ partial, float *__restrict__ tmp,
                                                          int n_blocks, int S) {
@@ -311,6 +390,24 @@ extern "C" int rgcn_bwd_fused_f32(const float *G, const float *X, const float *W
     hipLaunchKernelGGL(dw_reduce_a_kernel, dim3((unsigned)R, (unsigned)S), dim3(WG), 0, st, scratch, tmp, n_blocks, S);
     hipLaunchKernelGGL(dw_reduce_b_kernel, dim3((unsigned)R), dim3(WG), 0, st, tmp, dW, S);
   }
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_bwd_scatter_dw_f32(const float *G, const float *X, const float *Wt_packed, float *Y, float *dW,
+                                       const int32_t *p_src, const int32_t *p_dst, const float *p_val,
+                                       const int32_t *chunk_rel, const int32_t *items, int64_t n_items, int32_t R, int32_t d,
+                                       void *stream) {
+  if (!G || !X || !Wt_packed || !Y || !dW || R <= 0 || n_items < 0 || (n_items && (!p_src || !p_dst || !p_val || !chunk_rel || !items))) {
+    rgcn_set_error("bwd_scatter_dw: bad argument");
+    return RGCN_EINVAL;
+  }
+  if (d != 16) { rgcn_set_error("bwd_scatter_dw: only d = 16"); return RGCN_EUNSUPPORTED; }
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(dW, 0, (size_t)R * 256 * sizeof(float), st));
+  if (!n_items) return RGCN_OK;
+  hipLaunchKernelGGL(bwd_scatter_dw_d16_kernel<4>, dim3((unsigned)((n_items + WG / 64 - 1) / (WG / 64))), dim3(WG), 0, st, G, X,
+                     Wt_packed, Y, dW, p_src, p_dst, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), (int)n_items);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

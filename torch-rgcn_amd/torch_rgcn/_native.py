@@ -752,6 +752,32 @@ def spmm_two_pass(X, W, bias, scatter_plan, csr, relu=False):
     return out
 
 
+def bwd_two_pass_fused(G, X, W, scatter_plan, csr):
+    """(dX, dW) of the hidden-16 layer on a sparse-bucket graph: relation-major pass producing the transformed rows AND dW
+    (rgcn_bwd_scatter_dw_f32), then the per-destination sum of the rows."""
+    _req(G, "grad_output"); _req(X, "features"); _req(W, "weights")
+    p = scatter_plan
+    dev = G.device
+    Wtp = pack_w16t(W)
+    n_msg = int(csr.rowptr[-1].item()) if csr.n_messages is None else csr.n_messages
+    if getattr(p, "_inv", None) is None:     # destination-major position -> slot of the relation-major plan
+        live = p.dst >= 0
+        inv = torch.zeros(max(n_msg, 1), dtype=torch.int32, device=dev)
+        inv[p.aux[live].long()] = torch.arange(p.dst.shape[0], device=dev, dtype=torch.int32)[live]
+        p._inv = inv
+    Y = torch.empty((max(p.dst.shape[0], 1), 16), device=dev, dtype=torch.float32)
+    dW = torch.empty_like(W)
+    dX = torch.empty((csr.n_rows, 16), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev), _timed("bwd_scatter_dw"):
+        _check(lib().rgcn_bwd_scatter_dw_f32(_dp(G), _dp(X), _dp(Wtp), _dp(Y), _dp(dW), _dp(p.src), _dp(p.dst), _dp(p.val),
+                                             _dp(p.chunk_rel), _dp(p.items), c_i64(p.n_items), c_i32(W.shape[0]), c_i32(16),
+                                             _stream(dev)), "bwd_scatter_dw")
+    with torch.cuda.device(dev), _timed("segment_sum"):
+        _check(lib().rgcn_segment_gather_sum_f32(_dp(Y), _dp(p._inv), _dp(csr.rowptr), None, _dp(dX), c_i64(csr.n_rows),
+                                                 c_i32(16), c_i32(0), _stream(dev)), "segment_gather_sum")
+    return dX, dW
+
+
 def wgrad(X, G, plan, num_rels):
     """dW[R, d_in, d_out] = sum_slots val * X[src]^T G[dst], grouped by relation"""
     _req(X, "features"); _req(G, "grad_output")

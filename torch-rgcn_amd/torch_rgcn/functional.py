@@ -155,6 +155,10 @@ class _RelationalMP(torch.autograd.Function):
         both = None
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not sparse:
             both = _fused_backward(X, W, g, graph)
+        elif ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and os.environ.get("RGCN_BWD", "fused") != "split" \
+                and os.environ.get("RGCN_TWOPASS", "gather") == "gather" and not deterministic():
+            # sparse buckets: relation-major walk, G[s] and X[o] gathered once each for dX's rows and dW together
+            both = _native.bwd_two_pass_fused(g, X, W, graph.scatter_plan("bwd"), graph.csr("bwd"))
         if both is not None:
             dX, dW = both
         else:
