@@ -402,17 +402,20 @@ __global__ __launch_bounds__(TB) void basis_dcomps_kernel(
   if (range.x >= range.y) return;
   for (int b0 = 0; b0 < B; b0 += 4) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int e = range.x * RGCN_CHUNK + sub; e < range.y * RGCN_CHUNK; e += ngrp) {
-      const float v = p_val[e];
-      if (v == 0.f) continue;                    // pad
-      const float *x = X + (size_t)p_src[e] * d;
-      const float *dd = D + ((size_t)p_dst[e] * B + b0) * d;
+    const int e_end = range.y * RGCN_CHUNK;
+    for (int e = range.x * RGCN_CHUNK + sub; e < e_end; e += 2 * ngrp) {       // two messages' row loads in flight together
+      const int e2 = min(e + ngrp, e_end - 1);
+      const float v = p_val[e], v2 = (e + ngrp < e_end) ? p_val[e2] : 0.f;
+      if (v == 0.f && v2 == 0.f) continue;       // pads
+      // (either index array may carry the pads' -1: the callers swap them for the featureless layer)
+      const float *x = X + (size_t)max(p_src[e], 0) * d, *x2 = X + (size_t)max(p_src[e2], 0) * d;
+      const float *dd = D + ((size_t)max(p_dst[e], 0) * B + b0) * d, *dd2 = D + ((size_t)max(p_dst[e2], 0) * B + b0) * d;
       for (int i = il; i < d; i += lpr) {
-        const float xv = v * x[i];
-        a0 += xv * dd[i];
-        if (b0 + 1 < B) a1 += xv * dd[(size_t)d + i];
-        if (b0 + 2 < B) a2 += xv * dd[2 * (size_t)d + i];
-        if (b0 + 3 < B) a3 += xv * dd[3 * (size_t)d + i];
+        const float xv = v * x[i], xw = v2 * x2[i];
+        a0 += xv * dd[i] + xw * dd2[i];
+        if (b0 + 1 < B) a1 += xv * dd[(size_t)d + i] + xw * dd2[(size_t)d + i];
+        if (b0 + 2 < B) a2 += xv * dd[2 * (size_t)d + i] + xw * dd2[2 * (size_t)d + i];
+        if (b0 + 3 < B) a3 += xv * dd[3 * (size_t)d + i] + xw * dd2[3 * (size_t)d + i];
       }
     }
 #pragma unroll
@@ -457,7 +460,9 @@ extern "C" int rgcn_basis_dcomps_f32(const float *X, const float *D, float *dcom
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(hipMemsetAsync(dcomps, 0, (size_t)R * B * sizeof(float), st));
   if (!n_items) return RGCN_OK;
-  hipLaunchKernelGGL(basis_dcomps_kernel, dim3((unsigned)((n_items + TB / 64 - 1) / (TB / 64)), 16), dim3(TB), 0, st, X, D, dcomps,
+  // few items (small per-call graphs): cut every item into more pieces so that the chip is filled
+  const unsigned pieces = n_items < 2048 ? 64 : 16;
+  hipLaunchKernelGGL(basis_dcomps_kernel, dim3((unsigned)((n_items + TB / 64 - 1) / (TB / 64)), pieces), dim3(TB), 0, st, X, D, dcomps,
                      p_src, p_dst, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), (int)n_items, B, d, lanes_per_row(d));
   HIP_TRY(hipGetLastError());
   return RGCN_OK;

@@ -1232,7 +1232,9 @@ extern "C" int rgcn_colsum_f32(const float *G, float *db, float *scratch, int64_
   const bool vec4 = d % 4 == 0;
   const int lanes = vec4 ? d / 4 : d;
   const int groups = std::max(1, WG / lanes);
-  const unsigned gx = (unsigned)std::min<int64_t>((n + groups - 1) / groups, 512);
+  // stage B is one workgroup walking the partial rows: wide rows leave it few row groups, so they get fewer partials
+  const int64_t max_part = d <= 32 ? 512 : (d <= 128 ? 128 : 64);
+  const unsigned gx = (unsigned)std::min<int64_t>((n + groups - 1) / groups, max_part);
   if (vec4) hipLaunchKernelGGL(colsum_a_kernel<true>, dim3(gx), dim3(WG), 0, st, G, scratch, (long long)n, d);
   else hipLaunchKernelGGL(colsum_a_kernel<false>, dim3(gx), dim3(WG), 0, st, G, scratch, (long long)n, d);
   hipLaunchKernelGGL(colsum_b_kernel, dim3(1), dim3(WG), 0, st, scratch, db, (int)gx, d);
