@@ -337,10 +337,19 @@ RGCN_API int rgcn_distmult_fwd_f32(const int64_t *triples, int64_t T, const floa
                                    const float *sbias, const float *pbias, const float *obias, float *scores,
                                    int64_t n_nodes, int32_t n_rel, int32_t d, int32_t *err_flag, void *stream);
 /* Gradients of sum_t gs[t] * scores[t]; dnodes / drel (and the bias grads when
- * non-NULL) are zeroed first and accumulated with fp32 atomics.  Out-of-range triples are skipped. */
+ * non-NULL) are zeroed first and accumulated with fp32 atomics.  Out-of-range triples are skipped.  dnodes may be NULL
+ * (see rgcn_distmult_bwd_nodes_f32). */
 RGCN_API int rgcn_distmult_bwd_f32(const int64_t *triples, int64_t T, const float *nodes, const float *rel,
                                    const float *gs, float *dnodes, float *drel, float *dsbias, float *dpbias,
                                    float *dobias, int64_t n_nodes, int32_t n_rel, int32_t d, void *stream);
+/* Entity gradients without atomics: dnodes[n] = sum_{t: s_t = n} g_t rel[p_t] * nodes[o_t] + sum_{t: o_t = n} g_t rel[p_t] *
+ * nodes[s_t], one wave per entity over two CSRs of the scored triples (rows = subject, entries = (object, predicate, g);
+ * rows = object, entries = (subject, predicate, g) -- rgcn_dev_plan_count / _fill with R = 1, see rgcn_dev_plan_fill).
+ * dnodes is fully written.  rgcn_distmult_bwd_f32 with dnodes = NULL then yields the relation / bias gradients only. */
+RGCN_API int rgcn_distmult_bwd_nodes_f32(const int32_t *rowptr_s, const int32_t *other_s, const int32_t *rel_s,
+                                         const float *g_s, const int32_t *rowptr_o, const int32_t *other_o,
+                                         const int32_t *rel_o, const float *g_o, const float *nodes, const float *rel,
+                                         float *dnodes, int64_t n_nodes, int32_t d, void *stream);
 
 /* Ranking evaluator (utils/misc.py:60-110 + torch_rgcn/layers.py:87-98 on the expanded
  * [bn, N, 3] candidate tensor, which is never built here).  For each of the Q test triples in `batch` (int64

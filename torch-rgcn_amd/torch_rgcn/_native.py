@@ -947,9 +947,11 @@ def rank_count(scores, batch, head):
     return greater, ties
 
 
-def distmult_bwd(triples, nodes, rel, gs, with_bias):
+def distmult_bwd(triples, nodes, rel, gs, with_bias, nodes_grad=True):
+    """relation (and bias) gradients from predicate-sorted triples; nodes_grad=True also scatters the entity gradients with
+    atomics (round 1's form; the default path computes them with distmult_bwd_nodes instead)"""
     _req(gs, "grad_scores")
-    dn = torch.empty_like(nodes)
+    dn = torch.empty_like(nodes) if nodes_grad else None
     dr = torch.empty_like(rel)
     dsb = torch.empty(nodes.shape[0], device=nodes.device) if with_bias else None
     dob = torch.empty(nodes.shape[0], device=nodes.device) if with_bias else None
@@ -960,3 +962,23 @@ def distmult_bwd(triples, nodes, rel, gs, with_bias):
                                            c_i32(rel.shape[0]), c_i32(nodes.shape[1]), _stream(nodes.device)),
                "distmult_bwd")
     return dn, dr, dsb, dpb, dob
+
+
+def distmult_bwd_nodes(triples, nodes, rel, gs):
+    """entity gradients of DistMult without atomics: two CSRs of the scored triples (by subject, by object; device-side
+    counting sort, no host read-back) and one wave per entity (rgcn_distmult_bwd_nodes_f32)"""
+    _req(gs, "grad_scores"); _req(nodes, "nodes"); _req(rel, "relations")
+    N, d = nodes.shape
+    dev = nodes.device
+    s, p, o, _err = dev_split_triples(triples, N, rel.shape[0])
+    alive = None
+    if _deferred_mode():     # the forward's range check may not have been looked at yet: bad triples must not reach the sort
+        alive = ((triples >= 0).all(dim=1) & (triples[:, 0] < N) & (triples[:, 2] < N) & (triples[:, 1] < rel.shape[0])).to(torch.uint8)
+    by_s = build_csr_device(s, o, p, gs, alive, N, sync_free=True)
+    by_o = build_csr_device(o, s, p, gs, alive, N, sync_free=True)
+    dn = torch.empty_like(nodes)
+    with torch.cuda.device(dev), _timed("distmult_bwd_nodes"):
+        _check(lib().rgcn_distmult_bwd_nodes_f32(_dp(by_s.rowptr), _dp(by_s.src), _dp(by_s.rel), _dp(by_s.val), _dp(by_o.rowptr),
+                                                 _dp(by_o.src), _dp(by_o.rel), _dp(by_o.val), _dp(nodes), _dp(rel), _dp(dn),
+                                                 c_i64(N), c_i32(d), _stream(dev)), "distmult_bwd_nodes")
+    return dn

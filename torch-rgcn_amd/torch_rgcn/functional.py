@@ -446,9 +446,13 @@ class _DistMultScore(torch.autograd.Function):
     def backward(ctx, gs):
         tr, nodes, relations = ctx.saved_tensors
         gs = gs.reshape(-1)
+        gs = gs.contiguous()
         order = torch.argsort(tr[:, 1], stable=True)   # predicate runs -> relation gradient accumulates in registers
+        scatter = os.environ.get("RGCN_DISTMULT_BWD", "csr") == "atomic" or tr.shape[0] == 0
         dn, dr, dsb, dpb, dob = _native.distmult_bwd(tr[order].contiguous(), nodes, relations, gs[order].contiguous(),
-                                                     ctx.with_bias)
+                                                     ctx.with_bias, nodes_grad=scatter)
+        if not scatter:      # entity gradients: CSR by subject / by object, one wave per entity, no atomics
+            dn = _native.distmult_bwd_nodes(tr, nodes, relations, gs)
         return None, dn, dr, dsb, dpb, dob
 
 
