@@ -328,6 +328,23 @@ RGCN_API int rgcn_gemm_f32(const float *A, const float *B, const float *bias, fl
                            int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t flags, int32_t split_k,
                            void *stream);
 
+/* Undecomposed weights above width 64 (layers.py:293-301 with W [R, d_in, d_out], d = 100, 200, ...): the relation-major
+ * plan (rgcn_dev_plan_fill with tile_rows >= n_dst; work items of <= 8 chunks = 128 slots of one relation) as the row
+ * blocks of an LDS-tiled MFMA GEMM with gathered rows:
+ *   rgcn_rel_rows_f32               Y[slot, :] = val[slot] * Xs[p_src[slot], :] @ W[rel]        (Y: [slots, d_out], slot order)
+ *   rgcn_segment_gather_sum_wide_f32  out[row, :] = bias + sum_j Y[perm[j], :] over the row's CSR range (any width)
+ *   rgcn_rel_wgrad_f32              dW[rel] += sum_slots Xs[p_src[slot], :]^T (val[slot] G[p_dst[slot], :])   (dW zeroed first,
+ *                                   fp32 atomics across the items of a relation)
+ * The feature gradient is rgcn_rel_rows_f32 on the transposed relation-major plan with G and W^T. */
+RGCN_API int rgcn_rel_rows_f32(const float *Xs, const float *W, float *Y, const int32_t *p_src, const float *p_val,
+                               const int32_t *chunk_rel, const int32_t *items, int64_t n_items, int32_t R, int32_t d_in,
+                               int32_t d_out, void *stream);
+RGCN_API int rgcn_rel_wgrad_f32(const float *Xs, const float *G, float *dW, const int32_t *p_src, const int32_t *p_dst,
+                                const float *p_val, const int32_t *chunk_rel, const int32_t *items, int64_t n_items,
+                                int32_t R, int32_t d_in, int32_t d_out, void *stream);
+RGCN_API int rgcn_segment_gather_sum_wide_f32(const float *Y, const int32_t *perm, const int32_t *rowptr, const float *bias,
+                                              float *out, int64_t n_rows, int32_t d, int32_t flags, void *stream);
+
 /* DistMult decoder (torch_rgcn/layers.py:86-98):
  * scores[t] = sum_k nodes[s,k] rel[p,k] nodes[o,k] (+ sbias[s] + pbias[p] + obias[o]);
  * triples int64 [T,3] on the device.  Biases may all be NULL.  Triples whose s / o are outside [0, n_nodes) or whose p

@@ -173,6 +173,264 @@ __global__ __launch_bounds__(WG) void sum_slices_kernel(const float *__restrict_
   }
 }
 
+// ------------------------------------------------------------------ wide undecomposed layers: relation-grouped gather-GEMM
+// Widths above 64 without a decomposition (W [R, d_in, d_out]; layers.py:293-301 with e.g. d = 100, 200).  Round 1 cut W into
+// 64-wide block pairs and launched the hidden-16-style block kernel once per pair, re-gathering X for every column block.
+// Here the RELATION-major plan (chunks of 16 slots of one relation, contiguous per relation) is read as row blocks of a
+// GEMM: a work item (<= 8 chunks = 128 message slots of ONE relation r) x a 128-column block of the output is one
+// workgroup tile of the LDS-tiled MFMA GEMM above, with the A rows GATHERED (val[slot] * Xs[src[slot], :]) and B = W_r:
+//     Y[slot, :] = val[slot] * Xs[src[slot], :] @ W_r                       (rel_rows_kernel; forward and, with W^T and G, dX)
+// followed by the per-destination sum of the rows (segment_gather_sum_wide_kernel) -- X is gathered once per message,
+// every W_r streams through LDS once per 128 messages.  The weight gradient is the same tiling transposed:
+//     dW_r[m, n] += sum_{slots of r} Xs[src[slot], m] * (val[slot] * G[dst[slot], n])      (rel_wgrad_kernel, K = slots)
+// one workgroup per (item, 128 x 128 block of dW_r), fp32 atomics across the items of a relation.
+__global__ __launch_bounds__(WG) void rel_rows_kernel(
+    const float *__restrict__ Xs, const float *__restrict__ W /* [R][K][N] */, float *__restrict__ Y /* [slots][N] */,
+    const int *__restrict__ p_src, const float *__restrict__ p_val, const int *__restrict__ chunk_rel,
+    const int2 *__restrict__ items, int K, int N) {
+  __shared__ __attribute__((aligned(16))) float sA[2][GT * LD_IN];
+  __shared__ __attribute__((aligned(16))) float sB[2][GK * LD_OUT];
+  const int2 range = items[blockIdx.x];
+  if (range.x >= range.y) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, kq = lane >> 4;
+  const int rel = chunk_rel[range.x];
+  const int slot0 = range.x * RGCN_CHUNK, M = (range.y - range.x) * RGCN_CHUNK;        // <= 128 rows
+  const int n0 = blockIdx.y * GT;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const float *Wr = W + (size_t)rel * K * N;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // A staging: thread -> rows (tid >> 2) and (tid >> 2) + 64 (gathered source rows, scaled), k group 4 (tid & 3)
+  const float *arow[2];
+  float ascale[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int rr = (tid >> 2) + 64 * h;
+    const bool on = rr < M;
+    const int slot = slot0 + (on ? rr : 0);
+    arow[h] = Xs + (size_t)p_src[slot] * K;
+    ascale[h] = on ? p_val[slot] : 0.f;            // pads carry val = 0
+  }
+  const bool vec_a = (K & 3) == 0, vec_b = (N & 3) == 0;
+  f32x4 ra[2], rb[2];
+  auto fetch = [&](int k0) {
+    const int kk = k0 + 4 * (tid & 3);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (vec_a) {
+        ra[h] = *reinterpret_cast<const f32x4 *>(arow[h] + min(kk, K - 4));
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ra[h][c] = arow[h][min(kk + c, K - 1)];
+      }
+      const float *brow = Wr + (size_t)min(k0 + (tid >> 5) + 8 * h, K - 1) * N;
+      const int cc = n0 + 4 * (tid & 31);
+      if (vec_b) {
+        rb[h] = *reinterpret_cast<const f32x4 *>(brow + min(cc, N - 4));
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rb[h][c] = brow[min(cc + c, N - 1)];
+      }
+    }
+  };
+  auto stash = [&](int buf, int k0) {
+    const int kk = k0 + 4 * (tid & 3);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 v = ra[h] * ascale[h];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = (kk + c < K && ascale[h] != 0.f) ? v[c] : 0.f;
+      *reinterpret_cast<f32x4 *>(&sA[buf][((tid >> 2) + 64 * h) * LD_IN + 4 * (tid & 3)]) = v;
+      const bool live = k0 + (tid >> 5) + 8 * h < K;
+      *reinterpret_cast<f32x4 *>(&sB[buf][((tid >> 5) + 8 * h) * LD_OUT + 4 * (tid & 31)]) = live ? rb[h] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  const int steps = (K + GK - 1) / GK;
+  fetch(0);
+  stash(0, 0);
+  __syncthreads();
+  for (int t = 0; t < steps; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < steps) fetch(GK * (t + 1));
+    f32x4 av[4], bv[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      av[a] = *reinterpret_cast<const f32x4 *>(&sA[cur][(wm + 16 * a + i) * LD_IN + 4 * kq]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bv[a][c] = sB[cur][(4 * kq + c) * LD_OUT + wn + 16 * a + i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][c], bv[b][c], acc[a][b], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < steps) stash(cur ^ 1, GK * (t + 1));
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wm + 16 * a + 4 * kq + r;
+      if (row >= M) continue;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int col = n0 + wn + 16 * b + i;
+        if (col < N) Y[(size_t)(slot0 + row) * N + col] = acc[a][b][r];
+      }
+    }
+}
+
+// dW[rel][m0.., n0..] += sum over the item's slots of Xs[src[slot], m] * val[slot] * G[dst[slot], n]
+__global__ __launch_bounds__(WG) void rel_wgrad_kernel(
+    const float *__restrict__ Xs, const float *__restrict__ G, float *__restrict__ dW /* [R][Mw][Nw] */,
+    const int *__restrict__ p_src, const int *__restrict__ p_dst, const float *__restrict__ p_val,
+    const int *__restrict__ chunk_rel, const int2 *__restrict__ items, int Mw, int Nw, int tiles_m) {
+  __shared__ __attribute__((aligned(16))) float sA[2][GK * LD_OUT];
+  __shared__ __attribute__((aligned(16))) float sB[2][GK * LD_OUT];
+  const int2 range = items[blockIdx.x];
+  if (range.x >= range.y) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, kq = lane >> 4;
+  const int rel = chunk_rel[range.x];
+  const int slot0 = range.x * RGCN_CHUNK, Ks = (range.y - range.x) * RGCN_CHUNK;        // K = the item's slots
+  const int m0 = (blockIdx.y % tiles_m) * GT, n0 = (blockIdx.y / tiles_m) * GT;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool vec_a = (Mw & 3) == 0, vec_b = (Nw & 3) == 0;
+  f32x4 ra[2], rb[2];
+  float sc[2];
+  auto fetch = [&](int k0) {     // thread -> slots k0 + (tid >> 5) (+ 8), column group 4 (tid & 31) of both gathered rows
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int kk = k0 + (tid >> 5) + 8 * h;
+      const bool on = kk < Ks;
+      const int slot = slot0 + (on ? kk : 0);
+      const float v = on ? p_val[slot] : 0.f;
+      sc[h] = v;
+      const float *xr = Xs + (size_t)p_src[slot] * Mw, *gr = G + (size_t)max(p_dst[slot], 0) * Nw;   // pads: dst = -1, val = 0
+      const int ca = m0 + 4 * (tid & 31), cb = n0 + 4 * (tid & 31);
+      if (vec_a) {
+        ra[h] = *reinterpret_cast<const f32x4 *>(xr + min(ca, Mw - 4));
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ra[h][c] = xr[min(ca + c, Mw - 1)];
+      }
+      if (vec_b) {
+        rb[h] = *reinterpret_cast<const f32x4 *>(gr + min(cb, Nw - 4));
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rb[h][c] = gr[min(cb + c, Nw - 1)];
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bool live = sc[h] != 0.f;
+      *reinterpret_cast<f32x4 *>(&sA[buf][((tid >> 5) + 8 * h) * LD_OUT + 4 * (tid & 31)]) = live ? ra[h] : f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4 *>(&sB[buf][((tid >> 5) + 8 * h) * LD_OUT + 4 * (tid & 31)]) = live ? rb[h] * sc[h] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  const int steps = (Ks + GK - 1) / GK;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int t = 0; t < steps; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < steps) fetch(GK * (t + 1));
+    f32x4 av[4], bv[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        av[a][c] = sA[cur][(4 * kq + c) * LD_OUT + wm + 16 * a + i];
+        bv[a][c] = sB[cur][(4 * kq + c) * LD_OUT + wn + 16 * a + i];
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][c], bv[b][c], acc[a][b], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < steps) stash(cur ^ 1);
+    __syncthreads();
+  }
+  float *Wr = dW + (size_t)rel * Mw * Nw;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + wm + 16 * a + 4 * kq + r;
+      if (row >= Mw) continue;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int col = n0 + wn + 16 * b + i;
+        if (col < Nw) atomicAdd(&Wr[(size_t)row * Nw + col], acc[a][b][r]);
+      }
+    }
+}
+
+// out[row, :] = bias + sum_{j in rowptr[row] .. rowptr[row+1]} Y[perm[j], :]   (rows of any width; one wave per row)
+__global__ __launch_bounds__(WG) void segment_gather_sum_wide_kernel(const float *__restrict__ Y, const int *__restrict__ perm,
+                                                                     const int *__restrict__ rowptr, const float *__restrict__ bias,
+                                                                     float *__restrict__ out, long long n_rows, int d, int relu_out) {
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = ((long long)blockIdx.x * WG + threadIdx.x) >> 6, nw = ((long long)gridDim.x * WG) >> 6;
+  const bool vec = (d & 3) == 0;
+  for (long long row = wave0; row < n_rows; row += nw) {
+    const int e0 = rowptr[row], e1 = rowptr[row + 1];
+    for (int f0 = 0; f0 < d; f0 += 256) {
+      const int f = f0 + 4 * lane;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+      if (f < d) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = (bias && f + q < d) ? bias[f + q] : 0.f;
+        for (int e = e0; e < e1; e += 2) {
+          const float *ya = Y + (size_t)perm[e] * d, *yb = Y + (size_t)perm[min(e + 1, e1 - 1)] * d;
+          const float wb = (e + 1 < e1) ? 1.f : 0.f;
+          if (vec) {
+            a += *reinterpret_cast<const f32x4 *>(ya + f);
+            b += *reinterpret_cast<const f32x4 *>(yb + f) * wb;
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (f + q < d) { a[q] += ya[f + q]; b[q] += yb[f + q] * wb; }
+          }
+        }
+        a += b;
+        if (relu_out) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a[q] = fmaxf(a[q], 0.f);
+        }
+        float *o = out + (size_t)row * d + f;
+        if (vec) {
+          *reinterpret_cast<f32x4 *>(o) = a;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (f + q < d) o[q] = a[q];
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ fused basis forward
 // LDS: ag tile [FT rows][ldk] with ldk = B d_in rounded up so that (ldk % 32) == 4 (16 rows x 4 k-groups of a ds_read_b128
 // spread over the banks).  K = B d_in is padded with zeros to a multiple of 16.
@@ -356,6 +614,49 @@ extern "C" int rgcn_basis_fused_fwd_f32(const float *X, const float *comps, cons
   if (!n_rows) return RGCN_OK;
   hipLaunchKernelGGL(basis_fused_fwd_kernel, dim3((unsigned)((n_rows + FT - 1) / FT)), dim3(WG), lds, (hipStream_t)stream, X,
                      comps, bases, bias, out, ag_out, rowptr, p_src, p_rel, p_val, (int)n_rows, B, d_in, d_out, ldk);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_rel_rows_f32(const float *Xs, const float *W, float *Y, const int32_t *p_src, const float *p_val,
+                                 const int32_t *chunk_rel, const int32_t *items, int64_t n_items, int32_t R, int32_t d_in,
+                                 int32_t d_out, void *stream) {
+  (void)R;
+  if (!Xs || !W || !Y || n_items < 0 || d_in <= 0 || d_out <= 0 || (n_items && (!p_src || !p_val || !chunk_rel || !items))) {
+    rgcn_set_error("rel_rows: bad argument");
+    return RGCN_EINVAL;
+  }
+  if (!n_items) return RGCN_OK;
+  hipLaunchKernelGGL(rel_rows_kernel, dim3((unsigned)n_items, (unsigned)((d_out + GT - 1) / GT)), dim3(WG), 0, (hipStream_t)stream,
+                     Xs, W, Y, p_src, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), d_in, d_out);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_rel_wgrad_f32(const float *Xs, const float *G, float *dW, const int32_t *p_src, const int32_t *p_dst,
+                                  const float *p_val, const int32_t *chunk_rel, const int32_t *items, int64_t n_items,
+                                  int32_t R, int32_t d_in, int32_t d_out, void *stream) {
+  if (!Xs || !G || !dW || n_items < 0 || R <= 0 || d_in <= 0 || d_out <= 0 || (n_items && (!p_src || !p_dst || !p_val || !chunk_rel || !items))) {
+    rgcn_set_error("rel_wgrad: bad argument");
+    return RGCN_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(dW, 0, (size_t)R * d_in * d_out * sizeof(float), st));
+  if (!n_items) return RGCN_OK;
+  const int tiles_m = (d_in + GT - 1) / GT, tiles_n = (d_out + GT - 1) / GT;
+  hipLaunchKernelGGL(rel_wgrad_kernel, dim3((unsigned)n_items, (unsigned)(tiles_m * tiles_n)), dim3(WG), 0, st, Xs, G, dW, p_src,
+                     p_dst, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), d_in, d_out, tiles_m);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_segment_gather_sum_wide_f32(const float *Y, const int32_t *perm, const int32_t *rowptr, const float *bias,
+                                                float *out, int64_t n_rows, int32_t d, int32_t flags, void *stream) {
+  if (!Y || !perm || !rowptr || !out || n_rows < 0 || d <= 0) { rgcn_set_error("segment_gather_sum_wide: bad argument"); return RGCN_EINVAL; }
+  if (!n_rows) return RGCN_OK;
+  const unsigned gx = (unsigned)std::min<int64_t>((n_rows + 3) / 4, 256 * 32);
+  hipLaunchKernelGGL(segment_gather_sum_wide_kernel, dim3(gx), dim3(WG), 0, (hipStream_t)stream, Y, perm, rowptr, bias, out,
+                     (long long)n_rows, d, flags & RGCN_F_RELU);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

@@ -752,6 +752,48 @@ def spmm_two_pass(X, W, bias, scatter_plan, csr, relu=False):
     return out
 
 
+def _slot_perm(p, n_msg, dev):
+    """destination-major position -> slot of the relation-major plan `p` (cached on the plan)"""
+    if getattr(p, "_inv", None) is None:
+        live = p.dst >= 0
+        inv = torch.zeros(max(n_msg, 1), dtype=torch.int32, device=dev)
+        inv[p.aux[live].long()] = torch.arange(p.dst.shape[0], device=dev, dtype=torch.int32)[live]
+        p._inv = inv
+    return p._inv
+
+
+def spmm_wide_two_pass(X, W, bias, scatter_plan, csr, relu=False):
+    """out = bias + sum val X[src] @ W[rel] for undecomposed weights of any width: relation-grouped gather-GEMM on the
+    matrix cores (rgcn_rel_rows_f32; work items of <= 128 slots) + per-destination sum of the rows"""
+    _req(X, "features"); _req(W, "weights"); _req(bias, "bias")
+    p, dev = scatter_plan, X.device
+    R, d_in, d_out = W.shape
+    n_msg = int(csr.rowptr[-1].item()) if csr.n_messages is None else csr.n_messages
+    perm = _slot_perm(p, n_msg, dev)
+    Y = torch.empty((max(p.dst.shape[0], 1), d_out), device=dev, dtype=torch.float32)
+    out = torch.empty((csr.n_rows, d_out), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev), _timed("rel_rows"):
+        _check(lib().rgcn_rel_rows_f32(_dp(X), _dp(W), _dp(Y), _dp(p.src), _dp(p.val), _dp(p.chunk_rel), _dp(p.items),
+                                       c_i64(p.n_items), c_i32(R), c_i32(d_in), c_i32(d_out), _stream(dev)), "rel_rows")
+    with torch.cuda.device(dev), _timed("segment_sum_wide"):
+        _check(lib().rgcn_segment_gather_sum_wide_f32(_dp(Y), _dp(perm), _dp(csr.rowptr), _dp(bias), _dp(out), c_i64(csr.n_rows),
+                                                      c_i32(d_out), c_i32(F_RELU if relu else 0), _stream(dev)),
+               "segment_gather_sum_wide")
+    return out
+
+
+def wgrad_wide(X, G, scatter_plan, num_rels):
+    """dW[R, d_in, d_out] = sum_slots val X[src]^T G[dst] on the matrix cores (rgcn_rel_wgrad_f32), any width"""
+    _req(X, "features"); _req(G, "grad_output")
+    p = scatter_plan
+    dW = torch.empty((num_rels, X.shape[1], G.shape[1]), device=X.device, dtype=torch.float32)
+    with torch.cuda.device(X.device), _timed("rel_wgrad"):
+        _check(lib().rgcn_rel_wgrad_f32(_dp(X), _dp(G), _dp(dW), _dp(p.src), _dp(p.dst), _dp(p.val), _dp(p.chunk_rel),
+                                        _dp(p.items), c_i64(p.n_items), c_i32(num_rels), c_i32(X.shape[1]), c_i32(G.shape[1]),
+                                        _stream(X.device)), "rel_wgrad")
+    return dW
+
+
 def bwd_two_pass_fused(G, X, W, scatter_plan, csr):
     """(dX, dW) of the hidden-16 layer on a sparse-bucket graph: relation-major pass producing the transformed rows AND dW
     (rgcn_bwd_scatter_dw_f32), then the per-destination sum of the rows."""

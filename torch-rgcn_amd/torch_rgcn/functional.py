@@ -36,7 +36,7 @@ def _sparse_buckets(graph, W):
     return graph.max_degree() <= 4096
 
 
-def _pad_blocks(X, W, bias):
+def _pad_blocks(X, W, bias, graph=None):
     """Widths up to 64 run on the MFMA block kernels (hidden-16 scheme over blocks of 16 features) with operands
     zero-padded to multiples of 16: a 40-byte row costs the same 128-byte fabric request as a 64-byte one, and these
     kernels (packed slots, pre-swizzled weight fragments, DPP folds) are several times faster than the generic-width
@@ -44,7 +44,8 @@ def _pad_blocks(X, W, bias):
     -> (X', W', bias', (d_in, d_out)) or the inputs unchanged and None."""
     d_in, d_out = W.shape[1], W.shape[2]
     pi, po = -d_in % 16, -d_out % 16
-    if max(d_in, d_out) > _BLOCKED_MAX or (pi == 0 and po == 0) or os.environ.get("RGCN_PAD16", "1") == "0":
+    if max(d_in, d_out) > _BLOCKED_MAX or (pi == 0 and po == 0) or os.environ.get("RGCN_PAD16", "1") == "0" or \
+            (graph is not None and _wide_gemm_path(graph, d_in, d_out)):       # (the gather-GEMM takes ragged widths as they are)
         return X, W, bias, None
     pad = torch.nn.functional.pad
     return (X if pi == 0 else pad(X, (0, pi)), pad(W, (0, po, 0, pi)), None if bias is None else pad(bias, (0, po)),
@@ -54,12 +55,21 @@ def _pad_blocks(X, W, bias):
 _BLOCKED_MAX = 512     # widest layer that is cut into 64-wide blocks of the MFMA block kernel
 
 
-def _spmm_blocked(X, W, bias, plan_of, relu=False):
-    """spmm for any width.  Up to 64 x 64 it is one launch; above (undecomposed weights at d = 100, 200, ...) W is cut into
-    64-wide row / column blocks and every block pair is one launch of the block kernel on a contiguous 64-column slice of
-    X -- (d_in / 64) x (d_out / 64) launches that re-gather X once per column block, against a generic-width kernel that is
-    ~8x slower per launch at these widths."""
+def _wide_gemm_path(graph, d_in, d_out):
+    """undecomposed weights above width 64: relation-grouped gather-GEMM on the matrix cores + per-destination row sum
+    (csrc/rgcn_gemm.hip); needs the device-side graph and host-known message counts (not the sync-free per-call build)"""
+    return (max(d_in, d_out) > 64 and getattr(graph, "_dev", None) is not None and not getattr(graph, "sync_free", False)
+            and os.environ.get("RGCN_WIDE", "gemm") == "gemm")
+
+
+def _spmm_blocked(X, W, bias, plan_of, relu=False, graph=None, kind="fwd"):
+    """spmm for any width.  Up to 64 x 64 it is one launch of the block kernels.  Above (undecomposed weights at d = 100,
+    200, ...): relation-grouped gather-GEMM (X gathered once per message, every W_r through LDS once per 128 messages) + row
+    sum; RGCN_WIDE=blocks keeps round 1's (d_in / 64) x (d_out / 64) launches of the block kernel, which is also the route
+    of graphs without a device-side build."""
     d_in, d_out = W.shape[1], W.shape[2]
+    if graph is not None and _wide_gemm_path(graph, d_in, d_out):
+        return _native.spmm_wide_two_pass(X, W, bias, graph.scatter_plan(kind, 8), graph.csr(kind), relu=relu)
     if max(d_in, d_out) <= 64 or d_in % 16 or d_out % 16 or max(d_in, d_out) > _BLOCKED_MAX or \
             os.environ.get("RGCN_PAD16", "1") == "0":
         return _native.spmm(X, W, bias, plan_of(d_out), relu=relu and max(d_in, d_out) <= 64)
@@ -108,6 +118,10 @@ def _fused_backward(X, W, g, graph):
 
 
 def _weight_gradient(X, W, g, graph):
+    if _wide_gemm_path(graph, W.shape[1], W.shape[2]):
+        # (the same 128-slot work items as the row GEMM: longer items flush fewer partial blocks but leave too few
+        # workgroups on small per-call graphs -- measured 0.104 -> 0.184 ms at FB15k-237 shape -- and cost a second plan)
+        return _native.wgrad_wide(X, g, graph.scatter_plan("fwd", 8), W.shape[0])
     fp = graph.fwd_plan(min(W.shape[2], 64))
     # tile-major walk (one random gather per message) unless a (tile, relation) run is so long that
     # one wave would serialise it (hub nodes): then the relation-major kernel with bounded work items
@@ -121,15 +135,15 @@ def _weight_gradient(X, W, g, graph):
 class _RelationalMP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, W, bias, graph, relu=False):
-        X, W, bias, ctx.dims = _pad_blocks(X, W, bias)
+        X, W, bias, ctx.dims = _pad_blocks(X, W, bias, graph)
         X = X.contiguous()
         W = W.contiguous()
         b = None if bias is None else bias.contiguous()
-        fused_relu = relu and max(W.shape[1], W.shape[2]) <= 64     # the kernels' own epilogue (RGCN_F_RELU)
+        fused_relu = relu and (max(W.shape[1], W.shape[2]) <= 64 or _wide_gemm_path(graph, W.shape[1], W.shape[2]))   # kernel epilogues
         if _sparse_buckets(graph, W):
             out = _native.spmm_two_pass(X, W, b, graph.scatter_plan("fwd"), graph.csr("fwd"), relu=fused_relu)
         else:
-            out = _spmm_blocked(X, W, b, graph.fwd_plan, relu=fused_relu)
+            out = _spmm_blocked(X, W, b, graph.fwd_plan, relu=fused_relu, graph=graph, kind="fwd")
         if relu and not fused_relu:
             out = torch.relu_(out)
         ctx.graph = graph
@@ -167,7 +181,7 @@ class _RelationalMP(torch.autograd.Function):
                 if sparse:
                     dX = _native.spmm_two_pass(g, Wt, None, graph.scatter_plan("bwd"), graph.csr("bwd"))
                 else:
-                    dX = _spmm_blocked(g, Wt, None, graph.bwd_plan)
+                    dX = _spmm_blocked(g, Wt, None, graph.bwd_plan, graph=graph, kind="bwd")
             if ctx.needs_input_grad[1]:
                 dW = _weight_gradient(X, W, g, graph)
         if ctx.has_bias and ctx.needs_input_grad[2]:

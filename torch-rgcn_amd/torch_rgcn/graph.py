@@ -133,12 +133,13 @@ class RelGraph:
             self._plans["maxdeg"] = m
         return self._plans["maxdeg"]
 
-    def scatter_plan(self, kind):
-        """relation-major plan whose slots know their position in the destination-major CSR (sparse-bucket path)"""
-        key = ("scatter", kind)
+    def scatter_plan(self, kind, item_chunks=64):
+        """relation-major plan whose slots know their position in the destination-major CSR (sparse-bucket path; with
+        item_chunks = 8 its work items are the 128-row blocks of the wide-layer gather-GEMM)"""
+        key = ("scatter", kind, item_chunks)
         if key not in self._plans:
             if self._dev is None:
-                raise RuntimeError("the sparse-bucket path needs the device-side graph build")
+                raise RuntimeError("the relation-major two-pass paths need the device-side graph build")
             s, p, o, val, alive = self._dev
             dst, src = (s, o) if kind == "fwd" else (o, s)
             csr = self.csr(kind)
@@ -146,7 +147,7 @@ class RelGraph:
                 csr.n_messages = int(csr.rowptr[-1].item())
             N, R = self.num_nodes, self.num_rels
             self._plans[key] = _native.build_plan_device(dst, src, p, val, alive, N, N, R, max(N, 1), self.num_messages,
-                                                         64, aux=csr.msg_slot)
+                                                         item_chunks, aux=csr.msg_slot)
         return self._plans[key]
 
     def selfloop_edges(self, self_rel):
