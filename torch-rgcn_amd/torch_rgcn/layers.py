@@ -146,9 +146,15 @@ def _block_messages(features, blocks):
 
 
 def _wide_block(weight_decomp, in_dim, out_dim, num_relations, num_nodes):
+    """Block-diagonal weights above width 16: which route?  Small graphs: transform first (`_block_messages`: the
+    R x N x d_out message table, 1/nb of a dense product) and aggregate with the featureless gather kernels.  The table grows
+    with R N: at FB15k-237 shape (R = 475, N = 14,545, d = 500) it is 13.8 GB (27.9 GB peak with its gradient) and the
+    step takes 56 ms -- there the blocks are expanded to dense R x d x d weights and the relation-grouped gather-GEMM of
+    csrc/rgcn_gemm.hip does the per-message products on the matrix cores: 6.3 ms, 1.7 GB (tools/block_probe.py)."""
     if weight_decomp != 'block' or (in_dim <= 16 and out_dim <= 16) or os.environ.get("RGCN_BLOCK_TABLE", "1") == "0":
         return False
-    return num_relations * num_nodes * out_dim * 4 <= 64 << 30        # the table (and its gradient) must fit comfortably
+    limit_mb = float(os.environ.get("RGCN_BLOCK_TABLE_MAX_MB", "256"))
+    return num_relations * num_nodes * out_dim * 4 <= limit_mb * (1 << 20)
 
 
 class RelationalGraphConvolutionNC(_RGCBase):
