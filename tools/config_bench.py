@@ -183,6 +183,27 @@ def line_node_classifier(tag, N, R0, E, nhid, ncls, decomp, labelled, baseline_c
         opt.step()
     ms = timed(step, iters=10, warm=3)
     name, kms, per_step, allk = _dominant(step)
+    # the same step as a hipGraph replay (static graph, static shapes: these small graphs are launch-bound in eager mode)
+    ms_graph = None
+    try:
+        opt_g = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
+
+        def gstep():
+            opt_g.zero_grad(set_to_none=False)
+            torch.nn.functional.cross_entropy(model()[idx], y).backward()
+            opt_g.step()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                gstep()
+        torch.cuda.current_stream().wait_stream(side)
+        hg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(hg):
+            gstep()
+        ms_graph = round(timed(hg.replay, iters=10, warm=3), 3)
+    except Exception as exc:  # noqa: BLE001
+        ms_graph = f"capture failed: {type(exc).__name__}: {exc}"[:200]
     M = 2 * E + N
     B = (decomp or {}).get("num_bases")
     # featureless first layer: one weight-table row (basis: the node's B x d block) per message + index, one output row per node
@@ -192,6 +213,7 @@ def line_node_classifier(tag, N, R0, E, nhid, ncls, decomp, labelled, baseline_c
            "fbasis_bwd": M * (nhid * 4 + 8) + 2 * N * row}.get(name, fwd)
     return {"baseline_config": baseline_config, "workload": tag, "N": N, "R0": R0, "E": E, "params": sum(p.numel() for p in model.parameters()),
             "step": "NodeClassifier forward + cross-entropy + backward + Adam", "ms_per_step": round(ms, 3),
+            "ms_per_step_hipgraph_replay": ms_graph,
             "edges_per_s": round(E / ms * 1e3), "kernels_ms": allk,
             "roofline": _roof(name, kms, alg, "messages x (weight-table row + 8 B index) + node rows written")}
 

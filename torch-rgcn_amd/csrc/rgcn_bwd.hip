@@ -372,7 +372,7 @@ extern "C" int rgcn_bwd_fused_f32(const float *G, const float *X, const float *W
   static const int DSEL = getenv("RGCN_BWD_D") ? atoi(getenv("RGCN_BWD_D")) : 4;
   const int Dv = DSEL >= 4 ? 4 : (DSEL >= 2 ? 2 : 1);
   const size_t lds = ((size_t)4 * tile_rows * 16 + 4 * BW_SCR + 4 * Dv * 256) * sizeof(float);
-  if (lds > 160 * 1024) { rgcn_set_error("bwd_fused: LDS tile too large"); return RGCN_EINVAL; }
+  if (lds > 64 * 1024) { rgcn_set_error("bwd_fused: tile_rows = %d needs %zu bytes of LDS per workgroup (limit 64 KiB)", tile_rows, lds); return RGCN_EUNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
   const int n_blocks = (int)((n_tiles + 3) / 4);
   static const int USEL = getenv("RGCN_BWD_U") ? atoi(getenv("RGCN_BWD_U")) : 4;

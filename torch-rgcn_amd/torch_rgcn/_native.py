@@ -718,6 +718,16 @@ def spmm_slabs(X, W, bias, plan, n_slabs, after_slab):
     return out
 
 
+def _slot_perm(p, n_msg, dev):
+    """destination-major position -> slot of the relation-major plan `p` (cached on the plan)"""
+    if getattr(p, "_inv", None) is None:
+        live = p.dst >= 0
+        inv = torch.zeros(max(n_msg, 1), dtype=torch.int32, device=dev)
+        inv[p.aux[live].long()] = torch.arange(p.dst.shape[0], device=dev, dtype=torch.int32)[live]
+        p._inv = inv
+    return p._inv
+
+
 def spmm_two_pass(X, W, bias, scatter_plan, csr, relu=False):
     """sparse-bucket path (d = 16): relation-major transform, then per-destination sum.  Default: pass 1 writes its rows
     in slot order (sequential, full lines) and pass 2 gathers them through a permutation; RGCN_TWOPASS=scatter: pass 1
@@ -729,11 +739,7 @@ def spmm_two_pass(X, W, bias, scatter_plan, csr, relu=False):
     out = torch.empty((csr.n_rows, 16), device=X.device, dtype=torch.float32)
     gather = os.environ.get("RGCN_TWOPASS", "gather") == "gather"
     if gather:
-        if getattr(p, "_inv", None) is None:     # destination-major position -> slot of the relation-major plan
-            live = p.dst >= 0
-            inv = torch.zeros(max(n_msg, 1), dtype=torch.int32, device=X.device)
-            inv[p.aux[live].long()] = torch.arange(p.dst.shape[0], device=X.device, dtype=torch.int32)[live]
-            p._inv = inv
+        _slot_perm(p, n_msg, X.device)
         Y = torch.empty((max(p.dst.shape[0], 1), 16), device=X.device, dtype=torch.float32)
     else:
         Y = torch.empty((max(n_msg, 1), 16), device=X.device, dtype=torch.float32)
@@ -750,16 +756,6 @@ def spmm_two_pass(X, W, bias, scatter_plan, csr, relu=False):
             _check(lib().rgcn_segment_sum_f32(_dp(Y), _dp(csr.rowptr), _dp(bias), _dp(out), c_i64(csr.n_rows), c_i32(16),
                                               c_i32(F_RELU if relu else 0), _stream(X.device)), "segment_sum")
     return out
-
-
-def _slot_perm(p, n_msg, dev):
-    """destination-major position -> slot of the relation-major plan `p` (cached on the plan)"""
-    if getattr(p, "_inv", None) is None:
-        live = p.dst >= 0
-        inv = torch.zeros(max(n_msg, 1), dtype=torch.int32, device=dev)
-        inv[p.aux[live].long()] = torch.arange(p.dst.shape[0], device=dev, dtype=torch.int32)[live]
-        p._inv = inv
-    return p._inv
 
 
 def spmm_wide_two_pass(X, W, bias, scatter_plan, csr, relu=False):
@@ -802,11 +798,7 @@ def bwd_two_pass_fused(G, X, W, scatter_plan, csr):
     dev = G.device
     Wtp = pack_w16t(W)
     n_msg = int(csr.rowptr[-1].item()) if csr.n_messages is None else csr.n_messages
-    if getattr(p, "_inv", None) is None:     # destination-major position -> slot of the relation-major plan
-        live = p.dst >= 0
-        inv = torch.zeros(max(n_msg, 1), dtype=torch.int32, device=dev)
-        inv[p.aux[live].long()] = torch.arange(p.dst.shape[0], device=dev, dtype=torch.int32)[live]
-        p._inv = inv
+    _slot_perm(p, n_msg, dev)
     Y = torch.empty((max(p.dst.shape[0], 1), 16), device=dev, dtype=torch.float32)
     dW = torch.empty_like(W)
     dX = torch.empty((csr.n_rows, 16), device=dev, dtype=torch.float32)
@@ -862,7 +854,7 @@ def pack_w16t(W):
 def bwd_fused_ok(plan):
     """the fused backward kernel walks the transposed plan tile by tile: packed slots, run pointers, no hub-split tiles"""
     return (plan.pack is not None and plan.run_ptr is not None and plan.n_split == 0 and plan.n_units == plan.n_tiles
-            and plan.tile_rows <= 255 and plan.n_tiles > 0)
+            and plan.tile_rows <= 160 and plan.n_tiles > 0)      # 160 rows: dX tiles + scratch + staging within 64 KiB of LDS
 
 
 def bwd_fused(G, X, W, plan, atomic=False):
