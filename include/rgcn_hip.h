@@ -247,6 +247,7 @@ RGCN_API int rgcn_wgrad_tiled_f32(const float *X, const float *G, float *dW, con
  *                by two small kernels (bit-reproducible); with RGCN_F_DW_ATOMIC the partials are added to dW with
  *                fp32 atomics instead and scratch may be NULL. */
 #define RGCN_F_DW_ATOMIC 4
+#define RGCN_F_TRANSPOSE_W 8   /* rgcn_block_spmm_f32: multiply by the transposed blocks */
 RGCN_API int64_t rgcn_bwd_fused_scratch_floats(int64_t n_tiles, int32_t R);
 RGCN_API int rgcn_bwd_fused_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW,
                                 float *scratch, const int32_t *p_pack, const int32_t *chunk_rel,
@@ -270,6 +271,43 @@ RGCN_API int rgcn_featureless_fwd_f32(const float *table, const float *bias, flo
                                       const int32_t *p_dst, const float *p_val, const int32_t *chunk_rel,
                                       const int32_t *units, int64_t n_units, int64_t n_split, int32_t tile_rows,
                                       int64_t n_dst, int64_t n_src, int32_t R, int32_t d_out, void *stream);
+
+/* Block-diagonal weights (decomposition {type: block}): blocks [n_rel_blocks][nb][bi][bo], X [n_src][nb*bi] ->
+ * out[row, b, :] = bias + sum over the row's messages of val * X[src, b, :] . blocks[rel, b].  Replaces
+ * block_diag(self.blocks) (layers.py:243-244, :520-527: dense R x d_in x d_out) + the dense message passing (:297-300,
+ * :536-541): 1/nb of the flops, no expanded weights.  Destination-major CSR as for rgcn_diag_spmm_f32; `units` may be NULL
+ * (one unit per row, n_units = n_rows: the sync-free LP build has no host-side row statistics) -- then `rowptr` is read.
+ * Messages with rel >= n_rel_blocks are skipped (the LP layer's dense self-loop relation, layers.py:514-527, is the
+ * caller's).  flags: RGCN_F_TRANSPOSE_W = multiply by the transposed blocks (X is [.][nb*bo], out [.][nb*bi]: the feature
+ * gradient on the transposed CSR), RGCN_F_RELU (not with shared units).  bi, bo <= 8 (rgcn_block_supported). */
+RGCN_API int rgcn_block_supported(int32_t bi, int32_t bo);
+RGCN_API int rgcn_block_spmm_f32(const float *X, const float *blocks, const float *bias, float *out, const int32_t *units,
+                                 const int32_t *rowptr, int64_t n_units, int64_t n_split, const int32_t *e_src,
+                                 const int32_t *e_rel, const float *e_val, int64_t n_rows, int32_t n_rel_blocks, int32_t nb,
+                                 int32_t bi, int32_t bo, int32_t flags, void *stream);
+
+/* Its weight gradient: dblocks[rel, b] = sum over the messages of rel of val * X[src, b, :]^T G[dst, b, :] over a
+ * RELATION-MAJOR plan (items as for rgcn_rel_wgrad_f32); dblocks is zeroed first, fp32 atomics across items. */
+RGCN_API int rgcn_block_wgrad_f32(const float *X, const float *G, float *dblocks, const int32_t *p_src, const int32_t *p_dst,
+                                  const float *p_val, const int32_t *chunk_rel, const int32_t *items, int64_t n_items,
+                                  int32_t n_rel_blocks, int32_t nb, int32_t bi, int32_t bo, void *stream);
+
+/* Diagonal-weight layer (diag_weight_matrix=True, the first layer of the reference's EmbeddingNodeClassifier,
+ * models.py:272-280): out[row, :] = bias + sum over the row's messages of val * X[src, :] * w[rel, :].  Replaces
+ * einsum('ij,kj->kij') + reshape + torch.mm(adj, fw) of layers.py:289-292 (which materialises the [R*N, d] product) --
+ * d multiplies per message, nothing materialised.  Destination-major CSR: e_src / e_rel / e_val are the entries,
+ * `units` = int32 [n_units][4] = {row, first entry, end entry, flags (RGCN_U_SHARED | RGCN_U_FIRST)}, one per row with
+ * long rows cut into pieces (n_split = number of shared units; > 0 zeroes `out` first).  On the transposed CSR with G in
+ * place of X it is the feature gradient of the same layer.  Any d. */
+RGCN_API int rgcn_diag_spmm_f32(const float *X, const float *w, const float *bias, float *out, const int32_t *units,
+                                int64_t n_units, int64_t n_split, const int32_t *e_src, const int32_t *e_rel,
+                                const float *e_val, int64_t n_rows, int32_t R, int32_t d, void *stream);
+
+/* Its weight gradient: dw[rel, j] = sum_{slots of rel} val * X[src, j] * G[dst, j] over a RELATION-MAJOR plan (items =
+ * chunk ranges of one relation, as for rgcn_rel_wgrad_f32); dw ([R, d]) is zeroed first, fp32 atomics across items. */
+RGCN_API int rgcn_diag_wgrad_f32(const float *X, const float *G, float *dw, const int32_t *p_src, const int32_t *p_dst,
+                                 const float *p_val, const int32_t *chunk_rel, const int32_t *items, int64_t n_items,
+                                 int32_t R, int32_t d, void *stream);
 
 /* Its weight gradient: dtable[rel*n_src + src, :] += val * G[dst,:]; dtable
  * ([R*n_src, d_out]) is zeroed first. */

@@ -22,16 +22,20 @@ MUTAG = dict(N=23_644, R0=23, E=74_227)
 
 
 @pytest.mark.parametrize("vertical", [False, True])
-@pytest.mark.parametrize("sparse_path", ["1", "0"])
+@pytest.mark.parametrize("sparse_path", ["block", "1", "0"])
 def test_am_tenth_scale_block_diagonal_layer_vs_oracle(monkeypatch, sparse_path, vertical):
-    """1/10 of AM, block-diagonal nb = 4, d = 16, both stackings, both the two-pass (sparse (tile, relation) buckets:
-    267 relations) and the tile kernels: out / dX / dblocks / db against the oracle"""
+    """1/10 of AM, block-diagonal nb = 4, d = 16, both stackings: the block kernels (RGCN_BLOCK_PATH=2: 4 x 4 blocks applied
+    as they are; at width 16 not the default), and with the blocks expanded to dense 16 x 16 weights both the two-pass (sparse (tile, relation) buckets: 267
+    relations) and the tile kernels: out / dX / dblocks / db against the oracle"""
     from torch_rgcn import _native
-    monkeypatch.setenv("RGCN_SPARSE_PATH", sparse_path)
+    monkeypatch.setenv("RGCN_BLOCK_PATH", "2" if sparse_path == "block" else "0")
+    if sparse_path != "block":
+        monkeypatch.setenv("RGCN_SPARSE_PATH", sparse_path)
     _native.profile_start()
     run_layer_vs_oracle(N=166_676, R0=133, E=598_832, d_in=16, d_out=16, mode="block", num_blocks=4, vertical=vertical,
                         seed=301 + int(vertical))
     prof = _native.profile_stop()
+    assert ("block_spmm" in prof and "block_wgrad" in prof) == (sparse_path == "block")
     assert ("spmm_scatter" in prof) == (sparse_path == "1")
     # backward: relation-major fused pass (dX rows + dW from one walk) on the sparse path, tile-walk fused kernel otherwise
     assert ("bwd_scatter_dw" in prof) == (sparse_path == "1") and ("bwd_fused" in prof) == (sparse_path == "0")

@@ -235,7 +235,8 @@ def line_featured(tag, N, R0, E, d, decomposition, seed, baseline_config):
     M = 2 * E + N
     alg = {"spmm": M * (4 * d + 8) + N * 4 * d, "spmm_scatter": M * (4 * d + 8) + M * 4 * d, "segment_sum": M * (4 * d + 4) + N * 4 * d,
            "bwd_fused": M * (4 * d + 8) + 2 * N * 4 * d, "wgrad": M * (4 * d + 8) + N * 4 * d,
-           "bwd_scatter_dw": M * (2 * 4 * d + 12) + M * 4 * d}.get(name, M * (4 * d + 8) + N * 4 * d)
+           "bwd_scatter_dw": M * (2 * 4 * d + 12) + M * 4 * d, "block_spmm": M * (4 * d + 12) + N * 4 * d,
+           "block_wgrad": M * (2 * 4 * d + 12)}.get(name, M * (4 * d + 8) + N * 4 * d)
     return {"baseline_config": baseline_config, "workload": tag, "N": N, "R0": R0, "E": E, "step": "2 featured layers, forward + backward",
             "ms_per_step": round(ms, 3), "edges_per_s": round(E / ms * 1e3), "kernels_ms": allk,
             "roofline": _roof(name, kms, alg, "SURVEY 8(d): M (4 d + 8) + N 4 d (two-pass: the transformed rows once more; bwd_scatter_dw: two gathered rows + indices + one written row per message)")}

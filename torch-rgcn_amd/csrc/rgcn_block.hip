@@ -1,0 +1,277 @@
+// Block-diagonal per-relation weights (decomposition {type: block}; reference layers.py:176-183 parameters, :243-244 /
+// :520-527 `block_diag(self.blocks)` expanded to dense R x d_in x d_out, then the dense message passing).
+//
+// Here the blocks are never expanded: a message is a row of nb segments, each multiplied by its own bi x bo block --
+// 1/nb of the flops of the dense product and no R x d x d tensor.
+//
+//   block_csr_kernel   out[row, b, :] = bias + sum over the row's messages of val * X[src, b, :] . W[rel, b]      (forward; with
+//                      the blocks read transposed and the transposed CSR: the feature gradient)
+//   block_wgrad_kernel dW[rel, b] = sum over the messages of rel of val * X[src, b, :]^T G[dst, b, :]           (relation-major)
+//
+// Both are gather-bound (HBM): per message d_in * 4 bytes of features + 12 bytes of indices, the blocks (R nb bi bo floats:
+// 68 KB for AM at width 16, 4.75 MB for FB15k-237 at width 500) come from L2.  Destination-major CSR rather than the
+// (tile, relation) buckets of the dense kernels: nothing is shared between the messages of a bucket here, and with
+// hundreds of relations the buckets of a small tile are nearly all padding.
+//
+// Lane layout (both kernels): `lpm` lanes per message, one block each (lpm = the number of blocks rounded up to a power of
+// two, at most 64; wider rows loop); the remaining 64 / lpm (forward: lr / lpm within a unit) lane groups hold different
+// messages and are summed with wave shuffles at the end.  gfx950 only.
+#include <algorithm>
+
+#include "rgcn_device.h"
+
+namespace {
+
+constexpr int MAXB = 8;      // runtime-sized blocks up to 8 x 8 (larger blocks: the gather-GEMM of rgcn_gemm.hip is the better tool)
+
+// BI_ x BO_ = the block as stored ([bi][bo] row-major); TR: multiply by the transposed block (input width bo, output bi).
+// BI_ = 0: sizes at run time (bi, bo <= MAXB).
+template <int BI_, int BO_, bool TR>
+__global__ __launch_bounds__(WG) void block_csr_kernel(
+    const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ out,
+    const int4 *__restrict__ units, const int *__restrict__ rowptr, long long n_units, const int *__restrict__ e_src,
+    const int *__restrict__ e_rel, const float *__restrict__ e_val, int nb, int bi_rt, int bo_rt, int n_rel_blocks, int lpm,
+    int lr, int relu) {
+  constexpr bool FIXED = BI_ > 0;
+  constexpr int CAP_IN = FIXED ? (TR ? BO_ : BI_) : MAXB, CAP_OUT = FIXED ? (TR ? BI_ : BO_) : MAXB;
+  const int bi = FIXED ? BI_ : bi_rt, bo = FIXED ? BO_ : bo_rt;
+  const int n_in = TR ? bo : bi, n_out = TR ? bi : bo;          // floats per block on the input / output side
+  const long long u = ((long long)blockIdx.x * WG + threadIdx.x) / lr;
+  const int sub = threadIdx.x % lr, g = sub / lpm, j = sub % lpm, gpr = lr / lpm;
+  const bool on = u < n_units;
+  int4 unit = {0, 0, 0, 0};
+  if (on) {
+    if (units) unit = units[u];
+    else unit = int4{(int)u, rowptr[u], rowptr[u + 1], 0};
+  }
+  const int e1 = unit.z;
+  const bool shared = unit.w & RGCN_U_SHARED;
+  const bool add_bias = bias && (!shared || (unit.w & RGCN_U_FIRST));
+  const size_t d_in = (size_t)nb * n_in, d_out = (size_t)nb * n_out;
+  const bool vec_in = FIXED && (CAP_IN % 4 == 0), vec_w = FIXED && ((BI_ * BO_) % 4 == 0);
+  for (int b0 = 0; b0 < nb; b0 += lpm) {
+    const int b = b0 + j;
+    float acc[CAP_OUT];
+#pragma unroll
+    for (int o = 0; o < CAP_OUT; ++o) acc[o] = 0.f;
+    if (b < nb)
+      for (int e = unit.y + g; e < e1; e += gpr) {
+        const int rel = e_rel[e];
+        const float v = rel < n_rel_blocks ? e_val[e] : 0.f;        // relations past the block table (LP self loops): not ours
+        if (v == 0.f) continue;
+        const float *xr = X + (size_t)e_src[e] * d_in + (size_t)b * n_in;
+        const float *wr = W + ((size_t)rel * nb + b) * (size_t)(bi * bo);
+        float x[CAP_IN], w[FIXED ? BI_ * BO_ : MAXB * MAXB];
+        if (vec_in) {
+#pragma unroll
+          for (int i = 0; i < CAP_IN / 4; ++i) {
+            const f32x4 t = reinterpret_cast<const f32x4 *>(xr)[i];
+            x[4 * i] = t[0] * v; x[4 * i + 1] = t[1] * v; x[4 * i + 2] = t[2] * v; x[4 * i + 3] = t[3] * v;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < CAP_IN; ++i) x[i] = (FIXED || i < n_in) ? xr[i] * v : 0.f;
+        }
+        if (vec_w) {
+#pragma unroll
+          for (int i = 0; i < (FIXED ? BI_ * BO_ : 4) / 4; ++i) {
+            const f32x4 t = reinterpret_cast<const f32x4 *>(wr)[i];
+            w[4 * i] = t[0]; w[4 * i + 1] = t[1]; w[4 * i + 2] = t[2]; w[4 * i + 3] = t[3];
+          }
+        } else if (FIXED) {
+#pragma unroll
+          for (int i = 0; i < BI_ * BO_; ++i) w[i] = wr[i];
+        }
+        if (FIXED) {
+#pragma unroll
+          for (int o = 0; o < CAP_OUT; ++o)
+#pragma unroll
+            for (int i = 0; i < CAP_IN; ++i) acc[o] = fmaf(x[i], TR ? w[o * BO_ + i] : w[i * BO_ + o], acc[o]);
+        } else {
+#pragma unroll
+          for (int o = 0; o < MAXB; ++o)
+            if (o < n_out) {
+#pragma unroll
+              for (int i = 0; i < MAXB; ++i)
+                if (i < n_in) acc[o] = fmaf(x[i], TR ? wr[o * bo + i] : wr[i * bo + o], acc[o]);
+            }
+        }
+      }
+    for (int s = lpm; s < lr; s *= 2) {          // sum over the message groups of the unit (same trip count in every lane)
+#pragma unroll
+      for (int o = 0; o < CAP_OUT; ++o) acc[o] += __shfl_xor(acc[o], s, 64);
+    }
+    if (on && g == 0 && b < nb) {
+      float *orow = out + (size_t)unit.x * d_out + (size_t)b * n_out;
+#pragma unroll
+      for (int o = 0; o < CAP_OUT; ++o)
+        if (FIXED || o < n_out) {
+          float r = acc[o] + (add_bias ? bias[(size_t)b * n_out + o] : 0.f);
+          if (shared) {
+            atomicAdd(orow + o, r);
+          } else {
+            if (relu) r = fmaxf(r, 0.f);
+            orow[o] = r;
+          }
+        }
+    }
+  }
+}
+
+// One wave per work item (a chunk range of ONE relation in the relation-major plan; pads carry val = 0).
+template <int BI_, int BO_>
+__global__ __launch_bounds__(WG) void block_wgrad_kernel(
+    const float *__restrict__ X, const float *__restrict__ G, float *__restrict__ dW, const int *__restrict__ p_src,
+    const int *__restrict__ p_dst, const float *__restrict__ p_val, const int *__restrict__ chunk_rel,
+    const int2 *__restrict__ items, long long n_items, int nb, int bi_rt, int bo_rt, int n_rel_blocks, int lpm) {
+  constexpr bool FIXED = BI_ > 0;
+  constexpr int CAP_I = FIXED ? BI_ : MAXB, CAP_O = FIXED ? BO_ : MAXB;
+  const int bi = FIXED ? BI_ : bi_rt, bo = FIXED ? BO_ : bo_rt;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long it = (long long)blockIdx.x * (WG / 64) + wave;
+  if (it >= n_items) return;
+  const int2 range = items[it];
+  if (range.x >= range.y) return;
+  const int rel = chunk_rel[range.x];
+  if (rel >= n_rel_blocks) return;
+  const int g = lane / lpm, j = lane % lpm, groups = 64 / lpm;
+  const size_t d_in = (size_t)nb * bi, d_out = (size_t)nb * bo;
+  const int s0 = range.x * RGCN_CHUNK, s1 = range.y * RGCN_CHUNK;
+  const bool vec_i = FIXED && (BI_ % 4 == 0), vec_o = FIXED && (BO_ % 4 == 0);
+  for (int b0 = 0; b0 < nb; b0 += lpm) {
+    const int b = b0 + j;
+    float acc[CAP_I][CAP_O];
+#pragma unroll
+    for (int i = 0; i < CAP_I; ++i)
+#pragma unroll
+      for (int o = 0; o < CAP_O; ++o) acc[i][o] = 0.f;
+    if (b < nb)
+      for (int s = s0 + g; s < s1; s += groups) {
+        const float v = p_val[s];
+        if (v == 0.f) continue;
+        const float *xr = X + (size_t)p_src[s] * d_in + (size_t)b * bi, *gr = G + (size_t)p_dst[s] * d_out + (size_t)b * bo;
+        float x[CAP_I], gg[CAP_O];
+        if (vec_i) {
+#pragma unroll
+          for (int i = 0; i < CAP_I / 4; ++i) {
+            const f32x4 t = reinterpret_cast<const f32x4 *>(xr)[i];
+            x[4 * i] = t[0] * v; x[4 * i + 1] = t[1] * v; x[4 * i + 2] = t[2] * v; x[4 * i + 3] = t[3] * v;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < CAP_I; ++i) x[i] = (FIXED || i < bi) ? xr[i] * v : 0.f;
+        }
+        if (vec_o) {
+#pragma unroll
+          for (int o = 0; o < CAP_O / 4; ++o) {
+            const f32x4 t = reinterpret_cast<const f32x4 *>(gr)[o];
+            gg[4 * o] = t[0]; gg[4 * o + 1] = t[1]; gg[4 * o + 2] = t[2]; gg[4 * o + 3] = t[3];
+          }
+        } else {
+#pragma unroll
+          for (int o = 0; o < CAP_O; ++o) gg[o] = (FIXED || o < bo) ? gr[o] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < CAP_I; ++i)
+#pragma unroll
+          for (int o = 0; o < CAP_O; ++o) acc[i][o] = fmaf(x[i], gg[o], acc[i][o]);
+      }
+    for (int s = lpm; s < 64; s *= 2) {
+#pragma unroll
+      for (int i = 0; i < CAP_I; ++i)
+#pragma unroll
+        for (int o = 0; o < CAP_O; ++o) acc[i][o] += __shfl_xor(acc[i][o], s, 64);
+    }
+    if (g == 0 && b < nb) {
+      float *w = dW + ((size_t)rel * nb + b) * (size_t)(bi * bo);
+#pragma unroll
+      for (int i = 0; i < CAP_I; ++i)
+#pragma unroll
+        for (int o = 0; o < CAP_O; ++o)
+          if ((FIXED || (i < bi && o < bo)) && acc[i][o] != 0.f) atomicAdd(w + i * bo + o, acc[i][o]);
+    }
+  }
+}
+
+int lanes_per_message(int nb) {
+  int lpm = 1;
+  while (lpm < 64 && lpm < nb) lpm *= 2;
+  return lpm;
+}
+
+}  // namespace
+
+extern "C" int rgcn_block_supported(int32_t bi, int32_t bo) { return bi >= 1 && bo >= 1 && bi <= MAXB && bo <= MAXB; }
+
+extern "C" int rgcn_block_spmm_f32(const float *X, const float *blocks, const float *bias, float *out, const int32_t *units,
+                                   const int32_t *rowptr, int64_t n_units, int64_t n_split, const int32_t *e_src,
+                                   const int32_t *e_rel, const float *e_val, int64_t n_rows, int32_t n_rel_blocks, int32_t nb,
+                                   int32_t bi, int32_t bo, int32_t flags, void *stream) {
+  if (!X || !blocks || !out || n_rows < 0 || n_units < 0 || n_split < 0 || nb <= 0 || n_rel_blocks < 0 || (!units && !rowptr) ||
+      (n_units && (!e_src || !e_rel || !e_val))) {
+    rgcn_set_error("block_spmm: bad argument");
+    return RGCN_EINVAL;
+  }
+  if (!rgcn_block_supported(bi, bo)) {
+    rgcn_set_error("block_spmm: blocks of %d x %d (limit %d x %d)", bi, bo, MAXB, MAXB);
+    return RGCN_EUNSUPPORTED;
+  }
+  if (!units && n_units != n_rows) { rgcn_set_error("block_spmm: without units, one unit per row"); return RGCN_EINVAL; }
+  const bool tr = flags & RGCN_F_TRANSPOSE_W, relu = flags & RGCN_F_RELU;
+  if (relu && n_split) { rgcn_set_error("block_spmm: RGCN_F_RELU with shared units"); return RGCN_EINVAL; }
+  if (n_rows == 0 || n_units == 0) return RGCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int n_out = tr ? bi : bo;
+  if (n_split) HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_rows * nb * n_out * sizeof(float), st));
+  const int lpm = lanes_per_message(nb);
+  const int lr = std::min(64, std::max(16, 2 * lpm));
+  const int upw = WG / lr;
+  const dim3 grid((unsigned)((n_units + upw - 1) / upw)), block(WG);
+  const int4 *un = reinterpret_cast<const int4 *>(units);
+#define RGCN_BLOCK_LAUNCH(BI, BO)                                                                                              \
+  do {                                                                                                                         \
+    if (tr) hipLaunchKernelGGL((block_csr_kernel<BI, BO, true>), grid, block, 0, st, X, blocks, bias, out, un, rowptr,         \
+                               (long long)n_units, e_src, e_rel, e_val, nb, bi, bo, n_rel_blocks, lpm, lr, (int)relu);         \
+    else hipLaunchKernelGGL((block_csr_kernel<BI, BO, false>), grid, block, 0, st, X, blocks, bias, out, un, rowptr,           \
+                            (long long)n_units, e_src, e_rel, e_val, nb, bi, bo, n_rel_blocks, lpm, lr, (int)relu);            \
+  } while (0)
+  if (bi == 4 && bo == 4) RGCN_BLOCK_LAUNCH(4, 4);
+  else if (bi == 5 && bo == 5) RGCN_BLOCK_LAUNCH(5, 5);
+  else if (bi == 8 && bo == 8) RGCN_BLOCK_LAUNCH(8, 8);
+  else if (bi == 2 && bo == 2) RGCN_BLOCK_LAUNCH(2, 2);
+  else RGCN_BLOCK_LAUNCH(0, 0);
+#undef RGCN_BLOCK_LAUNCH
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_block_wgrad_f32(const float *X, const float *G, float *dblocks, const int32_t *p_src, const int32_t *p_dst,
+                                    const float *p_val, const int32_t *chunk_rel, const int32_t *items, int64_t n_items,
+                                    int32_t n_rel_blocks, int32_t nb, int32_t bi, int32_t bo, void *stream) {
+  if (!X || !G || !dblocks || n_items < 0 || nb <= 0 || n_rel_blocks < 0 ||
+      (n_items && (!items || !p_src || !p_dst || !p_val || !chunk_rel))) {
+    rgcn_set_error("block_wgrad: bad argument");
+    return RGCN_EINVAL;
+  }
+  if (!rgcn_block_supported(bi, bo)) {
+    rgcn_set_error("block_wgrad: blocks of %d x %d (limit %d x %d)", bi, bo, MAXB, MAXB);
+    return RGCN_EUNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (n_rel_blocks) HIP_TRY(hipMemsetAsync(dblocks, 0, (size_t)n_rel_blocks * nb * bi * bo * sizeof(float), st));
+  if (n_items == 0 || n_rel_blocks == 0) return RGCN_OK;
+  const int lpm = lanes_per_message(nb);
+  const dim3 grid((unsigned)((n_items + WG / 64 - 1) / (WG / 64))), block(WG);
+  const int2 *its = reinterpret_cast<const int2 *>(items);
+#define RGCN_BLOCK_LAUNCH(BI, BO)                                                                                              \
+  hipLaunchKernelGGL((block_wgrad_kernel<BI, BO>), grid, block, 0, st, X, G, dblocks, p_src, p_dst, p_val, chunk_rel, its,     \
+                     (long long)n_items, nb, bi, bo, n_rel_blocks, lpm)
+  if (bi == 4 && bo == 4) RGCN_BLOCK_LAUNCH(4, 4);
+  else if (bi == 5 && bo == 5) RGCN_BLOCK_LAUNCH(5, 5);
+  else if (bi == 8 && bo == 8) RGCN_BLOCK_LAUNCH(8, 8);
+  else if (bi == 2 && bo == 2) RGCN_BLOCK_LAUNCH(2, 2);
+  else RGCN_BLOCK_LAUNCH(0, 0);
+#undef RGCN_BLOCK_LAUNCH
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}

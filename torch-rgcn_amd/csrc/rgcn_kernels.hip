@@ -808,6 +808,115 @@ __global__ __launch_bounds__(WG) void featureless_wgrad_kernel(
   }
 }
 
+// Diagonal-weight layer (reference layers.py:289-292: einsum('ij,kj->kij') + torch.mm(adj, fw)): out[row, :] = bias + the sum over
+// the row's messages of val * X[src, :] * w[rel, :] -- d multiplies per message instead of the d x d product of the embedded
+// diagonal, and nothing materialised.  Destination-major CSR (no (tile, relation) buckets: with hundreds of relations and
+// wide rows those are nearly all padding); work units = rows, long rows cut into pieces (RGCN_U_SHARED: fp32 atomics into
+// the zeroed output).  `lr` lanes per unit = lr / lpm messages in flight x lpm lanes x float4; unrolled by two.
+__global__ __launch_bounds__(WG) void diag_csr_kernel(
+    const float *__restrict__ X, const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ out,
+    const int4 *__restrict__ units, long long n_units, const int *__restrict__ e_src, const int *__restrict__ e_rel,
+    const float *__restrict__ e_val, int d, int lpm, int lr) {
+  const long long u = ((long long)blockIdx.x * WG + threadIdx.x) / lr;
+  const int sub = threadIdx.x % lr, g = sub / lpm, j = sub % lpm, gpr = lr / lpm;
+  const bool on = u < n_units;
+  const int4 unit = on ? units[u] : int4{0, 0, 0, 0};
+  const int e1 = unit.z;
+  const bool vec = (d & 3) == 0;
+  const bool shared = unit.w & RGCN_U_SHARED;
+  const bool add_bias = bias && (!shared || (unit.w & RGCN_U_FIRST));
+  for (int f0 = 0; f0 < d; f0 += 4 * lpm) {
+    const int f = f0 + 4 * j;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    if (f < d)
+      for (int e = unit.y + g; e < e1; e += 2 * gpr) {
+        const int eb = e + gpr;
+        const bool hb = eb < e1;
+        const float va = e_val[e], vb = hb ? e_val[eb] : 0.f;
+        const float *xa = X + (size_t)e_src[e] * d + f, *wa = w + (size_t)e_rel[e] * d + f;
+        const float *xb = X + (size_t)e_src[hb ? eb : e] * d + f, *wb = w + (size_t)e_rel[hb ? eb : e] * d + f;
+        if (vec) {
+          const f32x4 x0 = *reinterpret_cast<const f32x4 *>(xa), x1 = *reinterpret_cast<const f32x4 *>(xb);
+          const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wa), w1 = *reinterpret_cast<const f32x4 *>(wb);
+          a += x0 * w0 * va;
+          b += x1 * w1 * vb;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (f + q < d) { a[q] += xa[q] * wa[q] * va; b[q] += xb[q] * wb[q] * vb; }
+        }
+      }
+    a += b;
+    for (int s = lpm; s < lr; s *= 2) {          // sum over the message groups of the unit (same trip count in every lane)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[q] += __shfl_xor(a[q], s, 64);
+    }
+    if (on && g == 0 && f < d) {
+      float *o = out + (size_t)unit.x * d + f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (add_bias && f + q < d) a[q] += bias[f + q];
+      if (vec && !shared) {
+        *reinterpret_cast<f32x4 *>(o) = a;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (f + q < d) {
+            if (shared) atomicAdd(o + q, a[q]);
+            else o[q] = a[q];
+          }
+      }
+    }
+  }
+}
+
+// Diagonal-weight layer, weight gradient: dw[r, j] = sum_{slots of r} val * X[src, j] * G[dst, j].  Relation-major plan; one
+// wave per work item (a chunk range of one relation): lane 16q+m accumulates columns jb+4q..+3 over slot m of every chunk
+// of the item, the 16 slot lanes are summed with DPP row shifts, one float4 of atomics per (item, 4 columns).
+__global__ __launch_bounds__(WG) void diag_wgrad_kernel(
+    const float *__restrict__ X, const float *__restrict__ G, float *__restrict__ dw, const int *__restrict__ p_src,
+    const int *__restrict__ p_dst, const float *__restrict__ p_val, const int *__restrict__ chunk_rel,
+    const int2 *__restrict__ items, long long n_items, int d) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long it = (long long)blockIdx.x * (WG / 64) + wave;
+  if (it >= n_items) return;
+  const int2 range = items[it];
+  if (range.x >= range.y) return;
+  const int rel = chunk_rel[range.x];
+  const int m = lane & 15, q = lane >> 4;
+  const bool vec4 = (d & 3) == 0;
+  for (int jb = 0; jb < d; jb += 16) {
+    const int col = jb + 4 * q;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int c = range.x; c < range.y; ++c) {
+      const int e = c * RGCN_CHUNK + m;
+      const float v = p_val[e];
+      if (v == 0.f || col >= d) continue;              // pads: val = 0, dst = -1
+      const float *x = X + (size_t)p_src[e] * d + col, *g = G + (size_t)p_dst[e] * d + col;
+      if (vec4) {
+        const float4 a = *reinterpret_cast<const float4 *>(x), b = *reinterpret_cast<const float4 *>(g);
+        acc[0] += v * a.x * b.x; acc[1] += v * a.y * b.y; acc[2] += v * a.z * b.z; acc[3] += v * a.w * b.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (col + i < d) acc[i] += v * x[i] * g[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                       // sum over the 16 slot lanes of the row
+      float a = acc[i];
+      a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 4, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 1, 64);
+      acc[i] = a;
+    }
+    if (m == 0 && col < d) {
+      float *o = dw + (size_t)rel * d + col;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (col + i < d && acc[i] != 0.f) atomicAdd(o + i, acc[i]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ column sum (bias gradient)
 // Two stages, no atomics, fixed summation order (bit-reproducible): stage A -- every workgroup streams its rows (float4 per
 // thread when d % 4 == 0) and leaves one partial row in `partial[block][d]`; stage B -- one workgroup sums the partial rows.
@@ -1251,6 +1360,43 @@ extern "C" int rgcn_featureless_fwd_f32(const float *table, const float *bias, f
                      (hipStream_t)stream, table, bias, out, p_src, p_dst, p_val, chunk_rel,
                      reinterpret_cast<const int4 *>(units), (int)n_tiles,
                      tile_rows, (int)n_dst, (long long)n_src, d_out, ldt);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_diag_spmm_f32(const float *X, const float *w, const float *bias, float *out, const int32_t *rowptr_units,
+                                  int64_t n_units, int64_t n_split, const int32_t *e_src, const int32_t *e_rel,
+                                  const float *e_val, int64_t n_rows, int32_t R, int32_t d, void *stream) {
+  (void)R;
+  if (!X || !w || !out || d <= 0 || n_rows < 0 || n_units < 0 || n_split < 0 ||
+      (n_units && (!rowptr_units || !e_src || !e_rel || !e_val))) {
+    rgcn_set_error("diag_spmm: bad argument");
+    return RGCN_EINVAL;
+  }
+  if (n_rows == 0 || n_units == 0) return RGCN_OK;
+  if (n_split) HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_rows * d * sizeof(float), (hipStream_t)stream));
+  int lpm = 1;                                  // lanes per message: float4 each, a power of two
+  while (lpm < 64 && 4 * lpm < d) lpm *= 2;
+  const int lr = std::min(64, std::max(16, 2 * lpm));   // lanes per unit: >= 2 messages of a row in flight
+  const int upw = WG / lr;                      // units per workgroup
+  const unsigned gx = (unsigned)((n_units + upw - 1) / upw);
+  hipLaunchKernelGGL(diag_csr_kernel, dim3(gx), dim3(WG), 0, (hipStream_t)stream, X, w, bias, out,
+                     reinterpret_cast<const int4 *>(rowptr_units), (long long)n_units, e_src, e_rel, e_val, d, lpm, lr);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_diag_wgrad_f32(const float *X, const float *G, float *dw, const int32_t *p_src, const int32_t *p_dst,
+                                   const float *p_val, const int32_t *chunk_rel, const int32_t *items, int64_t n_items,
+                                   int32_t R, int32_t d, void *stream) {
+  if (!X || !G || !dw || R <= 0 || d <= 0 || n_items < 0 || (n_items && (!items || !p_src || !p_dst || !p_val || !chunk_rel))) {
+    rgcn_set_error("diag_wgrad: bad argument");
+    return RGCN_EINVAL;
+  }
+  HIP_TRY(hipMemsetAsync(dw, 0, (size_t)R * d * sizeof(float), (hipStream_t)stream));
+  if (n_items == 0) return RGCN_OK;
+  hipLaunchKernelGGL(diag_wgrad_kernel, dim3((unsigned)((n_items + WG / 64 - 1) / (WG / 64))), dim3(WG), 0, (hipStream_t)stream,
+                     X, G, dw, p_src, p_dst, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), (long long)n_items, d);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

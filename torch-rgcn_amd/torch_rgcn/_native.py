@@ -443,6 +443,8 @@ def build_csr_device(dst, src, rel, val, alive, n_rows, sync_free=False):
                                     _dp(rel), _dp(p.rel), _dp(p.msg_slot), c_i64(m_pad // CHUNK), _stream(dev)),
                "dev_plan_fill")
     p.rowptr = rowbuf[: n_rows + 1]
+    p.sync_free = sync_free
+    p.units = None
     return p
 
 
@@ -841,6 +843,7 @@ def wgrad_tiled(X, G, plan, num_rels, tiles_per_item=4):
 
 
 F_DW_ATOMIC = 4
+F_TRANSPOSE_W = 8
 
 
 def pack_w16t(W):
@@ -891,6 +894,80 @@ def featureless_fwd(table, bias, plan):
                                               c_i64(n_src), c_i32(R), c_i32(d), _stream(table.device)),
                "featureless_fwd")
     return out
+
+
+def _csr_units(csr):
+    """(units, n_units, n_split) of a CSR: one unit per row, hub rows cut into 512-entry pieces -- computed once per static
+    graph (host statistics); a CSR of a per-call LP graph has none: (None, n_rows, 0) = every row is one unit"""
+    if getattr(csr, "sync_free", False) or getattr(csr, "per_call", False):
+        return None, csr.n_rows, 0              # (per-call graphs of the LP layer: the statistics would cost two read-backs a step)
+    if getattr(csr, "units", None) is None:
+        csr.units = row_units(csr.rowptr, csr.n_rows, 512)
+    return csr.units
+
+
+def block_supported(bi, bo):
+    return bool(lib().rgcn_block_supported(c_i32(bi), c_i32(bo)))
+
+
+def block_spmm(X, blocks, bias, csr, transposed=False, relu=False):
+    """out[n_rows, nb * bo] = bias + sum over the row's CSR entries of val * X[src] . blockdiag(blocks[rel])   (blocks:
+    [R', nb, bi, bo]; entries with rel >= R' are skipped; transposed: X is [., nb * bo] and the blocks are applied
+    transposed -> [n_rows, nb * bi])"""
+    _req(X, "features"); _req(blocks, "blocks"); _req(bias, "bias")
+    Rb, nb, bi, bo = blocks.shape
+    assert X.shape[1] == nb * (bo if transposed else bi)
+    units, n_units, n_split = _csr_units(csr)
+    fuse_relu = relu and n_split == 0
+    out = torch.empty((csr.n_rows, nb * (bi if transposed else bo)), device=X.device, dtype=torch.float32)
+    flags = (F_TRANSPOSE_W if transposed else 0) | (F_RELU if fuse_relu else 0)
+    with torch.cuda.device(X.device), _timed("block_spmm"):
+        _check(lib().rgcn_block_spmm_f32(_dp(X), _dp(blocks), _dp(bias), _dp(out), _dp(units), _dp(csr.rowptr), c_i64(n_units),
+                                         c_i64(n_split), _dp(csr.src), _dp(csr.rel), _dp(csr.val), c_i64(csr.n_rows), c_i32(Rb),
+                                         c_i32(nb), c_i32(bi), c_i32(bo), c_i32(flags), _stream(X.device)), "block_spmm")
+    if relu and not fuse_relu:
+        out.relu_()
+    return out
+
+
+def block_wgrad(X, G, scatter_plan, shape):
+    """dblocks[R', nb, bi, bo] = sum_slots val * X[src, b, :]^T G[dst, b, :] grouped by relation (relation-major plan)"""
+    _req(X, "features"); _req(G, "grad_output")
+    p = scatter_plan
+    Rb, nb, bi, bo = shape
+    dB = torch.empty(shape, device=X.device, dtype=torch.float32)
+    with torch.cuda.device(X.device), _timed("block_wgrad"):
+        _check(lib().rgcn_block_wgrad_f32(_dp(X), _dp(G), _dp(dB), _dp(p.src), _dp(p.dst), _dp(p.val), _dp(p.chunk_rel),
+                                          _dp(p.items), c_i64(p.n_items), c_i32(Rb), c_i32(nb), c_i32(bi), c_i32(bo),
+                                          _stream(X.device)), "block_wgrad")
+    return dB
+
+
+def diag_spmm(X, w, bias, csr):
+    """out[n_rows, d] = bias + sum over the row's CSR entries of val * X[src, :] * w[rel, :]   (diagonal weights, w: [R, d])"""
+    _req(X, "features"); _req(w, "weights"); _req(bias, "bias")
+    R, d = w.shape
+    assert X.shape[1] == d
+    units, n_units, n_split = _csr_units(csr)
+    assert units is not None, "the diagonal layer is not part of the sync-free LP step"
+    out = torch.empty((csr.n_rows, d), device=X.device, dtype=torch.float32)
+    with torch.cuda.device(X.device), _timed("diag_spmm"):
+        _check(lib().rgcn_diag_spmm_f32(_dp(X), _dp(w), _dp(bias), _dp(out), _dp(units), c_i64(n_units), c_i64(n_split),
+                                        _dp(csr.src), _dp(csr.rel), _dp(csr.val), c_i64(csr.n_rows), c_i32(R), c_i32(d),
+                                        _stream(X.device)), "diag_spmm")
+    return out
+
+
+def diag_wgrad(X, G, scatter_plan, num_rels):
+    """dw[R, d] = sum_slots val * X[src, :] * G[dst, :] grouped by relation (relation-major plan)"""
+    _req(X, "features"); _req(G, "grad_output")
+    p, d = scatter_plan, X.shape[1]
+    dw = torch.empty((num_rels, d), device=X.device, dtype=torch.float32)
+    with torch.cuda.device(X.device), _timed("diag_wgrad"):
+        _check(lib().rgcn_diag_wgrad_f32(_dp(X), _dp(G), _dp(dw), _dp(p.src), _dp(p.dst), _dp(p.val), _dp(p.chunk_rel),
+                                         _dp(p.items), c_i64(p.n_items), c_i32(num_rels), c_i32(d), _stream(X.device)),
+               "diag_wgrad")
+    return dw
 
 
 def featureless_wgrad(G, plan, num_rels):

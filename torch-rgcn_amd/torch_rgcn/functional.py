@@ -301,6 +301,95 @@ class _FeaturelessMP(torch.autograd.Function):
         return dT, db, None
 
 
+class _BlockMP(torch.autograd.Function):
+    """Block-diagonal per-relation weights without expanding them (reference layers.py:243-244 / :520-527 build
+    block_diag(blocks) and run the dense path): out = sum_r A_r X blockdiag(B_r) + b on the CSR kernels of csrc/rgcn_block.hip.
+    Relations past blocks.shape[0] (the LP layer's dense self-loop relation) are skipped -- the caller adds them."""
+
+    @staticmethod
+    def forward(ctx, X, blocks, bias, graph, relu):
+        X, blocks = X.contiguous(), blocks.contiguous()
+        b = None if bias is None else bias.contiguous()
+        out = _native.block_spmm(X, blocks, b, graph.csr("fwd"), relu=relu)
+        ctx.save_for_backward(X, blocks, out if relu else None)
+        ctx.graph = graph
+        ctx.has_bias = bias is not None
+        ctx.relu = relu
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        X, blocks, out = ctx.saved_tensors
+        g = g.contiguous()
+        if ctx.relu:
+            g = torch.ops.aten.threshold_backward(g, out, 0.0)
+        graph = ctx.graph
+        dX = dB = db = None
+        if ctx.needs_input_grad[0]:
+            dX = _native.block_spmm(g, blocks, None, graph.csr("bwd"), transposed=True)
+        if ctx.needs_input_grad[1]:
+            dB = _native.block_wgrad(X, g, graph.wgt_plan(), tuple(blocks.shape))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _native.colsum(g)
+        return dX, dB, db, None, None
+
+
+def block_mp(features, blocks, bias, graph, relu=False):
+    """features [N, nb * bi], blocks [R', nb, bi, bo] -> [N, nb * bo]"""
+    return _BlockMP.apply(features, blocks, bias, graph, relu)
+
+
+def use_block_path(graph, blocks):
+    """The block kernels need the device-side graph build (CSR + relation-major plan) and blocks of at most 8 x 8.  At
+    width 16 the expanded 16 x 16 weights on the matrix-core kernels are faster (AM shape, 4 x 4 blocks: 1.96 ms per layer
+    forward + backward against 2.43 -- every message re-reads its blocks from L2, 4x the bytes of its feature row), so
+    RGCN_BLOCK_PATH=1 (default) takes the block kernels only above width 16; 2 = whenever supported; 0 = never."""
+    mode = os.environ.get("RGCN_BLOCK_PATH", "1")
+    if mode == "0" or getattr(graph, "_dev", None) is None or not _native.block_supported(blocks.shape[2], blocks.shape[3]):
+        return False
+    wide = blocks.shape[1] * blocks.shape[2] > 16 or blocks.shape[1] * blocks.shape[3] > 16
+    return wide or mode == "2"
+
+
+class _DiagMP(torch.autograd.Function):
+    """Diagonal per-relation weights (reference layers.py:289-292): out = sum_r A_r (X * w_r) + b, backward
+    dX = sum_r A_r^T (G * w_r) (the same kernel on the transposed plan), dw_r = sum over the messages of r of val X[src] * G[dst]."""
+
+    @staticmethod
+    def forward(ctx, X, w, bias, graph):
+        X, w = X.contiguous(), w.contiguous()
+        b = None if bias is None else bias.contiguous()
+        out = _native.diag_spmm(X, w, b, graph.csr("fwd"))
+        ctx.save_for_backward(X, w)
+        ctx.graph = graph
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        X, w = ctx.saved_tensors
+        g = g.contiguous()
+        graph = ctx.graph
+        dX = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dX = _native.diag_spmm(g, w, None, graph.csr("bwd"))
+        if ctx.needs_input_grad[1]:
+            dw = _native.diag_wgrad(X, g, graph.wgt_plan(), w.shape[0])
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _native.colsum(g)
+        return dX, dw, db, None
+
+
+def diag_mp(features, w, bias, graph):
+    """features [N, d], w [R, d] -> [N, d]"""
+    return _DiagMP.apply(features, w, bias, graph)
+
+
+def use_diag_path(graph, d):
+    """the diagonal kernels need the device-side graph build (CSR + relation-major plan)"""
+    return getattr(graph, "_dev", None) is not None and os.environ.get("RGCN_DIAG_PATH") != "0"
+
+
 def _split_k(K, M, N):
     """slices of the K dimension so that a skinny product (K = number of nodes, M x N = a weight matrix) still fills the chip"""
     tiles = -(-M // 128) * -(-N // 128)
@@ -322,7 +411,9 @@ class _MatmulMFMA(torch.autograd.Function):
         A, B = ctx.saved_tensors
         g = g.contiguous()
         dA = _native.gemm(g, B, trans_b=True) if ctx.needs_input_grad[0] else None          # g B^T
-        dB = _native.gemm(A, g, trans_a=True) if ctx.needs_input_grad[1] else None          # A^T g
+        # A^T g: K = the rows of A (nodes) -- split so that a small M x N output still fills the chip (fixed-order reduction)
+        dB = _native.gemm(A, g, trans_a=True, split_k=_split_k(A.shape[0], A.shape[1], g.shape[1])) \
+            if ctx.needs_input_grad[1] else None
         return dA, dB
 
 

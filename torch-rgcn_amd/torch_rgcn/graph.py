@@ -113,6 +113,7 @@ class RelGraph:
             s, p, o, val, alive = self._dev
             dst, src = (s, o) if kind == "fwd" else (o, s)
             self._plans[key] = _native.build_csr_device(dst, src, p, val, alive, self.num_nodes, sync_free=self.sync_free)
+            self._plans[key].per_call = getattr(self, "per_call", False)
         return self._plans[key]
 
     def fbasis_plan(self):
@@ -200,6 +201,7 @@ def graph_from_lp_triples(triples, num_nodes, num_rels, vertical, keep_mask, dev
         n_live = 3 * E + (num_nodes if (keep_mask is None or sync_free) else int(keep_mask.sum().item()))
         g = RelGraph.on_device(s, p, o, val, alive, n_live, num_nodes, num_rels)
         g.sync_free = sync_free
+        g.per_call = True
         return g
     t = triples.detach().cpu().numpy() if torch.is_tensor(triples) else np.asarray(triples)
     t = np.ascontiguousarray(t, dtype=np.int64).reshape(-1, 3)

@@ -239,15 +239,22 @@ class RelationalGraphConvolutionNC(_RGCBase):
 
         fl_basis = (self.in_features is None and self.weight_decomp == 'basis' and not self.vertical_stacking and
                     getattr(graph, "_dev", None) is not None and os.environ.get("RGCN_BASIS_PATH") != "0")
-        block_table = self.in_features is not None and not self.diag_weight_matrix and \
+        # block-diagonal weights: the blocks are applied as they are (csrc/rgcn_block.hip); only blocks above 8 x 8, or a
+        # host-built graph, fall back to the message table / the expanded dense weights
+        block_path = self.in_features is not None and self.weight_decomp == 'block' and not self.diag_weight_matrix and \
+            F_.use_block_path(graph, self.blocks)
+        block_table = self.in_features is not None and not self.diag_weight_matrix and not block_path and \
             _wide_block(self.weight_decomp, in_dim, out_dim, R, N)
+        diag_path = self.diag_weight_matrix and self.in_features is not None and not self.vertical_stacking and \
+            getattr(self, "_shard_group", None) is None and F_.use_diag_path(graph, in_dim)
         if self.diag_weight_matrix:
             assert self.weights.size() == (R, in_dim)
-            weights = torch.diag_embed(self.weights)           # W_r = diag(w_r)
+            # W_r = diag(w_r): scaled on the way into the aggregation (rgcn_diag_spmm_f32); embedded only off that path
+            weights = None if diag_path else torch.diag_embed(self.weights)
         elif fl_basis:
             weights = None                                     # never materialise the R x N x d_out table
             assert self.bases.size() == (self.num_bases, in_dim, out_dim) and self.comps.size() == (R, self.num_bases)
-        elif block_table:
+        elif block_table or block_path:
             weights = None                                     # never expand the blocks to R x d x d
         elif self.in_features is not None and self.weight_decomp == 'basis' and \
                 F_.use_basis_path(self.num_bases, in_dim, out_dim, graph):
@@ -267,7 +274,14 @@ class RelationalGraphConvolutionNC(_RGCBase):
         else:
             _require_gpu(features, "features")
             assert features.size() == (N, in_dim), f"features {tuple(features.size())} vs ({N}, {in_dim})"
-            if self.weight_decomp == 'basis' and not self.diag_weight_matrix and weights is None:
+            if diag_path:
+                local = lambda x, b: F_.diag_mp(x, self.weights, b, graph)
+            elif block_path:
+                fuse_act = activation == "relu" and getattr(self, "_shard_group", None) is None
+                local = lambda x, b: F_.block_mp(x, self.blocks, b, graph, relu=fuse_act)
+                if fuse_act:
+                    activation = None
+            elif self.weight_decomp == 'basis' and not self.diag_weight_matrix and weights is None:
                 local = lambda x, b: F_.basis_mp(x, self.bases, self.comps, b, graph)
             elif block_table:
                 local = lambda x, b: F_.featureless_mp(_block_messages(x, self.blocks), b, graph)
@@ -367,12 +381,15 @@ class RelationalGraphConvolutionLP(_RGCBase):
 
         assert features.size() == (N, in_dim)
         self_drop = None
-        block_table = _wide_block(self.weight_decomp, in_dim, out_dim, R, N)
+        block_path = self.weight_decomp == 'block' and F_.use_block_path(graph, self.blocks)
+        block_table = not block_path and _wide_block(self.weight_decomp, in_dim, out_dim, R, N)
         if self.weight_decomp == 'block':
             if training_dropout and self.edge_dropout["self_loop"] > 0:
                 # dense dropout on the self-loop messages X @ blocks_self before aggregation (added below)
                 self_drop = self.edge_dropout["self_loop"]
-            if block_table:     # messages of every relation, transformed first: [R, N, d_out]
+            if block_path:      # blocks applied as they are; the dense self-loop relation is added below
+                weights = None
+            elif block_table:   # messages of every relation, transformed first: [R, N, d_out]
                 own = torch.zeros(N, out_dim, device=device) if self_drop is not None else F_.matmul_mfma(features, self.blocks_self)
                 weights = None
                 table = torch.cat([_block_messages(features, self.blocks), own[None]], dim=0)
@@ -387,6 +404,14 @@ class RelationalGraphConvolutionLP(_RGCBase):
 
         if self.weight_decomp == 'basis' and weights is None:
             output = F_.basis_mp(features, self.bases, self.comps, self.bias, graph)
+        elif block_path:
+            # relations 0 .. R-2 on the block kernels (they skip relation R-1); the self-loop relation has a dense weight
+            # (layers.py:514-527), one message per node and -- horizontal stacking, one per (relation, row) -- the
+            # normalisation constant 1: its messages are the rows of X @ blocks_self, for the nodes whose loop survived
+            output = F_.block_mp(features, self.blocks, self.bias, graph)
+            if self_drop is None:
+                own = F_.matmul_mfma(features, self.blocks_self)
+                output = output + (own if (mask is None or keep == 1) else own * mask[:, None].to(own.dtype))
         elif block_table:
             output = F_.featureless_mp(table, self.bias, graph)
         else:
