@@ -96,7 +96,7 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None, synthetic=N
     # hipGraph mode: between replays NOTHING but copies may run on the GPU.  On this stack (ROCm 7.2 hipcc code objects under
     # PyTorch 2.10 + ROCm 7.0 runtime) eager kernel launches between replays of a graph that contains this library's
     # kernels end in "write access to a read-only page" inside the replay (torch-only graphs are unaffected; bisected with
-    # tools/dbg_lp.py / dbg_lp2.py / dbg_graph_torch*.py), while host-to-device copies are fine.  So the per-epoch
+    # the scripts under tools/hipgraph_repro/), while host-to-device copies are fine.  So the per-epoch
     # sampling (negatives, edge dropout permutation) is done with numpy on the host and copied into the static buffers.
     host_rng = np.random.default_rng(int(torch.initial_seed()) & 0x7FFFFFFF) if hipgraph else None
 

@@ -417,7 +417,7 @@ def build_csr_device(dst, src, rel, val, alive, n_rows, sync_free=False):
     # `cells` (one counter per row) lives at rowbuf[1:]: the count pass leaves the rows' exclusive offsets there and the fill
     # pass advances every counter to the END of its row -- which is the start of the next one, so rowbuf (rowbuf[0] = 0)
     # IS the CSR row pointer afterwards.  No device-to-device copy: inside a captured hipGraph such copies become memcpy
-    # nodes, and those fault on this ROCm build when pageable host-to-device copies run between replays (tools/dbg_lp.py).
+    # nodes, and those fault on this ROCm build when pageable host-to-device copies run between replays (tools/hipgraph_repro/).
     rowbuf = torch.zeros(n_rows + 2, dtype=torch.int32, device=dev)
     cells, cells_tmp = rowbuf[1:], _i32(n_rows + 1, dev)
     bucket_cnt, bucket_base, scan_tmp = _i32(1, dev), _i32(2, dev), _i32(n_rows // 1024 + 4, dev)
