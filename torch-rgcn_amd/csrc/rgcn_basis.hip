@@ -22,6 +22,7 @@
 #include <algorithm>
 
 #include "rgcn_hip.h"
+#include "rgcn_zero.h"
 
 extern "C" void rgcn_set_error(const char *fmt, ...);
 
@@ -252,7 +253,7 @@ extern "C" int rgcn_fbasis_bwd_f32(const float *bases, const float *comps, const
   }
   if (B > 64 || d > 16) { rgcn_set_error("fbasis_bwd: needs B <= 64 and d_out <= 16"); return RGCN_EUNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
-  if (dbases && n_split) HIP_TRY(hipMemsetAsync(dbases, 0, (size_t)B * n_nodes * d * sizeof(float), st));
+  if (dbases && n_split) HIP_TRY(zero_async(dbases, (size_t)B * n_nodes * d * sizeof(float), st));
   if (n_units == 0) return RGCN_OK;
   const dim3 grid((unsigned)((n_units + WAVES - 1) / WAVES));
   const int4 *un = reinterpret_cast<const int4 *>(units);
@@ -274,7 +275,7 @@ extern "C" int rgcn_gather_rows_sum_f32(const float *Y, const int32_t *perm, con
   }
   if (w > 64) { rgcn_set_error("gather_rows_sum: width > 64 unsupported"); return RGCN_EUNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
-  if (n_split) HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_rows * w * sizeof(float), st));
+  if (n_split) HIP_TRY(zero_async(out, (size_t)n_rows * w * sizeof(float), st));
   if (n_units == 0) return RGCN_OK;
   hipLaunchKernelGGL(gather_rows_sum_kernel, dim3((unsigned)((n_units + WAVES - 1) / WAVES)), dim3(WG), 0, st, Y, perm,
                      reinterpret_cast<const int4 *>(units), (int)n_units, bias, out, w, pow2_at_least(w, 4));
@@ -458,7 +459,7 @@ extern "C" int rgcn_basis_dcomps_f32(const float *X, const float *D, float *dcom
                                      void *stream) {
   if (!X || !D || !dcomps || n_items < 0 || R <= 0 || B <= 0 || d <= 0) { rgcn_set_error("basis_dcomps: bad argument"); return RGCN_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(dcomps, 0, (size_t)R * B * sizeof(float), st));
+  HIP_TRY(zero_async(dcomps, (size_t)R * B * sizeof(float), st));
   if (!n_items) return RGCN_OK;
   // few items (small per-call graphs): cut every item into more pieces so that the chip is filled
   const unsigned pieces = n_items < 2048 ? 64 : 16;

@@ -222,7 +222,7 @@ extern "C" int rgcn_block_spmm_f32(const float *X, const float *blocks, const fl
   if (n_rows == 0 || n_units == 0) return RGCN_OK;
   hipStream_t st = (hipStream_t)stream;
   const int n_out = tr ? bi : bo;
-  if (n_split) HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_rows * nb * n_out * sizeof(float), st));
+  if (n_split) HIP_TRY(zero_async(out, (size_t)n_rows * nb * n_out * sizeof(float), st));
   const int lpm = lanes_per_message(nb);
   const int lr = std::min(64, std::max(16, 2 * lpm));
   const int upw = WG / lr;
@@ -258,7 +258,7 @@ extern "C" int rgcn_block_wgrad_f32(const float *X, const float *G, float *dbloc
     return RGCN_EUNSUPPORTED;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (n_rel_blocks) HIP_TRY(hipMemsetAsync(dblocks, 0, (size_t)n_rel_blocks * nb * bi * bo * sizeof(float), st));
+  if (n_rel_blocks) HIP_TRY(zero_async(dblocks, (size_t)n_rel_blocks * nb * bi * bo * sizeof(float), st));
   if (n_items == 0 || n_rel_blocks == 0) return RGCN_OK;
   const int lpm = lanes_per_message(nb);
   const dim3 grid((unsigned)((n_items + WG / 64 - 1) / (WG / 64))), block(WG);

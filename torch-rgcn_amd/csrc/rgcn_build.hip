@@ -18,6 +18,7 @@
 #include <algorithm>
 
 #include "rgcn_hip.h"
+#include "rgcn_zero.h"
 
 extern "C" void rgcn_set_error(const char *fmt, ...);
 
@@ -345,7 +346,7 @@ extern "C" int rgcn_dev_split_triples(const int64_t *triples_plus, int64_t M, in
                                       int32_t *o, int32_t *err_flag, void *stream) {
   if (M < 0 || N <= 0 || R <= 0 || !err_flag || (M && (!triples_plus || !s || !p || !o))) { rgcn_set_error("dev_split_triples: bad argument"); return RGCN_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(err_flag, 0, sizeof(int), st));
+  HIP_TRY(zero_async(err_flag, sizeof(int), st));
   if (!M) return RGCN_OK;
   hipLaunchKernelGGL(split_triples_kernel, dim3(blocks_for(M)), dim3(TB), 0, st, (const long long *)triples_plus,
                      (long long)M, (long long)N, R, s, p, o, err_flag);
@@ -357,7 +358,7 @@ extern "C" int rgcn_dev_lp_expand(const int64_t *triples, int64_t E, int64_t N, 
                                   int32_t *p, int32_t *o, uint8_t *alive, int32_t *err_flag, void *stream) {
   if (E < 0 || N <= 0 || R0 <= 0 || !s || !p || !o || !alive || !err_flag || (E && !triples)) { rgcn_set_error("dev_lp_expand: bad argument"); return RGCN_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(err_flag, 0, sizeof(int), st));
+  HIP_TRY(zero_async(err_flag, sizeof(int), st));
   hipLaunchKernelGGL(lp_expand_kernel, dim3(blocks_for(3 * E + N)), dim3(TB), 0, st, (const long long *)triples,
                      (long long)E, (long long)N, R0, keep, s, p, o, alive, err_flag);
   HIP_TRY(hipGetLastError());
@@ -369,7 +370,7 @@ extern "C" int rgcn_dev_edge_norm(const int32_t *s, const int32_t *p, const int3
                                   void *stream) {
   if (M < 0 || N <= 0 || R <= 0 || !table || (M && (!s || !p || !o || !val)) || n_swap < 0 || 2 * n_swap > M) { rgcn_set_error("dev_edge_norm: bad argument"); return RGCN_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(table, 0, (size_t)R * N * sizeof(int), st));
+  HIP_TRY(zero_async(table, (size_t)R * N * sizeof(int), st));
   if (!M) return RGCN_OK;
   hipLaunchKernelGGL(norm_count_kernel, dim3(blocks_for(M)), dim3(TB), 0, st, s, p, o, alive, (long long)M, (long long)N,
                      vertical, table);
@@ -386,7 +387,7 @@ extern "C" int rgcn_dev_plan_count(const int32_t *dst, const int32_t *rel, const
   const int64_t n_tiles = (n_dst + tile_rows - 1) / tile_rows, nbk = n_tiles * R;
   if (nbk * tile_rows >= (int64_t(1) << 40)) { rgcn_set_error("dev_plan_count: cell table too large"); return RGCN_EUNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(cells, 0, (size_t)nbk * tile_rows * sizeof(int), st));
+  HIP_TRY(zero_async(cells, (size_t)nbk * tile_rows * sizeof(int), st));
   if (M) hipLaunchKernelGGL(cell_count_kernel, dim3(blocks_for(M)), dim3(TB), 0, st, dst, rel, alive, (long long)M, R, tile_rows, cells);
   // bucket_base doubles as the padded-size array before the scan
   if (cells_tmp && tile_rows > 1024) {

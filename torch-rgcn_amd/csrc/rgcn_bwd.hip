@@ -381,7 +381,7 @@ extern "C" int rgcn_bwd_fused_f32(const float *G, const float *X, const float *W
   const BwdLaunch L{G, X, Wt_packed, dX, atomic ? dW : scratch, pk, chunk_rel, run_ptr, (int)n_tiles, n_blocks, tile_rows,
                     (int)n_dst, R, ABL, lds, st};
   if (atomic) {
-    HIP_TRY(hipMemsetAsync(dW, 0, (size_t)R * 256 * sizeof(float), st));
+    HIP_TRY(zero_async(dW, (size_t)R * 256 * sizeof(float), st));
     if (USEL >= 4) launch_bwd_d<4, true>(L, Dv); else launch_bwd_d<2, true>(L, Dv);
   } else {
     if (USEL >= 4) launch_bwd_d<4, false>(L, Dv); else launch_bwd_d<2, false>(L, Dv);
@@ -404,7 +404,7 @@ extern "C" int rgcn_bwd_scatter_dw_f32(const float *G, const float *X, const flo
   }
   if (d != 16) { rgcn_set_error("bwd_scatter_dw: only d = 16"); return RGCN_EUNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(dW, 0, (size_t)R * 256 * sizeof(float), st));
+  HIP_TRY(zero_async(dW, (size_t)R * 256 * sizeof(float), st));
   if (!n_items) return RGCN_OK;
   hipLaunchKernelGGL(bwd_scatter_dw_d16_kernel<4>, dim3((unsigned)((n_items + WG / 64 - 1) / (WG / 64))), dim3(WG), 0, st, G, X,
                      Wt_packed, Y, dW, p_src, p_dst, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), (int)n_items);

@@ -4,7 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "rgcn_hip.h"
+#include "rgcn_zero.h"
 
 extern "C" void rgcn_set_error(const char *fmt, ...);
 

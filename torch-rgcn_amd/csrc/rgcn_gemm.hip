@@ -641,7 +641,7 @@ extern "C" int rgcn_rel_wgrad_f32(const float *Xs, const float *G, float *dW, co
     return RGCN_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(dW, 0, (size_t)R * d_in * d_out * sizeof(float), st));
+  HIP_TRY(zero_async(dW, (size_t)R * d_in * d_out * sizeof(float), st));
   if (!n_items) return RGCN_OK;
   const int tiles_m = (d_in + GT - 1) / GT, tiles_n = (d_out + GT - 1) / GT;
   hipLaunchKernelGGL(rel_wgrad_kernel, dim3((unsigned)n_items, (unsigned)(tiles_m * tiles_n)), dim3(WG), 0, st, Xs, G, dW, p_src,

@@ -1173,7 +1173,7 @@ extern "C" int rgcn_spmm_f32(const float *X, const float *W, const float *bias, 
     return RGCN_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (n_split) HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_dst * d_out * sizeof(float), st));  // hub tiles are summed atomically
+  if (n_split) HIP_TRY(zero_async(out, (size_t)n_dst * d_out * sizeof(float), st));  // hub tiles are summed atomically
   dim3 grid((unsigned)((n_tiles + SPMM_WAVES - 1) / SPMM_WAVES)), block(WG);
   const int nt = (int)n_tiles;
   const int2 *pk = reinterpret_cast<const int2 *>(p_pack);
@@ -1279,7 +1279,7 @@ extern "C" int rgcn_wgrad_f32(const float *X, const float *G, float *dW, const i
     return RGCN_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(dW, 0, (size_t)R * d_in * d_out * sizeof(float), st));
+  HIP_TRY(zero_async(dW, (size_t)R * d_in * d_out * sizeof(float), st));
   if (n_items == 0) return RGCN_OK;
   const unsigned gx = (unsigned)((n_items + WG / 64 - 1) / (WG / 64));
   const int2 *it2 = reinterpret_cast<const int2 *>(items);
@@ -1311,7 +1311,7 @@ extern "C" int rgcn_wgrad_tiled_f32(const float *X, const float *G, float *dW, c
   }
   if (d_in != 16 || d_out != 16) { rgcn_set_error("wgrad_tiled: only d_in = d_out = 16"); return RGCN_EUNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(dW, 0, (size_t)R * 256 * sizeof(float), st));
+  HIP_TRY(zero_async(dW, (size_t)R * 256 * sizeof(float), st));
   if (n_tiles == 0) return RGCN_OK;
   static const int RGSEL = getenv("RGCN_WGRAD_RG") ? atoi(getenv("RGCN_WGRAD_RG")) : 1;
   static const int USEL = getenv("RGCN_WGRAD_U") ? atoi(getenv("RGCN_WGRAD_U")) : 2;
@@ -1355,7 +1355,7 @@ extern "C" int rgcn_featureless_fwd_f32(const float *table, const float *bias, f
   const int ldt = (d_out + 3) & ~3;
   const size_t lds = (size_t)SPMM_WAVES * tile_rows * ldt * sizeof(float);
   if (lds > LDS_TILE_BYTES) { rgcn_set_error("featureless_fwd: LDS tile too large"); return RGCN_EINVAL; }
-  if (n_split) HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_dst * d_out * sizeof(float), (hipStream_t)stream));
+  if (n_split) HIP_TRY(zero_async(out, (size_t)n_dst * d_out * sizeof(float), (hipStream_t)stream));
   hipLaunchKernelGGL(featureless_fwd_kernel, dim3((unsigned)((n_tiles + SPMM_WAVES - 1) / SPMM_WAVES)), dim3(WG), lds,
                      (hipStream_t)stream, table, bias, out, p_src, p_dst, p_val, chunk_rel,
                      reinterpret_cast<const int4 *>(units), (int)n_tiles,
@@ -1374,7 +1374,7 @@ extern "C" int rgcn_diag_spmm_f32(const float *X, const float *w, const float *b
     return RGCN_EINVAL;
   }
   if (n_rows == 0 || n_units == 0) return RGCN_OK;
-  if (n_split) HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_rows * d * sizeof(float), (hipStream_t)stream));
+  if (n_split) HIP_TRY(zero_async(out, (size_t)n_rows * d * sizeof(float), (hipStream_t)stream));
   int lpm = 1;                                  // lanes per message: float4 each, a power of two
   while (lpm < 64 && 4 * lpm < d) lpm *= 2;
   const int lr = std::min(64, std::max(16, 2 * lpm));   // lanes per unit: >= 2 messages of a row in flight
@@ -1393,7 +1393,7 @@ extern "C" int rgcn_diag_wgrad_f32(const float *X, const float *G, float *dw, co
     rgcn_set_error("diag_wgrad: bad argument");
     return RGCN_EINVAL;
   }
-  HIP_TRY(hipMemsetAsync(dw, 0, (size_t)R * d * sizeof(float), (hipStream_t)stream));
+  HIP_TRY(zero_async(dw, (size_t)R * d * sizeof(float), (hipStream_t)stream));
   if (n_items == 0) return RGCN_OK;
   hipLaunchKernelGGL(diag_wgrad_kernel, dim3((unsigned)((n_items + WG / 64 - 1) / (WG / 64))), dim3(WG), 0, (hipStream_t)stream,
                      X, G, dw, p_src, p_dst, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), (long long)n_items, d);
@@ -1407,7 +1407,7 @@ extern "C" int rgcn_featureless_wgrad_f32(const float *G, float *dtable, const i
   (void)n_dst;
   if (!G || !dtable || R <= 0 || d_out <= 0 || n_chunks < 0) { rgcn_set_error("featureless_wgrad: bad argument"); return RGCN_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(dtable, 0, (size_t)R * n_src * d_out * sizeof(float), st));
+  HIP_TRY(zero_async(dtable, (size_t)R * n_src * d_out * sizeof(float), st));
   if (n_chunks == 0) return RGCN_OK;
   const unsigned gx = (unsigned)std::min<int64_t>((n_chunks + 3) / 4, 256 * 16);
   hipLaunchKernelGGL(featureless_wgrad_kernel, dim3(gx), dim3(WG), 0, st, G, dtable, p_src, p_dst, p_val, chunk_rel,
@@ -1424,7 +1424,7 @@ extern "C" int64_t rgcn_colsum_scratch_floats(int64_t n, int32_t d) {
 extern "C" int rgcn_colsum_f32(const float *G, float *db, float *scratch, int64_t n, int32_t d, void *stream) {
   if (!G || !db || !scratch || n < 0 || d <= 0) { rgcn_set_error("colsum: bad argument"); return RGCN_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
-  if (n == 0) { HIP_TRY(hipMemsetAsync(db, 0, (size_t)d * sizeof(float), st)); return RGCN_OK; }
+  if (n == 0) { HIP_TRY(zero_async(db, (size_t)d * sizeof(float), st)); return RGCN_OK; }
   const bool vec4 = d % 4 == 0;
   const int lanes = vec4 ? d / 4 : d;
   const int groups = std::max(1, WG / lanes);
@@ -1443,7 +1443,7 @@ extern "C" int rgcn_distmult_fwd_f32(const int64_t *triples, int64_t T, const fl
                                      int64_t n_nodes, int32_t n_rel, int32_t d, int32_t *err_flag, void *stream) {
   if (T < 0 || d <= 0 || (T && (!triples || !nodes || !rel || !scores))) { rgcn_set_error("distmult_fwd: bad argument"); return RGCN_EINVAL; }
   if ((sbias != nullptr) != (pbias != nullptr) || (sbias != nullptr) != (obias != nullptr)) { rgcn_set_error("distmult_fwd: biases must be all set or all NULL"); return RGCN_EINVAL; }
-  if (err_flag) HIP_TRY(hipMemsetAsync(err_flag, 0, sizeof(int32_t), (hipStream_t)stream));
+  if (err_flag) HIP_TRY(zero_async(err_flag, sizeof(int32_t), (hipStream_t)stream));
   if (T == 0) return RGCN_OK;
   const unsigned gx = (unsigned)std::min<int64_t>((T + 3) / 4, 256 * 32);
   hipLaunchKernelGGL(distmult_fwd_kernel, dim3(gx), dim3(WG), 0, (hipStream_t)stream,
@@ -1460,12 +1460,12 @@ extern "C" int rgcn_distmult_bwd_f32(const int64_t *triples, int64_t T, const fl
   hipStream_t st = (hipStream_t)stream;
   // dnodes == NULL: the entity gradients are computed by rgcn_distmult_bwd_nodes_f32 (no atomics); this call then yields the
   // relation (and bias) gradients only
-  if (dnodes) HIP_TRY(hipMemsetAsync(dnodes, 0, (size_t)n_nodes * d * sizeof(float), st));
-  HIP_TRY(hipMemsetAsync(drel, 0, (size_t)n_rel * d * sizeof(float), st));
+  if (dnodes) HIP_TRY(zero_async(dnodes, (size_t)n_nodes * d * sizeof(float), st));
+  HIP_TRY(zero_async(drel, (size_t)n_rel * d * sizeof(float), st));
   if (dsbias) {
-    HIP_TRY(hipMemsetAsync(dsbias, 0, (size_t)n_nodes * sizeof(float), st));
-    HIP_TRY(hipMemsetAsync(dobias, 0, (size_t)n_nodes * sizeof(float), st));
-    HIP_TRY(hipMemsetAsync(dpbias, 0, (size_t)n_rel * sizeof(float), st));
+    HIP_TRY(zero_async(dsbias, (size_t)n_nodes * sizeof(float), st));
+    HIP_TRY(zero_async(dobias, (size_t)n_nodes * sizeof(float), st));
+    HIP_TRY(zero_async(dpbias, (size_t)n_rel * sizeof(float), st));
   }
   if (T == 0) return RGCN_OK;
   const unsigned gx = (unsigned)std::min<int64_t>((T + 255) / 256, 256 * 32);
