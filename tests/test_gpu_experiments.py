@@ -88,7 +88,7 @@ def test_predict_links_training_step_as_hipgraph_learns():
     c["dataset"]["name"] = "fb-toy"
     c["encoder"].update(node_embedding=64, hidden1_size=64)
     c["training"].update(graph_batch_size=2000)
-    c["evaluation"].update(check_every=1000, batch_size=32, verbose=False)
+    c["evaluation"].update(check_every=10, batch_size=32, verbose=False)    # ranking evaluations (eager kernels) between replays
     hist, metrics = predict_links.run(c, epochs=40, quiet=True, max_test=50, synthetic=True, hipgraph=True)
     assert len(hist) == 40 and all(np.isfinite(hist)) and np.mean(hist[-5:]) < np.mean(hist[:5])
     assert 0.0 < metrics["mrr"] <= 1.0

@@ -93,29 +93,6 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None, synthetic=N
         print(f"{tag} MRR({kind_}): {mrr:.4f} \tHits@1({kind_}): {hits[0]:.4f} \tHits@3({kind_}): {hits[1]:.4f} \t"
               f"Hits@10({kind_}): {hits[2]:.4f}")
 
-    # hipGraph mode: between replays NOTHING but copies may run on the GPU.  On this stack (ROCm 7.2 hipcc code objects under
-    # PyTorch 2.10 + ROCm 7.0 runtime) eager kernel launches between replays of a graph that contains this library's
-    # kernels end in "write access to a read-only page" inside the replay (torch-only graphs are unaffected; bisected with
-    # the scripts under tools/hipgraph_repro/), while host-to-device copies are fine.  So the per-epoch
-    # sampling (negatives, edge dropout permutation) is done with numpy on the host and copied into the static buffers.
-    host_rng = np.random.default_rng(int(torch.initial_seed()) & 0x7FFFFFFF) if hipgraph else None
-
-    def sample_inputs_host():
-        nonlocal graph_batch_size
-        if graph_batch_size is None:
-            positives, graph_batch_size = train, len(train)
-        else:
-            positives = np.asarray(sampling_function(train, sample_size=graph_batch_size, entities=n2i), dtype=np.int64)
-        negatives = np.repeat(positives, neg_sample_rate, axis=0)
-        corrupt_head = host_rng.random(len(negatives)) < head_corrupt_prob
-        fresh = host_rng.integers(0, num_nodes, len(negatives))
-        negatives[corrupt_head, 0] = fresh[corrupt_head]
-        negatives[~corrupt_head, 2] = fresh[~corrupt_head]
-        graph = positives
-        if edge_dropout > 0.0:
-            graph = positives[host_rng.permutation(len(positives))][round((1 - edge_dropout) * len(positives)):]
-        return torch.from_numpy(np.ascontiguousarray(graph)), torch.from_numpy(np.concatenate([positives, negatives], axis=0))
-
     def sample_inputs():
         """one epoch's positives / negatives / labels / message graph (all sizes are the same every epoch)"""
         nonlocal graph_batch_size
@@ -147,9 +124,10 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None, synthetic=N
     captured = None
     if hipgraph:
         model.train()
-        g0, b0 = sample_inputs_host()
-        static = [g0.to(device), b0.to(device),
-                  torch.cat([torch.ones(graph_batch_size, device=device), torch.zeros(graph_batch_size * neg_sample_rate, device=device)])]
+        # the step is captured once on static input buffers; every epoch samples as the eager loop does (on the GPU) and copies
+        # into them.  (Round 2 history: replays used to fault whenever eager kernels ran between them -- the HIP runtime replays
+        # hipMemsetAsync NODES with stale arguments; the library zero-fills with kernels now, tools/hipgraph_repro/.)
+        static = [t.clone() for t in sample_inputs()]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                        # warm-up off the capture: allocator pools, lazy inits
@@ -165,9 +143,8 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None, synthetic=N
         t1 = time.time()
         model.train()
         if captured is not None:
-            g_h, b_h = sample_inputs_host()
-            static[0].copy_(g_h)
-            static[1].copy_(b_h)
+            for buf, fresh in zip(static, sample_inputs()):
+                buf.copy_(fresh)
             captured.replay()
             loss = static_loss
             t2 = time.time()

@@ -371,12 +371,8 @@ class RelationalGraphConvolutionLP(_RGCBase):
 
         with torch.no_grad():
             # The reference draws the Bernoulli mask on every call, also with keep = 1 (layers.py:481-487): the draw is kept so
-            # that a seeded run consumes the generator exactly as upstream does.  Only a step that must be capturable in a
-            # hipGraph (RGCN_DEFERRED_CHECKS=1) skips the all-ones draw: eager kernels between replays of a graph that
-            # contains RNG ops fault on this ROCm build.
-            from ._native import _deferred_mode
-            mask = None if (keep == 1 and _deferred_mode()) else \
-                torch.bernoulli(torch.full((N,), float(keep), dtype=torch.float, device=device)).to(torch.bool)
+            # that a seeded run consumes the generator exactly as upstream does (also inside a captured hipGraph).
+            mask = torch.bernoulli(torch.full((N,), float(keep), dtype=torch.float, device=device)).to(torch.bool)
             graph = graph_from_lp_triples(triples, N, R, self.vertical_stacking, mask, device)
 
         assert features.size() == (N, in_dim)
