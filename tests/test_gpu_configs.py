@@ -22,23 +22,27 @@ MUTAG = dict(N=23_644, R0=23, E=74_227)
 
 
 @pytest.mark.parametrize("vertical", [False, True])
-@pytest.mark.parametrize("sparse_path", ["block", "1", "0"])
-def test_am_tenth_scale_block_diagonal_layer_vs_oracle(monkeypatch, sparse_path, vertical):
-    """1/10 of AM, block-diagonal nb = 4, d = 16, both stackings: the block kernels (RGCN_BLOCK_PATH=2: 4 x 4 blocks applied
-    as they are; at width 16 not the default), and with the blocks expanded to dense 16 x 16 weights both the two-pass (sparse (tile, relation) buckets: 267
-    relations) and the tile kernels: out / dX / dblocks / db against the oracle"""
+@pytest.mark.parametrize("route", ["block", "hybrid", "twopass", "tile"])
+def test_am_tenth_scale_block_diagonal_layer_vs_oracle(monkeypatch, route, vertical):
+    """1/10 of AM, block-diagonal nb = 4, d = 16, both stackings, every route: out / dX / dblocks / db against the oracle.
+      hybrid   the default for sparse (tile, relation) buckets (267 relations): forward on the block CSR kernel (4 x 4 blocks as
+               they are), backward on the expanded 16 x 16 weights (relation-major fused pass + row sums)
+      twopass  forward too on the expanded weights (transform in relation-major order, sum per destination)
+      tile     the (tile, relation) kernels of dense-bucket graphs
+      block    forward and backward on the block kernels (RGCN_BLOCK_PATH=2; at width 16 not the default)"""
     from torch_rgcn import _native
-    monkeypatch.setenv("RGCN_BLOCK_PATH", "2" if sparse_path == "block" else "0")
-    if sparse_path != "block":
-        monkeypatch.setenv("RGCN_SPARSE_PATH", sparse_path)
+    monkeypatch.setenv("RGCN_BLOCK_PATH", "2" if route == "block" else "0")
+    monkeypatch.setenv("RGCN_BLOCK_FWD", "1" if route == "hybrid" else "0")
+    if route in ("twopass", "tile"):
+        monkeypatch.setenv("RGCN_SPARSE_PATH", "1" if route == "twopass" else "0")
     _native.profile_start()
     run_layer_vs_oracle(N=166_676, R0=133, E=598_832, d_in=16, d_out=16, mode="block", num_blocks=4, vertical=vertical,
                         seed=301 + int(vertical))
     prof = _native.profile_stop()
-    assert ("block_spmm" in prof and "block_wgrad" in prof) == (sparse_path == "block")
-    assert ("spmm_scatter" in prof) == (sparse_path == "1")
+    assert ("block_spmm" in prof) == (route in ("block", "hybrid")) and ("block_wgrad" in prof) == (route == "block")
+    assert ("spmm_scatter" in prof) == (route == "twopass")
     # backward: relation-major fused pass (dX rows + dW from one walk) on the sparse path, tile-walk fused kernel otherwise
-    assert ("bwd_scatter_dw" in prof) == (sparse_path == "1") and ("bwd_fused" in prof) == (sparse_path == "0")
+    assert ("bwd_scatter_dw" in prof) == (route in ("hybrid", "twopass")) and ("bwd_fused" in prof) == (route == "tile")
 
 
 def test_am_tenth_scale_default_path_is_the_sparse_one():
@@ -76,7 +80,7 @@ def test_am_full_size_block_layer_properties():
         assert torch.allclose(y, cnt, rtol=1e-5, atol=1e-5)
         assert abs(y.sum().item() - cnt.sum().item()) < 1e-3 * cnt.sum().item()
     prof = _native.profile_stop()
-    assert "spmm_scatter" in prof, "full-size AM should run on the sparse-bucket two-pass path"
+    assert "block_spmm" in prof and "spmm" not in prof, "full-size AM: sparse buckets -> the forward reads the 4 x 4 blocks on the CSR kernel"
     # gradients at full size: dX of a constant upstream gradient with W_r[0,0] = 1 is the count of (relation, object)
     # groups each node SENDS into, weighted by 1/c of the receiving group -- checked as a checksum: sum(dX[:,0]) = sum(out[:,0])
     X = torch.ones(N, 16, device=DEV, requires_grad=True)
@@ -84,6 +88,16 @@ def test_am_full_size_block_layer_properties():
     out.backward(torch.ones_like(out))
     assert abs(X.grad[:, 0].sum().item() - out[:, 0].sum().item()) < 1e-3 * abs(out[:, 0].sum().item())
     assert torch.isfinite(layer.blocks.grad).all()
+    # the same forward with the block table read from L2 instead of LDS (68 KB: above the default 64 KB LDS limit) and on the
+    # two-pass kernels
+    import os
+    ref = out.detach()
+    for var, val in (("RGCN_BLOCK_FWD", "0"),):
+        os.environ[var] = val
+        try:
+            assert rel_err(layer(X).detach(), ref.cpu().numpy()) < 1e-5
+        finally:
+            del os.environ[var]
 
 
 def test_am_full_size_featureless_basis40_properties():

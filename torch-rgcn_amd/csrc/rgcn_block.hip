@@ -16,6 +16,8 @@
 // Lane layout (both kernels): `lpm` lanes per message, one block each (lpm = the number of blocks rounded up to a power of
 // two, at most 64; wider rows loop); the remaining 64 / lpm (forward: lr / lpm within a unit) lane groups hold different
 // messages and are summed with wave shuffles at the end.  gfx950 only.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "rgcn_device.h"
@@ -26,17 +28,17 @@ constexpr int MAXB = 8;      // runtime-sized blocks up to 8 x 8 (larger blocks:
 
 // BI_ x BO_ = the block as stored ([bi][bo] row-major); TR: multiply by the transposed block (input width bo, output bi).
 // BI_ = 0: sizes at run time (bi, bo <= MAXB).
+// one work unit (a row, or a piece of a hub row) on `lr` lanes; W = the block table in global memory or in LDS
 template <int BI_, int BO_, bool TR>
-__global__ __launch_bounds__(WG) void block_csr_kernel(
-    const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ out,
-    const int4 *__restrict__ units, const int *__restrict__ rowptr, long long n_units, const int *__restrict__ e_src,
-    const int *__restrict__ e_rel, const float *__restrict__ e_val, int nb, int bi_rt, int bo_rt, int n_rel_blocks, int lpm,
-    int lr, int relu) {
+__device__ __forceinline__ void block_unit(
+    const float *__restrict__ X, const float *W, const float *__restrict__ bias, float *__restrict__ out,
+    const int4 *__restrict__ units, const int *__restrict__ rowptr, long long u, long long n_units,
+    const int *__restrict__ e_src, const int *__restrict__ e_rel, const float *__restrict__ e_val, int nb, int bi_rt, int bo_rt,
+    int n_rel_blocks, int lpm, int lr, int relu, int rel_stride) {
   constexpr bool FIXED = BI_ > 0;
   constexpr int CAP_IN = FIXED ? (TR ? BO_ : BI_) : MAXB, CAP_OUT = FIXED ? (TR ? BI_ : BO_) : MAXB;
   const int bi = FIXED ? BI_ : bi_rt, bo = FIXED ? BO_ : bo_rt;
   const int n_in = TR ? bo : bi, n_out = TR ? bi : bo;          // floats per block on the input / output side
-  const long long u = ((long long)blockIdx.x * WG + threadIdx.x) / lr;
   const int sub = threadIdx.x % lr, g = sub / lpm, j = sub % lpm, gpr = lr / lpm;
   const bool on = u < n_units;
   int4 unit = {0, 0, 0, 0};
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(WG) void block_csr_kernel(
         const float v = rel < n_rel_blocks ? e_val[e] : 0.f;        // relations past the block table (LP self loops): not ours
         if (v == 0.f) continue;
         const float *xr = X + (size_t)e_src[e] * d_in + (size_t)b * n_in;
-        const float *wr = W + ((size_t)rel * nb + b) * (size_t)(bi * bo);
+        const float *wr = W + (size_t)rel * rel_stride + (size_t)b * (bi * bo);
         float x[CAP_IN], w[FIXED ? BI_ * BO_ : MAXB * MAXB];
         if (vec_in) {
 #pragma unroll
@@ -118,6 +120,40 @@ __global__ __launch_bounds__(WG) void block_csr_kernel(
   }
 }
 
+template <int BI_, int BO_, bool TR>
+__global__ __launch_bounds__(WG) void block_csr_kernel(
+    const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ out,
+    const int4 *__restrict__ units, const int *__restrict__ rowptr, long long n_units, const int *__restrict__ e_src,
+    const int *__restrict__ e_rel, const float *__restrict__ e_val, int nb, int bi_rt, int bo_rt, int n_rel_blocks, int lpm,
+    int lr, int relu) {
+  block_unit<BI_, BO_, TR>(X, W, bias, out, units, rowptr, ((long long)blockIdx.x * WG + threadIdx.x) / lr, n_units, e_src, e_rel,
+                           e_val, nb, bi_rt, bo_rt, n_rel_blocks, lpm, lr, relu, nb * (BI_ > 0 ? BI_ * BO_ : bi_rt * bo_rt));
+}
+
+// The same with the WHOLE block table resident in LDS (tables up to LDS_TABLE_BYTES: AM at width 16 is 267 x 4 x 16 floats =
+// 68 KB): the per-message block reads (4x the bytes of the feature row at 4 x 4) leave L2 alone.  Persistent 1024-thread
+// workgroups (two per CU), each loads the table once and walks the units grid-stride.
+constexpr int BIG_WG = 1024;
+constexpr size_t LDS_TABLE_BYTES = 76 * 1024;
+
+template <int BI_, int BO_, bool TR>
+__global__ __launch_bounds__(BIG_WG) void block_csr_lds_kernel(
+    const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ out,
+    const int4 *__restrict__ units, const int *__restrict__ rowptr, long long n_units, const int *__restrict__ e_src,
+    const int *__restrict__ e_rel, const float *__restrict__ e_val, int nb, int bi_rt, int bo_rt, int n_rel_blocks, int lpm,
+    int lr, int relu, int table_floats) {
+  extern __shared__ __attribute__((aligned(16))) float wt[];
+  // a relation's blocks are padded by 4 floats: unpadded, every relation starts on bank 0 (nb x 16 floats = a multiple of the
+  // 64 banks at nb = 4) and the 16 messages of a ds_read_b128 collide 16 ways
+  const int per_rel = nb * BI_ * BO_, rel_stride = per_rel + 4;
+  for (int i = threadIdx.x; i < table_floats; i += BIG_WG) wt[(i / per_rel) * rel_stride + i % per_rel] = W[i];
+  __syncthreads();
+  const int upw = BIG_WG / lr;
+  for (long long base = (long long)blockIdx.x * upw; base < n_units; base += (long long)gridDim.x * upw)
+    block_unit<BI_, BO_, TR>(X, wt, bias, out, units, rowptr, base + threadIdx.x / lr, n_units, e_src, e_rel, e_val, nb, bi_rt,
+                             bo_rt, n_rel_blocks, lpm, lr, relu, rel_stride);
+}
+
 // One wave per work item (a chunk range of ONE relation in the relation-major plan; pads carry val = 0).
 template <int BI_, int BO_>
 __global__ __launch_bounds__(WG) void block_wgrad_kernel(
@@ -145,12 +181,13 @@ __global__ __launch_bounds__(WG) void block_wgrad_kernel(
     for (int i = 0; i < CAP_I; ++i)
 #pragma unroll
       for (int o = 0; o < CAP_O; ++o) acc[i][o] = 0.f;
-    if (b < nb)
-      for (int s = s0 + g; s < s1; s += groups) {
-        const float v = p_val[s];
-        if (v == 0.f) continue;
-        const float *xr = X + (size_t)p_src[s] * d_in + (size_t)b * bi, *gr = G + (size_t)p_dst[s] * d_out + (size_t)b * bo;
-        float x[CAP_I], gg[CAP_O];
+    if (b < nb) {
+      // branch-free body (pads: val = 0, src = 0, dst = -1 -> row 0), two slots in flight per lane
+      auto rows = [&](int s, bool have, float (&x)[CAP_I], float (&gg)[CAP_O]) {
+        const int ss = have ? s : s0;
+        const float v = have ? p_val[ss] : 0.f;
+        const float *xr = X + (size_t)p_src[ss] * d_in + (size_t)b * bi;
+        const float *gr = G + (size_t)max(p_dst[ss], 0) * d_out + (size_t)b * bo;
         if (vec_i) {
 #pragma unroll
           for (int i = 0; i < CAP_I / 4; ++i) {
@@ -171,11 +208,17 @@ __global__ __launch_bounds__(WG) void block_wgrad_kernel(
 #pragma unroll
           for (int o = 0; o < CAP_O; ++o) gg[o] = (FIXED || o < bo) ? gr[o] : 0.f;
         }
+      };
+      for (int s = s0 + g; s < s1; s += 2 * groups) {
+        float xa[CAP_I], ga[CAP_O], xb[CAP_I], gb[CAP_O];
+        rows(s, true, xa, ga);
+        rows(s + groups, s + groups < s1, xb, gb);
 #pragma unroll
         for (int i = 0; i < CAP_I; ++i)
 #pragma unroll
-          for (int o = 0; o < CAP_O; ++o) acc[i][o] = fmaf(x[i], gg[o], acc[i][o]);
+          for (int o = 0; o < CAP_O; ++o) acc[i][o] = fmaf(xb[i], gb[o], fmaf(xa[i], ga[o], acc[i][o]));
       }
+    }
     for (int s = lpm; s < 64; s *= 2) {
 #pragma unroll
       for (int i = 0; i < CAP_I; ++i)
@@ -228,6 +271,26 @@ extern "C" int rgcn_block_spmm_f32(const float *X, const float *blocks, const fl
   const int upw = WG / lr;
   const dim3 grid((unsigned)((n_units + upw - 1) / upw)), block(WG);
   const int4 *un = reinterpret_cast<const int4 *>(units);
+  // table in LDS: worth it when the graph is large enough to amortise 512 table loads (and the table fits)
+  const size_t table_bytes = (size_t)n_rel_blocks * nb * bi * bo * sizeof(float);
+  static const int lds_mode = getenv("RGCN_BLOCK_LDS") ? atoi(getenv("RGCN_BLOCK_LDS")) : 1;
+  const size_t lds_bytes = table_bytes + (size_t)n_rel_blocks * 4 * sizeof(float);          // + the per-relation pad
+  if (bi == 4 && bo == 4 && lds_mode && lds_bytes <= LDS_TABLE_BYTES && n_units >= 64 * 1024) {
+    const dim3 pgrid((unsigned)std::min<int64_t>(512, (n_units * lr + BIG_WG - 1) / BIG_WG));
+    auto launch = [&](auto kern) -> hipError_t {
+      if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)LDS_TABLE_BYTES);
+        if (e != hipSuccess) return e;
+      }
+      hipLaunchKernelGGL(kern, pgrid, dim3(BIG_WG), lds_bytes, st, X, blocks, bias, out, un, rowptr, (long long)n_units, e_src,
+                         e_rel, e_val, nb, bi, bo, n_rel_blocks, lpm, lr, (int)relu, (int)(table_bytes / sizeof(float)));
+      return hipGetLastError();
+    };
+    if (tr) HIP_TRY(launch(block_csr_lds_kernel<4, 4, true>));
+    else HIP_TRY(launch(block_csr_lds_kernel<4, 4, false>));
+    return RGCN_OK;
+  }
 #define RGCN_BLOCK_LAUNCH(BI, BO)                                                                                              \
   do {                                                                                                                         \
     if (tr) hipLaunchKernelGGL((block_csr_kernel<BI, BO, true>), grid, block, 0, st, X, blocks, bias, out, un, rowptr,         \

@@ -134,13 +134,20 @@ def _weight_gradient(X, W, g, graph):
 
 class _RelationalMP(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, X, W, bias, graph, relu=False):
+    def forward(ctx, X, W, bias, graph, relu=False, blocks=None):
         X, W, bias, ctx.dims = _pad_blocks(X, W, bias, graph)
         X = X.contiguous()
         W = W.contiguous()
         b = None if bias is None else bias.contiguous()
         fused_relu = relu and (max(W.shape[1], W.shape[2]) <= 64 or _wide_gemm_path(graph, W.shape[1], W.shape[2]))   # kernel epilogues
-        if _sparse_buckets(graph, W):
+        if _sparse_buckets(graph, W) and blocks is not None and ctx.dims is None and tuple(blocks.shape[2:]) == (4, 4) and \
+                os.environ.get("RGCN_BLOCK_FWD", "1") != "0":
+            # W = block_diag(blocks), 4 x 4 blocks, sparse buckets (AM): the forward reads the blocks themselves on the CSR
+            # kernel (block table in LDS; one gather per message, no transformed-row buffer): 0.46 ms against 0.65 ms for the
+            # two passes below.  The backward stays on the dense W (dX rows + dW from one relation-major walk; autograd
+            # through block_diag() picks the blocks' gradient out of dW).
+            out = _native.block_spmm(X, blocks.detach().contiguous(), b, graph.csr("fwd"), relu=fused_relu)
+        elif _sparse_buckets(graph, W):
             out = _native.spmm_two_pass(X, W, b, graph.scatter_plan("fwd"), graph.csr("fwd"), relu=fused_relu)
         else:
             out = _spmm_blocked(X, W, b, graph.fwd_plan, relu=fused_relu, graph=graph, kind="fwd")
@@ -186,7 +193,7 @@ class _RelationalMP(torch.autograd.Function):
                 dW = _weight_gradient(X, W, g, graph)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _native.colsum(g)
-        return (*_unpad_blocks(ctx.dims, dX, dW, db), None, None)
+        return (*_unpad_blocks(ctx.dims, dX, dW, db), None, None, None)
 
 
 def _join_shards(partial, group, works=None):
@@ -523,10 +530,11 @@ def use_basis_path(num_bases, d_in, d_out, graph):
     return d_in * d_out >= 64 * 64 and num_bases <= 8
 
 
-def relational_mp(features, weights, bias, graph, relu=False):
+def relational_mp(features, weights, bias, graph, relu=False, blocks=None):
     """features [N, d_in], weights [R, d_in, d_out] (dense), bias [d_out] or None -> [N, d_out]; relu=True applies the
-    activation in the kernel's epilogue (the backward masks the upstream gradient with the stored output)"""
-    return _RelationalMP.apply(features, weights, bias, graph, relu)
+    activation in the kernel's epilogue (the backward masks the upstream gradient with the stored output); blocks: the
+    [R, nb, bi, bo] parameter when weights = block_diag(blocks) (a hint: lets the forward skip the zero entries)"""
+    return _RelationalMP.apply(features, weights, bias, graph, relu, blocks)
 
 
 def featureless_mp(table, bias, graph):

@@ -287,7 +287,8 @@ class RelationalGraphConvolutionNC(_RGCBase):
                 local = lambda x, b: F_.featureless_mp(_block_messages(x, self.blocks), b, graph)
             else:
                 fuse_act = activation == "relu" and getattr(self, "_shard_group", None) is None
-                local = lambda x, b: F_.relational_mp(x, weights, b, graph, relu=fuse_act)
+                hint = self.blocks if (self.weight_decomp == 'block' and not self.diag_weight_matrix) else None
+                local = lambda x, b: F_.relational_mp(x, weights, b, graph, relu=fuse_act, blocks=hint)
                 if fuse_act:
                     activation = None
         group = getattr(self, "_shard_group", None)
