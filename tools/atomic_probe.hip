@@ -12,7 +12,16 @@
 __device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15; }   // HW_REG_XCC_ID[3:0]
 
 // MODE 0: one copy; 1: copy per XCC id; 2: copy = blockIdx % n_copies; GATHER: also do `chunks` random 16-row gathers per run
-template <int MODE, bool GATHER, bool FLUSH>
+// SCOPE 0: atomicAdd (agent scope); 1: workgroup scope; 2: wavefront scope (executed in the XCD's own L2 -- only sound for
+// per-XCC copies, where every updater of a copy sits behind the same L2)
+template <int SCOPE>
+__device__ __forceinline__ void add_f32(float* p, float v) {
+  if (SCOPE == 0) atomicAdd(p, v);
+  else if (SCOPE == 1) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+template <int MODE, bool GATHER, bool FLUSH, int SCOPE = 0>
 __global__ __launch_bounds__(256) void probe(float* __restrict__ dW, int n_copies, int R, int n_tiles, const float4* __restrict__ tab,
                                              const int* __restrict__ idx, int chunks, float* out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -36,19 +45,19 @@ __global__ __launch_bounds__(256) void probe(float* __restrict__ dW, int n_copie
     }
     if (FLUSH) {
       float* p = base + (size_t)r * 256 + lane;
-      atomicAdd(p, acc.x); atomicAdd(p + 64, acc.y); atomicAdd(p + 128, acc.z); atomicAdd(p + 192, acc.w);
+      add_f32<SCOPE>(p, acc.x); add_f32<SCOPE>(p + 64, acc.y); add_f32<SCOPE>(p + 128, acc.z); add_f32<SCOPE>(p + 192, acc.w);
     }
   }
   if (acc.x == 12345.678f) out[0] = acc.x;
 }
 
-template <int MODE, bool GATHER, bool FLUSH>
+template <int MODE, bool GATHER, bool FLUSH, int SCOPE = 0>
 float run(float* dW, int n_copies, int R, int n_tiles, const float4* tab, const int* idx, int chunks, float* out) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   const int grid = (n_tiles + 3) / 4;
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((probe<MODE, GATHER, FLUSH>), dim3(grid), dim3(256), 0, 0, dW, n_copies, R, n_tiles, tab, idx, chunks, out);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((probe<MODE, GATHER, FLUSH, SCOPE>), dim3(grid), dim3(256), 0, 0, dW, n_copies, R, n_tiles, tab, idx, chunks, out);
   CK(hipEventRecord(a));
-  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((probe<MODE, GATHER, FLUSH>), dim3(grid), dim3(256), 0, 0, dW, n_copies, R, n_tiles, tab, idx, chunks, out);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((probe<MODE, GATHER, FLUSH, SCOPE>), dim3(grid), dim3(256), 0, 0, dW, n_copies, R, n_tiles, tab, idx, chunks, out);
   CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
   float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms / 5;
 }
@@ -73,6 +82,23 @@ int main() {
          run<0, true, true>(dW, 1, R, n_tiles, tab, idx, chunks, out), run<1, true, true>(dW, 8, R, n_tiles, tab, idx, chunks, out),
          run<2, true, true>(dW, 8, R, n_tiles, tab, idx, chunks, out), run<2, true, true>(dW, 64, R, n_tiles, tab, idx, chunks, out),
          run<2, true, true>(dW, 512, R, n_tiles, tab, idx, chunks, out), run<2, true, true>(dW, 2048, R, n_tiles, tab, idx, chunks, out));
+  printf("scopes, per-XCC-id x8 copies: flush only  agent %.3f | workgroup %.3f | wavefront %.3f ms\n",
+         run<1, false, true, 0>(dW, 8, R, n_tiles, tab, idx, chunks, out), run<1, false, true, 1>(dW, 8, R, n_tiles, tab, idx, chunks, out),
+         run<1, false, true, 2>(dW, 8, R, n_tiles, tab, idx, chunks, out));
+  printf("scopes, per-XCC-id x8 copies: gather+flush agent %.3f | workgroup %.3f | wavefront %.3f ms\n",
+         run<1, true, true, 0>(dW, 8, R, n_tiles, tab, idx, chunks, out), run<1, true, true, 1>(dW, 8, R, n_tiles, tab, idx, chunks, out),
+         run<1, true, true, 2>(dW, 8, R, n_tiles, tab, idx, chunks, out));
+  for (int scope = 1; scope <= 2; ++scope) {      // do the narrow scopes still add up?
+    CK(hipMemset(dW, 0, (size_t)8 * R * 256 * 4));
+    if (scope == 1) hipLaunchKernelGGL((probe<1, false, true, 1>), dim3((n_tiles + 3) / 4), dim3(256), 0, 0, dW, 8, R, n_tiles, tab, idx, chunks, out);
+    else hipLaunchKernelGGL((probe<1, false, true, 2>), dim3((n_tiles + 3) / 4), dim3(256), 0, 0, dW, 8, R, n_tiles, tab, idx, chunks, out);
+    CK(hipDeviceSynchronize());
+    std::vector<float> w2((size_t)8 * R * 256);
+    CK(hipMemcpy(w2.data(), dW, w2.size() * 4, hipMemcpyDeviceToHost));
+    double tot2 = 0;
+    for (int c = 0; c < 8; ++c) for (int i = 0; i < 64; ++i) tot2 += w2[(size_t)c * R * 256 + i];
+    printf("scope %d: sum over copies of dW[0][0..63] = %.0f (expected %d)\n", scope, tot2, 64 * n_tiles);
+  }
   // correctness of the per-XCC copies: the sum over copies must equal the number of flushes times the flushed value
   CK(hipMemset(dW, 0, (size_t)8 * R * 256 * 4));
   hipLaunchKernelGGL((probe<1, false, true>), dim3((n_tiles + 3) / 4), dim3(256), 0, 0, dW, 8, R, n_tiles, tab, idx, chunks, out);
