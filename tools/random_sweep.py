@@ -16,14 +16,19 @@ for case in range(400):
     vertical = bool(rng.random() < 0.5) and not featureless
     d_in, d_out = int(rng.choice(widths)), int(rng.choice(widths))
     if featureless and N*d_out > 400000: d_out = 16
+    nb = 2
     if mode == "block":
-        d_in, d_out = 2 * max(1, d_in // 2), 2 * max(1, d_out // 2)
-        if featureless and N % 2: N += 1
+        if featureless:
+            d_in, d_out = 2 * max(1, d_in // 2), 2 * max(1, d_out // 2)
+            if N % 2: N += 1
+        else:       # block sizes 1 x 1 .. 10 x 10 (the block kernels take up to 8 x 8), 1 .. 70 blocks
+            nb = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 25, 70]))
+            d_in, d_out = nb * int(rng.integers(1, 11)), nb * int(rng.integers(1, 11))
     if mode == "diag": d_out = d_in
     try:
         T.run_layer_vs_oracle(N=N, R0=R0, E=E, d_in=d_in, d_out=d_out, mode=mode, featureless=featureless, vertical=vertical,
-                              seed=5000 + case, hub=bool(rng.random() < 0.3) and N > 1, num_bases=int(rng.integers(1, 70)))
+                              seed=5000 + case, hub=bool(rng.random() < 0.3) and N > 1, num_bases=int(rng.integers(1, 70)), num_blocks=nb)
     except Exception as exc:
         fails+=1
-        print(f"FAIL case {case}: N={N} R0={R0} E={E} mode={mode} fl={featureless} vert={vertical} d=({d_in},{d_out}): {type(exc).__name__}: {str(exc)[:200]}", flush=True)
+        print(f"FAIL case {case}: N={N} R0={R0} E={E} mode={mode} nb={nb} fl={featureless} vert={vertical} d=({d_in},{d_out}): {type(exc).__name__}: {str(exc)[:200]}", flush=True)
 print("done, failures:", fails)
