@@ -258,14 +258,19 @@ def main():
     if group is not None:
         # Untimed set-up: which form of the collective is fastest on THIS link (xGMI ring / direct, one rank, gloo)?
         # 3 steps per candidate, max over ranks, the same choice on every rank.
-        cands = [("allreduce", "0"), ("rs_ag", "0"), ("allreduce", "2")] + ([("allreduce", "4")] if mode == "weak" else [])
+        cands = [("allreduce", "0"), ("rs_ag", "0"), ("a2a", "0"), ("allreduce", "2")] + ([("allreduce", "4")] if mode == "weak" else [])
         if "RGCN_DIST_COMM" in os.environ or "RGCN_DIST_SLABS" in os.environ:
             cands = [(os.environ.get("RGCN_DIST_COMM", "allreduce"), os.environ.get("RGCN_DIST_SLABS", "0"))]
         tried = {}
         for c, s in cands:
             os.environ["RGCN_DIST_COMM"], os.environ["RGCN_DIST_SLABS"] = c, s
-            tried[f"{c}/slabs={s}"] = round(timed_steps(3), 4)
-        best = min(tried, key=tried.get)
+            try:
+                tried[f"{c}/slabs={s}"] = round(timed_steps(3), 4)
+            except RuntimeError as exc:       # a collective this backend lacks fails on every rank alike: drop the candidate
+                tried[f"{c}/slabs={s}"] = None
+                if rank == 0:
+                    print(f"bench.py: transport {c}/slabs={s} unavailable: {str(exc)[:120]}", file=sys.stderr)
+        best = min((k for k in tried if tried[k] is not None), key=tried.get)
         os.environ["RGCN_DIST_COMM"], os.environ["RGCN_DIST_SLABS"] = best.split("/slabs=")
         comm = {"collective": best, "candidates_ms_per_step": tried}
 

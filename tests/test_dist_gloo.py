@@ -117,7 +117,7 @@ def _join_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from torch_rgcn.functional import _join_shards
     out = {}
-    for mode in ("allreduce", "rs_ag", "none"):
+    for mode in ("allreduce", "rs_ag", "a2a", "none"):
         os.environ["RGCN_DIST_COMM"] = mode
         for n in (10, 11):                                   # 11 rows: not divisible by the world size (padded blocks)
             part = torch.arange(n * 3, dtype=torch.float32).view(n, 3) * (rank + 1)
@@ -129,8 +129,8 @@ def _join_worker(rank, world, port, q):
 
 
 def test_join_shards_collective_variants_agree():
-    """the three transports of the partial-sum join (torch_rgcn.functional._join_shards): all-reduce and
-    reduce-scatter + all-gather give the sum over ranks, "none" (bench.py's compute-alone timing leg) leaves the partial"""
+    """the transports of the partial-sum join (torch_rgcn.functional._join_shards): all-reduce, reduce-scatter + all-gather
+    and the direct exchange (all-to-all + local sum + all-gather) give the sum over ranks, "none" (bench.py's compute-alone timing leg) leaves the partial"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -145,4 +145,5 @@ def test_join_shards_collective_variants_agree():
         base = np.arange(n * 3, dtype=np.float32).reshape(n, 3)
         assert np.array_equal(out[("allreduce", n)], 3 * base)
         assert np.array_equal(out[("rs_ag", n)], 3 * base) and out[("rs_ag", n)].shape == (n, 3)
+        assert np.array_equal(out[("a2a", n)], 3 * base) and out[("a2a", n)].shape == (n, 3)
         assert np.array_equal(out[("none", n)], base)

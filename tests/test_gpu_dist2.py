@@ -131,7 +131,7 @@ def _bench_path_worker(rank, world, port, outdir, backend="gloo"):
             res[tag] = [t.detach().cpu().numpy() for t in (out, X.grad, grads[0], grads[1], l1.bias.grad, l2.bias.grad)]
 
         run("ref", None)
-        for comm, slabs in (("allreduce", "0"), ("rs_ag", "0"), ("allreduce", "2")):
+        for comm, slabs in (("allreduce", "0"), ("rs_ag", "0"), ("a2a", "0"), ("allreduce", "2")):
             run(f"{comm}{slabs}", dist.group.WORLD, comm, slabs)
         if rank == 0:
             np.savez(os.path.join(outdir, "bench_path.npz"), **{f"{k}_{i}": a for k, v in res.items() for i, a in enumerate(v)})
@@ -141,7 +141,7 @@ def _bench_path_worker(rank, world, port, outdir, backend="gloo"):
 
 def _check_bench_path(tmp_path):
     z = np.load(os.path.join(str(tmp_path), "bench_path.npz"))
-    for tag in ("allreduce0", "rs_ag0", "allreduce2"):
+    for tag in ("allreduce0", "rs_ag0", "a2a0", "allreduce2"):
         for i, name in enumerate(("out", "dX", "dW1", "dW2", "db1", "db2")):
             a, b = z[f"{tag}_{i}"], z[f"ref_{i}"]
             assert np.abs(a - b).max() <= 3e-5 * np.abs(b).max(), (tag, name)

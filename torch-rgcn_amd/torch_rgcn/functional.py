@@ -201,11 +201,24 @@ def _join_shards(partial, group, works=None):
       allreduce (default)  one RCCL all-reduce of the whole matrix
       rs_ag                reduce-scatter of row blocks + all-gather (the two halves of an all-reduce as separate
                            collectives: lets RCCL pick its direct algorithms per half; same bytes on every link)
+      a2a                  direct exchange: all-to-all of the row blocks (every rank sends block j straight to rank j: on the
+                           fully connected xGMI mesh all 7 links carry 1/8 of the matrix at once, a ring carries 7/8 of it
+                           through every link in turn), local sum of the world_size received blocks, all-gather
       none                 no collective at all -- TIMING ONLY (bench.py's compute-alone leg); results are wrong"""
     import torch.distributed as dist
     mode = os.environ.get("RGCN_DIST_COMM", "allreduce")
     if mode == "none":
         return partial
+    if mode == "a2a":
+        world = dist.get_world_size(group)
+        n, d = partial.shape
+        rows = -(-n // world)
+        buf = partial if rows * world == n else torch.nn.functional.pad(partial, (0, 0, 0, rows * world - n))
+        recv = torch.empty_like(buf)                         # recv[j] = rank j's partial of MY row block
+        dist.all_to_all_single(recv, buf, group=group)
+        shard = recv.view(world, rows * d).sum(dim=0).view(rows, d)      # fixed order: rank 0 .. world-1
+        dist.all_gather_into_tensor(buf, shard, group=group)
+        return buf if rows * world == n else buf[:n].contiguous()
     if mode == "rs_ag":
         world = dist.get_world_size(group)
         n, d = partial.shape
