@@ -871,44 +871,53 @@ __global__ __launch_bounds__(WG) void diag_csr_kernel(
 }
 
 // Diagonal-weight layer, weight gradient: dw[r, j] = sum_{slots of r} val * X[src, j] * G[dst, j].  Relation-major plan; one
-// wave per work item (a chunk range of one relation): lane 16q+m accumulates columns jb+4q..+3 over slot m of every chunk
-// of the item, the 16 slot lanes are summed with DPP row shifts, one float4 of atomics per (item, 4 columns).
+// wave per work item (a chunk range of one relation).  `lpm` lanes per slot (one float4 of the row each: a slot's two rows
+// are read ONCE, whole -- the first version walked 16 columns per pass and fetched every 128-byte line of a d = 32 row
+// twice: 57 M fabric requests per launch on the AM-shaped graph instead of 27 M, profiles/r02_pmc_csr_kernels.json),
+// 64 / lpm slots in flight, two per lane; the slot groups are summed with wave shuffles, one float4 of atomics per
+// (item, 4 columns).  Rows wider than 256 floats loop over column blocks.
 __global__ __launch_bounds__(WG) void diag_wgrad_kernel(
     const float *__restrict__ X, const float *__restrict__ G, float *__restrict__ dw, const int *__restrict__ p_src,
     const int *__restrict__ p_dst, const float *__restrict__ p_val, const int *__restrict__ chunk_rel,
-    const int2 *__restrict__ items, long long n_items, int d) {
+    const int2 *__restrict__ items, long long n_items, int d, int lpm) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long long it = (long long)blockIdx.x * (WG / 64) + wave;
   if (it >= n_items) return;
   const int2 range = items[it];
   if (range.x >= range.y) return;
   const int rel = chunk_rel[range.x];
-  const int m = lane & 15, q = lane >> 4;
+  const int g = lane / lpm, j = lane % lpm, groups = 64 / lpm;
+  const int s0 = range.x * RGCN_CHUNK, s1 = range.y * RGCN_CHUNK;
   const bool vec4 = (d & 3) == 0;
-  for (int jb = 0; jb < d; jb += 16) {
-    const int col = jb + 4 * q;
+  for (int f0 = 0; f0 < d; f0 += 4 * lpm) {
+    const int col = f0 + 4 * j;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int c = range.x; c < range.y; ++c) {
-      const int e = c * RGCN_CHUNK + m;
-      const float v = p_val[e];
-      if (v == 0.f || col >= d) continue;              // pads: val = 0, dst = -1
-      const float *x = X + (size_t)p_src[e] * d + col, *g = G + (size_t)p_dst[e] * d + col;
-      if (vec4) {
-        const float4 a = *reinterpret_cast<const float4 *>(x), b = *reinterpret_cast<const float4 *>(g);
-        acc[0] += v * a.x * b.x; acc[1] += v * a.y * b.y; acc[2] += v * a.z * b.z; acc[3] += v * a.w * b.w;
-      } else {
+    if (col < d) {
+      // branch-free (pads: val = 0, src = 0, dst = -1 -> row 0)
+      auto one = [&](int s, bool have) -> f32x4 {
+        const int ss = have ? s : s0;
+        const float v = have ? p_val[ss] : 0.f;
+        const float *x = X + (size_t)p_src[ss] * d + col, *gr = G + (size_t)max(p_dst[ss], 0) * d + col;
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (vec4) {
+          r = *reinterpret_cast<const f32x4 *>(x) * *reinterpret_cast<const f32x4 *>(gr) * v;
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (col + i < d) acc[i] += v * x[i] * g[i];
+          for (int i = 0; i < 4; ++i)
+            if (col + i < d) r[i] = v * x[i] * gr[i];
+        }
+        return r;
+      };
+      for (int s = s0 + g; s < s1; s += 2 * groups) {
+        const f32x4 a = one(s, true), b2 = one(s + groups, s + groups < s1);
+        acc += a + b2;
       }
     }
+    for (int sh = lpm; sh < 64; sh *= 2) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {                       // sum over the 16 slot lanes of the row
-      float a = acc[i];
-      a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 4, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 1, 64);
-      acc[i] = a;
+      for (int i = 0; i < 4; ++i) acc[i] += __shfl_xor(acc[i], sh, 64);
     }
-    if (m == 0 && col < d) {
+    if (g == 0 && col < d) {
       float *o = dw + (size_t)rel * d + col;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -1395,8 +1404,10 @@ extern "C" int rgcn_diag_wgrad_f32(const float *X, const float *G, float *dw, co
   }
   HIP_TRY(zero_async(dw, (size_t)R * d * sizeof(float), (hipStream_t)stream));
   if (n_items == 0) return RGCN_OK;
+  int lpm = 1;                                  // lanes per slot: float4 each, a power of two
+  while (lpm < 64 && 4 * lpm < d) lpm *= 2;
   hipLaunchKernelGGL(diag_wgrad_kernel, dim3((unsigned)((n_items + WG / 64 - 1) / (WG / 64))), dim3(WG), 0, (hipStream_t)stream,
-                     X, G, dw, p_src, p_dst, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), (long long)n_items, d);
+                     X, G, dw, p_src, p_dst, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), (long long)n_items, d, lpm);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
