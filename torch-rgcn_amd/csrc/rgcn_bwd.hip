@@ -55,19 +55,19 @@ struct BwdStage {
   float4 xn[U];    // X[o_m][4k..4k+3] (tile-local row of the destination)
 };
 
-template <int U, bool ATOMIC, int BW_D>
-__global__ __launch_bounds__(WG, 4) void bwd_fused_d16_kernel(
+template <int U, bool ATOMIC, int BW_D, int NW = 4>      // NW = waves (= tiles) per workgroup
+__global__ __launch_bounds__(64 * NW, 16 / NW) void bwd_fused_d16_kernel(
     const float *__restrict__ G, const float *__restrict__ X, const float *__restrict__ Wtp, float *__restrict__ dX,
     float *__restrict__ dWout, const int2 *__restrict__ p_pack, const int *__restrict__ chunk_rel,
     const int *__restrict__ run_ptr, int n_tiles, int n_blocks, int tile_rows, int n_dst, int R, int ablate) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int t = blockIdx.x * 4 + wave;
+  const int t = blockIdx.x * NW + wave;
   const bool valid = t < n_tiles;
   float *tile = lds + wave * tile_rows * 16;
-  float *xs = lds + 4 * tile_rows * 16 + wave * BW_SCR;
-  float *stage = lds + 4 * tile_rows * 16 + 4 * BW_SCR;        // [wave][BW_D][256], fragment order
+  float *xs = lds + NW * tile_rows * 16 + wave * BW_SCR;
+  float *stage = lds + NW * tile_rows * 16 + NW * BW_SCR;      // [wave][BW_D][256], fragment order
   float *my_stage = stage + wave * (BW_D * 256);
   const int row0 = t * tile_rows;
   const int nrows = valid ? min(tile_rows, n_dst - row0) : 0;
@@ -94,9 +94,8 @@ __global__ __launch_bounds__(WG, 4) void bwd_fused_d16_kernel(
     const int r = iv * BW_D + wave;
     if (wave < BW_D && r < R) {
       f32x4 sum = reinterpret_cast<const f32x4 *>(stage + (0 * BW_D + wave) * 256)[lane];
-      sum += reinterpret_cast<const f32x4 *>(stage + (1 * BW_D + wave) * 256)[lane];
-      sum += reinterpret_cast<const f32x4 *>(stage + (2 * BW_D + wave) * 256)[lane];
-      sum += reinterpret_cast<const f32x4 *>(stage + (3 * BW_D + wave) * 256)[lane];
+#pragma unroll
+      for (int w2 = 1; w2 < NW; ++w2) sum += reinterpret_cast<const f32x4 *>(stage + (w2 * BW_D + wave) * 256)[lane];
       if (ATOMIC) {       // D: lane 16q+j holds rows 4q..4q+3 (input feature), column j (output feature)
         float *wr = dWout + (size_t)r * 256 + (4 * k) * 16 + m;
         atomicAdd(wr, sum[0]); atomicAdd(wr + 16, sum[1]); atomicAdd(wr + 32, sum[2]); atomicAdd(wr + 48, sum[3]);
@@ -335,6 +334,19 @@ void launch_bwd(const BwdLaunch &a) {
                      a.dX, a.dWout, a.pk, a.chunk_rel, a.run_ptr, a.n_tiles, a.n_blocks, a.tile_rows, a.n_dst, a.R, a.ablate);
 }
 
+// 8 tiles per workgroup (512 threads, 2 workgroups per CU): half the dW flushes of the 4-tile form; needs > 64 KiB of LDS
+template <bool AT>
+hipError_t launch_bwd8(const BwdLaunch &a) {
+  auto kern = bwd_fused_d16_kernel<4, AT, 4, 8>;
+  if (a.lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.n_blocks), dim3(512), a.lds, a.st, a.G, a.X, a.Wtp, a.dX, a.dWout, a.pk, a.chunk_rel,
+                     a.run_ptr, a.n_tiles, a.n_blocks, a.tile_rows, a.n_dst, a.R, a.ablate);
+  return hipGetLastError();
+}
+
 template <int U, bool AT>
 void launch_bwd_d(const BwdLaunch &a, int D) {
   if (D == 4) launch_bwd<U, AT, 4>(a);
@@ -371,10 +383,16 @@ extern "C" int rgcn_bwd_fused_f32(const float *G, const float *X, const float *W
   if (!atomic && !scratch) { rgcn_set_error("bwd_fused: the deterministic reduction needs a scratch buffer"); return RGCN_EINVAL; }
   static const int DSEL = getenv("RGCN_BWD_D") ? atoi(getenv("RGCN_BWD_D")) : 4;
   const int Dv = DSEL >= 4 ? 4 : (DSEL >= 2 ? 2 : 1);
-  const size_t lds = ((size_t)4 * tile_rows * 16 + 4 * BW_SCR + 4 * Dv * 256) * sizeof(float);
-  if (lds > 64 * 1024) { rgcn_set_error("bwd_fused: tile_rows = %d needs %zu bytes of LDS per workgroup (limit 64 KiB)", tile_rows, lds); return RGCN_EUNSUPPORTED; }
+  // tiles per workgroup: 8 halve the number of dW partials -- measured at S1 (profiles/r02_bwd_fused_ablation.txt): atomic flush
+  // 0.719 -> 0.740 ms (the barrier now waits for the slowest of 8 waves, which costs more than the saved atomics), plain-store
+  // flush of the deterministic mode 0.798 -> 0.769 ms (half the partial bytes) -- so 8 only there
+  static const int NWSEL = getenv("RGCN_BWD_WAVES") ? atoi(getenv("RGCN_BWD_WAVES")) : 0;
+  const int NWwant = NWSEL ? NWSEL : (atomic ? 4 : 8);
+  const int NWv = (NWwant >= 8 && Dv == 4 && tile_rows <= 64) ? 8 : 4;
+  const size_t lds = ((size_t)NWv * tile_rows * 16 + NWv * BW_SCR + NWv * Dv * 256) * sizeof(float);
+  if (lds > (NWv == 8 ? 80 : 64) * 1024) { rgcn_set_error("bwd_fused: tile_rows = %d needs %zu bytes of LDS per workgroup", tile_rows, lds); return RGCN_EUNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
-  const int n_blocks = (int)((n_tiles + 3) / 4);
+  const int n_blocks = (int)((n_tiles + NWv - 1) / NWv);
   static const int USEL = getenv("RGCN_BWD_U") ? atoi(getenv("RGCN_BWD_U")) : 4;
   static const int ABL = getenv("RGCN_BWD_ABLATE") ? atoi(getenv("RGCN_BWD_ABLATE")) : 0;   // diagnosis only (results are wrong)
   const int2 *pk = reinterpret_cast<const int2 *>(p_pack);
@@ -382,9 +400,11 @@ extern "C" int rgcn_bwd_fused_f32(const float *G, const float *X, const float *W
                     (int)n_dst, R, ABL, lds, st};
   if (atomic) {
     HIP_TRY(zero_async(dW, (size_t)R * 256 * sizeof(float), st));
-    if (USEL >= 4) launch_bwd_d<4, true>(L, Dv); else launch_bwd_d<2, true>(L, Dv);
+    if (NWv == 8) HIP_TRY(launch_bwd8<true>(L));
+    else if (USEL >= 4) launch_bwd_d<4, true>(L, Dv); else launch_bwd_d<2, true>(L, Dv);
   } else {
-    if (USEL >= 4) launch_bwd_d<4, false>(L, Dv); else launch_bwd_d<2, false>(L, Dv);
+    if (NWv == 8) HIP_TRY(launch_bwd8<false>(L));
+    else if (USEL >= 4) launch_bwd_d<4, false>(L, Dv); else launch_bwd_d<2, false>(L, Dv);
     const int S = (int)std::max<int64_t>(1, std::min<int64_t>(16, n_blocks / 64));
     float *tmp = scratch + (size_t)n_blocks * R * 256;
     hipLaunchKernelGGL(dw_reduce_a_kernel, dim3((unsigned)R, (unsigned)S), dim3(WG), 0, st, scratch, tmp, n_blocks, S);
