@@ -398,10 +398,137 @@ def g9():
     save("g9_lp_loader", **{f"file_{k}": np.asarray(v) for k, v in files.items()}, **res)
 
 
+def _rdflib_standin():
+    """rdflib (a dependency of the reference's node-classification loader, utils/data.py:1-5) is not installed in this image and
+    cannot be (no network).  This stand-in provides exactly what the loader touches (utils/data.py:15-25 st(), :28-43
+    add_neighbors(), :131-160): a Graph that is a SET of triples with .parse(file=, format='nt'), iteration and
+    .triples((s|None, p|None, o|None)); URIRef / BNode / Literal terms with .n3().  Term parsing restates the W3C N-Triples
+    grammar.  The G10 fixture keeps to terms whose rdflib .n3() is the input token itself (ASCII IRIs, blank nodes, plain /
+    language-tagged / datatyped literals without escapes), so what G10 pins is the REFERENCE's loader logic around the parser:
+    label category codes, validation split, two-hop pruning, node / relation inventories, the relation limit."""
+    import re
+    import types
+
+    class URIRef(str):
+        def n3(self):
+            return f"<{self}>"
+
+    class BNode(str):
+        def n3(self):
+            return f"_:{self}"
+
+    class Literal(str):
+        def __new__(cls, lex, suffix=""):
+            obj = str.__new__(cls, lex + "\0" + suffix)     # identity = lexical form + language / datatype
+            obj.lex, obj.suffix = lex, suffix
+            return obj
+
+        def n3(self):
+            return f'"{self.lex}"{self.suffix}'
+
+    term = r'(<[^>]*>|_:[A-Za-z0-9]+|"[^"\\]*"(?:@[A-Za-z]+(?:-[A-Za-z0-9]+)*|\^\^<[^>]*>)?)'
+    line_re = re.compile(r"^\s*" + term + r"\s*" + term + r"\s*" + term + r"\s*\.\s*(#.*)?$")
+
+    def make(tok):
+        if tok.startswith("<"):
+            return URIRef(tok[1:-1])
+        if tok.startswith("_:"):
+            return BNode(tok[2:])
+        end = tok.rindex('"')
+        return Literal(tok[1:end], tok[end + 1:])
+
+    class Graph:
+        def __init__(self):
+            self._t = set()
+
+        def parse(self, file=None, format=None):
+            assert format == "nt"
+            for raw in file:
+                line = raw.decode("utf8") if isinstance(raw, bytes) else raw
+                if not line.strip() or line.lstrip().startswith("#"):
+                    continue
+                m = line_re.match(line)
+                assert m, line
+                self._t.add(tuple(make(m.group(i)) for i in (1, 2, 3)))
+            return self
+
+        def __iter__(self):
+            return iter(self._t)
+
+        def __len__(self):
+            return len(self._t)
+
+        def triples(self, pattern):
+            s, p, o = pattern
+            for t in self._t:
+                if (s is None or t[0] == s) and (p is None or t[1] == p) and (o is None or t[2] == o):
+                    yield t
+
+    mod = types.ModuleType("rdflib")
+    mod.URIRef, mod.BNode, mod.Literal, mod.Graph = URIRef, BNode, Literal, Graph
+    mod.util = types.SimpleNamespace(guess_format=lambda f: "nt")
+    return mod
+
+
+G10_NT = """# tiny AIFB-layout graph for G10
+<http://ex.org/a> <http://ex.org/p> <http://ex.org/b> .
+<http://ex.org/a> <http://ex.org/p> <http://ex.org/b> .
+<http://ex.org/b> <http://ex.org/p> <http://ex.org/c> .
+<http://ex.org/c> <http://ex.org/p> <http://ex.org/a> .
+<http://ex.org/d> <http://ex.org/p> <http://ex.org/a> .
+<http://ex.org/b> <http://ex.org/q> _:blank1 .
+_:blank1 <http://ex.org/q> "a literal with spaces" .
+<http://ex.org/b> <http://ex.org/q> "Bob"@en-GB .
+<http://ex.org/b> <http://ex.org/age> "42"^^<http://www.w3.org/2001/XMLSchema#integer> .
+<http://ex.org/c> <http://ex.org/age> "42" .
+<http://ex.org/far> <http://ex.org/p> <http://ex.org/farther> .
+<http://ex.org/farther> <http://ex.org/p> <http://ex.org/farthest> .
+<http://ex.org/farthest> <http://ex.org/r> <http://ex.org/beyond> .
+<http://ex.org/beyond> <http://ex.org/r> <http://ex.org/outer> .
+"""
+G10_TRAIN = [("http://ex.org/a", "x"), ("http://ex.org/b", "y"), ("http://ex.org/c", "x"), ("http://ex.org/far", "z"),
+             ("http://ex.org/d", "y"), ("http://ex.org/a", "x")]
+G10_TEST = [("http://ex.org/c", "y"), ("http://ex.org/b", "x")]
+
+
+def g10():
+    """utils/data.py:50-186 load_node_classification_data -- the REFERENCE's loader, run on a tiny AIFB-layout dataset with the
+    rdflib stand-in above.  The reference numbers nodes and relations in set / dict iteration order, so the fixture stores
+    label-level facts: decoded edges (sorted), node and relation label sets, the train / test dictionaries."""
+    import gzip
+    import importlib.util
+    import tempfile
+    sys.modules["rdflib"] = _rdflib_standin()
+    spec = importlib.util.spec_from_file_location("ref_utils_data_nc", os.path.join(REF, "utils", "data.py"))
+    data = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(data)
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        d = os.path.join(tmp, "data", "aifb")
+        os.makedirs(d)
+        with gzip.open(os.path.join(d, "aifb_stripped.nt.gz"), "wb") as f:
+            f.write(G10_NT.encode("utf8"))
+        for fname, rows in (("trainingSet.tsv", G10_TRAIN), ("testSet.tsv", G10_TEST)):
+            with open(os.path.join(d, fname), "w") as f:
+                f.write("id\tperson\tlabel_affiliation\n" + "".join(f"{i}\t{n}\t{c}\n" for i, (n, c) in enumerate(rows)))
+        data.locate_file = lambda rel: os.path.join(tmp, rel)
+        for tag, kw in (("valid", {}), ("test", {"use_test_set": True}), ("prune", {"use_test_set": True, "prune": True}),
+                        ("limit", {"use_test_set": True, "limit": 1}), ("valprop", {"val_prop": 0.5})):
+            edges, (n2i, i2n), (r2i, i2r), train, test = data.load_node_classification_data("AIFB", enable_cache=False, **kw)
+            assert [n2i[x] for x in i2n] == list(range(len(i2n))) and [r2i[x] for x in i2r] == list(range(len(i2r)))
+            dec = sorted([i2n[s_], i2r[p_], i2n[o_]] for s_, p_, o_ in edges)
+            res.update({f"{tag}_edges": np.asarray(dec), f"{tag}_nodes": np.asarray(sorted(i2n)),
+                        f"{tag}_rels": np.asarray(i2r if "limit" in kw else sorted(i2r)),
+                        f"{tag}_train": np.asarray(sorted((k, str(int(v))) for k, v in train.items())),
+                        f"{tag}_test": np.asarray(sorted((k, str(int(v))) for k, v in test.items()))})
+    save("g10_nc_loader", file_nt=np.asarray(G10_NT), file_train=np.asarray([list(r) for r in G10_TRAIN]),
+         file_test=np.asarray([list(r) for r in G10_TEST]), **res)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10):
         if only and fn.__name__ not in only:
             continue
         fn()
