@@ -166,3 +166,10 @@ def test_mutag_full_shape_node_classifier_matches_oracle_composition():
                           (l2["dX"] * (l1["out"] > 0)).astype(np.float32))
     for n, gv in l1b["grads"].items():
         assert rel_err(getattr(model.rgc1, n).grad, gv) < TOL, n
+
+
+def test_more_than_2_31_relation_node_cells_vs_oracle():
+    """num_nodes x num_relations past 2^31 (27 M nodes x 81 relations = 2.19e9 cells of the counting
+    tables, 64-bit cell indices; also past the 24-bit source id of the packed slots -> unpacked slot arrays): one featured
+    layer, forward and backward, against the oracle"""
+    run_layer_vs_oracle(N=27_000_000, R0=40, E=3_000_000, d_in=16, d_out=16, mode="none", seed=77)

@@ -1,12 +1,13 @@
 """More than 2^24 nodes (the packed 8-byte slot holds a 24-bit source id): the unpacked slot arrays against the oracle
-at N = 17 M (python tools/big_n_check.py; ~20 s of oracle time)."""
+at N = 17 M (python tools/big_n_check.py; ~20 s of oracle time); `python tools/big_n_check.py 30000000 40 5000000 16` = 2.43e9
+(relation, node) cells, past 2^31 (64-bit cell indices in the device-side graph build)."""
 import sys, os, time
 ROOT=os.environ.get("GRAFT_REPO_ROOT","/root/repo")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT,"torch-rgcn_amd"))
 import numpy as np, torch
 from oracle import oracle
 from torch_rgcn.layers import RelationalGraphConvolutionNC
-N,R0,E,d=17_000_000,10,5_000_000,16
+N,R0,E,d=(int(a) for a in (sys.argv[1:5] if len(sys.argv) > 4 else ("17000000","10","5000000","16")))
 T=oracle.synthetic_triples(N,R0,E,seed=1); tp=oracle.add_inverse_and_self(T,N,R0); R=2*R0+1
 layer=RelationalGraphConvolutionNC(triples=torch.from_numpy(tp),num_nodes=N,num_relations=R,in_features=d,out_features=d).cuda()
 rng=np.random.default_rng(0)

@@ -36,6 +36,9 @@ def pick_tile_rows(width, n_rows=None):
     return int(rows)
 
 
+_MAX_CELLS = 2 ** 34      # 64 GiB per counting table
+
+
 class RelGraph:
     def __init__(self, triples_plus, val, num_nodes, num_rels, device):
         """triples_plus: int64 numpy [M,3] (s,p,o); val: float32 numpy [M].  (host-built plans)"""
@@ -43,8 +46,11 @@ class RelGraph:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("RelGraph lives on a GPU: torch_rgcn runs on HIP kernels only (no CPU fallback)")
-        if self.num_nodes * self.num_rels >= 2 ** 31:
-            raise NotImplementedError("num_nodes * num_relations must stay below 2^31")
+        # the graph build counts messages in dense (relation, node) tables: 4 bytes x num_nodes x num_relations each (64-bit
+        # cell indices on the device).  The limit is memory, not addressing: 2^36 cells = 256 GiB is past one MI355X.
+        if self.num_nodes * self.num_rels >= _MAX_CELLS:
+            raise NotImplementedError(f"num_nodes * num_relations = {self.num_nodes * self.num_rels:,} needs a "
+                                      f"{4 * self.num_nodes * self.num_rels / 2**30:.0f} GiB counting table (limit {_MAX_CELLS:,} cells)")
         self._dev = None
         self._plans = {}
         self.sync_free = False      # True: plans are sized by upper bounds and finished on the device (no host read-back)
@@ -171,7 +177,7 @@ def _device_build_enabled():
 
 def graph_from_nc_triples(triples_plus, num_nodes, num_rels, vertical, device):
     """NC layer: n = int((M - N) / 2), i = N  (torch_rgcn/layers.py:235-236, :269-271)."""
-    if _device_build_enabled() and num_nodes * num_rels < 2 ** 31:
+    if _device_build_enabled() and num_nodes * num_rels < _MAX_CELLS:
         t = torch.as_tensor(triples_plus, dtype=torch.long).reshape(-1, 3).to(device)
         M = t.shape[0]
         n_swap = int((M - num_nodes) / 2)
@@ -190,7 +196,7 @@ def graph_from_nc_triples(triples_plus, num_nodes, num_rels, vertical, device):
 
 def graph_from_lp_triples(triples, num_nodes, num_rels, vertical, keep_mask, device):
     """LP layer: [T | inv | T | kept self loops], n = E, i = E + #kept (layers.py:481-487, :505-510)."""
-    if _device_build_enabled() and num_nodes * num_rels < 2 ** 31:
+    if _device_build_enabled() and num_nodes * num_rels < _MAX_CELLS:
         t = torch.as_tensor(triples, dtype=torch.long).reshape(-1, 3).to(device)
         E = t.shape[0]
         s, p, o, alive, err = _native.dev_lp_expand(t, num_nodes, (num_rels - 1) // 2, keep_mask)
