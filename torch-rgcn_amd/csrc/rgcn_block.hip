@@ -277,18 +277,20 @@ extern "C" int rgcn_block_spmm_f32(const float *X, const float *blocks, const fl
   const size_t lds_bytes = table_bytes + (size_t)n_rel_blocks * 4 * sizeof(float);          // + the per-relation pad
   if (bi == 4 && bo == 4 && lds_mode && lds_bytes <= LDS_TABLE_BYTES && n_units >= 64 * 1024) {
     const dim3 pgrid((unsigned)std::min<int64_t>(512, (n_units * lr + BIG_WG - 1) / BIG_WG));
-    auto launch = [&](auto kern) -> hipError_t {
-      if (lds_bytes > 64 * 1024) {
+    auto launch = [&](auto kern, bool &raised) -> hipError_t {
+      if (lds_bytes > 64 * 1024 && !raised) {     // once per process and kernel (not a stream operation: keep it out of captures)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)LDS_TABLE_BYTES);
         if (e != hipSuccess) return e;
+        raised = true;
       }
       hipLaunchKernelGGL(kern, pgrid, dim3(BIG_WG), lds_bytes, st, X, blocks, bias, out, un, rowptr, (long long)n_units, e_src,
                          e_rel, e_val, nb, bi, bo, n_rel_blocks, lpm, lr, (int)relu, (int)(table_bytes / sizeof(float)));
       return hipGetLastError();
     };
-    if (tr) HIP_TRY(launch(block_csr_lds_kernel<4, 4, true>));
-    else HIP_TRY(launch(block_csr_lds_kernel<4, 4, false>));
+    static bool raised_t = false, raised_n = false;
+    if (tr) HIP_TRY(launch(block_csr_lds_kernel<4, 4, true>, raised_t));
+    else HIP_TRY(launch(block_csr_lds_kernel<4, 4, false>, raised_n));
     return RGCN_OK;
   }
 #define RGCN_BLOCK_LAUNCH(BI, BO)                                                                                              \

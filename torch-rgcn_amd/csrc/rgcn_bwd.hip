@@ -338,9 +338,11 @@ void launch_bwd(const BwdLaunch &a) {
 template <bool AT>
 hipError_t launch_bwd8(const BwdLaunch &a) {
   auto kern = bwd_fused_d16_kernel<4, AT, 4, 8>;
-  if (a.lds > 64 * 1024) {
+  static bool raised = false;                    // once per process (not a stream operation: keep it out of captures)
+  if (a.lds > 64 * 1024 && !raised) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (e != hipSuccess) return e;
+    raised = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)a.n_blocks), dim3(512), a.lds, a.st, a.G, a.X, a.Wtp, a.dX, a.dWout, a.pk, a.chunk_rel,
                      a.run_ptr, a.n_tiles, a.n_blocks, a.tile_rows, a.n_dst, a.R, a.ablate);
