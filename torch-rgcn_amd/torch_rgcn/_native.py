@@ -427,8 +427,9 @@ def build_csr_device(dst, src, rel, val, alive, n_rows, sync_free=False):
         _check(L.rgcn_dev_plan_count(_dp(dst), _dp(zeros), _dp(alive), c_i64(M), c_i64(n_rows), c_i32(1), c_i32(n_rows),
                                      _dp(cells), _dp(bucket_cnt), _dp(bucket_base), _dp(scan_tmp), _dp(cells_tmp),
                                      _stream(dev)), "dev_plan_count")
-    # one bucket: the padded size is the live message count rounded up to 16 -- bounded by the list length (sync_free)
-    m_pad = (M + CHUNK - 1) // CHUNK * CHUNK if sync_free else int(bucket_base[1].item())
+    # one bucket: the padded size is the live message count rounded up to 16 -- sized by its bound, the list length (dead
+    # messages are few: dropped self loops), so that building a CSR never reads anything back from the device
+    m_pad = (M + CHUNK - 1) // CHUNK * CHUNK
     p = CsrPlan()
     p.n_rows = n_rows
     p.msg_slot = torch.full((max(M, 1),), -1, dtype=torch.int32, device=dev)[:M]   # CSR position of every live input message

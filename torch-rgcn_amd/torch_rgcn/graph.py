@@ -79,9 +79,11 @@ class RelGraph:
             N, R = self.num_nodes, self.num_rels
             s, p, o, val, alive = self._dev
             dst, src = (s, o) if kind == "fwd" else (o, s)
+            # relation-major plans (one tile) of per-call graphs are always finished on the device: the upper bound costs
+            # 15 slots per relation and the work items are cut on the device -- nothing to gain from the 4 read-backs
+            nosync = self.sync_free or (getattr(self, "per_call", False) and tile_rows >= N)
             self._plans[key] = _native.build_plan_device(dst, src, p, val, alive, N, N, R, tile_rows, self.num_messages,
-                                                         max_item_chunks, want_runs=True, want_pack=True,
-                                                         sync_free=self.sync_free)
+                                                         max_item_chunks, want_runs=True, want_pack=True, sync_free=nosync)
         if key not in self._plans:
             N, R = self.num_nodes, self.num_rels
             if kind == "fwd":
@@ -203,8 +205,8 @@ def graph_from_lp_triples(triples, num_nodes, num_rels, vertical, keep_mask, dev
         _native.dev_check_err(err, "stack_matrices")
         val = _native.dev_edge_norm(s, p, o, alive, num_nodes, num_rels, vertical, E)
         sync_free = _native._deferred_mode()
-        # live messages: exact (one read-back) or, in a step that must not synchronise, the upper bound (all self loops kept)
-        n_live = 3 * E + (num_nodes if (keep_mask is None or sync_free) else int(keep_mask.sum().item()))
+        # live messages: the upper bound (all self loops kept) -- it only feeds sizing heuristics, not worth a read-back
+        n_live = 3 * E + num_nodes
         g = RelGraph.on_device(s, p, o, val, alive, n_live, num_nodes, num_rels)
         g.sync_free = sync_free
         g.per_call = True
