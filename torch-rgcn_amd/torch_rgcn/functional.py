@@ -24,7 +24,8 @@ def _wgrad_tiles(plan):
 
 def _sparse_buckets(graph, W):
     """hidden 16 and (tile, relation) buckets so small that the 16-slot chunks are mostly padding"""
-    if W.shape[1] != 16 or W.shape[2] != 16 or getattr(graph, "_dev", None) is None or getattr(graph, "sync_free", False):
+    if W.shape[1] != 16 or W.shape[2] != 16 or getattr(graph, "_dev", None) is None or getattr(graph, "sync_free", False) or \
+            getattr(graph, "per_call", False):
         return False            # (the two-pass path sizes its scratch by a message count read back from the device)
     mode = os.environ.get("RGCN_SPARSE_PATH", "auto")
     if mode != "auto":

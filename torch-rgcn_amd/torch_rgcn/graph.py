@@ -79,9 +79,10 @@ class RelGraph:
             N, R = self.num_nodes, self.num_rels
             s, p, o, val, alive = self._dev
             dst, src = (s, o) if kind == "fwd" else (o, s)
-            # relation-major plans (one tile) of per-call graphs are always finished on the device: the upper bound costs
-            # 15 slots per relation and the work items are cut on the device -- nothing to gain from the 4 read-backs
-            nosync = self.sync_free or (getattr(self, "per_call", False) and tile_rows >= N)
+            # plans of per-call (LP) graphs are always finished on the device: 4 read-backs per plan cost more than they buy on
+            # graphs that live for one step (upper-bound sizes: at most 16 slots per message; one work unit per tile, no hub
+            # splitting -- a sampled graph's hub is a few thousand messages).  Static (NC) graphs keep the exact path.
+            nosync = self.sync_free or getattr(self, "per_call", False)
             self._plans[key] = _native.build_plan_device(dst, src, p, val, alive, N, N, R, tile_rows, self.num_messages,
                                                          max_item_chunks, want_runs=True, want_pack=True, sync_free=nosync)
         if key not in self._plans:
