@@ -31,7 +31,12 @@ constexpr int LD_OUT = 132;      // LDS row stride of a K-outer slab [16][128]: 
 
 // ------------------------------------------------------------------ general GEMM  C[M,N] = op(A) op(B) (+ bias[n])
 // TA: A is stored [K][M] (M contiguous) instead of [M][K];  TB: B is stored [N][K] (K contiguous) instead of [K][N].
-template <bool TA, bool TB>
+// VEC: both operands are read with 16-byte loads (aligned bases, leading dimensions and contiguous extents multiples of 4) -- a
+// TEMPLATE parameter: decided at run time inside the kernel, the two load forms become branches, and hipcc then waits for the
+// outstanding loads between the four loads of a slab (s_waitcnt vmcnt(2) at every join) -- the global latency of each slab was
+// paid before its MFMAs started instead of under them (ablation: loads 12 us + MFMAs 22 us + rest 19 us = the whole 53 us of a
+// one-workgroup-per-CU launch, nothing overlapped).
+template <bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(WG) void gemm_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                   const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K,
                                                   long long lda, long long ldb, long long ldc, int tiles_m, int k_per_split,
@@ -55,8 +60,7 @@ __global__ __launch_bounds__(WG) void gemm_kernel(const float *__restrict__ A, c
   f32x4 ra[2], rb[2];
   // 16-byte loads when rows / columns are 16-byte aligned (K and the leading dimension multiples of 4): the K tail is
   // then whole groups of 4 and is zeroed by the stash; otherwise element loads with clamped indices
-  const bool vec_a = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (((TA ? M : K) & 3) == 0);
-  const bool vec_b = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (((TB ? K : N) & 3) == 0);
+  constexpr bool vec_a = VEC, vec_b = VEC;
   auto fetch_inner = [&](const float *P, long long ld, int r0, int rows, int k0, bool vec, f32x4 (&reg)[2]) {
     const int kk = k0 + 4 * (tid & 3);
 #pragma unroll
@@ -582,9 +586,17 @@ extern "C" int rgcn_gemm_f32(const float *A, const float *B, const float *bias, 
   const long long ldo = S > 1 ? N : ldc, sstride = S > 1 ? (long long)M * N : 0;
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)S), block(WG);
   const bool ta = flags & RGCN_G_TRANS_A, tb = flags & RGCN_G_TRANS_B;
-#define RGCN_GEMM_LAUNCH(TAc, TBc)                                                                                    \
-  hipLaunchKernelGGL((gemm_kernel<TAc, TBc>), grid, block, 0, st, A, B, bias, out, (int)M, (int)N, (int)K, (long long)lda, \
-                     (long long)ldb, ldo, tiles_m, kps > 0 ? kps : GK, sstride)
+  // 16-byte loads when rows / columns are 16-byte aligned (the contiguous extent and the leading dimension multiples of 4): the
+  // K tail is then whole groups of 4 and is zeroed by the stash; otherwise element loads with clamped indices
+  const bool vec = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (((ta ? M : K) & 3) == 0) &&
+                   ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (((tb ? K : N) & 3) == 0);
+#define RGCN_GEMM_LAUNCH(TAc, TBc)                                                                                           \
+  do {                                                                                                                        \
+    if (vec) hipLaunchKernelGGL((gemm_kernel<TAc, TBc, true>), grid, block, 0, st, A, B, bias, out, (int)M, (int)N, (int)K,    \
+                                (long long)lda, (long long)ldb, ldo, tiles_m, kps > 0 ? kps : GK, sstride);                   \
+    else hipLaunchKernelGGL((gemm_kernel<TAc, TBc, false>), grid, block, 0, st, A, B, bias, out, (int)M, (int)N, (int)K,       \
+                            (long long)lda, (long long)ldb, ldo, tiles_m, kps > 0 ? kps : GK, sstride);                       \
+  } while (0)
   if (ta && tb) RGCN_GEMM_LAUNCH(true, true);
   else if (ta) RGCN_GEMM_LAUNCH(true, false);
   else if (tb) RGCN_GEMM_LAUNCH(false, true);
