@@ -188,6 +188,7 @@ __global__ __launch_bounds__(WG) void sum_slices_kernel(const float *__restrict_
 // every W_r streams through LDS once per 128 messages.  The weight gradient is the same tiling transposed:
 //     dW_r[m, n] += sum_{slots of r} Xs[src[slot], m] * (val[slot] * G[dst[slot], n])      (rel_wgrad_kernel, K = slots)
 // one workgroup per (item, 128 x 128 block of dW_r), fp32 atomics across the items of a relation.
+template <bool VEC>      // 16-byte loads of both operands (K and N multiples of 4): compile-time, see gemm_kernel
 __global__ __launch_bounds__(WG) void rel_rows_kernel(
     const float *__restrict__ Xs, const float *__restrict__ W /* [R][K][N] */, float *__restrict__ Y /* [slots][N] */,
     const int *__restrict__ p_src, const float *__restrict__ p_val, const int *__restrict__ chunk_rel,
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(WG) void rel_rows_kernel(
     arow[h] = Xs + (size_t)p_src[slot] * K;
     ascale[h] = on ? p_val[slot] : 0.f;            // pads carry val = 0
   }
-  const bool vec_a = (K & 3) == 0, vec_b = (N & 3) == 0;
+  constexpr bool vec_a = VEC, vec_b = VEC;
   f32x4 ra[2], rb[2];
   auto fetch = [&](int k0) {
     const int kk = k0 + 4 * (tid & 3);
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(WG) void rel_rows_kernel(
 }
 
 // dW[rel][m0.., n0..] += sum over the item's slots of Xs[src[slot], m] * val[slot] * G[dst[slot], n]
+template <bool VEC>      // 16-byte loads of both gathered rows (both widths multiples of 4): compile-time, see gemm_kernel
 __global__ __launch_bounds__(WG) void rel_wgrad_kernel(
     const float *__restrict__ Xs, const float *__restrict__ G, float *__restrict__ dW /* [R][Mw][Nw] */,
     const int *__restrict__ p_src, const int *__restrict__ p_dst, const float *__restrict__ p_val,
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(WG) void rel_wgrad_kernel(
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool vec_a = (Mw & 3) == 0, vec_b = (Nw & 3) == 0;
+  constexpr bool vec_a = VEC, vec_b = VEC;
   f32x4 ra[2], rb[2];
   float sc[2];
   auto fetch = [&](int k0) {     // thread -> slots k0 + (tid >> 5) (+ 8), column group 4 (tid & 31) of both gathered rows
@@ -639,8 +641,13 @@ extern "C" int rgcn_rel_rows_f32(const float *Xs, const float *W, float *Y, cons
     return RGCN_EINVAL;
   }
   if (!n_items) return RGCN_OK;
-  hipLaunchKernelGGL(rel_rows_kernel, dim3((unsigned)n_items, (unsigned)((d_out + GT - 1) / GT)), dim3(WG), 0, (hipStream_t)stream,
+  if (((d_in | d_out) & 3) == 0) {
+    hipLaunchKernelGGL(rel_rows_kernel<true>, dim3((unsigned)n_items, (unsigned)((d_out + GT - 1) / GT)), dim3(WG), 0, (hipStream_t)stream,
                      Xs, W, Y, p_src, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), d_in, d_out);
+  } else {
+    hipLaunchKernelGGL(rel_rows_kernel<false>, dim3((unsigned)n_items, (unsigned)((d_out + GT - 1) / GT)), dim3(WG), 0, (hipStream_t)stream,
+                     Xs, W, Y, p_src, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), d_in, d_out);
+  }
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
@@ -656,8 +663,13 @@ extern "C" int rgcn_rel_wgrad_f32(const float *Xs, const float *G, float *dW, co
   HIP_TRY(zero_async(dW, (size_t)R * d_in * d_out * sizeof(float), st));
   if (!n_items) return RGCN_OK;
   const int tiles_m = (d_in + GT - 1) / GT, tiles_n = (d_out + GT - 1) / GT;
-  hipLaunchKernelGGL(rel_wgrad_kernel, dim3((unsigned)n_items, (unsigned)(tiles_m * tiles_n)), dim3(WG), 0, st, Xs, G, dW, p_src,
+  if (((d_in | d_out) & 3) == 0) {
+    hipLaunchKernelGGL(rel_wgrad_kernel<true>, dim3((unsigned)n_items, (unsigned)(tiles_m * tiles_n)), dim3(WG), 0, st, Xs, G, dW, p_src,
                      p_dst, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), d_in, d_out, tiles_m);
+  } else {
+    hipLaunchKernelGGL(rel_wgrad_kernel<false>, dim3((unsigned)n_items, (unsigned)(tiles_m * tiles_n)), dim3(WG), 0, st, Xs, G, dW, p_src,
+                     p_dst, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), d_in, d_out, tiles_m);
+  }
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

@@ -822,7 +822,7 @@ __global__ __launch_bounds__(WG) void diag_csr_kernel(
   const bool on = u < n_units;
   const int4 unit = on ? units[u] : int4{0, 0, 0, 0};
   const int e1 = unit.z;
-  const bool vec = (d & 3) == 0;
+  const bool vec = (d & 3) == 0;      // (as a template parameter this kernel measured 6-10 % slower)
   const bool shared = unit.w & RGCN_U_SHARED;
   const bool add_bias = bias && (!shared || (unit.w & RGCN_U_FIRST));
   for (int f0 = 0; f0 < d; f0 += 4 * lpm) {
@@ -876,6 +876,7 @@ __global__ __launch_bounds__(WG) void diag_csr_kernel(
 // twice: 57 M fabric requests per launch on the AM-shaped graph instead of 27 M, profiles/r02_pmc_csr_kernels.json),
 // 64 / lpm slots in flight, two per lane; the slot groups are summed with wave shuffles, one float4 of atomics per
 // (item, 4 columns).  Rows wider than 256 floats loop over column blocks.
+template <bool VEC>
 __global__ __launch_bounds__(WG) void diag_wgrad_kernel(
     const float *__restrict__ X, const float *__restrict__ G, float *__restrict__ dw, const int *__restrict__ p_src,
     const int *__restrict__ p_dst, const float *__restrict__ p_val, const int *__restrict__ chunk_rel,
@@ -888,7 +889,7 @@ __global__ __launch_bounds__(WG) void diag_wgrad_kernel(
   const int rel = chunk_rel[range.x];
   const int g = lane / lpm, j = lane % lpm, groups = 64 / lpm;
   const int s0 = range.x * RGCN_CHUNK, s1 = range.y * RGCN_CHUNK;
-  const bool vec4 = (d & 3) == 0;
+  constexpr bool vec4 = VEC;
   for (int f0 = 0; f0 < d; f0 += 4 * lpm) {
     const int col = f0 + 4 * j;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1406,8 +1407,13 @@ extern "C" int rgcn_diag_wgrad_f32(const float *X, const float *G, float *dw, co
   if (n_items == 0) return RGCN_OK;
   int lpm = 1;                                  // lanes per slot: float4 each, a power of two
   while (lpm < 64 && 4 * lpm < d) lpm *= 2;
-  hipLaunchKernelGGL(diag_wgrad_kernel, dim3((unsigned)((n_items + WG / 64 - 1) / (WG / 64))), dim3(WG), 0, (hipStream_t)stream,
+  if ((d & 3) == 0) {
+    hipLaunchKernelGGL(diag_wgrad_kernel<true>, dim3((unsigned)((n_items + WG / 64 - 1) / (WG / 64))), dim3(WG), 0, (hipStream_t)stream,
                      X, G, dw, p_src, p_dst, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), (long long)n_items, d, lpm);
+  } else {
+    hipLaunchKernelGGL(diag_wgrad_kernel<false>, dim3((unsigned)((n_items + WG / 64 - 1) / (WG / 64))), dim3(WG), 0, (hipStream_t)stream,
+                     X, G, dw, p_src, p_dst, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), (long long)n_items, d, lpm);
+  }
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
