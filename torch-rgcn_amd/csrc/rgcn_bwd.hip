@@ -59,7 +59,7 @@ template <int U, bool ATOMIC, int BW_D, int NW = 4>      // NW = waves (= tiles)
 __global__ __launch_bounds__(64 * NW, 16 / NW) void bwd_fused_d16_kernel(
     const float *__restrict__ G, const float *__restrict__ X, const float *__restrict__ Wtp, float *__restrict__ dX,
     float *__restrict__ dWout, const int2 *__restrict__ p_pack, const int *__restrict__ chunk_rel,
-    const int *__restrict__ run_ptr, int n_tiles, int n_blocks, int tile_rows, int n_dst, int R, int ablate) {
+    const int *__restrict__ run_ptr, int n_tiles, int n_blocks, int tile_rows, int n_dst, int R) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -89,7 +89,6 @@ __global__ __launch_bounds__(64 * NW, 16 / NW) void bwd_fused_d16_kernel(
       cur = -1;
       acc_w = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (ablate & 2) { ++iv; return; }
     __syncthreads();
     const int r = iv * BW_D + wave;
     if (wave < BW_D && r < R) {
@@ -145,8 +144,7 @@ __global__ __launch_bounds__(64 * NW, 16 / NW) void bwd_fused_d16_kernel(
       for (int j = 0; j < U; ++j) {
         A.g[j] = *reinterpret_cast<const float4 *>(G + (size_t)A.s[j] * 16 + 4 * k);
         A.w[j] = reinterpret_cast<const float4 *>(Wtp)[(size_t)A.r[j] * 64 + lane];
-        A.xn[j] = (ablate & 4) ? make_float4(1.f, 1.f, 1.f, 1.f)
-                               : *reinterpret_cast<const float4 *>(X + (size_t)(row0 + (A.dl[j] == 0xFF ? 0 : A.dl[j])) * 16 + 4 * k);
+        A.xn[j] = *reinterpret_cast<const float4 *>(X + (size_t)(row0 + (A.dl[j] == 0xFF ? 0 : A.dl[j])) * 16 + 4 * k);
       }
       __builtin_amdgcn_sched_barrier(0);
       request_idx(c + U);                  // behind the gathers in the (in-order) memory pipeline; used next iteration
@@ -168,7 +166,6 @@ __global__ __launch_bounds__(64 * NW, 16 / NW) void bwd_fused_d16_kernel(
           f32x4 *p = reinterpret_cast<f32x4 *>(tile + A.dl[j] * 16 + 4 * (k ^ ((A.dl[j] >> 2) & 3)));   // swizzled: see tile_swz
           *p += acc[0];
         }
-        if (ablate & 1) continue;
         // ---- dW: relation / interval bookkeeping (wave-uniform), then K over the chunk's 16 messages
         const int rj = __builtin_amdgcn_readfirstlane(A.r[j]);
         while (rj >= (iv + 1) * BW_D) close_interval();
@@ -323,7 +320,7 @@ struct BwdLaunch {
   float *dX, *dWout;
   const int2 *pk;
   const int *chunk_rel, *run_ptr;
-  int n_tiles, n_blocks, tile_rows, n_dst, R, ablate;
+  int n_tiles, n_blocks, tile_rows, n_dst, R;
   size_t lds;
   hipStream_t st;
 };
@@ -331,7 +328,7 @@ struct BwdLaunch {
 template <int U, bool AT, int D>
 void launch_bwd(const BwdLaunch &a) {
   hipLaunchKernelGGL((bwd_fused_d16_kernel<U, AT, D>), dim3((unsigned)a.n_blocks), dim3(WG), a.lds, a.st, a.G, a.X, a.Wtp,
-                     a.dX, a.dWout, a.pk, a.chunk_rel, a.run_ptr, a.n_tiles, a.n_blocks, a.tile_rows, a.n_dst, a.R, a.ablate);
+                     a.dX, a.dWout, a.pk, a.chunk_rel, a.run_ptr, a.n_tiles, a.n_blocks, a.tile_rows, a.n_dst, a.R);
 }
 
 // 8 tiles per workgroup (512 threads, 2 workgroups per CU): half the dW flushes of the 4-tile form; needs > 64 KiB of LDS
@@ -345,7 +342,7 @@ hipError_t launch_bwd8(const BwdLaunch &a) {
     raised = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)a.n_blocks), dim3(512), a.lds, a.st, a.G, a.X, a.Wtp, a.dX, a.dWout, a.pk, a.chunk_rel,
-                     a.run_ptr, a.n_tiles, a.n_blocks, a.tile_rows, a.n_dst, a.R, a.ablate);
+                     a.run_ptr, a.n_tiles, a.n_blocks, a.tile_rows, a.n_dst, a.R);
   return hipGetLastError();
 }
 
@@ -396,10 +393,9 @@ extern "C" int rgcn_bwd_fused_f32(const float *G, const float *X, const float *W
   hipStream_t st = (hipStream_t)stream;
   const int n_blocks = (int)((n_tiles + NWv - 1) / NWv);
   static const int USEL = getenv("RGCN_BWD_U") ? atoi(getenv("RGCN_BWD_U")) : 4;
-  static const int ABL = getenv("RGCN_BWD_ABLATE") ? atoi(getenv("RGCN_BWD_ABLATE")) : 0;   // diagnosis only (results are wrong)
   const int2 *pk = reinterpret_cast<const int2 *>(p_pack);
   const BwdLaunch L{G, X, Wt_packed, dX, atomic ? dW : scratch, pk, chunk_rel, run_ptr, (int)n_tiles, n_blocks, tile_rows,
-                    (int)n_dst, R, ABL, lds, st};
+                    (int)n_dst, R, lds, st};
   if (atomic) {
     HIP_TRY(zero_async(dW, (size_t)R * 256 * sizeof(float), st));
     if (NWv == 8) HIP_TRY(launch_bwd8<true>(L));

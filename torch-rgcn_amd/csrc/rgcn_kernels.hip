@@ -44,7 +44,7 @@ __global__ __launch_bounds__(WG) void spmm_d16_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias,
     float *__restrict__ out, const int *__restrict__ p_src, const int *__restrict__ p_dst,
     const float *__restrict__ p_val, const int2 *__restrict__ p_pack, const int *__restrict__ chunk_rel,
-    const int4 *__restrict__ units, int n_units, int tile_rows, int n_dst, int relu_out, int ablate) {
+    const int4 *__restrict__ units, int n_units, int tile_rows, int n_dst, int relu_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -109,10 +109,6 @@ __global__ __launch_bounds__(WG) void spmm_d16_kernel(
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g.w[j].y, live ? g.x[j].y * v : 0.f, acc[0], 0, 0, 0);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g.w[j].z, live ? g.x[j].z * v : 0.f, acc[0], 0, 0, 0);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g.w[j].w, live ? g.x[j].w * v : 0.f, acc[0], 0, 0, 0);
-        if (ablate & 1) {  // diagnosis: skip the accumulation
-          asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]), "v"(acc[0][3]), "v"(g.d[j]));
-          continue;
-        }
         const bool tail = fold_segments<1>(acc, g.d[j]);
         if (tail) {
           const int dl = g.d[j] - row0;
@@ -1193,10 +1189,9 @@ extern "C" int rgcn_spmm_f32(const float *X, const float *W, const float *bias, 
                      chunk_rel, tile_ptr, nt, tile_rows, (int)n_dst, d_in, d_out, ldt, relu_out)
 #define RGCN_LAUNCH_D16(U, P)                                                                                      \
   hipLaunchKernelGGL((spmm_d16_kernel<U, P>), grid, block, lds, st, X, W, bias, out, p_src, p_dst, p_val, pk,      \
-                     chunk_rel, tile_ptr, nt, tile_rows, (int)n_dst, relu_out, ABL)
+                     chunk_rel, tile_ptr, nt, tile_rows, (int)n_dst, relu_out)
   if (d_in == 16 && d_out == 16) {
     static const int U = getenv("RGCN_SPMM_U") ? atoi(getenv("RGCN_SPMM_U")) : 4;
-    static const int ABL = getenv("RGCN_ABLATE") ? atoi(getenv("RGCN_ABLATE")) : 0;  // diagnosis only
     if (packed) {
       if (U >= 8) RGCN_LAUNCH_D16(8, true);
       else if (U >= 4) RGCN_LAUNCH_D16(4, true);
