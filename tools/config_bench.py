@@ -40,7 +40,7 @@ def nc_model(name, N, R0, E, nhid, ncls, decomp, labelled):
     model = NodeClassifier(triples=T, nnodes=N, nrel=R0, nhid=nhid, nclass=ncls, decomposition=decomp).to(DEV)
     idx = torch.arange(labelled, device=DEV)
     y = torch.randint(0, ncls, (labelled,), device=DEV)
-    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, fused=True)      # as experiments/classify_nodes.py does
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -175,7 +175,7 @@ def line_node_classifier(tag, N, R0, E, nhid, ncls, decomp, labelled, baseline_c
     model = NodeClassifier(triples=T, nnodes=N, nrel=R0, nhid=nhid, nclass=ncls, decomposition=decomp).to(DEV)
     idx = torch.arange(labelled, device=DEV)
     y = torch.randint(0, ncls, (labelled,), device=DEV)
-    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, fused=True)      # as experiments/classify_nodes.py does
 
     def step():
         opt.zero_grad(set_to_none=True)
