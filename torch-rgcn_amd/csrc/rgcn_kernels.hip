@@ -961,6 +961,54 @@ __global__ __launch_bounds__(WG) void colsum_a_kernel(const float *__restrict__ 
   }
 }
 
+// Wide rows (d >= 128, d % 4 == 0): the narrow form above gives a row to d / 4 threads and the launch few workgroups (one
+// partial row each, summed serially by stage B): 330,000 x 200 took 320 us, 0.8 TB/s.  Here a workgroup owns a block of 64
+// columns (16 lanes x float4) and 16 rows at a time (256-byte contiguous pieces per row), grid = column blocks x row
+// partitions (~1024 workgroups), fixed summation order: rows of a partition in stride order per lane, then the 16 row lanes.
+__global__ __launch_bounds__(WG) void colsum_wide_a_kernel(const float *__restrict__ G, float *__restrict__ partial, long long n, int d) {
+  __shared__ f32x4 part[WG];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int col = blockIdx.x * 64 + 4 * cl;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+  if (col < d) {
+    const long long step = (long long)gridDim.y * 16;
+    long long row = (long long)blockIdx.y * 16 + rl;
+    for (; row + step < n; row += 2 * step) {             // two independent chains: two loads in flight per thread
+      a0 += *reinterpret_cast<const f32x4 *>(G + (size_t)row * d + col);
+      a1 += *reinterpret_cast<const f32x4 *>(G + (size_t)(row + step) * d + col);
+    }
+    if (row < n) a0 += *reinterpret_cast<const f32x4 *>(G + (size_t)row * d + col);
+  }
+  part[threadIdx.x] = a0 + a1;
+  __syncthreads();
+  if (rl == 0 && col < d) {
+    f32x4 t = part[cl];
+    for (int r = 1; r < 16; ++r) t += part[16 * r + cl];
+    *reinterpret_cast<f32x4 *>(partial + (size_t)blockIdx.y * d + col) = t;
+  }
+}
+
+// partial [n_part][d] -> db: one workgroup per 64 columns, 4 row groups x 64 columns, four chains per thread
+__global__ __launch_bounds__(WG) void colsum_wide_b_kernel(const float *__restrict__ partial, float *__restrict__ db, int n_part, int d) {
+  __shared__ float part[WG];
+  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (col < d) {
+    int p = grp;
+    for (; p + 12 < n_part; p += 16) {
+      a0 += partial[(size_t)p * d + col];
+      a1 += partial[(size_t)(p + 4) * d + col];
+      a2 += partial[(size_t)(p + 8) * d + col];
+      a3 += partial[(size_t)(p + 12) * d + col];
+    }
+    for (; p < n_part; p += 4) a0 += partial[(size_t)p * d + col];
+  }
+  part[threadIdx.x] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (grp == 0 && col < d) db[col] = (part[c] + part[64 + c]) + (part[128 + c] + part[192 + c]);
+}
+
 __global__ __launch_bounds__(WG) void colsum_b_kernel(const float *__restrict__ partial, float *__restrict__ db, int n_part, int d) {
   __shared__ float part[WG];
   const int tid = threadIdx.x;
@@ -1438,6 +1486,14 @@ extern "C" int rgcn_colsum_f32(const float *G, float *db, float *scratch, int64_
   hipStream_t st = (hipStream_t)stream;
   if (n == 0) { HIP_TRY(zero_async(db, (size_t)d * sizeof(float), st)); return RGCN_OK; }
   const bool vec4 = d % 4 == 0;
+  if (vec4 && d >= 128) {
+    const int cblocks = (d + 63) / 64;
+    const int parts = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)1024 / cblocks, (n + 15) / 16, (int64_t)1024}));
+    hipLaunchKernelGGL(colsum_wide_a_kernel, dim3((unsigned)cblocks, (unsigned)parts), dim3(WG), 0, st, G, scratch, (long long)n, d);
+    hipLaunchKernelGGL(colsum_wide_b_kernel, dim3((unsigned)cblocks), dim3(WG), 0, st, scratch, db, parts, d);
+    HIP_TRY(hipGetLastError());
+    return RGCN_OK;
+  }
   const int lanes = vec4 ? d / 4 : d;
   const int groups = std::max(1, WG / lanes);
   // stage B is one workgroup walking the partial rows: wide rows leave it few row groups, so they get fewer partials
