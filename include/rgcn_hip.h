@@ -406,6 +406,17 @@ RGCN_API int rgcn_distmult_bwd_nodes_f32(const int32_t *rowptr_s, const int32_t 
                                          const int32_t *rel_o, const float *g_o, const float *nodes, const float *rel,
                                          float *dnodes, int64_t n_nodes, int32_t d, void *stream);
 
+/* All DistMult gradients from the two CSRs of the scored triples (by subject: entries = (object, predicate, g); by object:
+ * entries = (subject, predicate, g)) -- entity gradient as above, relation gradient d_rel[p] += g x_s x_o accumulated in
+ * wave-private LDS tables (no predicate sort, no second pass over the triples), bias gradients (d_sbias[n] / d_obias[n] = the
+ * row sums of g, d_pbias via the LDS tables) when the three pointers are set.  The autograd dual of layers.py:87-101.
+ * Needs n_rel (d + 1) <= 4096 (rgcn_distmult_bwd_all_supported); d_rel / d_pbias are zeroed first. */
+RGCN_API int rgcn_distmult_bwd_all_supported(int32_t n_rel, int32_t d);
+RGCN_API int rgcn_distmult_bwd_all_f32(const int32_t *rowptr_s, const int32_t *other_s, const int32_t *rel_s, const float *g_s,
+                                       const int32_t *rowptr_o, const int32_t *other_o, const int32_t *rel_o, const float *g_o,
+                                       const float *nodes, const float *rel, float *dnodes, float *drel, float *dsbias,
+                                       float *dpbias, float *dobias, int64_t n_nodes, int32_t n_rel, int32_t d, void *stream);
+
 /* Ranking evaluator (utils/misc.py:60-110 + torch_rgcn/layers.py:87-98 on the expanded
  * [bn, N, 3] candidate tensor, which is never built here).  For each of the Q test triples in `batch` (int64
  * [Q,3], device) every entity n is scored as its head (head != 0: (n, p, o)) or tail ((s, p, n)):

@@ -1169,6 +1169,97 @@ __global__ __launch_bounds__(WG) void distmult_bwd_nodes_kernel(
   }
 }
 
+// All of DistMult's gradients from the two CSRs, no sort and no second pass over the triples: the entity walk above already
+// holds, for every triple of the subject-side CSR, the row of the object; with the entity's own row it is the triple's
+// contribution to the RELATION gradient, d_rel[p] += g * x_s * x_o.  Each wave keeps a private [n_rel][d] table (+ the
+// predicate bias) in LDS -- plain read-modify-write, no atomics --, the four tables of a workgroup are summed at the end and
+// added to d_rel with one atomic per workgroup and element (<= 512 persistent workgroups).  Needs n_rel (d + 1) <= 4096 floats
+// per wave (WN18: 18 x 200); larger relation tables keep the predicate-sorted kernel above.  Round 2 before this: torch.argsort
+// by predicate (rocPRIM merge sort, 0.15 ms for 330 k triples) + two index gathers + distmult_bwd_kernel (0.12 ms).
+__global__ __launch_bounds__(WG) void distmult_bwd_all_kernel(
+    const int *__restrict__ rp_s, const int *__restrict__ oth_s, const int *__restrict__ rel_s, const float *__restrict__ g_s,
+    const int *__restrict__ rp_o, const int *__restrict__ oth_o, const int *__restrict__ rel_o, const float *__restrict__ g_o,
+    const float *__restrict__ nodes, const float *__restrict__ rel, float *__restrict__ dnodes, float *__restrict__ drel,
+    float *__restrict__ dsb, float *__restrict__ dpb, float *__restrict__ dob, long long N, int n_rel, int d) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tab_floats = n_rel * d + n_rel;                 // [n_rel][d] + predicate bias [n_rel]
+  float *tab = lds + (size_t)wave * tab_floats, *pb = tab + (size_t)n_rel * d;
+  for (int i = lane; i < tab_floats; i += 64) tab[i] = 0.f;
+  const bool vec = (d & 3) == 0;
+  const long long wave0 = ((long long)blockIdx.x * WG + threadIdx.x) >> 6, nw = ((long long)gridDim.x * WG) >> 6;
+  for (long long n = wave0; n < N; n += nw) {
+    for (int f0 = 0; f0 < d; f0 += 256) {
+      const int f = f0 + 4 * lane;
+      const bool full = vec && f + 3 < d;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, xn = {0.f, 0.f, 0.f, 0.f};
+      if (full) {
+        xn = *reinterpret_cast<const f32x4 *>(nodes + (size_t)n * d + f);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (f + q < d) xn[q] = nodes[(size_t)n * d + f + q];
+      }
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        const int *rp = side ? rp_o : rp_s, *oth = side ? oth_o : oth_s, *rl = side ? rel_o : rel_s;
+        const float *gv = side ? g_o : g_s;
+        const int e0 = rp[n], e1 = rp[n + 1];
+        float gsum = 0.f;
+        for (int e = e0; e < e1; e += 2) {
+          const int ea = e, eb = min(e + 1, e1 - 1);
+          const bool hb = e + 1 < e1;
+          const float ga = gv[ea], gb = hb ? gv[eb] : 0.f;
+          const int pa = rl[ea], pbi = rl[eb];
+          const float *na = nodes + (size_t)oth[ea] * d, *nb = nodes + (size_t)oth[eb] * d;
+          const float *ra = rel + (size_t)pa * d, *rb = rel + (size_t)pbi * d;
+          f32x4 xa = {0.f, 0.f, 0.f, 0.f}, xb = xa, wa = xa, wb = xa;
+          if (full) {
+            xa = *reinterpret_cast<const f32x4 *>(na + f); xb = *reinterpret_cast<const f32x4 *>(nb + f);
+            wa = *reinterpret_cast<const f32x4 *>(ra + f); wb = *reinterpret_cast<const f32x4 *>(rb + f);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (f + q < d) { xa[q] = na[f + q]; xb[q] = nb[f + q]; wa[q] = ra[f + q]; wb[q] = rb[f + q]; }
+          }
+          acc += xa * wa * ga + xb * wb * gb;
+          gsum += ga + gb;
+          if (side == 0 && f < d) {            // relation gradient: this wave's LDS table, plain RMW (the LDS pipeline is in order)
+            float *ta = tab + (size_t)pa * d + f, *tb = tab + (size_t)pbi * d + f;
+            const f32x4 ca = xn * xa * ga, cb = xn * xb * gb;
+            if (full) {
+              *reinterpret_cast<f32x4 *>(ta) += ca;
+              if (hb) *reinterpret_cast<f32x4 *>(tb) += cb;
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (f + q < d) { ta[q] += ca[q]; if (hb) tb[q] += cb[q]; }
+            }
+            if (f0 == 0 && lane == 0 && dpb) { pb[pa] += ga; if (hb) pb[pbi] += gb; }
+          }
+        }
+        if (f0 == 0 && lane == 0 && dsb) (side ? dob : dsb)[n] = gsum;
+      }
+      float *o = dnodes + (size_t)n * d + f;
+      if (full) {
+        *reinterpret_cast<f32x4 *>(o) = acc;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (f + q < d) o[q] = acc[q];
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < tab_floats; i += WG) {
+    const float t = (lds[i] + lds[tab_floats + i]) + (lds[2 * tab_floats + i] + lds[3 * tab_floats + i]);
+    if (t != 0.f) {
+      if (i < n_rel * d) atomicAdd(drel + i, t);
+      else if (dpb) atomicAdd(dpb + (i - n_rel * d), t);
+    }
+  }
+}
+
 int pow2_lanes(int d) {
   int l = 1;
   while (l < d && l < 64) l <<= 1;
@@ -1539,6 +1630,27 @@ extern "C" int rgcn_distmult_bwd_f32(const int64_t *triples, int64_t T, const fl
   const unsigned gx = (unsigned)std::min<int64_t>((T + 255) / 256, 256 * 32);
   hipLaunchKernelGGL(distmult_bwd_kernel, dim3(gx), dim3(WG), 0, st, reinterpret_cast<const long long *>(triples),
                      (long long)T, nodes, rel, gs, dnodes, drel, dsbias, dpbias, dobias, d, (long long)n_nodes, n_rel, dnodes ? 0 : 1);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_distmult_bwd_all_supported(int32_t n_rel, int32_t d) { return n_rel > 0 && d > 0 && (int64_t)n_rel * (d + 1) <= 4096; }
+
+extern "C" int rgcn_distmult_bwd_all_f32(const int32_t *rowptr_s, const int32_t *other_s, const int32_t *rel_s, const float *g_s,
+                                         const int32_t *rowptr_o, const int32_t *other_o, const int32_t *rel_o, const float *g_o,
+                                         const float *nodes, const float *rel, float *dnodes, float *drel, float *dsbias,
+                                         float *dpbias, float *dobias, int64_t n_nodes, int32_t n_rel, int32_t d, void *stream) {
+  if (!rowptr_s || !rowptr_o || !nodes || !rel || !dnodes || !drel || n_nodes < 0 || d <= 0 || n_rel <= 0) { rgcn_set_error("distmult_bwd_all: bad argument"); return RGCN_EINVAL; }
+  if ((dsbias != nullptr) != (dpbias != nullptr) || (dsbias != nullptr) != (dobias != nullptr)) { rgcn_set_error("distmult_bwd_all: bias gradients must be all set or all NULL"); return RGCN_EINVAL; }
+  if (!rgcn_distmult_bwd_all_supported(n_rel, d)) { rgcn_set_error("distmult_bwd_all: n_rel (d + 1) = %lld floats do not fit a wave's LDS table (4096)", (long long)n_rel * (d + 1)); return RGCN_EUNSUPPORTED; }
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(zero_async(drel, (size_t)n_rel * d * sizeof(float), st));
+  if (dpbias) HIP_TRY(zero_async(dpbias, (size_t)n_rel * sizeof(float), st));
+  if (!n_nodes) return RGCN_OK;
+  const unsigned gx = (unsigned)std::min<int64_t>((n_nodes + 3) / 4, 512);
+  const size_t lds = (size_t)4 * ((size_t)n_rel * d + n_rel) * sizeof(float);
+  hipLaunchKernelGGL(distmult_bwd_all_kernel, dim3(gx), dim3(WG), lds, st, rowptr_s, other_s, rel_s, g_s, rowptr_o, other_o, rel_o,
+                     g_o, nodes, rel, dnodes, drel, dsbias, dpbias, dobias, (long long)n_nodes, n_rel, d);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

@@ -1076,6 +1076,36 @@ def distmult_bwd(triples, nodes, rel, gs, with_bias, nodes_grad=True):
     return dn, dr, dsb, dpb, dob
 
 
+def distmult_bwd_all_supported(n_rel, d):
+    return bool(lib().rgcn_distmult_bwd_all_supported(c_i32(n_rel), c_i32(d)))
+
+
+def distmult_bwd_all(triples, nodes, rel, gs, with_bias):
+    """(dnodes, drel, dsbias, dpbias, dobias) of DistMult from two CSRs of the scored triples -- no predicate sort, no atomics on
+    the entity rows (rgcn_distmult_bwd_all_f32); bias gradients None unless with_bias"""
+    _req(gs, "grad_scores"); _req(nodes, "nodes"); _req(rel, "relations")
+    N, d = nodes.shape
+    R = rel.shape[0]
+    dev = nodes.device
+    s, p, o, _err = dev_split_triples(triples, N, R)
+    alive = None
+    if _deferred_mode():     # the forward's range check may not have been looked at yet: bad triples must not reach the sort
+        alive = ((triples >= 0).all(dim=1) & (triples[:, 0] < N) & (triples[:, 2] < N) & (triples[:, 1] < R)).to(torch.uint8)
+    by_s = build_csr_device(s, o, p, gs, alive, N, sync_free=True)
+    by_o = build_csr_device(o, s, p, gs, alive, N, sync_free=True)
+    dn, dr = torch.empty_like(nodes), torch.empty_like(rel)
+    dsb = dpb = dob = None
+    if with_bias:
+        dsb, dob = torch.empty(N, device=dev, dtype=torch.float32), torch.empty(N, device=dev, dtype=torch.float32)
+        dpb = torch.empty(R, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev), _timed("distmult_bwd_all"):
+        _check(lib().rgcn_distmult_bwd_all_f32(_dp(by_s.rowptr), _dp(by_s.src), _dp(by_s.rel), _dp(by_s.val), _dp(by_o.rowptr),
+                                               _dp(by_o.src), _dp(by_o.rel), _dp(by_o.val), _dp(nodes), _dp(rel), _dp(dn), _dp(dr),
+                                               _dp(dsb), _dp(dpb), _dp(dob), c_i64(N), c_i32(R), c_i32(d), _stream(dev)),
+               "distmult_bwd_all")
+    return dn, dr, dsb, dpb, dob
+
+
 def distmult_bwd_nodes(triples, nodes, rel, gs):
     """entity gradients of DistMult without atomics: two CSRs of the scored triples (by subject, by object; device-side
     counting sort, no host read-back) and one wave per entity (rgcn_distmult_bwd_nodes_f32)"""

@@ -574,8 +574,13 @@ class _DistMultScore(torch.autograd.Function):
         tr, nodes, relations = ctx.saved_tensors
         gs = gs.reshape(-1)
         gs = gs.contiguous()
+        mode = os.environ.get("RGCN_DISTMULT_BWD", "csr")
+        scatter = mode == "atomic" or tr.shape[0] == 0
+        if not scatter and mode != "split" and _native.distmult_bwd_all_supported(relations.shape[0], nodes.shape[1]):
+            # small relation tables (WN18: 18 x 200): every gradient from the two CSR walks, no predicate sort
+            dn, dr, dsb, dpb, dob = _native.distmult_bwd_all(tr, nodes, relations, gs, ctx.with_bias)
+            return None, dn, dr, dsb, dpb, dob
         order = torch.argsort(tr[:, 1], stable=True)   # predicate runs -> relation gradient accumulates in registers
-        scatter = os.environ.get("RGCN_DISTMULT_BWD", "csr") == "atomic" or tr.shape[0] == 0
         dn, dr, dsb, dpb, dob = _native.distmult_bwd(tr[order].contiguous(), nodes, relations, gs[order].contiguous(),
                                                      ctx.with_bias, nodes_grad=scatter)
         if not scatter:      # entity gradients: CSR by subject / by object, one wave per entity, no atomics
