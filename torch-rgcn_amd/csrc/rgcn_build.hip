@@ -102,7 +102,7 @@ __global__ void cell_count_kernel(const int *__restrict__ dst, const int *__rest
                                   int *__restrict__ cells) {
   for (long long e = (long long)blockIdx.x * TB + threadIdx.x; e < M; e += (long long)gridDim.x * TB) {
     if (alive && !alive[e]) continue;
-    atomicAdd(&cells[cell_of(dst[e], rel[e], R, T)], 1);
+    atomicAdd(&cells[cell_of(dst[e], rel ? rel[e] : 0, R, T)], 1);
   }
 }
 
@@ -135,13 +135,13 @@ __global__ void bucket_scan_kernel(int *__restrict__ cells, long long n_buckets,
 
 // Few, very tall buckets (relation-major plan: T = N; CSR: one bucket): a wave per bucket would walk millions of
 // cells serially, so scan ALL cells at once (G) and take the bucket-local offsets as differences.
-__global__ void cells_from_global_scan_kernel(const int *__restrict__ G, int *__restrict__ cells, long long n_cells, int T) {
-  for (long long i = (long long)blockIdx.x * TB + threadIdx.x; i < n_cells; i += (long long)gridDim.x * TB)
-    cells[i] = G[i] - G[(i / T) * T];
-}
-__global__ void buckets_from_global_scan_kernel(const int *__restrict__ G, const int *__restrict__ total, long long n_buckets,
-                                                int T, int *__restrict__ bucket_cnt, int *__restrict__ bucket_pad) {
-  for (long long b = (long long)blockIdx.x * TB + threadIdx.x; b < n_buckets; b += (long long)gridDim.x * TB) {
+// (one launch: cells -> bucket-local offsets, and the bucket sizes / padded sizes)
+__global__ void from_global_scan_kernel(const int *__restrict__ G, const int *__restrict__ total, int *__restrict__ cells,
+                                        long long n_cells, long long n_buckets, int T, int *__restrict__ bucket_cnt,
+                                        int *__restrict__ bucket_pad) {
+  const long long i0 = (long long)blockIdx.x * TB + threadIdx.x, stride = (long long)gridDim.x * TB;
+  for (long long i = i0; i < n_cells; i += stride) cells[i] = G[i] - G[(i / T) * T];
+  for (long long b = i0; b < n_buckets; b += stride) {
     const int end = b + 1 < n_buckets ? G[(b + 1) * T] : *total;
     const int cnt = end - G[b * T];
     bucket_cnt[b] = cnt;
@@ -238,7 +238,7 @@ __global__ void plan_scatter_kernel(const int *__restrict__ dst, const int *__re
                                     int *__restrict__ msg_slot) {
   for (long long e = (long long)blockIdx.x * TB + threadIdx.x; e < M; e += (long long)gridDim.x * TB) {
     if (alive && !alive[e]) continue;
-    const int d = dst[e], r = rel[e];
+    const int d = dst[e], r = rel ? rel[e] : 0;           // rel == NULL: one relation (CSR builds)
     const long long bucket = (long long)(d / T) * R + r;
     const int pos = bucket_base[bucket] + atomicAdd(&cells[bucket * T + d % T], 1);
     p_src[pos] = src[e];
@@ -331,11 +331,38 @@ __global__ __launch_bounds__(TB) void plan_items_kernel(const int *__restrict__ 
   for (long long q = carry + threadIdx.x; q < n_items_ub; q += TB) items[q] = make_int2(0, 0);
 }
 
+// the last two steps of the scan in one launch when there are few blocks: workgroup b sums the totals of the blocks before it
+// (<= 1024 values) instead of reading a scanned copy, adds the offset to its 1024 items; the last one writes the grand total
+__global__ __launch_bounds__(TB) void scan_add_small_kernel(int *__restrict__ out, const int *__restrict__ totals, long long n,
+                                                            int nb, int *__restrict__ grand) {
+  __shared__ int wsum[TB / 64];
+  const int b = blockIdx.x;
+  int part = 0;
+  for (int j = threadIdx.x; j < b; j += TB) part += totals[j];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
+  __syncthreads();
+  int off0 = 0;
+  for (int w = 0; w < TB / 64; ++w) off0 += wsum[w];
+  const long long base = (long long)b * (TB * 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long long i = base + (long long)threadIdx.x * 4 + j;
+    if (i < n) out[i] += off0;
+  }
+  if (b == nb - 1 && threadIdx.x == 0) *grand = off0 + totals[b];
+}
+
 int exclusive_scan(const int *in, int *out, int *totals, long long n, int *grand, hipStream_t st) {
   const long long nb = (n + TB * 4 - 1) / (TB * 4);
   hipLaunchKernelGGL(scan_blocks_kernel, dim3((unsigned)nb), dim3(TB), 0, st, in, out, totals, n);
-  hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(TB), 0, st, totals, nb, grand);
-  hipLaunchKernelGGL(scan_add_kernel, dim3(blocks_for(n)), dim3(TB), 0, st, out, totals, n);
+  if (nb <= 1024) {        // (the per-call graphs of the LP layer: a step builds five plans, every launch counts)
+    hipLaunchKernelGGL(scan_add_small_kernel, dim3((unsigned)nb), dim3(TB), 0, st, out, totals, n, (int)nb, grand);
+  } else {
+    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(TB), 0, st, totals, nb, grand);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(blocks_for(n)), dim3(TB), 0, st, out, totals, n);
+  }
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
@@ -383,7 +410,7 @@ extern "C" int rgcn_dev_edge_norm(const int32_t *s, const int32_t *p, const int3
 extern "C" int rgcn_dev_plan_count(const int32_t *dst, const int32_t *rel, const uint8_t *alive, int64_t M, int64_t n_dst,
                                    int32_t R, int32_t tile_rows, int32_t *cells, int32_t *bucket_cnt,
                                    int32_t *bucket_base, int32_t *scan_tmp, int32_t *cells_tmp, void *stream) {
-  if (M < 0 || n_dst <= 0 || R <= 0 || tile_rows <= 0 || !cells || !bucket_cnt || !bucket_base || !scan_tmp || (M && (!dst || !rel))) { rgcn_set_error("dev_plan_count: bad argument"); return RGCN_EINVAL; }
+  if (M < 0 || n_dst <= 0 || R <= 0 || tile_rows <= 0 || !cells || !bucket_cnt || !bucket_base || !scan_tmp || (M && (!dst || (!rel && R != 1)))) { rgcn_set_error("dev_plan_count: bad argument"); return RGCN_EINVAL; }
   const int64_t n_tiles = (n_dst + tile_rows - 1) / tile_rows, nbk = n_tiles * R;
   if (nbk * tile_rows >= (int64_t(1) << 40)) { rgcn_set_error("dev_plan_count: cell table too large"); return RGCN_EUNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
@@ -396,10 +423,8 @@ extern "C" int rgcn_dev_plan_count(const int32_t *dst, const int32_t *rel, const
     int *total = scan_tmp + (n_cells / (TB * 4) + 2);
     int rc = exclusive_scan(cells, cells_tmp, scan_tmp, n_cells, total, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(buckets_from_global_scan_kernel, dim3(blocks_for(nbk)), dim3(TB), 0, st, cells_tmp, total,
+    hipLaunchKernelGGL(from_global_scan_kernel, dim3(blocks_for(n_cells)), dim3(TB), 0, st, cells_tmp, total, cells, n_cells,
                        (long long)nbk, tile_rows, bucket_cnt, bucket_base);
-    hipLaunchKernelGGL(cells_from_global_scan_kernel, dim3(blocks_for(n_cells)), dim3(TB), 0, st, cells_tmp, cells, n_cells,
-                       tile_rows);
   } else {
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(blocks_for(nbk * 64)), dim3(TB), 0, st, cells, (long long)nbk, tile_rows,
                        bucket_cnt, bucket_base);
@@ -415,7 +440,7 @@ extern "C" int rgcn_dev_plan_fill(const int32_t *dst, const int32_t *src, const 
                                   int32_t *tile_ptr, int32_t *run_ptr, const int32_t *aux, int32_t *p_aux,
                                   int32_t *msg_slot, int64_t n_chunks, void *stream) {
   if (M < 0 || n_dst <= 0 || R <= 0 || tile_rows <= 0 || !cells || !bucket_cnt || !bucket_base || !tile_ptr ||
-      (M && (!dst || !src || !rel || !val || !p_src || !p_dst || !p_val || !chunk_rel))) { rgcn_set_error("dev_plan_fill: bad argument"); return RGCN_EINVAL; }
+      (M && (!dst || !src || (!rel && R != 1) || !val || !p_src || !p_dst || !p_val || (!chunk_rel && R != 1)))) { rgcn_set_error("dev_plan_fill: bad argument"); return RGCN_EINVAL; }
   if (p_pack && (n_src >= (int64_t(1) << 24) || tile_rows > 255)) { rgcn_set_error("dev_plan_fill: packed slots need n_src < 2^24 and tile_rows <= 255"); return RGCN_EUNSUPPORTED; }
   const int64_t n_tiles = (n_dst + tile_rows - 1) / tile_rows, nbk = n_tiles * R;
   hipStream_t st = (hipStream_t)stream;
@@ -424,7 +449,7 @@ extern "C" int rgcn_dev_plan_fill(const int32_t *dst, const int32_t *src, const 
                             msg_slot);
   hipLaunchKernelGGL(plan_finish_kernel, dim3(blocks_for(nbk + 1)), dim3(TB), 0, st, (long long)nbk, R, bucket_cnt, bucket_base,
                      p_src, p_dst, p_val, reinterpret_cast<int2 *>(p_pack), chunk_rel, tile_ptr, run_ptr);
-  if (n_chunks > 0)
+  if (n_chunks > 0 && chunk_rel)
     hipLaunchKernelGGL(chunk_rel_kernel, dim3(blocks_for(n_chunks)), dim3(TB), 0, st, bucket_base, (long long)nbk, R,
                        (long long)n_chunks, chunk_rel);
   HIP_TRY(hipGetLastError());

@@ -411,7 +411,8 @@ class CsrPlan:
     """destination-major CSR (rowptr, src, rel, val) built on the device: the layout of the basis kernels"""
 
 
-def build_csr_device(dst, src, rel, val, alive, n_rows, sync_free=False):
+def build_csr_device(dst, src, rel, val, alive, n_rows, sync_free=False, want_slot=True):
+    """want_slot=False: no msg_slot array (input message -> CSR position; only the two-pass / featureless-basis routes read it)"""
     dev = dst.device
     M = dst.shape[0]
     # `cells` (one counter per row) lives at rowbuf[1:]: the count pass leaves the rows' exclusive offsets there and the fill
@@ -421,10 +422,9 @@ def build_csr_device(dst, src, rel, val, alive, n_rows, sync_free=False):
     rowbuf = torch.zeros(n_rows + 2, dtype=torch.int32, device=dev)
     cells, cells_tmp = rowbuf[1:], _i32(n_rows + 1, dev)
     bucket_cnt, bucket_base, scan_tmp = _i32(1, dev), _i32(2, dev), _i32(n_rows // 1024 + 4, dev)
-    zeros = torch.zeros(max(M, 1), dtype=torch.int32, device=dev)
     L = lib()
-    with torch.cuda.device(dev):
-        _check(L.rgcn_dev_plan_count(_dp(dst), _dp(zeros), _dp(alive), c_i64(M), c_i64(n_rows), c_i32(1), c_i32(n_rows),
+    with torch.cuda.device(dev):         # (one bucket, one "relation": the relation array of the builder is NULL)
+        _check(L.rgcn_dev_plan_count(_dp(dst), None, _dp(alive), c_i64(M), c_i64(n_rows), c_i32(1), c_i32(n_rows),
                                      _dp(cells), _dp(bucket_cnt), _dp(bucket_base), _dp(scan_tmp), _dp(cells_tmp),
                                      _stream(dev)), "dev_plan_count")
     # one bucket: the padded size is the live message count rounded up to 16 -- sized by its bound, the list length (dead
@@ -432,15 +432,16 @@ def build_csr_device(dst, src, rel, val, alive, n_rows, sync_free=False):
     m_pad = (M + CHUNK - 1) // CHUNK * CHUNK
     p = CsrPlan()
     p.n_rows = n_rows
-    p.msg_slot = torch.full((max(M, 1),), -1, dtype=torch.int32, device=dev)[:M]   # CSR position of every live input message
+    # CSR position of every live input message
+    p.msg_slot = torch.full((max(M, 1),), -1, dtype=torch.int32, device=dev)[:M] if want_slot else None
     p.n_messages = None
     p.src, pdst, p.rel = _i32(m_pad, dev), _i32(m_pad, dev), _i32(m_pad, dev)
     p.val = torch.empty(max(m_pad, 1), dtype=torch.float32, device=dev)
-    chunk_rel, tile_ptr = _i32(m_pad // CHUNK, dev), _i32(2, dev)
+    tile_ptr = _i32(2, dev)
     with torch.cuda.device(dev):
-        _check(L.rgcn_dev_plan_fill(_dp(dst), _dp(src), _dp(zeros), _dp(val), _dp(alive), c_i64(M), c_i64(n_rows),
+        _check(L.rgcn_dev_plan_fill(_dp(dst), _dp(src), None, _dp(val), _dp(alive), c_i64(M), c_i64(n_rows),
                                     c_i64(n_rows), c_i32(1), c_i32(n_rows), _dp(cells), _dp(bucket_cnt), _dp(bucket_base),
-                                    _dp(p.src), _dp(pdst), _dp(p.val), None, _dp(chunk_rel), _dp(tile_ptr), None,
+                                    _dp(p.src), _dp(pdst), _dp(p.val), None, None, _dp(tile_ptr), None,
                                     _dp(rel), _dp(p.rel), _dp(p.msg_slot), c_i64(m_pad // CHUNK), _stream(dev)),
                "dev_plan_fill")
     p.rowptr = rowbuf[: n_rows + 1]
@@ -1091,8 +1092,8 @@ def distmult_bwd_all(triples, nodes, rel, gs, with_bias):
     alive = None
     if _deferred_mode():     # the forward's range check may not have been looked at yet: bad triples must not reach the sort
         alive = ((triples >= 0).all(dim=1) & (triples[:, 0] < N) & (triples[:, 2] < N) & (triples[:, 1] < R)).to(torch.uint8)
-    by_s = build_csr_device(s, o, p, gs, alive, N, sync_free=True)
-    by_o = build_csr_device(o, s, p, gs, alive, N, sync_free=True)
+    by_s = build_csr_device(s, o, p, gs, alive, N, sync_free=True, want_slot=False)
+    by_o = build_csr_device(o, s, p, gs, alive, N, sync_free=True, want_slot=False)
     dn, dr = torch.empty_like(nodes), torch.empty_like(rel)
     dsb = dpb = dob = None
     if with_bias:
@@ -1116,8 +1117,8 @@ def distmult_bwd_nodes(triples, nodes, rel, gs):
     alive = None
     if _deferred_mode():     # the forward's range check may not have been looked at yet: bad triples must not reach the sort
         alive = ((triples >= 0).all(dim=1) & (triples[:, 0] < N) & (triples[:, 2] < N) & (triples[:, 1] < rel.shape[0])).to(torch.uint8)
-    by_s = build_csr_device(s, o, p, gs, alive, N, sync_free=True)
-    by_o = build_csr_device(o, s, p, gs, alive, N, sync_free=True)
+    by_s = build_csr_device(s, o, p, gs, alive, N, sync_free=True, want_slot=False)
+    by_o = build_csr_device(o, s, p, gs, alive, N, sync_free=True, want_slot=False)
     dn = torch.empty_like(nodes)
     with torch.cuda.device(dev), _timed("distmult_bwd_nodes"):
         _check(lib().rgcn_distmult_bwd_nodes_f32(_dp(by_s.rowptr), _dp(by_s.src), _dp(by_s.rel), _dp(by_s.val), _dp(by_o.rowptr),

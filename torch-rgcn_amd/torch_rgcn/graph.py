@@ -113,15 +113,19 @@ class RelGraph:
         """relation-major (single tile): long runs per relation for the weight gradient"""
         return self._plan("fwd", max(self.num_nodes, 1), int(os.environ.get("RGCN_WGRAD_ITEM_CHUNKS", "64")))
 
-    def csr(self, kind):
-        """destination-major ("fwd": rows = subjects) or source-major ("bwd") CSR for the basis kernels"""
+    def csr(self, kind, need_slot=False):
+        """destination-major ("fwd": rows = subjects) or source-major ("bwd") CSR for the basis kernels.  need_slot: with the
+        msg_slot array (input message -> CSR position) the two-pass routes read; per-call graphs build it only on demand"""
         key = ("csr", kind)
+        if key in self._plans and need_slot and self._plans[key].msg_slot is None:
+            del self._plans[key]
         if key not in self._plans:
             if self._dev is None:
                 raise RuntimeError("the basis-aggregation path needs the device-side graph build")
             s, p, o, val, alive = self._dev
             dst, src = (s, o) if kind == "fwd" else (o, s)
-            self._plans[key] = _native.build_csr_device(dst, src, p, val, alive, self.num_nodes, sync_free=self.sync_free)
+            self._plans[key] = _native.build_csr_device(dst, src, p, val, alive, self.num_nodes, sync_free=self.sync_free,
+                                                        want_slot=need_slot or not getattr(self, "per_call", False))
             self._plans[key].per_call = getattr(self, "per_call", False)
         return self._plans[key]
 
@@ -152,7 +156,7 @@ class RelGraph:
                 raise RuntimeError("the relation-major two-pass paths need the device-side graph build")
             s, p, o, val, alive = self._dev
             dst, src = (s, o) if kind == "fwd" else (o, s)
-            csr = self.csr(kind)
+            csr = self.csr(kind, need_slot=True)
             if csr.n_messages is None:
                 csr.n_messages = int(csr.rowptr[-1].item())
             N, R = self.num_nodes, self.num_rels
