@@ -1176,6 +1176,8 @@ __global__ __launch_bounds__(WG) void distmult_bwd_nodes_kernel(
 // added to d_rel with one atomic per workgroup and element (<= 512 persistent workgroups).  Needs n_rel (d + 1) <= 4096 floats
 // per wave (WN18: 18 x 200); larger relation tables keep the predicate-sorted kernel above.  Round 2 before this: torch.argsort
 // by predicate (rocPRIM merge sort, 0.15 ms for 330 k triples) + two index gathers + distmult_bwd_kernel (0.12 ms).
+// (One table per WORKGROUP with ds_add_f32 -- 4x less LDS, twice the resident waves -- measured 0.37 ms against 0.21: LDS float
+// atomics are slow on gfx950 even without address conflicts.)
 __global__ __launch_bounds__(WG) void distmult_bwd_all_kernel(
     const int *__restrict__ rp_s, const int *__restrict__ oth_s, const int *__restrict__ rel_s, const float *__restrict__ g_s,
     const int *__restrict__ rp_o, const int *__restrict__ oth_o, const int *__restrict__ rel_o, const float *__restrict__ g_o,
