@@ -354,6 +354,29 @@ __global__ __launch_bounds__(TB) void scan_add_small_kernel(int *__restrict__ ou
   if (b == nb - 1 && threadIdx.x == 0) *grand = off0 + totals[b];
 }
 
+// exclusive scan of up to 1024 ints in place, total to v[n]: one workgroup, one launch (bucket bases of single-tile plans: a
+// CSR has one bucket, a relation-major plan R)
+__global__ __launch_bounds__(1024) void scan_small_kernel(int *__restrict__ v, int n) {
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int x = tid < n ? v[tid] : 0;
+  int incl = x;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int woff = 0, total = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) woff += wsum[w];
+    total += wsum[w];
+  }
+  if (tid < n) v[tid] = woff + incl - x;
+  if (tid == 0) v[n] = total;
+}
+
 int exclusive_scan(const int *in, int *out, int *totals, long long n, int *grand, hipStream_t st) {
   const long long nb = (n + TB * 4 - 1) / (TB * 4);
   hipLaunchKernelGGL(scan_blocks_kernel, dim3((unsigned)nb), dim3(TB), 0, st, in, out, totals, n);
@@ -430,6 +453,11 @@ extern "C" int rgcn_dev_plan_count(const int32_t *dst, const int32_t *rel, const
                        bucket_cnt, bucket_base);
   }
   HIP_TRY(hipGetLastError());
+  if (nbk <= 1024) {
+    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, bucket_base, (int)nbk);
+    HIP_TRY(hipGetLastError());
+    return RGCN_OK;
+  }
   return exclusive_scan(bucket_base, bucket_base, scan_tmp, nbk, bucket_base + nbk, st);
 }
 
