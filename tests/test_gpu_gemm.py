@@ -18,8 +18,12 @@ def _rel(a, b):
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (7, 5, 3), (128, 128, 16), (130, 127, 33), (400, 200, 513), (37, 256, 200),
                                    (300, 2, 64), (16, 400, 40), (257, 129, 4)])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
-def test_gemm_layouts_and_edges(M, N, K, ta, tb):
+@pytest.mark.parametrize("bm", ["128", "64"])
+def test_gemm_layouts_and_edges(monkeypatch, M, N, K, ta, tb, bm):
+    """bm: rows of the C tile per workgroup (rgcn_gemm_f32 picks 64-row tiles per launch when they balance better over the
+    CUs; RGCN_GEMM_BM forces either form)"""
     from torch_rgcn import _native
+    monkeypatch.setenv("RGCN_GEMM_BM", bm)
     rng = np.random.default_rng(M * 31 + N * 7 + K)
     A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
     B = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)

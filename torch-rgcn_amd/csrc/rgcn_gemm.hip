@@ -36,35 +36,39 @@ constexpr int LD_OUT = 132;      // LDS row stride of a K-outer slab [16][128]: 
 // outstanding loads between the four loads of a slab (s_waitcnt vmcnt(2) at every join) -- the global latency of each slab was
 // paid before its MFMAs started instead of under them (ablation: loads 12 us + MFMAs 22 us + rest 19 us = the whole 53 us of a
 // one-workgroup-per-CU launch, nothing overlapped).
-template <bool TA, bool TB, bool VEC>
+// BM: rows of the C tile (128 x 128 or 64 x 128 per workgroup).  64-row tiles halve the work of a tile: launches whose
+// 128-row tile count is an awkward multiple of the CU count (WN18: 640 tiles over 256 CUs = 3 rounds on some CUs, 2 on others)
+// balance better with twice as many half tiles (rgcn_gemm_f32 picks per launch).
+template <bool TA, bool TB, bool VEC, int BM>
 __global__ __launch_bounds__(WG) void gemm_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                   const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K,
                                                   long long lda, long long ldb, long long ldc, int tiles_m, int k_per_split,
                                                   long long split_stride) {
-  __shared__ __attribute__((aligned(16))) float sA[2][TA ? GK * LD_OUT : GT * LD_IN];
+  constexpr int LDA_OUT = BM + 4;          // K-outer A slab [16][BM]
+  constexpr int NA = BM / 32;              // 16 x 16 row tiles per wave (the wave's quadrant is BM / 2 x 64)
+  __shared__ __attribute__((aligned(16))) float sA[2][TA ? GK * LDA_OUT : BM * LD_IN];
   __shared__ __attribute__((aligned(16))) float sB[2][TB ? GT * LD_IN : GK * LD_OUT];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = lane & 15, kq = lane >> 4;
-  const int m0 = (blockIdx.x % tiles_m) * GT, n0 = (blockIdx.x / tiles_m) * GT;
+  const int m0 = (blockIdx.x % tiles_m) * BM, n0 = (blockIdx.x / tiles_m) * GT;
   const int kb = blockIdx.y * k_per_split, ke = min(K, kb + k_per_split);
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * 64;
 
-  f32x4 acc[4][4];
+  f32x4 acc[NA][4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // staging: K-inner slab: thread -> rows (tid >> 2) and (tid >> 2) + 64, k group 4 (tid & 3)
-  //          K-outer slab: thread -> k rows (tid >> 5) and (tid >> 5) + 8, column group 4 (tid & 31)
+  // staging: K-inner slab [ROWS][16]: thread -> rows (tid >> 2) (+ 64), k group 4 (tid & 3)
+  //          K-outer slab [16][COLS]: thread -> k rows tid / (COLS / 4) (+ 256 / (COLS / 4)), column group 4 (tid % (COLS / 4))
   f32x4 ra[2], rb[2];
-  // 16-byte loads when rows / columns are 16-byte aligned (K and the leading dimension multiples of 4): the K tail is
-  // then whole groups of 4 and is zeroed by the stash; otherwise element loads with clamped indices
   constexpr bool vec_a = VEC, vec_b = VEC;
-  auto fetch_inner = [&](const float *P, long long ld, int r0, int rows, int k0, bool vec, f32x4 (&reg)[2]) {
+  auto fetch_inner = [&](const float *P, long long ld, int r0, int rows, int k0, bool vec, f32x4 (&reg)[2], int passes) {
     const int kk = k0 + 4 * (tid & 3);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+      if (h >= passes) continue;
       const float *row = P + (size_t)min(r0 + (tid >> 2) + 64 * h, rows - 1) * ld;
       if (vec) {
         reg[h] = *reinterpret_cast<const f32x4 *>(row + min(kk, K - 4));
@@ -74,21 +78,24 @@ __global__ __launch_bounds__(WG) void gemm_kernel(const float *__restrict__ A, c
       }
     }
   };
-  auto stash_inner = [&](float *S, int k0, const f32x4 (&reg)[2]) {
+  auto stash_inner = [&](float *S, int k0, const f32x4 (&reg)[2], int passes) {
     const int kk = k0 + 4 * (tid & 3);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+      if (h >= passes) continue;
       f32x4 v = reg[h];
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = (kk + c < ke) ? v[c] : 0.f;
       *reinterpret_cast<f32x4 *>(S + ((tid >> 2) + 64 * h) * LD_IN + 4 * (tid & 3)) = v;
     }
   };
-  auto fetch_outer = [&](const float *P, long long ld, int c0, int cols, int k0, bool vec, f32x4 (&reg)[2]) {
-    const int cc = c0 + 4 * (tid & 31);
+  // cg = column groups of 4 per slab row (32 for 128 columns, 16 for 64), 256 / cg k rows per pass, 16 / (256 / cg) passes
+  auto fetch_outer = [&](const float *P, long long ld, int c0, int cols, int k0, bool vec, f32x4 (&reg)[2], int cg) {
+    const int cc = c0 + 4 * (tid % cg), rp = WG / cg;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const float *row = P + (size_t)min(k0 + (tid >> 5) + 8 * h, ke - 1) * ld;
+      if (h * rp >= GK) continue;
+      const float *row = P + (size_t)min(k0 + tid / cg + rp * h, ke - 1) * ld;
       if (vec) {          // columns past the matrix edge belong to rows / columns of C that are never stored
         reg[h] = *reinterpret_cast<const f32x4 *>(row + min(cc, cols - 4));
       } else {
@@ -97,20 +104,22 @@ __global__ __launch_bounds__(WG) void gemm_kernel(const float *__restrict__ A, c
       }
     }
   };
-  auto stash_outer = [&](float *S, int k0, const f32x4 (&reg)[2]) {
+  auto stash_outer = [&](float *S, int k0, const f32x4 (&reg)[2], int cg, int ld_s) {
+    const int rp = WG / cg;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const bool live = k0 + (tid >> 5) + 8 * h < ke;
-      *reinterpret_cast<f32x4 *>(S + ((tid >> 5) + 8 * h) * LD_OUT + 4 * (tid & 31)) = live ? reg[h] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (h * rp >= GK) continue;
+      const bool live = k0 + tid / cg + rp * h < ke;
+      *reinterpret_cast<f32x4 *>(S + (tid / cg + rp * h) * ld_s + 4 * (tid % cg)) = live ? reg[h] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto fetch = [&](int k0) {
-    if (TA) fetch_outer(A, lda, m0, M, k0, vec_a, ra); else fetch_inner(A, lda, m0, M, k0, vec_a, ra);
-    if (TB) fetch_inner(B, ldb, n0, N, k0, vec_b, rb); else fetch_outer(B, ldb, n0, N, k0, vec_b, rb);
+    if (TA) fetch_outer(A, lda, m0, M, k0, vec_a, ra, BM / 4); else fetch_inner(A, lda, m0, M, k0, vec_a, ra, BM / 64);
+    if (TB) fetch_inner(B, ldb, n0, N, k0, vec_b, rb, 2); else fetch_outer(B, ldb, n0, N, k0, vec_b, rb, GT / 4);
   };
   auto stash = [&](int buf, int k0) {
-    if (TA) stash_outer(sA[buf], k0, ra); else stash_inner(sA[buf], k0, ra);
-    if (TB) stash_inner(sB[buf], k0, rb); else stash_outer(sB[buf], k0, rb);
+    if (TA) stash_outer(sA[buf], k0, ra, BM / 4, LDA_OUT); else stash_inner(sA[buf], k0, ra, BM / 64);
+    if (TB) stash_inner(sB[buf], k0, rb, 2); else stash_outer(sB[buf], k0, rb, GT / 4, LD_OUT);
   };
 
   const int steps = (ke - kb + GK - 1) / GK;
@@ -121,27 +130,30 @@ __global__ __launch_bounds__(WG) void gemm_kernel(const float *__restrict__ A, c
     for (int t = 0; t < steps; ++t) {
       const int cur = t & 1;
       if (t + 1 < steps) fetch(kb + GK * (t + 1));
-      f32x4 av[4], bv[4];
+      f32x4 av[NA], bv[4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
+      for (int a = 0; a < NA; ++a) {
         if (TA) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) av[a][c] = sA[cur][(4 * kq + c) * LD_OUT + wm + 16 * a + i];
+          for (int c = 0; c < 4; ++c) av[a][c] = sA[cur][(4 * kq + c) * LDA_OUT + wm + 16 * a + i];
         } else {
           av[a] = *reinterpret_cast<const f32x4 *>(&sA[cur][(wm + 16 * a + i) * LD_IN + 4 * kq]);
         }
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
         if (TB) {
-          bv[a] = *reinterpret_cast<const f32x4 *>(&sB[cur][(wn + 16 * a + i) * LD_IN + 4 * kq]);
+          bv[b] = *reinterpret_cast<const f32x4 *>(&sB[cur][(wn + 16 * b + i) * LD_IN + 4 * kq]);
         } else {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) bv[a][c] = sB[cur][(4 * kq + c) * LD_OUT + wn + 16 * a + i];
+          for (int c = 0; c < 4; ++c) bv[b][c] = sB[cur][(4 * kq + c) * LD_OUT + wn + 16 * b + i];
         }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
           for (int b = 0; b < 4; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][c], bv[b][c], acc[a][b], 0, 0, 0);
@@ -153,7 +165,7 @@ __global__ __launch_bounds__(WG) void gemm_kernel(const float *__restrict__ A, c
   // D: lane 16 q + j holds rows 4 q .. 4 q + 3 (M index), column j (N index) of every 16 x 16 tile
   float *Cs = C + (size_t)blockIdx.y * split_stride;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + wm + 16 * a + 4 * kq + r;
@@ -580,30 +592,39 @@ extern "C" int rgcn_gemm_f32(const float *A, const float *B, const float *bias, 
     return RGCN_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int tiles_m = (int)((M + GT - 1) / GT), tiles_n = (int)((N + GT - 1) / GT);
+  int tiles_m = (int)((M + GT - 1) / GT);
+  const int tiles_n = (int)((N + GT - 1) / GT);
   int S = (int)std::min<int64_t>(split_k, std::max<int64_t>(1, (K + GK - 1) / GK));
   const int kps = (int)(((K + S - 1) / S + GK - 1) / GK * GK);
   S = K > 0 ? (int)((K + kps - 1) / kps) : 1;
   float *out = S > 1 ? scratch : C;
   const long long ldo = S > 1 ? N : ldc, sstride = S > 1 ? (long long)M * N : 0;
+  // 64-row tiles when they spread better over the 256 CUs: rounds of 128-row tile work on the busiest CU
+  const char *bm_s = getenv("RGCN_GEMM_BM");          // (read per call: the tests switch it)
+  const int bm_env = bm_s ? atoi(bm_s) : 0;
+  const int64_t t128 = (int64_t)tiles_m * tiles_n * S, t64 = ((M + 63) / 64) * tiles_n * S;
+  const bool half = bm_env ? bm_env == 64 : ((t64 + 255) / 256 < 2 * ((t128 + 255) / 256) && t128 > 256);
+  if (half) tiles_m = (int)((M + 63) / 64);
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)S), block(WG);
   const bool ta = flags & RGCN_G_TRANS_A, tb = flags & RGCN_G_TRANS_B;
   // 16-byte loads when rows / columns are 16-byte aligned (the contiguous extent and the leading dimension multiples of 4): the
   // K tail is then whole groups of 4 and is zeroed by the stash; otherwise element loads with clamped indices
   const bool vec = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (((ta ? M : K) & 3) == 0) &&
                    ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (((tb ? K : N) & 3) == 0);
-#define RGCN_GEMM_LAUNCH(TAc, TBc)                                                                                           \
-  do {                                                                                                                        \
-    if (vec) hipLaunchKernelGGL((gemm_kernel<TAc, TBc, true>), grid, block, 0, st, A, B, bias, out, (int)M, (int)N, (int)K,    \
-                                (long long)lda, (long long)ldb, ldo, tiles_m, kps > 0 ? kps : GK, sstride);                   \
-    else hipLaunchKernelGGL((gemm_kernel<TAc, TBc, false>), grid, block, 0, st, A, B, bias, out, (int)M, (int)N, (int)K,       \
-                            (long long)lda, (long long)ldb, ldo, tiles_m, kps > 0 ? kps : GK, sstride);                       \
+#define RGCN_GEMM_ARGS grid, block, 0, st, A, B, bias, out, (int)M, (int)N, (int)K, (long long)lda, (long long)ldb, ldo, tiles_m, kps > 0 ? kps : GK, sstride
+#define RGCN_GEMM_LAUNCH(TAc, TBc)                                                                  \
+  do {                                                                                               \
+    if (vec && half) hipLaunchKernelGGL((gemm_kernel<TAc, TBc, true, 64>), RGCN_GEMM_ARGS);          \
+    else if (vec) hipLaunchKernelGGL((gemm_kernel<TAc, TBc, true, 128>), RGCN_GEMM_ARGS);            \
+    else if (half) hipLaunchKernelGGL((gemm_kernel<TAc, TBc, false, 64>), RGCN_GEMM_ARGS);           \
+    else hipLaunchKernelGGL((gemm_kernel<TAc, TBc, false, 128>), RGCN_GEMM_ARGS);                    \
   } while (0)
   if (ta && tb) RGCN_GEMM_LAUNCH(true, true);
   else if (ta) RGCN_GEMM_LAUNCH(true, false);
   else if (tb) RGCN_GEMM_LAUNCH(false, true);
   else RGCN_GEMM_LAUNCH(false, false);
 #undef RGCN_GEMM_LAUNCH
+#undef RGCN_GEMM_ARGS
   if (S > 1) {
     const long long n = (long long)M * N;
     hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)std::min<long long>((n + WG - 1) / WG, 4096)), dim3(WG), 0, st, scratch,
