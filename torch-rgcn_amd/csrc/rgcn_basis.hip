@@ -382,6 +382,71 @@ __global__ __launch_bounds__(TB) void basis_aggregate_kernel(
   }
 }
 
+// The same with 16-byte loads (d % 4 == 0): a lane owns 4 consecutive columns, lpm = pow2 >= d / 4 (<= 64) lanes per message --
+// a 200-wide row is ONE pass of 50 lanes instead of four passes of 64 scalar loads, and the per-row set-up (index loads, loop,
+// reduction) -- which is what a 2-message row costs -- is paid once (WN18-shaped graph: 58 -> ~30 us per launch).
+// NB_IN = 1 takes up to 4 bases per pass.
+template <int NB_IN_ONE>
+__global__ __launch_bounds__(TB) void basis_aggregate_vec4_kernel(
+    const float *__restrict__ X, const float *__restrict__ comps, float *__restrict__ out,
+    const int *__restrict__ rowptr, const int *__restrict__ p_src, const int *__restrict__ p_rel,
+    const float *__restrict__ p_val, long long n_rows, int B, int d, int lpm) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / lpm, il = lane % lpm, ngrp = 64 / lpm;
+  const long long wave0 = ((long long)blockIdx.x * TB + threadIdx.x) >> 6, nw = ((long long)gridDim.x * TB) >> 6;
+  constexpr int MB = 2;      // messages in flight per lane group
+  for (long long row = wave0; row < n_rows; row += nw) {
+    const int e0 = rowptr[row], e1 = rowptr[row + 1];
+    for (int f0 = 0; f0 < d; f0 += 4 * lpm) {
+      const int f = f0 + 4 * il;
+      const bool on = f < d;
+      if (NB_IN_ONE) {
+        for (int b0 = 0; b0 < B; b0 += 4) {
+          f32x4 a[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+          for (int eb = e0 + sub; eb < e1; eb += ngrp * MB) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+              const int e = min(eb + m * ngrp, e1 - 1);
+              const float v = (eb + m * ngrp < e1) ? p_val[e] : 0.f;
+              const f32x4 x = on ? *reinterpret_cast<const f32x4 *>(X + (size_t)p_src[e] * d + f) : f32x4{0.f, 0.f, 0.f, 0.f};
+              const float *cp = comps + (size_t)p_rel[e] * B + b0;
+              a[0] += x * (cp[0] * v);
+              if (b0 + 1 < B) a[1] += x * (cp[1] * v);
+              if (b0 + 2 < B) a[2] += x * (cp[2] * v);
+              if (b0 + 3 < B) a[3] += x * (cp[3] * v);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[q][c] = group_sum(a[q][c], lpm);
+          if (sub == 0 && on) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (b0 + q < B) *reinterpret_cast<f32x4 *>(out + ((size_t)row * B + b0 + q) * d + f) = a[q];
+          }
+        }
+      } else {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int eb = e0 + sub; eb < e1; eb += ngrp * MB) {
+#pragma unroll
+          for (int m = 0; m < MB; ++m) {
+            const int e = min(eb + m * ngrp, e1 - 1);
+            const float v = (eb + m * ngrp < e1) ? p_val[e] : 0.f;
+            const float *cp = comps + (size_t)p_rel[e] * B;
+            const float *xr = X + (size_t)p_src[e] * B * d + f;
+            if (on)
+              for (int b = 0; b < B; ++b) a += *reinterpret_cast<const f32x4 *>(xr + (size_t)b * d) * (cp[b] * v);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[c] = group_sum(a[c], lpm);
+        if (sub == 0 && on) *reinterpret_cast<f32x4 *>(out + (size_t)row * d + f) = a;
+      }
+    }
+  }
+}
+
 // Relation-major work items (chunk ranges of one relation, relation-major plan): per-lane partial sums over the
 // whole item, ONE wave reduction and one atomic per (item piece, basis) -- not per message.  Lane groups of lpr
 // lanes take alternate slots so that narrow rows keep all 64 lanes busy.
@@ -447,6 +512,19 @@ extern "C" int rgcn_basis_aggregate_f32(const float *X, const float *comps, floa
   (void)R;
   if (!X || !comps || !out || !rowptr || n_rows < 0 || B <= 0 || d <= 0 || (n_b_in != 1 && n_b_in != B)) { rgcn_set_error("basis_aggregate: bad argument"); return RGCN_EINVAL; }
   if (!n_rows) return RGCN_OK;
+  static const int vec_mode = getenv("RGCN_BASIS_VEC4") ? atoi(getenv("RGCN_BASIS_VEC4")) : 1;
+  if (vec_mode && (d & 3) == 0 && d >= 32 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    int lpm = 1;
+    while (lpm < 64 && 4 * lpm < d) lpm *= 2;
+    if (n_b_in == 1)
+      hipLaunchKernelGGL(basis_aggregate_vec4_kernel<1>, dim3(blocks_for(n_rows * 64)), dim3(TB), 0, (hipStream_t)stream, X, comps, out,
+                         rowptr, p_src, p_rel, p_val, (long long)n_rows, B, d, lpm);
+    else
+      hipLaunchKernelGGL(basis_aggregate_vec4_kernel<0>, dim3(blocks_for(n_rows * 64)), dim3(TB), 0, (hipStream_t)stream, X, comps, out,
+                         rowptr, p_src, p_rel, p_val, (long long)n_rows, B, d, lpm);
+    HIP_TRY(hipGetLastError());
+    return RGCN_OK;
+  }
   hipLaunchKernelGGL(basis_aggregate_kernel, dim3(blocks_for(n_rows * 64)), dim3(TB), 0, (hipStream_t)stream, X, comps, out,
                      rowptr, p_src, p_rel, p_val, (long long)n_rows, B, d, n_b_in, lanes_per_row(d));
   HIP_TRY(hipGetLastError());
