@@ -170,11 +170,14 @@ RGCN_API int rgcn_basis_aggregate_f32(const float *X, const float *comps, float 
                                       int64_t n_rows, int32_t R, int32_t B, int32_t d, int32_t n_b_in,
                                       void *stream);
 /* dcomps[r, b] = sum_{e in r} val_e <X[src_e], D[dst_e, b, :]>   (D = d ag, rows of B*d), over the work
- * items of the relation-major plan (rgcn_plan_fill_host / rgcn_dev_plan_fill with tile_rows >= n_dst). */
+ * items of the relation-major plan (rgcn_plan_fill_host / rgcn_dev_plan_fill with tile_rows >= n_dst).
+ * dcomps is [n_copies][R][B] (zeroed here): the pieces an item is cut into add to different copies -- with few relations
+ * thousands of atomics on R * B addresses serialise at L2 (WN18: 15,000 on 74 addresses, 0.1 ms) -- and the caller sums the
+ * copies; n_copies = 1 gives the plain [R][B] result. */
 RGCN_API int rgcn_basis_dcomps_f32(const float *X, const float *D, float *dcomps, const int32_t *p_src,
                                    const int32_t *p_dst, const float *p_val, const int32_t *chunk_rel,
                                    const int32_t *items, int64_t n_items, int32_t R, int32_t B, int32_t d,
-                                   void *stream);
+                                   int32_t n_copies, void *stream);
 
 /* ------------------------------------------------------------------ device kernels */
 

@@ -450,14 +450,17 @@ __global__ __launch_bounds__(TB) void basis_aggregate_vec4_kernel(
 // Relation-major work items (chunk ranges of one relation, relation-major plan): per-lane partial sums over the
 // whole item, ONE wave reduction and one atomic per (item piece, basis) -- not per message.  Lane groups of lpr
 // lanes take alternate slots so that narrow rows keep all 64 lanes busy.
+template <bool VEC>      // VEC: rows read 16 bytes per lane (d % 4 == 0): a 200-wide row is one trip of 50 lanes instead of four of 64
 __global__ __launch_bounds__(TB) void basis_dcomps_kernel(
     const float *__restrict__ X, const float *__restrict__ D, float *__restrict__ dcomps,
     const int *__restrict__ p_src, const int *__restrict__ p_dst, const float *__restrict__ p_val,
-    const int *__restrict__ chunk_rel, const int2 *__restrict__ items, int n_items, int B, int d, int lpr) {
+    const int *__restrict__ chunk_rel, const int2 *__restrict__ items, int n_items, int B, int d, int lpr, int n_copies,
+    int copy_floats) {
   const int lane = threadIdx.x & 63;
   const int sub = lane / lpr, il = lane % lpr, ngrp = 64 / lpr;
   const int item = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
   if (item >= n_items) return;
+  dcomps += (size_t)(blockIdx.y % n_copies) * copy_floats;       // the pieces of an item add into different copies
   const int2 whole = items[item];
   const int r = chunk_rel[whole.x];
   // blockIdx.y = piece of the item (an item of the shared work list can hold 1024 messages: too long for one wave)
@@ -476,12 +479,23 @@ __global__ __launch_bounds__(TB) void basis_dcomps_kernel(
       // (either index array may carry the pads' -1: the callers swap them for the featureless layer)
       const float *x = X + (size_t)max(p_src[e], 0) * d, *x2 = X + (size_t)max(p_src[e2], 0) * d;
       const float *dd = D + ((size_t)max(p_dst[e], 0) * B + b0) * d, *dd2 = D + ((size_t)max(p_dst[e2], 0) * B + b0) * d;
-      for (int i = il; i < d; i += lpr) {
-        const float xv = v * x[i], xw = v2 * x2[i];
-        a0 += xv * dd[i] + xw * dd2[i];
-        if (b0 + 1 < B) a1 += xv * dd[(size_t)d + i] + xw * dd2[(size_t)d + i];
-        if (b0 + 2 < B) a2 += xv * dd[2 * (size_t)d + i] + xw * dd2[2 * (size_t)d + i];
-        if (b0 + 3 < B) a3 += xv * dd[3 * (size_t)d + i] + xw * dd2[3 * (size_t)d + i];
+      if (VEC) {
+        auto dot4 = [](const f32x4 &p, const f32x4 &q) { return (p[0] * q[0] + p[1] * q[1]) + (p[2] * q[2] + p[3] * q[3]); };
+        for (int f = 4 * il; f < d; f += 4 * lpr) {
+          const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + f) * v, xw = *reinterpret_cast<const f32x4 *>(x2 + f) * v2;
+          a0 += dot4(xv, *reinterpret_cast<const f32x4 *>(dd + f)) + dot4(xw, *reinterpret_cast<const f32x4 *>(dd2 + f));
+          if (b0 + 1 < B) a1 += dot4(xv, *reinterpret_cast<const f32x4 *>(dd + (size_t)d + f)) + dot4(xw, *reinterpret_cast<const f32x4 *>(dd2 + (size_t)d + f));
+          if (b0 + 2 < B) a2 += dot4(xv, *reinterpret_cast<const f32x4 *>(dd + 2 * (size_t)d + f)) + dot4(xw, *reinterpret_cast<const f32x4 *>(dd2 + 2 * (size_t)d + f));
+          if (b0 + 3 < B) a3 += dot4(xv, *reinterpret_cast<const f32x4 *>(dd + 3 * (size_t)d + f)) + dot4(xw, *reinterpret_cast<const f32x4 *>(dd2 + 3 * (size_t)d + f));
+        }
+      } else {
+        for (int i = il; i < d; i += lpr) {
+          const float xv = v * x[i], xw = v2 * x2[i];
+          a0 += xv * dd[i] + xw * dd2[i];
+          if (b0 + 1 < B) a1 += xv * dd[(size_t)d + i] + xw * dd2[(size_t)d + i];
+          if (b0 + 2 < B) a2 += xv * dd[2 * (size_t)d + i] + xw * dd2[2 * (size_t)d + i];
+          if (b0 + 3 < B) a3 += xv * dd[3 * (size_t)d + i] + xw * dd2[3 * (size_t)d + i];
+        }
       }
     }
 #pragma unroll
@@ -534,15 +548,23 @@ extern "C" int rgcn_basis_aggregate_f32(const float *X, const float *comps, floa
 extern "C" int rgcn_basis_dcomps_f32(const float *X, const float *D, float *dcomps, const int32_t *p_src,
                                      const int32_t *p_dst, const float *p_val, const int32_t *chunk_rel,
                                      const int32_t *items, int64_t n_items, int32_t R, int32_t B, int32_t d,
-                                     void *stream) {
-  if (!X || !D || !dcomps || n_items < 0 || R <= 0 || B <= 0 || d <= 0) { rgcn_set_error("basis_dcomps: bad argument"); return RGCN_EINVAL; }
+                                     int32_t n_copies, void *stream) {
+  if (!X || !D || !dcomps || n_items < 0 || R <= 0 || B <= 0 || d <= 0 || n_copies < 1) { rgcn_set_error("basis_dcomps: bad argument"); return RGCN_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(zero_async(dcomps, (size_t)R * B * sizeof(float), st));
+  HIP_TRY(zero_async(dcomps, (size_t)n_copies * R * B * sizeof(float), st));
   if (!n_items) return RGCN_OK;
   // few items (small per-call graphs): cut every item into more pieces so that the chip is filled
   const unsigned pieces = n_items < 2048 ? 64 : 16;
-  hipLaunchKernelGGL(basis_dcomps_kernel, dim3((unsigned)((n_items + TB / 64 - 1) / (TB / 64)), pieces), dim3(TB), 0, st, X, D, dcomps,
-                     p_src, p_dst, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), (int)n_items, B, d, lanes_per_row(d));
+  const bool vec = (d & 3) == 0 && d >= 32 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(D)) & 15) == 0;
+  int lpv = 1;                                   // lanes per row with 16-byte loads
+  while (lpv < 64 && 4 * lpv < d) lpv *= 2;
+  if (vec) {
+    hipLaunchKernelGGL(basis_dcomps_kernel<true>, dim3((unsigned)((n_items + TB / 64 - 1) / (TB / 64)), pieces), dim3(TB), 0, st, X, D, dcomps,
+                     p_src, p_dst, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), (int)n_items, B, d, lpv, (int)n_copies, R * B);
+  } else {
+    hipLaunchKernelGGL(basis_dcomps_kernel<false>, dim3((unsigned)((n_items + TB / 64 - 1) / (TB / 64)), pieces), dim3(TB), 0, st, X, D, dcomps,
+                     p_src, p_dst, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), (int)n_items, B, d, lanes_per_row(d), (int)n_copies, R * B);
+  }
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

@@ -565,13 +565,14 @@ def basis_dcomps(X, D, plan, R, B, d, swap=False):
     swap=True exchanges the roles of the two index arrays (featureless layers: X = grad rows by destination,
     D = the basis table by source)."""
     _req(X, "features"); _req(D, "grad")
-    dc = torch.empty((R, B), device=X.device, dtype=torch.float32)
+    copies = 16 if R * B <= 4096 else 1      # few addresses: spread the pieces' atomics over copies (summed below)
+    dc = torch.empty((copies, R, B), device=X.device, dtype=torch.float32)
     a, b = (plan.dst, plan.src) if swap else (plan.src, plan.dst)
     with torch.cuda.device(X.device), _timed("basis_dcomps"):
         _check(lib().rgcn_basis_dcomps_f32(_dp(X), _dp(D), _dp(dc), _dp(a), _dp(b), _dp(plan.val),
                                            _dp(plan.chunk_rel), _dp(plan.items), c_i64(plan.n_items), c_i32(R), c_i32(B),
-                                           c_i32(d), _stream(X.device)), "basis_dcomps")
-    return dc
+                                           c_i32(d), c_i32(copies), _stream(X.device)), "basis_dcomps")
+    return dc.sum(0) if copies > 1 else dc[0]
 
 
 G_TRANS_A, G_TRANS_B = 1, 2
