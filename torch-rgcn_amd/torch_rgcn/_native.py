@@ -89,24 +89,54 @@ def profile_stop():
     return {k: [a.elapsed_time(b) for a, b in v] for k, v in rec.items()}
 
 
-class _timed:
+class _Timed:
     def __init__(self, name):
         self.name = name
 
     def __enter__(self):
-        if _PROF is not None:
-            self.a = torch.cuda.Event(enable_timing=True)
-            self.a.record()
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.a.record()
 
     def __exit__(self, *exc):
+        b = torch.cuda.Event(enable_timing=True)
+        b.record()
         if _PROF is not None:
-            b = torch.cuda.Event(enable_timing=True)
-            b.record()
             _PROF.setdefault(self.name, []).append((self.a, b))
 
 
+def _timed(name):
+    return _NOCTX if _PROF is None else _Timed(name)
+
+
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(device):
+    """the current HIP stream of `device` as a void* (torch's raw-stream query when it exists: no Stream object per launch)"""
+    if _RAW_STREAM is not None:
+        idx = device.index
+        return c_void_p(_RAW_STREAM(torch.cuda.current_device() if idx is None else idx))
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _NoCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOCTX = _NoCtx()
+
+
+def _on(device):
+    """`with _on(dev):` = torch.cuda.device(dev), skipped when dev is already the current device (one process per GPU: always) --
+    a step of the LP layer makes ~60 native calls, the guard object and its two device switches were a measurable part of it"""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NOCTX
+    return torch.cuda.device(device)
 
 
 # ----------------------------------------------------------------------------- host side
@@ -290,7 +320,7 @@ def dev_split_triples(triples_plus, num_nodes, num_rels):
     t = triples_plus.contiguous()
     M, dev = t.shape[0], t.device
     s, p, o, err = _i32(M, dev), _i32(M, dev), _i32(M, dev), _i32(1, dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _check(lib().rgcn_dev_split_triples(_dp(t), c_i64(M), c_i64(num_nodes), c_i32(num_rels), _dp(s), _dp(p), _dp(o),
                                             _dp(err), _stream(dev)), "dev_split_triples")
     return s[:M], p[:M], o[:M], err
@@ -304,7 +334,7 @@ def dev_lp_expand(triples, num_nodes, num_rels0, keep):
     s, p, o, err = _i32(M, dev), _i32(M, dev), _i32(M, dev), _i32(1, dev)
     alive = torch.empty(M, dtype=torch.uint8, device=dev)
     k = None if keep is None else keep.to(torch.uint8).contiguous()
-    with torch.cuda.device(dev):
+    with _on(dev):
         _check(lib().rgcn_dev_lp_expand(_dp(t), c_i64(E), c_i64(num_nodes), c_i32(num_rels0), _dp(k), _dp(s), _dp(p),
                                         _dp(o), _dp(alive), _dp(err), _stream(dev)), "dev_lp_expand")
     return s, p, o, alive, err
@@ -314,7 +344,7 @@ def dev_edge_norm(s, p, o, alive, num_nodes, num_rels, vertical, n_swap):
     M, dev = s.shape[0], s.device
     table = _i32(num_nodes * num_rels, dev)
     val = torch.empty(max(M, 1), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _check(lib().rgcn_dev_edge_norm(_dp(s), _dp(p), _dp(o), _dp(alive), c_i64(M), c_i64(num_nodes), c_i32(num_rels),
                                         c_int(int(bool(vertical))), c_i64(n_swap), _dp(table), _dp(val), _stream(dev)),
                "dev_edge_norm")
@@ -341,7 +371,7 @@ def build_plan_device(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_ro
     bucket_cnt, bucket_base = _i32(nbk, dev), _i32(nbk + 1, dev)
     scan_tmp = _i32(max(nbk, nbk * tile_rows if tall else 0) // 1024 + 4, dev)
     L = lib()
-    with torch.cuda.device(dev):
+    with _on(dev):
         _check(L.rgcn_dev_plan_count(_dp(dst), _dp(rel), _dp(alive), c_i64(M), c_i64(n_dst), c_i32(num_rels),
                                      c_i32(tile_rows), _dp(cells), _dp(bucket_cnt), _dp(bucket_base), _dp(scan_tmp),
                                      _dp(cells_tmp), _stream(dev)), "dev_plan_count")
@@ -361,7 +391,7 @@ def build_plan_device(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_ro
     p.tile_ptr = _i32(n_tiles + 1, dev)
     p.run_ptr = _i32(n_tiles * (num_rels + 1), dev) if want_runs else None
     p.aux = _i32(m_pad, dev) if aux is not None else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         _check(L.rgcn_dev_plan_fill(_dp(dst), _dp(src), _dp(rel), _dp(val), _dp(alive), c_i64(M), c_i64(n_dst),
                                     c_i64(n_src), c_i32(num_rels), c_i32(tile_rows), _dp(cells), _dp(bucket_cnt),
                                     _dp(bucket_base), _dp(p.src), _dp(p.dst), _dp(p.val), _dp(p.pack), _dp(p.chunk_rel),
@@ -376,7 +406,7 @@ def build_plan_device(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_ro
             p.items = torch.empty((max(p.n_items, 1), 2), dtype=torch.int32, device=dev)
         else:
             p.n_items, p.items = 0, None
-        with torch.cuda.device(dev):
+        with _on(dev):
             _check(L.rgcn_dev_plan_finish_nosync(_dp(bucket_base), c_i64(n_tiles), c_i32(num_rels), c_i64(m_pad), _dp(p.src),
                                                  _dp(p.dst), _dp(p.val), _dp(p.pack), _dp(p.aux), _dp(p.tile_ptr), _dp(p.units),
                                                  _dp(p.items), c_i64(max(p.n_items, 1)), c_i32(max_item_chunks), _stream(dev)),
@@ -423,7 +453,7 @@ def build_csr_device(dst, src, rel, val, alive, n_rows, sync_free=False, want_sl
     cells, cells_tmp = rowbuf[1:], _i32(n_rows + 1, dev)
     bucket_cnt, bucket_base, scan_tmp = _i32(1, dev), _i32(2, dev), _i32(n_rows // 1024 + 4, dev)
     L = lib()
-    with torch.cuda.device(dev):         # (one bucket, one "relation": the relation array of the builder is NULL)
+    with _on(dev):         # (one bucket, one "relation": the relation array of the builder is NULL)
         _check(L.rgcn_dev_plan_count(_dp(dst), None, _dp(alive), c_i64(M), c_i64(n_rows), c_i32(1), c_i32(n_rows),
                                      _dp(cells), _dp(bucket_cnt), _dp(bucket_base), _dp(scan_tmp), _dp(cells_tmp),
                                      _stream(dev)), "dev_plan_count")
@@ -438,7 +468,7 @@ def build_csr_device(dst, src, rel, val, alive, n_rows, sync_free=False, want_sl
     p.src, pdst, p.rel = _i32(m_pad, dev), _i32(m_pad, dev), _i32(m_pad, dev)
     p.val = torch.empty(max(m_pad, 1), dtype=torch.float32, device=dev)
     tile_ptr = _i32(2, dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _check(L.rgcn_dev_plan_fill(_dp(dst), _dp(src), None, _dp(val), _dp(alive), c_i64(M), c_i64(n_rows),
                                     c_i64(n_rows), c_i32(1), c_i32(n_rows), _dp(cells), _dp(bucket_cnt), _dp(bucket_base),
                                     _dp(p.src), _dp(pdst), _dp(p.val), None, None, _dp(tile_ptr), None,
@@ -518,7 +548,7 @@ def fbasis_fwd(table, comps, bias, plan):
     Y = torch.empty(max(plan.n_messages, 1), d, device=dev, dtype=torch.float32)
     out = torch.empty(N, d, device=dev, dtype=torch.float32)
     units, n_units, _ = plan.units_src
-    with torch.cuda.device(dev), _timed("fbasis_fwd"):
+    with _on(dev), _timed("fbasis_fwd"):
         _check(lib().rgcn_fbasis_fwd_f32(_dp(bases), _dp(comps), _dp(Y), _dp(plan.e_rel), _dp(plan.e_val), _dp(units),
                                          c_i64(n_units), c_i64(N), c_i32(comps.shape[0]), c_i32(B), c_i32(d), _stream(dev)),
                "fbasis_fwd")
@@ -539,7 +569,7 @@ def fbasis_bwd(table, comps, g, plan, need_bases=True, need_comps=True):
     T = torch.empty(max(plan.n_messages, 1), B, device=dev, dtype=torch.float32) if need_comps else None
     dC = torch.empty(R, B, device=dev, dtype=torch.float32) if need_comps else None
     units, n_units, n_split = plan.units_src
-    with torch.cuda.device(dev), _timed("fbasis_bwd"):
+    with _on(dev), _timed("fbasis_bwd"):
         _check(lib().rgcn_fbasis_bwd_f32(_dp(bases), _dp(comps), _dp(g), _dp(dB), _dp(T), _dp(plan.e_dst), _dp(plan.e_rel),
                                          _dp(plan.e_val), _dp(units), c_i64(n_units), c_i64(n_split), c_i64(N), c_i32(R),
                                          c_i32(B), c_i32(d), _stream(dev)), "fbasis_bwd")
@@ -553,7 +583,7 @@ def fbasis_bwd(table, comps, g, plan, need_bases=True, need_comps=True):
 def basis_aggregate(X, comps, csr, B, d, n_b_in):
     _req(X, "features"); _req(comps, "comps")
     out = torch.empty((csr.n_rows, B * d) if n_b_in == 1 else (csr.n_rows, d), device=X.device, dtype=torch.float32)
-    with torch.cuda.device(X.device), _timed("basis_aggregate"):
+    with _on(X.device), _timed("basis_aggregate"):
         _check(lib().rgcn_basis_aggregate_f32(_dp(X), _dp(comps), _dp(out), _dp(csr.rowptr), _dp(csr.src), _dp(csr.rel),
                                               _dp(csr.val), c_i64(csr.n_rows), c_i32(comps.shape[0]), c_i32(B), c_i32(d),
                                               c_i32(n_b_in), _stream(X.device)), "basis_aggregate")
@@ -568,7 +598,7 @@ def basis_dcomps(X, D, plan, R, B, d, swap=False):
     copies = 16 if R * B <= 4096 else 1      # few addresses: spread the pieces' atomics over copies (summed below)
     dc = torch.empty((copies, R, B), device=X.device, dtype=torch.float32)
     a, b = (plan.dst, plan.src) if swap else (plan.src, plan.dst)
-    with torch.cuda.device(X.device), _timed("basis_dcomps"):
+    with _on(X.device), _timed("basis_dcomps"):
         _check(lib().rgcn_basis_dcomps_f32(_dp(X), _dp(D), _dp(dc), _dp(a), _dp(b), _dp(plan.val),
                                            _dp(plan.chunk_rel), _dp(plan.items), c_i64(plan.n_items), c_i32(R), c_i32(B),
                                            c_i32(d), c_i32(copies), _stream(X.device)), "basis_dcomps")
@@ -594,7 +624,7 @@ def gemm(A, B, bias=None, trans_a=False, trans_b=False, split_k=1):
         scratch = torch.empty(int(lib().rgcn_gemm_scratch_floats(c_i64(M), c_i64(N), c_i64(K), c_i32(split_k))),
                               device=A.device, dtype=torch.float32)
     flags = (G_TRANS_A if trans_a else 0) | (G_TRANS_B if trans_b else 0)
-    with torch.cuda.device(A.device), _timed("gemm"):
+    with _on(A.device), _timed("gemm"):
         _check(lib().rgcn_gemm_f32(_dp(A), _dp(B), _dp(bias), _dp(C), _dp(scratch), c_i64(M), c_i64(N), c_i64(K),
                                    c_i64(A.shape[1]), c_i64(B.shape[1]), c_i64(N), c_i32(flags), c_i32(split_k),
                                    _stream(A.device)), "gemm")
@@ -615,7 +645,7 @@ def basis_fused_fwd(X, comps, bases, bias, csr, keep_ag):
     Bn, d_in, d_out = bases.shape
     out = torch.empty((csr.n_rows, d_out), device=X.device, dtype=torch.float32)
     ag = torch.empty((csr.n_rows, Bn * d_in), device=X.device, dtype=torch.float32) if keep_ag else None
-    with torch.cuda.device(X.device), _timed("basis_fused_fwd"):
+    with _on(X.device), _timed("basis_fused_fwd"):
         _check(lib().rgcn_basis_fused_fwd_f32(_dp(X), _dp(comps), _dp(bases), _dp(bias), _dp(out), _dp(ag), _dp(csr.rowptr),
                                               _dp(csr.src), _dp(csr.rel), _dp(csr.val), c_i64(csr.n_rows),
                                               c_i32(comps.shape[0]), c_i32(Bn), c_i32(d_in), c_i32(d_out), _stream(X.device)),
@@ -640,7 +670,7 @@ F_RELU, F_WPACKED = 1, 2
 def pack_w16(W):
     """[R,16,16] weights -> MFMA fragment order (one float4 per lane), see rgcn_pack_w16_f32"""
     Wp = torch.empty_like(W)
-    with torch.cuda.device(W.device):
+    with _on(W.device):
         _check(lib().rgcn_pack_w16_f32(_dp(W), _dp(Wp), c_i32(W.shape[0]), _stream(W.device)), "pack_w16")
     return Wp
 
@@ -648,7 +678,7 @@ def pack_w16(W):
 def _spmm_launch(X, W, bias, plan, out, flags, u0, u1, n_split, tag):
     R, d_in, d_out = plan.num_rels, X.shape[1], out.shape[1]
     units = plan.units if u0 == 0 else plan.units[u0:]
-    with torch.cuda.device(X.device), _timed(tag):
+    with _on(X.device), _timed(tag):
         _check(lib().rgcn_spmm_f32(_dp(X), _dp(W), _dp(bias), _dp(out), _dp(plan.src), _dp(plan.dst), _dp(plan.val),
                                    _dp(plan.pack), _dp(plan.chunk_rel), _dp(units), c_i64(u1 - u0), c_i64(n_split),
                                    c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i64(plan.n_src), c_i32(R), c_i32(d_in),
@@ -658,7 +688,7 @@ def _spmm_launch(X, W, bias, plan, out, flags, u0, u1, n_split, tag):
 def pack_w_blocks(W):
     """[R, 16 NI, 16 NJ] weights -> per-(input block, output block) MFMA fragments for the wide spmm kernel"""
     Wp = torch.empty_like(W)
-    with torch.cuda.device(W.device):
+    with _on(W.device):
         _check(lib().rgcn_pack_w_blocks_f32(_dp(W), _dp(Wp), c_i32(W.shape[0]), c_i32(W.shape[1]), c_i32(W.shape[2]),
                                             _stream(W.device)), "pack_w_blocks")
     return Wp
@@ -748,11 +778,11 @@ def spmm_two_pass(X, W, bias, scatter_plan, csr, relu=False):
         Y = torch.empty((max(p.dst.shape[0], 1), 16), device=X.device, dtype=torch.float32)
     else:
         Y = torch.empty((max(n_msg, 1), 16), device=X.device, dtype=torch.float32)
-    with torch.cuda.device(X.device), _timed("spmm_scatter"):
+    with _on(X.device), _timed("spmm_scatter"):
         _check(lib().rgcn_spmm_scatter_f32(_dp(X), _dp(Wp), _dp(Y), _dp(p.src), _dp(p.val), None if gather else _dp(p.aux),
                                            _dp(p.chunk_rel), _dp(p.items), c_i64(p.n_items), c_i32(16), _stream(X.device)),
                "spmm_scatter")
-    with torch.cuda.device(X.device), _timed("segment_sum"):
+    with _on(X.device), _timed("segment_sum"):
         if gather:
             _check(lib().rgcn_segment_gather_sum_f32(_dp(Y), _dp(p._inv), _dp(csr.rowptr), _dp(bias), _dp(out),
                                                      c_i64(csr.n_rows), c_i32(16), c_i32(F_RELU if relu else 0),
@@ -773,10 +803,10 @@ def spmm_wide_two_pass(X, W, bias, scatter_plan, csr, relu=False):
     perm = _slot_perm(p, n_msg, dev)
     Y = torch.empty((max(p.dst.shape[0], 1), d_out), device=dev, dtype=torch.float32)
     out = torch.empty((csr.n_rows, d_out), device=dev, dtype=torch.float32)
-    with torch.cuda.device(dev), _timed("rel_rows"):
+    with _on(dev), _timed("rel_rows"):
         _check(lib().rgcn_rel_rows_f32(_dp(X), _dp(W), _dp(Y), _dp(p.src), _dp(p.val), _dp(p.chunk_rel), _dp(p.items),
                                        c_i64(p.n_items), c_i32(R), c_i32(d_in), c_i32(d_out), _stream(dev)), "rel_rows")
-    with torch.cuda.device(dev), _timed("segment_sum_wide"):
+    with _on(dev), _timed("segment_sum_wide"):
         _check(lib().rgcn_segment_gather_sum_wide_f32(_dp(Y), _dp(perm), _dp(csr.rowptr), _dp(bias), _dp(out), c_i64(csr.n_rows),
                                                       c_i32(d_out), c_i32(F_RELU if relu else 0), _stream(dev)),
                "segment_gather_sum_wide")
@@ -788,7 +818,7 @@ def wgrad_wide(X, G, scatter_plan, num_rels):
     _req(X, "features"); _req(G, "grad_output")
     p = scatter_plan
     dW = torch.empty((num_rels, X.shape[1], G.shape[1]), device=X.device, dtype=torch.float32)
-    with torch.cuda.device(X.device), _timed("rel_wgrad"):
+    with _on(X.device), _timed("rel_wgrad"):
         _check(lib().rgcn_rel_wgrad_f32(_dp(X), _dp(G), _dp(dW), _dp(p.src), _dp(p.dst), _dp(p.val), _dp(p.chunk_rel),
                                         _dp(p.items), c_i64(p.n_items), c_i32(num_rels), c_i32(X.shape[1]), c_i32(G.shape[1]),
                                         _stream(X.device)), "rel_wgrad")
@@ -807,11 +837,11 @@ def bwd_two_pass_fused(G, X, W, scatter_plan, csr):
     Y = torch.empty((max(p.dst.shape[0], 1), 16), device=dev, dtype=torch.float32)
     dW = torch.empty_like(W)
     dX = torch.empty((csr.n_rows, 16), device=dev, dtype=torch.float32)
-    with torch.cuda.device(dev), _timed("bwd_scatter_dw"):
+    with _on(dev), _timed("bwd_scatter_dw"):
         _check(lib().rgcn_bwd_scatter_dw_f32(_dp(G), _dp(X), _dp(Wtp), _dp(Y), _dp(dW), _dp(p.src), _dp(p.dst), _dp(p.val),
                                              _dp(p.chunk_rel), _dp(p.items), c_i64(p.n_items), c_i32(W.shape[0]), c_i32(16),
                                              _stream(dev)), "bwd_scatter_dw")
-    with torch.cuda.device(dev), _timed("segment_sum"):
+    with _on(dev), _timed("segment_sum"):
         _check(lib().rgcn_segment_gather_sum_f32(_dp(Y), _dp(p._inv), _dp(csr.rowptr), None, _dp(dX), c_i64(csr.n_rows),
                                                  c_i32(16), c_i32(0), _stream(dev)), "segment_gather_sum")
     return dX, dW
@@ -823,7 +853,7 @@ def wgrad(X, G, plan, num_rels):
     d_in, d_out = X.shape[1], G.shape[1]
     assert X.shape[0] == plan.n_src and G.shape[0] == plan.n_dst
     dW = torch.empty((num_rels, d_in, d_out), device=X.device, dtype=torch.float32)
-    with torch.cuda.device(X.device), _timed("wgrad"):
+    with _on(X.device), _timed("wgrad"):
         _check(lib().rgcn_wgrad_f32(_dp(X), _dp(G), _dp(dW), _dp(plan.src), _dp(plan.dst), _dp(plan.val),
                                     _dp(plan.chunk_rel), _dp(plan.items), c_i64(plan.n_items), c_i64(plan.n_dst),
                                     c_i64(plan.n_src), c_i32(num_rels), c_i32(d_in), c_i32(d_out),
@@ -836,7 +866,7 @@ def wgrad_tiled(X, G, plan, num_rels, tiles_per_item=4):
     _req(X, "features"); _req(G, "grad_output")
     assert plan.run_ptr is not None and X.shape[0] == plan.n_src and G.shape[0] == plan.n_dst
     dW = torch.empty((num_rels, X.shape[1], G.shape[1]), device=X.device, dtype=torch.float32)
-    with torch.cuda.device(X.device), _timed("wgrad"):
+    with _on(X.device), _timed("wgrad"):
         _check(lib().rgcn_wgrad_tiled_f32(_dp(X), _dp(G), _dp(dW), _dp(plan.src), _dp(plan.dst), _dp(plan.val),
                                           _dp(plan.chunk_rel), _dp(plan.run_ptr), c_i64(plan.n_tiles),
                                           c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i64(plan.n_src),
@@ -852,7 +882,7 @@ F_TRANSPOSE_W = 8
 def pack_w16t(W):
     """[R,16,16] weights -> fragments of W^T (what the feature-gradient kernels multiply by), see rgcn_pack_w16t_f32"""
     Wp = torch.empty_like(W)
-    with torch.cuda.device(W.device):
+    with _on(W.device):
         _check(lib().rgcn_pack_w16t_f32(_dp(W), _dp(Wp), c_i32(W.shape[0]), _stream(W.device)), "pack_w16t")
     return Wp
 
@@ -876,7 +906,7 @@ def bwd_fused(G, X, W, plan, atomic=False):
     if not atomic:
         n = int(lib().rgcn_bwd_fused_scratch_floats(c_i64(plan.n_tiles), c_i32(W.shape[0])))
         scratch = torch.empty(n, device=dev, dtype=torch.float32)
-    with torch.cuda.device(dev), _timed("bwd_fused"):
+    with _on(dev), _timed("bwd_fused"):
         _check(lib().rgcn_bwd_fused_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(scratch), _dp(plan.pack),
                                         _dp(plan.chunk_rel), _dp(plan.run_ptr), c_i64(plan.n_tiles), c_i32(plan.tile_rows),
                                         c_i64(plan.n_dst), c_i32(W.shape[0]), c_i32(F_DW_ATOMIC if atomic else 0),
@@ -890,7 +920,7 @@ def featureless_fwd(table, bias, plan):
     R, n_src, d = table.shape
     assert R == plan.num_rels and n_src == plan.n_src
     out = torch.empty((plan.n_dst, d), device=table.device, dtype=torch.float32)
-    with torch.cuda.device(table.device), _timed("featureless_fwd"):
+    with _on(table.device), _timed("featureless_fwd"):
         _check(lib().rgcn_featureless_fwd_f32(_dp(table), _dp(bias), _dp(out), _dp(plan.src), _dp(plan.dst),
                                               _dp(plan.val), _dp(plan.chunk_rel), _dp(plan.units),
                                               c_i64(plan.n_units), c_i64(plan.n_split), c_i32(plan.tile_rows), c_i64(plan.n_dst),
@@ -924,7 +954,7 @@ def block_spmm(X, blocks, bias, csr, transposed=False, relu=False):
     fuse_relu = relu and n_split == 0
     out = torch.empty((csr.n_rows, nb * (bi if transposed else bo)), device=X.device, dtype=torch.float32)
     flags = (F_TRANSPOSE_W if transposed else 0) | (F_RELU if fuse_relu else 0)
-    with torch.cuda.device(X.device), _timed("block_spmm"):
+    with _on(X.device), _timed("block_spmm"):
         _check(lib().rgcn_block_spmm_f32(_dp(X), _dp(blocks), _dp(bias), _dp(out), _dp(units), _dp(csr.rowptr), c_i64(n_units),
                                          c_i64(n_split), _dp(csr.src), _dp(csr.rel), _dp(csr.val), c_i64(csr.n_rows), c_i32(Rb),
                                          c_i32(nb), c_i32(bi), c_i32(bo), c_i32(flags), _stream(X.device)), "block_spmm")
@@ -939,7 +969,7 @@ def block_wgrad(X, G, scatter_plan, shape):
     p = scatter_plan
     Rb, nb, bi, bo = shape
     dB = torch.empty(shape, device=X.device, dtype=torch.float32)
-    with torch.cuda.device(X.device), _timed("block_wgrad"):
+    with _on(X.device), _timed("block_wgrad"):
         _check(lib().rgcn_block_wgrad_f32(_dp(X), _dp(G), _dp(dB), _dp(p.src), _dp(p.dst), _dp(p.val), _dp(p.chunk_rel),
                                           _dp(p.items), c_i64(p.n_items), c_i32(Rb), c_i32(nb), c_i32(bi), c_i32(bo),
                                           _stream(X.device)), "block_wgrad")
@@ -954,7 +984,7 @@ def diag_spmm(X, w, bias, csr):
     units, n_units, n_split = _csr_units(csr)
     assert units is not None, "the diagonal layer is not part of the sync-free LP step"
     out = torch.empty((csr.n_rows, d), device=X.device, dtype=torch.float32)
-    with torch.cuda.device(X.device), _timed("diag_spmm"):
+    with _on(X.device), _timed("diag_spmm"):
         _check(lib().rgcn_diag_spmm_f32(_dp(X), _dp(w), _dp(bias), _dp(out), _dp(units), c_i64(n_units), c_i64(n_split),
                                         _dp(csr.src), _dp(csr.rel), _dp(csr.val), c_i64(csr.n_rows), c_i32(R), c_i32(d),
                                         _stream(X.device)), "diag_spmm")
@@ -966,7 +996,7 @@ def diag_wgrad(X, G, scatter_plan, num_rels):
     _req(X, "features"); _req(G, "grad_output")
     p, d = scatter_plan, X.shape[1]
     dw = torch.empty((num_rels, d), device=X.device, dtype=torch.float32)
-    with torch.cuda.device(X.device), _timed("diag_wgrad"):
+    with _on(X.device), _timed("diag_wgrad"):
         _check(lib().rgcn_diag_wgrad_f32(_dp(X), _dp(G), _dp(dw), _dp(p.src), _dp(p.dst), _dp(p.val), _dp(p.chunk_rel),
                                          _dp(p.items), c_i64(p.n_items), c_i32(num_rels), c_i32(d), _stream(X.device)),
                "diag_wgrad")
@@ -977,7 +1007,7 @@ def featureless_wgrad(G, plan, num_rels):
     _req(G, "grad_output")
     d = G.shape[1]
     dT = torch.empty((num_rels, plan.n_src, d), device=G.device, dtype=torch.float32)
-    with torch.cuda.device(G.device), _timed("featureless_wgrad"):
+    with _on(G.device), _timed("featureless_wgrad"):
         _check(lib().rgcn_featureless_wgrad_f32(_dp(G), _dp(dT), _dp(plan.src), _dp(plan.dst), _dp(plan.val),
                                                 _dp(plan.chunk_rel), c_i64(plan.n_chunks), c_i64(plan.n_dst),
                                                 c_i64(plan.n_src), c_i32(num_rels), c_i32(d), _stream(G.device)),
@@ -990,7 +1020,7 @@ def colsum(G):
     db = torch.empty(G.shape[1], device=G.device, dtype=torch.float32)
     scratch = torch.empty(int(lib().rgcn_colsum_scratch_floats(c_i64(G.shape[0]), c_i32(G.shape[1]))), device=G.device,
                           dtype=torch.float32)
-    with torch.cuda.device(G.device), _timed("colsum"):
+    with _on(G.device), _timed("colsum"):
         _check(lib().rgcn_colsum_f32(_dp(G), _dp(db), _dp(scratch), c_i64(G.shape[0]), c_i32(G.shape[1]),
                                      _stream(G.device)), "colsum")
     return db
@@ -1003,7 +1033,7 @@ def distmult_fwd(triples, nodes, rel, sbias, pbias, obias):
     T = triples.shape[0]
     scores = torch.empty(T, device=nodes.device, dtype=torch.float32)
     err = _i32(1, nodes.device)
-    with torch.cuda.device(nodes.device), _timed("distmult_fwd"):
+    with _on(nodes.device), _timed("distmult_fwd"):
         _check(lib().rgcn_distmult_fwd_f32(_dp(triples), c_i64(T), _dp(nodes), _dp(rel), _dp(sbias), _dp(pbias),
                                            _dp(obias), _dp(scores), c_i64(nodes.shape[0]), c_i32(rel.shape[0]),
                                            c_i32(nodes.shape[1]), _dp(err), _stream(nodes.device)), "distmult_fwd")
@@ -1029,7 +1059,7 @@ def distmult_score_all(batch, head, nodes, rel, sbias=None, pbias=None, obias=No
     assert scores.shape == (Q, N) and scores.is_contiguous() and scores.dtype == torch.float32
     qvec = torch.empty(Q, d, device=nodes.device, dtype=torch.float32)
     qb = torch.empty(2 * Q, device=nodes.device, dtype=torch.float32) if sbias is not None else None
-    with torch.cuda.device(nodes.device), _timed("score_all"):
+    with _on(nodes.device), _timed("score_all"):
         _check(lib().rgcn_distmult_score_all_f32(_dp(batch), c_i64(Q), c_i32(1 if head else 0), _dp(nodes), _dp(rel),
                                                  _dp(sbias), _dp(pbias), _dp(obias), _dp(qvec), _dp(qb), _dp(scores),
                                                  c_i64(N), c_i32(rel.shape[0]), c_i32(d), _stream(nodes.device)),
@@ -1041,7 +1071,7 @@ def rank_filter(scores, filt_q, filt_n):
     """scores[filt_q[e], filt_n[e]] = -inf (utils/misc.py:40-58); int32 device index lists"""
     _req(scores, "scores"); _req(filt_q, "filt_q", torch.int32); _req(filt_n, "filt_n", torch.int32)
     assert filt_q.shape == filt_n.shape and filt_q.dim() == 1
-    with torch.cuda.device(scores.device):
+    with _on(scores.device):
         _check(lib().rgcn_rank_filter_f32(_dp(scores), c_i64(scores.shape[0]), c_i64(scores.shape[1]), _dp(filt_q),
                                           _dp(filt_n), c_i64(filt_q.shape[0]), _stream(scores.device)), "rank_filter")
     return scores
@@ -1054,7 +1084,7 @@ def rank_count(scores, batch, head):
     assert batch.shape == (Q, 3)
     greater = torch.empty(Q, device=scores.device, dtype=torch.int64)
     ties = torch.empty(Q, device=scores.device, dtype=torch.int64)
-    with torch.cuda.device(scores.device), _timed("rank_count"):
+    with _on(scores.device), _timed("rank_count"):
         _check(lib().rgcn_rank_count_f32(_dp(scores), _dp(batch), c_i64(Q), c_i32(1 if head else 0),
                                          c_i64(scores.shape[1]), _dp(greater), _dp(ties), _stream(scores.device)),
                "rank_count")
@@ -1070,7 +1100,7 @@ def distmult_bwd(triples, nodes, rel, gs, with_bias, nodes_grad=True):
     dsb = torch.empty(nodes.shape[0], device=nodes.device) if with_bias else None
     dob = torch.empty(nodes.shape[0], device=nodes.device) if with_bias else None
     dpb = torch.empty(rel.shape[0], device=nodes.device) if with_bias else None
-    with torch.cuda.device(nodes.device), _timed("distmult_bwd"):
+    with _on(nodes.device), _timed("distmult_bwd"):
         _check(lib().rgcn_distmult_bwd_f32(_dp(triples), c_i64(triples.shape[0]), _dp(nodes), _dp(rel), _dp(gs),
                                            _dp(dn), _dp(dr), _dp(dsb), _dp(dpb), _dp(dob), c_i64(nodes.shape[0]),
                                            c_i32(rel.shape[0]), c_i32(nodes.shape[1]), _stream(nodes.device)),
@@ -1100,7 +1130,7 @@ def distmult_bwd_all(triples, nodes, rel, gs, with_bias):
     if with_bias:
         dsb, dob = torch.empty(N, device=dev, dtype=torch.float32), torch.empty(N, device=dev, dtype=torch.float32)
         dpb = torch.empty(R, device=dev, dtype=torch.float32)
-    with torch.cuda.device(dev), _timed("distmult_bwd_all"):
+    with _on(dev), _timed("distmult_bwd_all"):
         _check(lib().rgcn_distmult_bwd_all_f32(_dp(by_s.rowptr), _dp(by_s.src), _dp(by_s.rel), _dp(by_s.val), _dp(by_o.rowptr),
                                                _dp(by_o.src), _dp(by_o.rel), _dp(by_o.val), _dp(nodes), _dp(rel), _dp(dn), _dp(dr),
                                                _dp(dsb), _dp(dpb), _dp(dob), c_i64(N), c_i32(R), c_i32(d), _stream(dev)),
@@ -1121,7 +1151,7 @@ def distmult_bwd_nodes(triples, nodes, rel, gs):
     by_s = build_csr_device(s, o, p, gs, alive, N, sync_free=True, want_slot=False)
     by_o = build_csr_device(o, s, p, gs, alive, N, sync_free=True, want_slot=False)
     dn = torch.empty_like(nodes)
-    with torch.cuda.device(dev), _timed("distmult_bwd_nodes"):
+    with _on(dev), _timed("distmult_bwd_nodes"):
         _check(lib().rgcn_distmult_bwd_nodes_f32(_dp(by_s.rowptr), _dp(by_s.src), _dp(by_s.rel), _dp(by_s.val), _dp(by_o.rowptr),
                                                  _dp(by_o.src), _dp(by_o.rel), _dp(by_o.val), _dp(nodes), _dp(rel), _dp(dn),
                                                  c_i64(N), c_i32(d), _stream(dev)), "distmult_bwd_nodes")
