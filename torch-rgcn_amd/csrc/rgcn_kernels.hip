@@ -1178,6 +1178,10 @@ __global__ __launch_bounds__(WG) void distmult_bwd_nodes_kernel(
 // by predicate (rocPRIM merge sort, 0.15 ms for 330 k triples) + two index gathers + distmult_bwd_kernel (0.12 ms).
 // (One table per WORKGROUP with ds_add_f32 -- 4x less LDS, twice the resident waves -- measured 0.37 ms against 0.21: LDS float
 // atomics are slow on gfx950 even without address conflicts.)
+// SIDES: 3 = both CSRs in one launch; 1 = subject side only (with the LDS tables), ADDING to the dnodes rows a previous launch
+// wrote; 2 = object side only (no LDS: launched with many more resident waves).  Two launches (2, then 1) measured faster than
+// one: the LDS tables hold the one-launch form at 8 waves per CU for ALL of its gathers.
+template <int SIDES>
 __global__ __launch_bounds__(WG) void distmult_bwd_all_kernel(
     const int *__restrict__ rp_s, const int *__restrict__ oth_s, const int *__restrict__ rel_s, const float *__restrict__ g_s,
     const int *__restrict__ rp_o, const int *__restrict__ oth_o, const int *__restrict__ rel_o, const float *__restrict__ g_o,
@@ -1187,7 +1191,8 @@ __global__ __launch_bounds__(WG) void distmult_bwd_all_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tab_floats = n_rel * d + n_rel;                 // [n_rel][d] + predicate bias [n_rel]
   float *tab = lds + (size_t)wave * tab_floats, *pb = tab + (size_t)n_rel * d;
-  for (int i = lane; i < tab_floats; i += 64) tab[i] = 0.f;
+  if (SIDES & 1)
+    for (int i = lane; i < tab_floats; i += 64) tab[i] = 0.f;
   const bool vec = (d & 3) == 0;
   const long long wave0 = ((long long)blockIdx.x * WG + threadIdx.x) >> 6, nw = ((long long)gridDim.x * WG) >> 6;
   for (long long n = wave0; n < N; n += nw) {
@@ -1204,6 +1209,7 @@ __global__ __launch_bounds__(WG) void distmult_bwd_all_kernel(
       }
 #pragma unroll
       for (int side = 0; side < 2; ++side) {
+        if (!((SIDES >> side) & 1)) continue;
         const int *rp = side ? rp_o : rp_s, *oth = side ? oth_o : oth_s, *rl = side ? rel_o : rel_s;
         const float *gv = side ? g_o : g_s;
         const int e0 = rp[n], e1 = rp[n + 1];
@@ -1244,14 +1250,16 @@ __global__ __launch_bounds__(WG) void distmult_bwd_all_kernel(
       }
       float *o = dnodes + (size_t)n * d + f;
       if (full) {
+        if (SIDES == 1) acc += *reinterpret_cast<const f32x4 *>(o);      // the object-side launch wrote this row
         *reinterpret_cast<f32x4 *>(o) = acc;
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          if (f + q < d) o[q] = acc[q];
+          if (f + q < d) o[q] = acc[q] + (SIDES == 1 ? o[q] : 0.f);
       }
     }
   }
+  if (!(SIDES & 1)) return;
   __syncthreads();
   for (int i = threadIdx.x; i < tab_floats; i += WG) {
     const float t = (lds[i] + lds[tab_floats + i]) + (lds[2 * tab_floats + i] + lds[3 * tab_floats + i]);
@@ -1651,8 +1659,17 @@ extern "C" int rgcn_distmult_bwd_all_f32(const int32_t *rowptr_s, const int32_t 
   if (!n_nodes) return RGCN_OK;
   const unsigned gx = (unsigned)std::min<int64_t>((n_nodes + 3) / 4, 512);
   const size_t lds = (size_t)4 * ((size_t)n_rel * d + n_rel) * sizeof(float);
-  hipLaunchKernelGGL(distmult_bwd_all_kernel, dim3(gx), dim3(WG), lds, st, rowptr_s, other_s, rel_s, g_s, rowptr_o, other_o, rel_o,
-                     g_o, nodes, rel, dnodes, drel, dsbias, dpbias, dobias, (long long)n_nodes, n_rel, d);
+  static const int one_launch = getenv("RGCN_DISTMULT_ONE_LAUNCH") ? atoi(getenv("RGCN_DISTMULT_ONE_LAUNCH")) : 0;
+  if (one_launch) {
+    hipLaunchKernelGGL(distmult_bwd_all_kernel<3>, dim3(gx), dim3(WG), lds, st, rowptr_s, other_s, rel_s, g_s, rowptr_o, other_o, rel_o,
+                       g_o, nodes, rel, dnodes, drel, dsbias, dpbias, dobias, (long long)n_nodes, n_rel, d);
+  } else {
+    const unsigned gx2 = (unsigned)std::min<int64_t>((n_nodes + 3) / 4, 256 * 32);
+    hipLaunchKernelGGL(distmult_bwd_all_kernel<2>, dim3(gx2), dim3(WG), 0, st, rowptr_s, other_s, rel_s, g_s, rowptr_o, other_o, rel_o,
+                       g_o, nodes, rel, dnodes, drel, dsbias, dpbias, dobias, (long long)n_nodes, n_rel, d);
+    hipLaunchKernelGGL(distmult_bwd_all_kernel<1>, dim3(gx), dim3(WG), lds, st, rowptr_s, other_s, rel_s, g_s, rowptr_o, other_o, rel_o,
+                       g_o, nodes, rel, dnodes, drel, dsbias, dpbias, dobias, (long long)n_nodes, n_rel, d);
+  }
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
