@@ -144,6 +144,14 @@ RGCN_API int rgcn_dev_plan_fill(const int32_t *dst, const int32_t *src, const in
                                 int32_t *p_pack, int32_t *chunk_rel, int32_t *tile_ptr, int32_t *run_ptr,
                                 const int32_t *aux, int32_t *p_aux, int32_t *msg_slot, int64_t n_chunks,
                                 void *stream);
+/* Two CSRs of one message list in five launches and without any read-back: rows = a[e] with entries (b[e], rel[e], val[e]) and
+ * rows = b[e] with entries (a[e], rel[e], val[e]) -- what the basis / diagonal / block kernels (forward and backward walks) and
+ * the DistMult backward (by subject, by object) read.  rowbuf: 2 N + 2 ints; afterwards rowbuf[0 .. N] is the row pointer of the
+ * first CSR and rowbuf[N + 1 .. 2 N + 1] of the second, both indexing the SAME entry arrays e_other / e_rel / e_val (2 M entries).
+ * scan_tmp: (2 N + 1) / 1024 + 3 ints.  rel may be NULL (0).  alive (may be NULL): uint8 per message, 0 = skipped. */
+RGCN_API int rgcn_dev_csr_pair(const int32_t *a, const int32_t *b, const int32_t *rel, const float *val, const uint8_t *alive,
+                               int64_t M, int64_t N, int32_t *rowbuf, int32_t *scan_tmp, int32_t *e_other, int32_t *e_rel,
+                               float *e_val, void *stream);
 /* Completion of a plan WITHOUT any device -> host read (per-call graphs of the link-prediction layer, layers.py:481-516,
  * inside a training step that must not synchronise / is captured in a hipGraph): the caller sizes p_src / p_dst / p_val /
  * p_pack / chunk_rel by the upper bound m_pad_ub >= M + 15 * min(n_buckets, M) (rounded up to 16), runs rgcn_dev_plan_count

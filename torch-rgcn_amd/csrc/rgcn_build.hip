@@ -390,6 +390,36 @@ int exclusive_scan(const int *in, int *out, int *totals, long long n, int *grand
   return RGCN_OK;
 }
 
+// ---- a PAIR of CSRs of one message list (rows = a with entries b, and rows = b with entries a), nothing else: no buckets,
+// pads, tiles or chunk relations.  The basis / diagonal / block kernels and the DistMult backward walk exactly these two
+// structures; through the general plan builder they cost 16 launches per pair, here 5: zero, count both keys, scan (2), scatter.
+// Layout: one row buffer R of 2 N + 2 ints = [0 | rows of the first CSR | rows of the second CSR shifted by one dummy row]; the
+// count pass leaves the row sizes in R[1..], the scan turns them into offsets, the scatter advances every counter to the end of
+// its row = the start of the next: afterwards R[0 .. N] is the first row pointer and R[N + 1 .. 2 N + 1] the second (its entries
+// live behind the first CSR's in the SAME entry arrays, so its offsets need no rebasing).
+__global__ void csr2_count_kernel(const int *__restrict__ a, const int *__restrict__ b, const unsigned char *__restrict__ alive,
+                                  long long M, long long N, int *__restrict__ R) {
+  for (long long e = (long long)blockIdx.x * TB + threadIdx.x; e < M; e += (long long)gridDim.x * TB) {
+    if (alive && !alive[e]) continue;
+    atomicAdd(&R[1 + a[e]], 1);
+    atomicAdd(&R[1 + N + 1 + b[e]], 1);
+  }
+}
+
+__global__ void csr2_scatter_kernel(const int *__restrict__ a, const int *__restrict__ b, const int *__restrict__ rel,
+                                    const float *__restrict__ val, const unsigned char *__restrict__ alive, long long M,
+                                    long long N, int *__restrict__ R, int *__restrict__ e_other, int *__restrict__ e_rel,
+                                    float *__restrict__ e_val) {
+  for (long long e = (long long)blockIdx.x * TB + threadIdx.x; e < M; e += (long long)gridDim.x * TB) {
+    if (alive && !alive[e]) continue;
+    const int ka = a[e], kb = b[e], r = rel ? rel[e] : 0;
+    const float v = val[e];
+    const int pa = atomicAdd(&R[1 + ka], 1), pb = atomicAdd(&R[1 + N + 1 + kb], 1);
+    e_other[pa] = kb; e_rel[pa] = r; e_val[pa] = v;
+    e_other[pb] = ka; e_rel[pb] = r; e_val[pb] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" int rgcn_dev_split_triples(const int64_t *triples_plus, int64_t M, int64_t N, int32_t R, int32_t *s, int32_t *p,
@@ -480,6 +510,26 @@ extern "C" int rgcn_dev_plan_fill(const int32_t *dst, const int32_t *src, const 
   if (n_chunks > 0 && chunk_rel)
     hipLaunchKernelGGL(chunk_rel_kernel, dim3(blocks_for(n_chunks)), dim3(TB), 0, st, bucket_base, (long long)nbk, R,
                        (long long)n_chunks, chunk_rel);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_dev_csr_pair(const int32_t *a, const int32_t *b, const int32_t *rel, const float *val, const uint8_t *alive,
+                                 int64_t M, int64_t N, int32_t *rowbuf, int32_t *scan_tmp, int32_t *e_other, int32_t *e_rel,
+                                 float *e_val, void *stream) {
+  if (M < 0 || N <= 0 || !rowbuf || !scan_tmp || (M && (!a || !b || !val || !e_other || !e_rel || !e_val))) {
+    rgcn_set_error("dev_csr_pair: bad argument");
+    return RGCN_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const long long n_cells = 2 * (long long)N + 1;                 // R[1 ..]: N rows, one dummy, N rows
+  HIP_TRY(zero_async(rowbuf, (size_t)(n_cells + 1) * sizeof(int), st));
+  if (M) hipLaunchKernelGGL(csr2_count_kernel, dim3(blocks_for(M)), dim3(TB), 0, st, a, b, alive, (long long)M, (long long)N, rowbuf);
+  // scan_tmp: n_cells / 1024 + 3 ints (block totals + the grand total, which nobody reads)
+  int rc = exclusive_scan(rowbuf + 1, rowbuf + 1, scan_tmp, n_cells, scan_tmp + (n_cells / (TB * 4) + 2), st);
+  if (rc) return rc;
+  if (M) hipLaunchKernelGGL(csr2_scatter_kernel, dim3(blocks_for(M)), dim3(TB), 0, st, a, b, rel, val, alive, (long long)M,
+                            (long long)N, rowbuf, e_other, e_rel, e_val);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

@@ -480,6 +480,30 @@ def build_csr_device(dst, src, rel, val, alive, n_rows, sync_free=False, want_sl
     return p
 
 
+def build_csr_pair_device(a, b, rel, val, alive, n_rows):
+    """(csr_by_a, csr_by_b): rows = a with entries (b, rel, val) and rows = b with entries (a, rel, val), built together in five
+    launches without a read-back (rgcn_dev_csr_pair); no msg_slot arrays -- for per-call graphs and the DistMult backward"""
+    dev = a.device
+    M = a.shape[0]
+    rowbuf = _i32(2 * n_rows + 2, dev)
+    scan_tmp = _i32((2 * n_rows + 1) // 1024 + 4, dev)
+    e_other, e_rel = _i32(2 * M, dev), _i32(2 * M, dev)
+    e_val = torch.empty(max(2 * M, 1), dtype=torch.float32, device=dev)
+    with _on(dev):
+        _check(lib().rgcn_dev_csr_pair(_dp(a), _dp(b), _dp(rel), _dp(val), _dp(alive), c_i64(M), c_i64(n_rows), _dp(rowbuf),
+                                       _dp(scan_tmp), _dp(e_other), _dp(e_rel), _dp(e_val), _stream(dev)), "dev_csr_pair")
+    out = []
+    for k in range(2):
+        p = CsrPlan()
+        p.n_rows = n_rows
+        p.msg_slot, p.n_messages = None, None
+        p.src, p.rel, p.val = e_other, e_rel, e_val
+        p.rowptr = rowbuf[k * (n_rows + 1): k * (n_rows + 1) + n_rows + 1]
+        p.sync_free, p.per_call, p.units = True, True, None
+        out.append(p)
+    return out[0], out[1]
+
+
 def row_units(rowptr, n_rows, max_len):
     """work units {row, first entry, end entry, flags} over a CSR: one per row, rows longer than max_len cut into pieces
     (flags RGCN_U_SHARED, first piece also RGCN_U_FIRST).  -> (units int32 [n_units, 4] on the device, n_units, n_split)"""
@@ -1123,8 +1147,7 @@ def distmult_bwd_all(triples, nodes, rel, gs, with_bias):
     alive = None
     if _deferred_mode():     # the forward's range check may not have been looked at yet: bad triples must not reach the sort
         alive = ((triples >= 0).all(dim=1) & (triples[:, 0] < N) & (triples[:, 2] < N) & (triples[:, 1] < R)).to(torch.uint8)
-    by_s = build_csr_device(s, o, p, gs, alive, N, sync_free=True, want_slot=False)
-    by_o = build_csr_device(o, s, p, gs, alive, N, sync_free=True, want_slot=False)
+    by_s, by_o = build_csr_pair_device(s, o, p, gs, alive, N)
     dn, dr = torch.empty_like(nodes), torch.empty_like(rel)
     dsb = dpb = dob = None
     if with_bias:
@@ -1148,8 +1171,7 @@ def distmult_bwd_nodes(triples, nodes, rel, gs):
     alive = None
     if _deferred_mode():     # the forward's range check may not have been looked at yet: bad triples must not reach the sort
         alive = ((triples >= 0).all(dim=1) & (triples[:, 0] < N) & (triples[:, 2] < N) & (triples[:, 1] < rel.shape[0])).to(torch.uint8)
-    by_s = build_csr_device(s, o, p, gs, alive, N, sync_free=True, want_slot=False)
-    by_o = build_csr_device(o, s, p, gs, alive, N, sync_free=True, want_slot=False)
+    by_s, by_o = build_csr_pair_device(s, o, p, gs, alive, N)
     dn = torch.empty_like(nodes)
     with _on(dev), _timed("distmult_bwd_nodes"):
         _check(lib().rgcn_distmult_bwd_nodes_f32(_dp(by_s.rowptr), _dp(by_s.src), _dp(by_s.rel), _dp(by_s.val), _dp(by_o.rowptr),

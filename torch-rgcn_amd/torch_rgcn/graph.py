@@ -123,6 +123,12 @@ class RelGraph:
             if self._dev is None:
                 raise RuntimeError("the basis-aggregation path needs the device-side graph build")
             s, p, o, val, alive = self._dev
+            if getattr(self, "per_call", False) and not need_slot and ("csr", "fwd") not in self._plans \
+                    and ("csr", "bwd") not in self._plans:
+                # per-call graphs: both directions at once (a training step walks both), five launches for the pair
+                self._plans[("csr", "fwd")], self._plans[("csr", "bwd")] = \
+                    _native.build_csr_pair_device(s, o, p, val, alive, self.num_nodes)
+                return self._plans[key]
             dst, src = (s, o) if kind == "fwd" else (o, s)
             self._plans[key] = _native.build_csr_device(dst, src, p, val, alive, self.num_nodes, sync_free=self.sync_free,
                                                         want_slot=need_slot or not getattr(self, "per_call", False))
