@@ -142,9 +142,13 @@ __global__ __launch_bounds__(64 * NW, 16 / NW) void bwd_fused_d16_kernel(
       // stage 2: the random gather, the W_r^T fragment, and the tile-local X rows in operand order
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        A.g[j] = *reinterpret_cast<const float4 *>(G + (size_t)A.s[j] * 16 + 4 * k);
+        // 32-bit byte offsets from the uniform base pointers (packed slots: source ids < 2^24, so row << 6 fits): the loads take
+        // the scalar-base + vector-offset form instead of a 64-bit address per lane
+        const unsigned og = ((unsigned)A.s[j] << 6) | ((unsigned)k << 4);
+        const unsigned ox = ((unsigned)(row0 + (A.dl[j] == 0xFF ? 0 : A.dl[j])) << 6) | ((unsigned)k << 4);
+        A.g[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(G) + og);
         A.w[j] = reinterpret_cast<const float4 *>(Wtp)[(size_t)A.r[j] * 64 + lane];
-        A.xn[j] = *reinterpret_cast<const float4 *>(X + (size_t)(row0 + (A.dl[j] == 0xFF ? 0 : A.dl[j])) * 16 + 4 * k);
+        A.xn[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(X) + ox);
       }
       __builtin_amdgcn_sched_barrier(0);
       request_idx(c + U);                  // behind the gathers in the (in-order) memory pipeline; used next iteration

@@ -89,7 +89,10 @@ __global__ __launch_bounds__(WG) void spmm_d16_kernel(
     auto gather = [&](D16Stage<U> &g) {
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        g.x[j] = *reinterpret_cast<const float4 *>(X + (size_t)g.s[j] * 16 + 4 * k);
+        if (PACKED)       // packed slots: source ids < 2^24 -> a 32-bit byte offset from the uniform base (scalar-base load form)
+          g.x[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(X) + (((unsigned)g.s[j] << 6) | ((unsigned)k << 4)));
+        else
+          g.x[j] = *reinterpret_cast<const float4 *>(X + (size_t)g.s[j] * 16 + 4 * k);
         if (PACKED) {
           g.w[j] = reinterpret_cast<const float4 *>(W)[(size_t)g.r[j] * 64 + lane];
         } else {
