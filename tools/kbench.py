@@ -111,8 +111,13 @@ if "bwd" in a.what:
         med, mn = timeit(lambda: _native.bwd_fused(G, X, W, bp, atomic=atomic), a.iters)
         _native.profile_stop()
         balg = M * (4 * d + 8) + 2 * N * 4 * d
-        print(f"[{tag} BU={os.environ.get('RGCN_BWD_U', '-')}] bwd_fused {'atomic' if atomic else 'partial'} tile={bp.tile_rows} relerr dX {e1:.2e} dW {e2:.2e} "
+        print(f"[{tag} K={os.environ.get('RGCN_BWD_KERNEL', 'win')} NW={os.environ.get('RGCN_BWD_NW', '-')} BP={os.environ.get('RGCN_BWD_BPERM', '-')}] bwd_fused {'atomic' if atomic else 'partial'} tile={bp.tile_rows} relerr dX {e1:.2e} dW {e2:.2e} "
               f"med {med:.3f} ms min {mn:.3f} ms -> {balg / med / 1e6:.0f} GB/s algorithmic (backward bytes)", flush=True)
+    if _native.bwd_fused_relu_ok(bp):        # ReLU mask fused into the dX epilogue (window kernel)
+        Xr = torch.relu(X)
+        dxr, dwr = _native.bwd_fused(G, Xr, W, bp, atomic=True, relu=True)
+        dx0, dw0 = _native.bwd_fused(G, Xr, W, bp, atomic=True)
+        print("relu-masked dX == mask(dX):", bool(torch.equal(dxr, dx0 * (Xr > 0))), "dW relerr", ((dwr - dw0).abs().max() / dw0.abs().max()).item(), flush=True)
     d2 = _native.bwd_fused(G, X, W, bp)
     d3 = _native.bwd_fused(G, X, W, bp)
     print("bwd_fused (partial) bitwise reproducible:", bool(torch.equal(d2[0], d3[0]) and torch.equal(d2[1], d3[1])), flush=True)

@@ -33,6 +33,7 @@
 //                waves and LDS traffic cost more than the saved requests); 4 x v_mfma_f32_16x16x4_f32 accumulate dW_r in
 //                4 registers per lane.
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -206,6 +207,238 @@ __global__ __launch_bounds__(64 * NW, 16 / NW) void bwd_fused_d16_kernel(
   for (int i = lane; i < nrows * 4; i += 64) o4[i] = reinterpret_cast<const float4 *>(tile)[tile_swz(i)];
 }
 
+// ---- round 3: the same walk with everything tile-local ON the CU and no workgroup barrier in the loop.
+//
+// Byte ledger of the kernel above at S1 (profiles/r02_pmc_kernels.json: 4.18 GB of fabric traffic per launch for 1.64 GB
+// of algorithmic bytes, the kernel sits at the ~6.3 TB/s fabric ceiling): G gathers 2.69 GB + packed slots 0.24 GB are
+// inherent; the rest is (a) the tile's X rows re-fetched through the fabric (the random gathers evict them from L1 / L2
+// between a wave's chunks) and (b) the dW flush -- 3,906 workgroups x 101 relations x 1 KiB of fp32 atomics = 394 MB.
+// Here:
+//   (a) the tile's X rows are copied to LDS once (4 KiB per wave, 64 MB per launch, coalesced) and the K-over-messages A
+//       operand of the dW MFMA is read straight from that copy: lane (k, m) reads X_lds[dl(4 t + k)][m] with ds_read_b32
+//       (one row = 16 consecutive banks).  The destination row of slot 4 t + k reaches every lane of DPP row k through
+//       three row rotations (row k rotated by k) and one row_share per MFMA step -- no second global load, no second trip
+//       through the transposition scratch.
+//   (b) a workgroup is NW = 16 (or 8) waves = 16 adjacent tiles, and the dW partials of a relation are summed across ALL
+//       of them before they leave the CU: 977 x 101 KiB = 98 MB instead of 394 MB.  With the X copy there is no room for
+//       NW x D staging slots (16 waves x (4 + 4 + 1.25) KiB = 148 KiB), so the waves share ONE window of DW relation slots
+//       (1 KiB each) and serialise on a slot with a state word in LDS -- state = relation << 8 | contributions << 1 | lock:
+//         wait until the slot serves my relation and is free; take it (ds_cmpst); v = (first ? 0 : slot) + my partial;
+//         not the last wave: slot = v, state = (r, c + 1); last wave: state = (r + DW, 0), then add v to dW[r].
+//       Every wave passes every relation in order (an empty run contributes nothing but its count), so the slowest wave
+//       never waits and nobody runs more than DW relations ahead: a sliding window instead of 26 workgroup barriers.
+//       ORDERED (RGCN_DETERMINISTIC=1): waves take the slot in wave order (state = (r, rank), no lock), the partial sums
+//       go to scratch with plain stores and the two reduce kernels sum them in a fixed order -- bit-reproducible.
+// RELU: dX is the gradient before the ReLU that produced X (X = relu(pre)): rows are masked with X > 0 in the epilogue
+// from the LDS copy (the caller's aten.threshold_backward launch, functional.py, disappears).
+template <int U, int NW, int DW, bool ATOMIC, bool RELU, bool BPERM>
+__global__ __launch_bounds__(64 * NW, 4) void bwd_win_d16_kernel(
+    const float *__restrict__ G, const float *__restrict__ X, const float *__restrict__ Wtp, float *__restrict__ dX,
+    float *__restrict__ dWout, const int2 *__restrict__ p_pack, const int *__restrict__ chunk_rel,
+    const int *__restrict__ run_ptr, int n_tiles, int n_blocks, int tile_rows, int n_dst, int R) {
+  static_assert((DW & (DW - 1)) == 0, "window slots: power of two");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int t = blockIdx.x * NW + wave;
+  const bool valid = t < n_tiles;
+  const int nwv = min(NW, n_tiles - (int)blockIdx.x * NW);       // waves of this workgroup that own a tile
+  float *tile = lds + wave * tile_rows * 16;                     // dX tile (swizzled, tile_swz)
+  float *xt = lds + (NW + wave) * tile_rows * 16;                // X tile (row-major)
+  float *xs = lds + 2 * NW * tile_rows * 16 + wave * BW_SCR;     // transposition scratch
+  float *win = lds + 2 * NW * tile_rows * 16 + NW * BW_SCR;      // [DW][256] fragment order
+  int *state = reinterpret_cast<int *>(win + DW * 256);          // [DW]
+  const int row0 = t * tile_rows;
+  const int nrows = valid ? min(tile_rows, n_dst - row0) : 0;
+  for (int i = lane; i < nrows * 4; i += 64) {
+    reinterpret_cast<float4 *>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4 *>(xt)[i] = reinterpret_cast<const float4 *>(X + (size_t)row0 * 16)[i];
+  }
+  if (tid < DW) state[tid] = tid << 8;                            // slot q serves relation q first, nothing contributed
+  __syncthreads();                                                // the only workgroup barrier
+  if (!valid) return;
+
+  const int my0 = run_ptr[(size_t)t * (R + 1)], my1 = run_ptr[(size_t)t * (R + 1) + R];
+  const int m = lane & 15, k = lane >> 4;
+  int done = 0;                 // relations [0, done) have been contributed by this wave
+  int cur = -1;                 // relation accumulating in acc_w (-1: none)
+  f32x4 acc_w = {0.f, 0.f, 0.f, 0.f};
+  const int xrd = (int)((xt - lds) * 4) + m * 4;       // byte address of X_lds[0][m]
+
+  // hand this wave's partial of relation r (has = false: nothing to add) to the shared window
+  auto contribute = [&](int r, const f32x4 part, bool has) {
+    int *st = state + (r & (DW - 1));
+    f32x4 *slot = reinterpret_cast<f32x4 *>(win + (r & (DW - 1)) * 256) + lane;
+    int s;
+    if (ATOMIC) {
+      for (;;) {
+        s = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if ((s >> 8) == r && !(s & 1)) {
+          int ok = 0;
+          if (lane == 0) {
+            int e = s;
+            ok = __hip_atomic_compare_exchange_strong(st, &e, s | 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          if (__builtin_amdgcn_readfirstlane(ok)) break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    } else {
+      const int want = (r << 8) | (wave << 1);
+      for (;;) {
+        s = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if ((s & ~0x40) == want) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int c = (s >> 1) & 31;
+    const bool dirty = (s & 0x40) != 0;                          // somebody added data to the slot
+    const bool last = c + 1 == nwv;
+    f32x4 v = part;
+    if (dirty && (has || last)) {
+      const f32x4 old = *slot;
+      v = has ? old + part : old;
+    }
+    if (!last) {
+      if (has) *slot = v;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0)
+        __hip_atomic_store(st, (r << 8) | ((c + 1) << 1) | ((dirty || has) ? 0x40 : 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(st, (r + DW) << 8, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (ATOMIC) {
+        if (dirty || has) {  // D: lane 16q+j holds rows 4q..4q+3 (input feature), column j (output feature)
+          float *wr = dWout + (size_t)r * 256 + (4 * k) * 16 + m;
+          atomicAdd(wr, v[0]); atomicAdd(wr + 16, v[1]); atomicAdd(wr + 32, v[2]); atomicAdd(wr + 48, v[3]);
+        }
+      } else {
+        if (!(dirty || has)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        reinterpret_cast<f32x4 *>(dWout + ((size_t)r * n_blocks + blockIdx.x) * 256)[lane] = v;
+      }
+    }
+  };
+  // relations [done, upto) other than the open one: this wave has nothing for them
+  auto pass_empty = [&](int upto) {
+    for (; done < upto; ++done) contribute(done, f32x4{0.f, 0.f, 0.f, 0.f}, false);
+  };
+
+  if (my0 < my1) {
+    const int last = my1 - 1;
+    int2 pk_n[U];
+    int relv_n;
+    auto request_idx = [&](int c) {
+      relv_n = chunk_rel[min(c + (lane & (U - 1)), last)];
+#pragma unroll
+      for (int j = 0; j < U; ++j) pk_n[j] = p_pack[min(c + j, last) * RGCN_CHUNK + m];
+    };
+    request_idx(my0);
+    for (int c = my0; c < my1; c += U) {
+      int s_[U], dl_[U], d_[U], r_[U];
+      float v_[U];
+      float4 g_[U], w_[U];
+      const int relv = relv_n;
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const int2 pk = pk_n[j];
+        s_[j] = pk.x & 0xFFFFFF;
+        dl_[j] = (int)((unsigned)pk.x >> 24);
+        d_[j] = dl_[j] == 0xFF ? -1 : row0 + dl_[j];
+        v_[j] = (c + j <= last) ? __builtin_bit_cast(float, pk.y) : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) r_[j] = __builtin_amdgcn_readlane(relv, j);
+#pragma unroll
+      for (int j = 0; j < U; ++j) asm volatile("" : "+v"(d_[j]), "+v"(v_[j]));   // pin the index data here
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const unsigned og = ((unsigned)s_[j] << 6) | ((unsigned)k << 4);
+        g_[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(G) + og);
+        w_[j] = reinterpret_cast<const float4 *>(Wtp)[(size_t)r_[j] * 64 + lane];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      request_idx(c + U);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const float v = v_[j];
+        const bool live = v != 0.f;
+        const f32x4 sc = {live ? g_[j].x * v : 0.f, live ? g_[j].y * v : 0.f, live ? g_[j].z * v : 0.f,
+                          live ? g_[j].w * v : 0.f};
+        // ---- dX
+        f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].x, sc[0], acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].y, sc[1], acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].z, sc[2], acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].w, sc[3], acc[0], 0, 0, 0);
+        if (fold_segments<1>(acc, d_[j])) {
+          f32x4 *p = reinterpret_cast<f32x4 *>(tile + dl_[j] * 16 + 4 * (k ^ ((dl_[j] >> 2) & 3)));   // swizzled: see tile_swz
+          *p += acc[0];
+        }
+        // ---- dW: relation bookkeeping (wave-uniform)
+        const int rj = __builtin_amdgcn_readfirstlane(r_[j]);
+        if (rj != cur) {
+          if (cur >= 0) {
+            pass_empty(cur);
+            contribute(cur, acc_w, true);
+            done = cur + 1;
+          }
+          acc_w = f32x4{0.f, 0.f, 0.f, 0.f};
+          cur = rj;
+        }
+        // B[mu][j'] = val G[s_mu][j'] through the scratch (written as rows of a slot, read as one feature of four slots);
+        // A[i][mu] = X[o_mu][i] from the LDS copy of the tile's rows
+        const int dlc = dl_[j] == 0xFF ? 0 : dl_[j];            // pads: B is 0, keep A finite and inside the tile
+        int rowk[4];
+        if (BPERM) {
+#pragma unroll
+          for (int t4 = 0; t4 < 4; ++t4) rowk[t4] = __builtin_amdgcn_ds_bpermute(4 * (4 * t4 + k), dlc);
+        } else {
+          int rot = dlc;                                          // lane (k, m) <- dl of slot (m + k) & 15
+          rot = __builtin_amdgcn_update_dpp(rot, rot, 0x120 + 15, 0x2, 0xF, false);
+          rot = __builtin_amdgcn_update_dpp(rot, rot, 0x120 + 14, 0x4, 0xF, false);
+          rot = __builtin_amdgcn_update_dpp(rot, rot, 0x120 + 13, 0x8, 0xF, false);
+          rowk[0] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 0, 0xF, 0xF, false);   // row_share: slot 4 t4 + k
+          rowk[1] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 4, 0xF, 0xF, false);
+          rowk[2] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 8, 0xF, 0xF, false);
+          rowk[3] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 12, 0xF, 0xF, false);
+        }
+        float bv[4], av[4];
+        asm volatile("" ::: "memory");
+        *reinterpret_cast<f32x4 *>(xs + m * 20 + 4 * k) = sc;
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) bv[t4] = xs[(4 * t4 + k) * 20 + m];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+          av[t4] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(lds) + (xrd + (rowk[t4] << 6)));
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) acc_w = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4], bv[t4], acc_w, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (cur >= 0) {
+    pass_empty(cur);
+    contribute(cur, acc_w, true);
+    done = cur + 1;
+  }
+  pass_empty(R);
+
+  float4 *o4 = reinterpret_cast<float4 *>(dX + (size_t)row0 * 16);
+  for (int i = lane; i < nrows * 4; i += 64) {
+    float4 a = reinterpret_cast<const float4 *>(tile)[tile_swz(i)];
+    if (RELU) {
+      const float4 x = reinterpret_cast<const float4 *>(xt)[i];
+      a.x = x.x > 0.f ? a.x : 0.f; a.y = x.y > 0.f ? a.y : 0.f; a.z = x.z > 0.f ? a.z : 0.f; a.w = x.w > 0.f ? a.w : 0.f;
+    }
+    o4[i] = a;
+  }
+}
+
 // ---- sparse (tile, relation) buckets (AM: 267 relations): backward of the two-pass path with ONE relation-major walk.
 // Round 1: pass 1 of the feature gradient gathers G[s] per message (relation-major chunks, dense), and the weight gradient
 // walks the same relation-major plan again gathering G[dst] AND X[src] -- three random row reads per message.  Here one
@@ -350,6 +583,30 @@ hipError_t launch_bwd8(const BwdLaunch &a) {
   return hipGetLastError();
 }
 
+// window kernel (round 3): NW waves per workgroup, DW window slots; needs more than 64 KiB of LDS at 64-row tiles
+template <int NW, int DW>
+size_t bwd_win_lds(int tile_rows) {
+  return ((size_t)2 * NW * tile_rows * 16 + NW * BW_SCR + DW * 256) * sizeof(float) + DW * sizeof(int);
+}
+template <int NW, int DW, bool AT, bool RELU, bool BPERM>
+hipError_t launch_bwd_win(const BwdLaunch &a) {
+  auto kern = bwd_win_d16_kernel<4, NW, DW, AT, RELU, BPERM>;
+  static bool raised = false;                    // once per process and instantiation (not a stream operation)
+  if (a.lds > 64 * 1024 && !raised) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    raised = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.n_blocks), dim3(64 * NW), a.lds, a.st, a.G, a.X, a.Wtp, a.dX, a.dWout, a.pk, a.chunk_rel,
+                     a.run_ptr, a.n_tiles, a.n_blocks, a.tile_rows, a.n_dst, a.R);
+  return hipGetLastError();
+}
+template <int NW, int DW, bool AT>
+hipError_t launch_bwd_win_f(const BwdLaunch &a, bool relu, bool bperm) {
+  if (bperm) return launch_bwd_win<NW, DW, AT, false, true>(a);
+  return relu ? launch_bwd_win<NW, DW, AT, true, false>(a) : launch_bwd_win<NW, DW, AT, false, false>(a);
+}
+
 template <int U, bool AT>
 void launch_bwd_d(const BwdLaunch &a, int D) {
   if (D == 4) launch_bwd<U, AT, 4>(a);
@@ -383,7 +640,39 @@ extern "C" int rgcn_bwd_fused_f32(const float *G, const float *X, const float *W
     return RGCN_EINVAL;
   }
   const bool atomic = (flags & RGCN_F_DW_ATOMIC) != 0;
+  const bool relu = (flags & RGCN_F_RELU) != 0;
   if (!atomic && !scratch) { rgcn_set_error("bwd_fused: the deterministic reduction needs a scratch buffer"); return RGCN_EINVAL; }
+  // round 3: the window kernel (X tile in LDS, dW partials summed across 16 tiles on the CU, no barrier in the loop) whenever
+  // its LDS fits (64-row tiles at 16 waves); RGCN_BWD_KERNEL=stage keeps round 2's staging kernel, which also serves taller tiles
+  static const bool WANT_WIN = !(getenv("RGCN_BWD_KERNEL") && !strcmp(getenv("RGCN_BWD_KERNEL"), "stage"));
+  static const int WIN_NW = getenv("RGCN_BWD_NW") ? atoi(getenv("RGCN_BWD_NW")) : 16;
+  static const bool WIN_BPERM = getenv("RGCN_BWD_BPERM") && atoi(getenv("RGCN_BWD_BPERM"));
+  if (WANT_WIN) {
+    const bool nw16 = WIN_NW >= 16 && bwd_win_lds<16, 8>(tile_rows) <= 160 * 1024;
+    const bool nw8 = !nw16 && bwd_win_lds<8, 4>(tile_rows) <= 160 * 1024;
+    if (nw16 || nw8) {
+      const int NWv = nw16 ? 16 : 8;
+      const int n_blocks = (int)((n_tiles + NWv - 1) / NWv);
+      hipStream_t st = (hipStream_t)stream;
+      const BwdLaunch L{G, X, Wt_packed, dX, atomic ? dW : scratch, reinterpret_cast<const int2 *>(p_pack), chunk_rel, run_ptr,
+                        (int)n_tiles, n_blocks, tile_rows, (int)n_dst, R, nw16 ? bwd_win_lds<16, 8>(tile_rows) : bwd_win_lds<8, 4>(tile_rows), st};
+      if (atomic) {
+        HIP_TRY(zero_async(dW, (size_t)R * 256 * sizeof(float), st));
+        if (nw16) HIP_TRY((launch_bwd_win_f<16, 8, true>(L, relu, WIN_BPERM)));
+        else HIP_TRY((launch_bwd_win_f<8, 4, true>(L, relu, WIN_BPERM)));
+      } else {
+        if (nw16) HIP_TRY((launch_bwd_win_f<16, 8, false>(L, relu, WIN_BPERM)));
+        else HIP_TRY((launch_bwd_win_f<8, 4, false>(L, relu, WIN_BPERM)));
+        const int S = (int)std::max<int64_t>(1, std::min<int64_t>(16, n_blocks / 64));
+        float *tmp = scratch + (size_t)n_blocks * R * 256;
+        hipLaunchKernelGGL(dw_reduce_a_kernel, dim3((unsigned)R, (unsigned)S), dim3(WG), 0, st, scratch, tmp, n_blocks, S);
+        hipLaunchKernelGGL(dw_reduce_b_kernel, dim3((unsigned)R), dim3(WG), 0, st, tmp, dW, S);
+        HIP_TRY(hipGetLastError());
+      }
+      return RGCN_OK;
+    }
+  }
+  if (relu) { rgcn_set_error("bwd_fused: RGCN_F_RELU needs the window kernel (tile_rows = %d)", tile_rows); return RGCN_EUNSUPPORTED; }
   static const int DSEL = getenv("RGCN_BWD_D") ? atoi(getenv("RGCN_BWD_D")) : 4;
   const int Dv = DSEL >= 4 ? 4 : (DSEL >= 2 ? 2 : 1);
   // tiles per workgroup: 8 halve the number of dW partials -- measured at S1 (profiles/r02_bwd_fused_ablation.txt): atomic flush

@@ -917,9 +917,17 @@ def bwd_fused_ok(plan):
             and plan.tile_rows <= 160 and plan.n_tiles > 0)      # 160 rows: dX tiles + scratch + staging within 64 KiB of LDS
 
 
-def bwd_fused(G, X, W, plan, atomic=False):
+def bwd_fused_relu_ok(plan):
+    """RGCN_F_RELU of rgcn_bwd_fused_f32 (dX masked with X > 0 in the epilogue) exists in the window kernel only: its LDS
+    (dX tile + X tile + scratch per wave, 8 waves at least) has to fit"""
+    return os.environ.get("RGCN_BWD_KERNEL", "win") != "stage" and \
+        (2 * 8 * plan.tile_rows * 16 + 8 * 320 + 4 * 256) * 4 + 16 <= 160 * 1024
+
+
+def bwd_fused(G, X, W, plan, atomic=False, relu=False):
     """(dX [n, 16], dW [R, 16, 16]) of the hidden-16 layer from one walk of the transposed plan (rgcn_bwd_fused_f32):
-    G upstream gradient, X the layer's input, W [R, 16, 16]."""
+    G upstream gradient, X the layer's input, W [R, 16, 16].  relu: X is the output of a ReLU and dX is wanted BEFORE it
+    (rows masked with X > 0 in the kernel's epilogue)."""
     _req(G, "grad_output"); _req(X, "features"); _req(W, "weights")
     assert W.shape[1:] == (16, 16) and G.shape == (plan.n_src, 16) and X.shape == (plan.n_dst, 16)
     dev = G.device
@@ -933,7 +941,7 @@ def bwd_fused(G, X, W, plan, atomic=False):
     with _on(dev), _timed("bwd_fused"):
         _check(lib().rgcn_bwd_fused_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(scratch), _dp(plan.pack),
                                         _dp(plan.chunk_rel), _dp(plan.run_ptr), c_i64(plan.n_tiles), c_i32(plan.tile_rows),
-                                        c_i64(plan.n_dst), c_i32(W.shape[0]), c_i32(F_DW_ATOMIC if atomic else 0),
+                                        c_i64(plan.n_dst), c_i32(W.shape[0]), c_i32((F_DW_ATOMIC if atomic else 0) | (1 if relu else 0)),
                                         _stream(dev)), "bwd_fused")
     return dX, dW
 
