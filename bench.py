@@ -43,7 +43,7 @@ import torch.distributed as dist  # noqa: E402
 
 METRIC = "edges/s/GPU (fwd+bwd) 2-layer RGCN, 1M nodes/10M edges/50 rels, h=16"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def fwd_bytes(M, N, d_in, d_out):
@@ -57,7 +57,7 @@ def bwd_bytes(M, N, d_in, d_out, x_needs_grad=True):
 
 
 def _profile_json(name):
-    for rnd in (PROFILE_ROUND, "r01"):
+    for rnd in (PROFILE_ROUND, "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")) as f:
                 return json.load(f), f"profiles/{rnd}_{name}.json"
@@ -93,6 +93,29 @@ def pmc_detail(kernel_key):
         return out
     except (TypeError, KeyError, ZeroDivisionError):
         return None
+
+
+def kernel_roofline(kernel, avg_ms, alg_bytes, bytes_model, step_ms, launches_per_step, pmc_substrs, pmc_key):
+    """roofline block of one kernel (group): achieved = SURVEY 8(d) ALGORITHMIC bytes / the average launch time measured
+    live with HIP events inside the timed region; traffic / pmc are STATIC (the committed rocprofv3 --pmc summaries of
+    the same S1 launch under profiles/), tagged as such."""
+    ach = alg_bytes / (avg_ms * 1e-3) / 1e9
+    traffic = traffic64 = tsrc = None
+    for sub in pmc_substrs:
+        traffic, tsrc = pmc_traffic(sub)
+        traffic64, _ = pmc_traffic(sub, doubled=False)
+        if traffic:
+            break
+    return {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
+            "share_of_step": round(launches_per_step * avg_ms / step_ms, 4),
+            "algorithmic_bytes_per_launch": alg_bytes, "bytes_model": bytes_model,
+            "traffic": traffic, "traffic_if_64B_requests": traffic64,
+            "traffic_rate_GBs": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None,
+            "traffic_static": (f"{tsrc}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on the same S1 launch, NOT measured in "
+                               "this run; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B, "
+                               "MI355X_MICROARCH.md HBM section)") if traffic else None,
+            "pmc": pmc_detail(pmc_key) if pmc_key else None}
 
 
 class _MeanSquare(torch.autograd.Function):
@@ -162,6 +185,33 @@ def cpu_baseline(full_scale):
     return res
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it: re-run this command line under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` (one process per GPU, RCCL over xGMI) on a free local
+    port.  The ranks' stderr passes through; of their stdout only rank 0's JSON line is printed, last."""
+    import socket
+    import subprocess
+    if not os.environ.get("RGCN_BENCH_ONE_DEVICE"):
+        have = torch.cuda.device_count()
+        assert have >= n, f"--gpus {n}: this node shows {have} GPU(s)"
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    result = [ln for ln in lines if ln.lstrip().startswith("{") and '"metric"' in ln]
+    for ln in lines:
+        if not result or ln is not result[-1]:
+            print(ln, file=sys.stderr)           # anything else the ranks wrote to stdout (RCCL banners ...) is not the result
+    if proc.returncode != 0 or not result:
+        print(f"bench.py: the {n}-rank run failed (exit code {proc.returncode})", file=sys.stderr)
+        return proc.returncode or 1
+    print(result[-1], flush=True)
+    return 0
+
+
 def host_ram_gb():
     try:
         with open("/proc/meminfo") as f:
@@ -188,6 +238,11 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary lines for BASELINE configs 1-4")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run, and pass
+        # rank 0's ONE JSON line through as the last line of stdout
+        return self_launch(args.gpus)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -211,6 +266,7 @@ def main():
     mode = "single" if group is None else ("weak" if args.weak else "strong")
 
     from torch_rgcn import _native
+    from torch_rgcn.dist import set_transport
     N, R0, E, d = args.nodes, args.rels, args.edges, args.hidden
     l1, l2, M = build_layers(N, R0, E, d, seed=rank if mode == "weak" else 0, device=device, group=group,
                              keep="all" if mode == "weak" else "lpt")
@@ -263,7 +319,7 @@ def main():
             cands = [(os.environ.get("RGCN_DIST_COMM", "allreduce"), os.environ.get("RGCN_DIST_SLABS", "0"))]
         tried = {}
         for c, s in cands:
-            os.environ["RGCN_DIST_COMM"], os.environ["RGCN_DIST_SLABS"] = c, s
+            set_transport(l1, c, int(s)), set_transport(l2, c, int(s))
             try:
                 tried[f"{c}/slabs={s}"] = round(timed_steps(3), 4)
             except RuntimeError as exc:       # a collective this backend lacks fails on every rank alike: drop the candidate
@@ -271,7 +327,8 @@ def main():
                 if rank == 0:
                     print(f"bench.py: transport {c}/slabs={s} unavailable: {str(exc)[:120]}", file=sys.stderr)
         best = min((k for k in tried if tried[k] is not None), key=tried.get)
-        os.environ["RGCN_DIST_COMM"], os.environ["RGCN_DIST_SLABS"] = best.split("/slabs=")
+        chosen = (best.split("/slabs=")[0], int(best.split("/slabs=")[1]))
+        set_transport(l1, *chosen), set_transport(l2, *chosen)
         comm = {"collective": best, "candidates_ms_per_step": tried}
 
     for _ in range(args.warmup):
@@ -298,16 +355,15 @@ def main():
     if group is not None:
         # what the collectives cost: (a) the step without them (RGCN_DIST_COMM=none: same kernels, wrong numbers),
         # (b) the four N x d collectives of one step on their own
-        chosen = os.environ["RGCN_DIST_COMM"]
-        os.environ["RGCN_DIST_COMM"] = "none"
+        set_transport(l1, "none"), set_transport(l2, "none")
         compute_ms = timed_steps(3)
-        os.environ["RGCN_DIST_COMM"] = chosen
+        set_transport(l1, *chosen), set_transport(l2, *chosen)
         from torch_rgcn.functional import _join_shards
         buf = torch.zeros(N, d, device=device)
         fence()
         t_c = time.perf_counter()
         for _ in range(3 * 4):
-            _join_shards(buf, group)
+            _join_shards(buf, group, chosen[0])
         fence()
         comm_ms = 1e3 * (time.perf_counter() - t_c) / 3
         counts = torch.zeros(world, device=device, dtype=torch.float64)
@@ -331,38 +387,39 @@ def main():
         launches = {k: (float(np.mean(v)), len(v) / args.steps) for k, v in prof.items()}
         spmm_key = "spmm" if "spmm" in launches else ("spmm_slab" if "spmm_slab" in launches else None)
         roof = None
+        step_alg = 2 * (fwd_bytes(M, N, d, d) + bwd_bytes(M, N, d, d))
         if spmm_key and mode != "strong":
             spmm_ms = launches[spmm_key][0]
             slabbed = spmm_key == "spmm_slab"
-            if slabbed:   # one spmm = the slabs of one launch group; 4 spmm per step unless the backward is fused
-                n_spmm = 2 if "bwd_fused" in launches else 4
+            n_spmm = 2 if "bwd_fused" in launches else 4       # launches per step: 2 forward (+ 2 feature-gradient without the fused backward)
+            if slabbed:   # one spmm = the slabs of one launch group
                 spmm_ms = float(np.sum(prof[spmm_key])) / (n_spmm * args.steps)
-            ach = alg / (spmm_ms * 1e-3) / 1e9
-            traffic, tsrc = pmc_traffic("spmm_d16_kernel")
-            traffic64, _ = pmc_traffic("spmm_d16_kernel", doubled=False)
-            roof = {"kernel": "spmm_d16_kernel (forward launches" + ("" if "bwd_fused" in launches else " and feature-gradient launches") + ")",
-                    "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_if_64B_requests": traffic64,
-                    "traffic_rate_GBs": round(traffic / (spmm_ms * 1e-3) / 1e9, 1) if traffic else None,
-                    "traffic_source": (f"{tsrc}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on the same S1 launch; "
-                                       "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B, "
-                                       "MI355X_MICROARCH.md HBM section)") if traffic else None,
-                    "pmc": pmc_detail("spmm"), "avg_launch_ms": round(spmm_ms, 4),
-                    "launches_per_step": launches[spmm_key][1] if not slabbed else None,
-                    "algorithmic_bytes_per_launch": alg}
+            fwd = kernel_roofline("spmm_d16_kernel (forward launches" + ("" if "bwd_fused" in launches else " and feature-gradient launches") + ")",
+                                  spmm_ms, alg, "SURVEY 8(d) forward, one layer: M(4 d_in + 8) + N 4 d_out", ms, n_spmm,
+                                  ("spmm_d16_kernel",), "spmm")
             # the backward of one layer, whatever kernels it is made of (SURVEY 8d backward bytes)
             balg = bwd_bytes(M, N, d, d)
+            bmodel = "SURVEY 8(d) backward, one layer: M(4 d_out + 8) + 2 N 4 d_in (X needs a gradient)"
+            bwd = None
             if "bwd_fused" in launches:
                 bms = launches["bwd_fused"][0] + launches.get("dw_reduce", (0.0, 0))[0]
-                roof["backward"] = {"kernels": "bwd_fused_d16_kernel (+ dw_reduce)", "avg_ms_per_layer": round(bms, 4),
-                                    "algorithmic_bytes_per_layer": balg, "achieved": round(balg / (bms * 1e-3) / 1e9, 1),
-                                    "frac": round(balg / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "unit": "GB/s",
-                                    "pmc": pmc_detail("bwd_fused")}
+                win = os.environ.get("RGCN_BWD_KERNEL", "win") != "stage"
+                bwd = kernel_roofline(("bwd_win_d16_kernel" if win else "bwd_fused_d16_kernel") + " (dX + dW of one layer from one gather per message"
+                                      + (" + dw_reduce)" if "dw_reduce" in launches else ")"), bms, balg, bmodel, ms, 2,
+                                      ("bwd_win_d16_kernel", "bwd_fused_d16_kernel") if win else ("bwd_fused_d16_kernel",),
+                                      "bwd_win" if win else "bwd_fused")
             elif "wgrad" in launches and not slabbed:
                 bms = spmm_ms + launches["wgrad"][0]
-                roof["backward"] = {"kernels": "spmm_d16_kernel (dX) + wgrad_tiled_d16_kernel (dW)", "avg_ms_per_layer": round(bms, 4),
-                                    "algorithmic_bytes_per_layer": balg, "achieved": round(balg / (bms * 1e-3) / 1e9, 1),
-                                    "frac": round(balg / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "unit": "GB/s"}
+                bwd = kernel_roofline("spmm_d16_kernel (dX) + wgrad_tiled_d16_kernel (dW)", bms, balg, bmodel, ms, 2, (), None)
+            # headline = the kernel with the largest share of the timed step; the other one and the whole step ride along
+            roof = dict(bwd if (bwd is not None and bwd["share_of_step"] >= fwd["share_of_step"]) else fwd)
+            roof["forward"] = fwd
+            if bwd is not None:
+                roof["backward"] = bwd
+            roof["step_algorithmic_bytes"] = step_alg
+            roof["step_frac"] = round(step_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            path_ms = n_spmm * spmm_ms + (2 * bwd["avg_launch_ms"] if "bwd_fused" in launches else (2 * launches["wgrad"][0] if "wgrad" in launches else 0.0))
+            roof["step_minus_path_kernels_ms"] = round(ms - path_ms, 4)
             roof["other_kernels_ms"] = {k: round(v[0], 4) for k, v in launches.items() if k != spmm_key}
         elif spmm_key:   # strong scaling: a rank's launch covers its share of the messages only
             spmm_ms = launches[spmm_key][0]
@@ -372,7 +429,6 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "avg_launch_ms": round(spmm_ms, 4), "algorithmic_bytes_per_launch": fwd_bytes(m_local, N, d, d),
                     "other_kernels_ms": {k: round(v[0], 4) for k, v in launches.items() if k != spmm_key}}
-        step_alg = 2 * (fwd_bytes(M, N, d, d) + bwd_bytes(M, N, d, d))
         res = {"metric": METRIC, "value": value, "unit": "edges/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
                "scaling": "weak" if mode == "weak" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -387,7 +443,7 @@ def main():
                                       (f"relation-sharded x{world} (LPT on message counts, ONE seed-0 graph), "
                                        if mode == "strong" else f"relation-sharded x{world} (each rank its own relations), ")
                                       + f"N x {d} fp32 partials joined by {comm['collective']}"},
-               "step_hbm_algorithmic_GBs": round((step_alg if mode != "weak" else step_alg) / (ms * 1e-3) / 1e9, 1),
+               "step_hbm_algorithmic_GBs": round(step_alg / (ms * 1e-3) / 1e9, 1),
                "roofline": roof}
         if comm is not None:
             res["comm"] = comm
@@ -413,4 +469,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -264,6 +264,10 @@ RGCN_API int rgcn_bwd_fused_f32(const float *G, const float *X, const float *Wt_
                                 float *scratch, const int32_t *p_pack, const int32_t *chunk_rel,
                                 const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R,
                                 int32_t flags, void *stream);
+/* Debug / tuning aid (tools/kbench.py with RGCN_BWD_ABL=128): shader-cycle totals the instrumented window kernel adds up --
+ * out8[0] all waves, [1] inside the window hand-over, [2] of that waiting for the slot, [3] waves, [4] hand-overs.
+ * reset != 0 clears the counters.  No reference counterpart. */
+RGCN_API int rgcn_debug_bwd_prof(uint64_t *out8, int32_t reset);
 /* The same for graphs whose (tile, relation) buckets are sparse (AM: 267 relations), on the RELATION-major plan of the
  * two-pass path: one wave per work item gathers G[p_src] and X[p_dst] once per message and produces
  *   Y[slot, :] = val G[p_src] W_r^T   (slot order; pass 2 = rgcn_segment_gather_sum_f32 sums them per destination -> dX)
@@ -275,6 +279,9 @@ RGCN_API int rgcn_bwd_scatter_dw_f32(const float *G, const float *X, const float
                                      void *stream);
 /* Wp[r][16k+f][c] = W[r][f][4k+c]: fragments of W_r^T straight from W (the feature-gradient kernels multiply by W^T). */
 RGCN_API int rgcn_pack_w16t_f32(const float *W, float *Wp, int32_t R, void *stream);
+/* rgcn_pack_w16_f32 and rgcn_pack_w16t_f32 in ONE launch (a training step needs both: forward and fused backward of the
+ * hidden-16 layer; the Python wrapper caches the pair per weight tensor and version). */
+RGCN_API int rgcn_pack_w16_pair_f32(const float *W, float *Wp, float *Wtp, int32_t R, void *stream);
 
 /* Featureless layer (X = I, d_in = N): out[dst,:] = bias + sum val * table[rel*n_src + src, :].
  * Replaces torch.mm(adj, weights.view(R*N, d_out)) of layers.py:286-288 / :518-523. */

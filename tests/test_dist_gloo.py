@@ -118,10 +118,9 @@ def _join_worker(rank, world, port, q):
     from torch_rgcn.functional import _join_shards
     out = {}
     for mode in ("allreduce", "rs_ag", "a2a", "none"):
-        os.environ["RGCN_DIST_COMM"] = mode
         for n in (10, 11):                                   # 11 rows: not divisible by the world size (padded blocks)
             part = torch.arange(n * 3, dtype=torch.float32).view(n, 3) * (rank + 1)
-            out[(mode, n)] = _join_shards(part.clone(), dist.group.WORLD).numpy()
+            out[(mode, n)] = _join_shards(part.clone(), dist.group.WORLD, mode).numpy()
     if rank == 0:
         q.put(out)
     dist.barrier()

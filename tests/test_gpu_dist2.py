@@ -110,9 +110,10 @@ def _bench_path_worker(rank, world, port, outdir, backend="gloo"):
         res = {}
 
         def run(tag, group, comm=None, slabs=None):
-            if comm is not None:
-                os.environ["RGCN_DIST_COMM"], os.environ["RGCN_DIST_SLABS"] = comm, slabs
             l1, l2, _ = bench.build_layers(N, R0, E, d, seed=0, device=dev, group=group, keep="lpt")
+            if comm is not None:
+                from torch_rgcn.dist import set_transport
+                set_transport(l1, comm, int(slabs)), set_transport(l2, comm, int(slabs))
             with torch.no_grad():
                 l1.bias.normal_()
                 l2.bias.normal_()
@@ -248,3 +249,24 @@ def test_bench_contract_with_two_ranks_on_one_gpu():
 def test_bench_weak_mode_still_available():
     res = _run_bench(["--weak"])
     assert res["scaling"] == "weak" and abs(res["value"] - 2 * 1_000_000 / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]
+
+
+def test_plain_bench_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2` -- the shape of the command the driver uses at N = 1, no launcher around
+    it -- re-runs itself under torch.distributed.run (one rank per GPU) instead of dying on WORLD_SIZE != --gpus, and the
+    launcher process prints rank 0's ONE JSON line as the last line of stdout.  Both ranks on cuda:0 over gloo here."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RGCN_BENCH_ONE_DEVICE="1", RGCN_DIST_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--nodes", "100000",
+           "--edges", "500000", "--rels", "10"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[-1].startswith("{"), out.stdout[-2000:]
+    res = json.loads(lines[-1])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "strong" and "relation-sharded x2" in res["config"]["sharding"]
+    assert abs(res["value"] - 500_000 / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]

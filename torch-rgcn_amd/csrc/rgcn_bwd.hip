@@ -231,35 +231,43 @@ __global__ __launch_bounds__(64 * NW, 16 / NW) void bwd_fused_d16_kernel(
 //       go to scratch with plain stores and the two reduce kernels sum them in a fixed order -- bit-reproducible.
 // RELU: dX is the gradient before the ReLU that produced X (X = relu(pre)): rows are masked with X > 0 in the epilogue
 // from the LDS copy (the caller's aten.threshold_backward launch, functional.py, disappears).
-template <int U, int NW, int DW, bool ATOMIC, bool RELU, bool BPERM>
+// ABL (timing experiments only, tools/kbench.py; results are wrong): 1 gathers hit the tile's own rows (no random HBM access),
+// 2 no dW part, 4 no window protocol (partials dropped), 8 no fold / dX tile update, 16 no compute at all (loads only)
+// timing instrumentation of the window kernel (ABL & 128, tools/kbench.py only): shader cycles summed over all waves --
+// [0] whole wave, [1] inside contribute(), [2] of that: waiting for the slot / the lock, [3] waves, [4] contribute() calls
+__device__ unsigned long long g_bwd_prof[8];
+
+template <int U, int NW, int DW, bool ATOMIC, bool RELU, bool BPERM, int ABL = 0, bool PIPE = false, int SG = NW>
 __global__ __launch_bounds__(64 * NW, 4) void bwd_win_d16_kernel(
     const float *__restrict__ G, const float *__restrict__ X, const float *__restrict__ Wtp, float *__restrict__ dX,
     float *__restrict__ dWout, const int2 *__restrict__ p_pack, const int *__restrict__ chunk_rel,
     const int *__restrict__ run_ptr, int n_tiles, int n_blocks, int tile_rows, int n_dst, int R) {
-  static_assert((DW & (DW - 1)) == 0, "window slots: power of two");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int t = blockIdx.x * NW + wave;
   const bool valid = t < n_tiles;
-  const int nwv = min(NW, n_tiles - (int)blockIdx.x * NW);       // waves of this workgroup that own a tile
+  // SG waves share one window (SG = NW: the whole workgroup; smaller subgroups: fewer waves queue at a slot, more partial sums leave the CU)
+  const int sub = wave / SG;
+  const int nwv = min(SG, n_tiles - ((int)blockIdx.x * NW + sub * SG));   // waves of this subgroup that own a tile
   float *tile = lds + wave * tile_rows * 16;                     // dX tile (swizzled, tile_swz)
   float *xt = lds + (NW + wave) * tile_rows * 16;                // X tile (row-major)
   float *xs = lds + 2 * NW * tile_rows * 16 + wave * BW_SCR;     // transposition scratch
-  float *win = lds + 2 * NW * tile_rows * 16 + NW * BW_SCR;      // [DW][256] fragment order
-  int *state = reinterpret_cast<int *>(win + DW * 256);          // [DW]
+  float *win = lds + 2 * NW * tile_rows * 16 + NW * BW_SCR + sub * (DW * 256);   // [NW / SG][DW][256] fragment order
+  int *state = reinterpret_cast<int *>(lds + 2 * NW * tile_rows * 16 + NW * BW_SCR + (NW / SG) * DW * 256) + sub * DW;   // [NW / SG][DW]
   const int row0 = t * tile_rows;
   const int nrows = valid ? min(tile_rows, n_dst - row0) : 0;
   for (int i = lane; i < nrows * 4; i += 64) {
     reinterpret_cast<float4 *>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     reinterpret_cast<float4 *>(xt)[i] = reinterpret_cast<const float4 *>(X + (size_t)row0 * 16)[i];
   }
-  if (tid < DW) state[tid] = tid << 8;                            // slot q serves relation q first, nothing contributed
+  if (tid < (NW / SG) * DW) reinterpret_cast<int *>(lds + 2 * NW * tile_rows * 16 + NW * BW_SCR + (NW / SG) * DW * 256)[tid] = (tid % DW) << 8;   // slot q serves relation q first
   __syncthreads();                                                // the only workgroup barrier
   if (!valid) return;
 
   const int my0 = run_ptr[(size_t)t * (R + 1)], my1 = run_ptr[(size_t)t * (R + 1) + R];
   const int m = lane & 15, k = lane >> 4;
+  unsigned n_contrib = 0, n_spin_tag = 0, n_spin_lock = 0, n_cas_fail = 0;     // ABL & 256: how often a hand-over finds the slot not ready / taken
   int done = 0;                 // relations [0, done) have been contributed by this wave
   int cur = -1;                 // relation accumulating in acc_w (-1: none)
   f32x4 acc_w = {0.f, 0.f, 0.f, 0.f};
@@ -267,9 +275,10 @@ __global__ __launch_bounds__(64 * NW, 4) void bwd_win_d16_kernel(
 
   // hand this wave's partial of relation r (has = false: nothing to add) to the shared window
   auto contribute = [&](int r, const f32x4 part, bool has) {
-    int *st = state + (r & (DW - 1));
-    f32x4 *slot = reinterpret_cast<f32x4 *>(win + (r & (DW - 1)) * 256) + lane;
+    int *st = state + (r % DW);
+    f32x4 *slot = reinterpret_cast<f32x4 *>(win + (r % DW) * 256) + lane;
     int s;
+    f32x4 old = {0.f, 0.f, 0.f, 0.f};
     if (ATOMIC) {
       for (;;) {
         s = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -277,37 +286,46 @@ __global__ __launch_bounds__(64 * NW, 4) void bwd_win_d16_kernel(
           int ok = 0;
           if (lane == 0) {
             int e = s;
-            ok = __hip_atomic_compare_exchange_strong(st, &e, s | 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            ok = __hip_atomic_compare_exchange_strong(st, &e, s | 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
           if (__builtin_amdgcn_readfirstlane(ok)) break;
+          if (ABL & 256) ++n_cas_fail;
+        } else if (ABL & 256) {
+          if ((s >> 8) != r) ++n_spin_tag; else ++n_spin_lock;
         }
         __builtin_amdgcn_s_sleep(1);
       }
+      if (ABL & 256) ++n_contrib;
+      asm volatile("" ::: "memory");
+      if (s & 0x40) old = *reinterpret_cast<volatile f32x4 *>(slot);
     } else {
-      const int want = (r << 8) | (wave << 1);
+      const int want = (r << 8) | ((wave % SG) << 1);
       for (;;) {
         s = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
         if ((s & ~0x40) == want) break;
         __builtin_amdgcn_s_sleep(1);
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (s & 0x40) old = *slot;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const int c = (s >> 1) & 31;
     const bool dirty = (s & 0x40) != 0;                          // somebody added data to the slot
     const bool last = c + 1 == nwv;
     f32x4 v = part;
-    if (dirty && (has || last)) {
-      const f32x4 old = *slot;
-      v = has ? old + part : old;
-    }
-    if (!last) {
-      if (has) *slot = v;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0)
-        __hip_atomic_store(st, (r << 8) | ((c + 1) << 1) | ((dirty || has) ? 0x40 : 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (dirty) v = has ? old + part : old;
+    const int ns = last ? ((r + DW) << 8) : ((r << 8) | ((c + 1) << 1) | ((dirty || has) ? 0x40 : 0));
+    if (ATOMIC) {
+      asm volatile("" ::: "memory");
+      if (!last && has) *reinterpret_cast<volatile f32x4 *>(slot) = v;
+      asm volatile("" ::: "memory");
+      if (lane == 0) *reinterpret_cast<volatile int *>(st) = ns;       // (clears the lock bit; in-order LDS: no fence)
+      asm volatile("" ::: "memory");
     } else {
+      if (!last && has) *slot = v;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) __hip_atomic_store(st, (r + DW) << 8, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0) __hip_atomic_store(st, ns, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (last) {
       if (ATOMIC) {
         if (dirty || has) {  // D: lane 16q+j holds rows 4q..4q+3 (input feature), column j (output feature)
           float *wr = dWout + (size_t)r * 256 + (4 * k) * 16 + m;
@@ -315,7 +333,7 @@ __global__ __launch_bounds__(64 * NW, 4) void bwd_win_d16_kernel(
         }
       } else {
         if (!(dirty || has)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        reinterpret_cast<f32x4 *>(dWout + ((size_t)r * n_blocks + blockIdx.x) * 256)[lane] = v;
+        reinterpret_cast<f32x4 *>(dWout + ((size_t)r * (n_blocks * (NW / SG)) + blockIdx.x * (NW / SG) + sub) * 256)[lane] = v;
       }
     }
   };
@@ -334,10 +352,61 @@ __global__ __launch_bounds__(64 * NW, 4) void bwd_win_d16_kernel(
       for (int j = 0; j < U; ++j) pk_n[j] = p_pack[min(c + j, last) * RGCN_CHUNK + m];
     };
     request_idx(my0);
+    // PIPE: the gathers and W fragments of a group of U chunks are requested ONE ITERATION AHEAD of their use (their slots two
+    // ahead): a wave's iteration was [issue gathers] -> wait out the memory latency (~2.4 us under load) -> compute (~2.5 us);
+    // with the next group's loads in flight during the compute it is max(latency, compute)
+    int2 pk_c[U];
+    int relv_c = 0;
+    float4 g_c[U], w_c[U];
+    auto gather_addr = [&](int pkx) {
+      const unsigned sj = (unsigned)pkx & 0xFFFFFFu;
+      return (ABL & 1) ? (((unsigned)(row0 + (sj & 63)) << 6) | ((unsigned)k << 4)) : ((sj << 6) | ((unsigned)k << 4));
+    };
+    if (PIPE) {
+      relv_c = relv_n;
+#pragma unroll
+      for (int j = 0; j < U; ++j) pk_c[j] = pk_n[j];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        g_c[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(G) + gather_addr(pk_c[j].x));
+        w_c[j] = reinterpret_cast<const float4 *>(Wtp)[(size_t)__builtin_amdgcn_readlane(relv_c, j) * 64 + lane];
+      }
+      request_idx(my0 + U);
+    }
     for (int c = my0; c < my1; c += U) {
       int s_[U], dl_[U], d_[U], r_[U];
       float v_[U];
       float4 g_[U], w_[U];
+      int2 pk_x[U];
+      int relv_x = 0;
+      float4 g_x[U], w_x[U];
+      if (PIPE) {
+        // next group: slots arrived during the last iteration -> request its rows and W fragments, then the slots after it
+        relv_x = relv_n;
+#pragma unroll
+        for (int j = 0; j < U; ++j) pk_x[j] = pk_n[j];
+#pragma unroll
+        for (int j = 0; j < U; ++j) asm volatile("" : "+v"(pk_x[j].x), "+v"(pk_x[j].y));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          g_x[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(G) + gather_addr(pk_x[j].x));
+          w_x[j] = reinterpret_cast<const float4 *>(Wtp)[(size_t)__builtin_amdgcn_readlane(relv_x, j) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        request_idx(c + 2 * U);
+        __builtin_amdgcn_sched_barrier(0);
+        // current group: requested one iteration ago
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          dl_[j] = (int)((unsigned)pk_c[j].x >> 24);
+          d_[j] = dl_[j] == 0xFF ? -1 : row0 + dl_[j];
+          v_[j] = (c + j <= last) ? __builtin_bit_cast(float, pk_c[j].y) : 0.f;
+          r_[j] = __builtin_amdgcn_readlane(relv_c, j);
+          g_[j] = g_c[j];
+          w_[j] = w_c[j];
+        }
+      } else {
       const int relv = relv_n;
 #pragma unroll
       for (int j = 0; j < U; ++j) {
@@ -354,13 +423,28 @@ __global__ __launch_bounds__(64 * NW, 4) void bwd_win_d16_kernel(
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        const unsigned og = ((unsigned)s_[j] << 6) | ((unsigned)k << 4);
+        const unsigned og = (ABL & 1) ? (((unsigned)(row0 + (s_[j] & 63)) << 6) | ((unsigned)k << 4))
+                                      : (((unsigned)s_[j] << 6) | ((unsigned)k << 4));
         g_[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(G) + og);
         w_[j] = reinterpret_cast<const float4 *>(Wtp)[(size_t)r_[j] * 64 + lane];
       }
       __builtin_amdgcn_sched_barrier(0);
       request_idx(c + U);
       __builtin_amdgcn_sched_barrier(0);
+      }
+      auto rotate = [&]() {
+        if (PIPE) {
+          relv_c = relv_x;
+#pragma unroll
+          for (int j = 0; j < U; ++j) { pk_c[j] = pk_x[j]; g_c[j] = g_x[j]; w_c[j] = w_x[j]; }
+        }
+      };
+      if (ABL & 16) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) asm volatile("" :: "v"(g_[j].x), "v"(g_[j].y), "v"(g_[j].z), "v"(g_[j].w), "v"(w_[j].x), "v"(w_[j].w), "v"(d_[j]), "v"(v_[j]));
+        rotate();
+        continue;
+      }
 #pragma unroll
       for (int j = 0; j < U; ++j) {
         const float v = v_[j];
@@ -373,14 +457,17 @@ __global__ __launch_bounds__(64 * NW, 4) void bwd_win_d16_kernel(
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].y, sc[1], acc[0], 0, 0, 0);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].z, sc[2], acc[0], 0, 0, 0);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].w, sc[3], acc[0], 0, 0, 0);
-        if (fold_segments<1>(acc, d_[j])) {
+        if (ABL & 8) {
+          asm volatile("" :: "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]), "v"(acc[0][3]));
+        } else if (fold_segments<1>(acc, d_[j])) {
           f32x4 *p = reinterpret_cast<f32x4 *>(tile + dl_[j] * 16 + 4 * (k ^ ((dl_[j] >> 2) & 3)));   // swizzled: see tile_swz
           *p += acc[0];
         }
+        if (ABL & 2) continue;
         // ---- dW: relation bookkeeping (wave-uniform)
         const int rj = __builtin_amdgcn_readfirstlane(r_[j]);
         if (rj != cur) {
-          if (cur >= 0) {
+          if (cur >= 0 && !(ABL & 4)) {
             pass_empty(cur);
             contribute(cur, acc_w, true);
             done = cur + 1;
@@ -419,15 +506,350 @@ __global__ __launch_bounds__(64 * NW, 4) void bwd_win_d16_kernel(
         for (int t4 = 0; t4 < 4; ++t4) acc_w = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4], bv[t4], acc_w, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+      rotate();
     }
   }
-  if (cur >= 0) {
-    pass_empty(cur);
-    contribute(cur, acc_w, true);
-    done = cur + 1;
+  if (!(ABL & (2 | 4 | 16))) {
+    if (cur >= 0) {
+      pass_empty(cur);
+      contribute(cur, acc_w, true);
+      done = cur + 1;
+    }
+    pass_empty(R);
+  } else {
+    asm volatile("" :: "v"(acc_w[0]), "v"(acc_w[1]), "v"(acc_w[2]), "v"(acc_w[3]));
   }
-  pass_empty(R);
 
+  if ((ABL & 256) && lane == 0 && (t & 15) == 0) {      // (every 16th wave: the counters' own atomics must not become the bottleneck)
+    atomicAdd(&g_bwd_prof[3], 1ull);
+    atomicAdd(&g_bwd_prof[4], (unsigned long long)n_contrib);
+    atomicAdd(&g_bwd_prof[5], (unsigned long long)n_spin_tag);
+    atomicAdd(&g_bwd_prof[6], (unsigned long long)n_spin_lock);
+    atomicAdd(&g_bwd_prof[7], (unsigned long long)n_cas_fail);
+  }
+  float4 *o4 = reinterpret_cast<float4 *>(dX + (size_t)row0 * 16);
+  for (int i = lane; i < nrows * 4; i += 64) {
+    float4 a = reinterpret_cast<const float4 *>(tile)[tile_swz(i)];
+    if (RELU) {
+      const float4 x = reinterpret_cast<const float4 *>(xt)[i];
+      a.x = x.x > 0.f ? a.x : 0.f; a.y = x.y > 0.f ? a.y : 0.f; a.z = x.z > 0.f ? a.z : 0.f; a.w = x.w > 0.f ? a.w : 0.f;
+    }
+    o4[i] = a;
+  }
+}
+
+// ---- window kernel, second form: the U = 4 chunks of an iteration go through each phase TOGETHER, and the window is taken per
+// GROUP of 4 relations.  Measured on the first form (profiles/r03_bwd_ablation.txt): with the random gathers replaced by
+// tile-local rows it runs as long as with them (0.69 ms) -- the kernel is bound by a wave's chain of dependent latencies (4
+// waves per SIMD): per chunk 4 dependent MFMAs, the fold, an LDS read-modify-write, the LDS transposition, 4 more MFMAs, and
+// one lock / read-modify-write / unlock of the window per relation (0.13 ms by itself, 101 critical sections per tile).  Here
+//   * the dX MFMAs of the four chunks are four independent chains, the four folds run in step (shared wave-uniform exits),
+//     the transposition writes / reads of the four chunks are issued back to back (the LDS pipeline is in order) and waited
+//     for once, each chunk's dW product starts from a zero accumulator (four independent chains) and is added to the held
+//     partial of its relation afterwards;
+//   * a wave holds the finished partials of a group of 4 consecutive relations in 16 registers and enters the window once per
+//     group: 26 critical sections per tile, each moving up to four 1 KiB slots; state = group << 16 | dirty (4 bits) << 8 |
+//     contributions << 1 | lock; NG groups in the window.
+constexpr int WIN_GS = 4;       // relations per window group
+
+
+// a * b with 0 * anything = 0 (v_mul_legacy_f32): a pad slot (val = 0) stays exactly zero whatever row it gathered
+__device__ __forceinline__ float mul0(float a, float b) {
+  float r;
+  asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+constexpr int BW_SCR2 = 16 * 16;  // floats of transposition scratch per wave: [16 slots][16 features], the float4 column of features 4k..4k+3 of
+                                  // slot m is stored at column (k + (m >> 1)) & 3 (b128 writes of 8 consecutive slots and b32 reads of two
+                                  // consecutive slots are conflict-free without the 4-float row padding of the first form: 1 KiB, not 1.25)
+
+template <int NW, int NG, bool ATOMIC, bool RELU, int ABL = 0>
+__global__ __launch_bounds__(64 * NW, 4) void bwd_win2_d16_kernel(
+    const float *__restrict__ G, const float *__restrict__ X, const float *__restrict__ Wtp, float *__restrict__ dX,
+    float *__restrict__ dWout, const int2 *__restrict__ p_pack, const int *__restrict__ chunk_rel,
+    const int *__restrict__ run_ptr, int n_tiles, int n_blocks, int tile_rows, int n_dst, int R) {
+  constexpr int U = 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int t = blockIdx.x * NW + wave;
+  const bool valid = t < n_tiles;
+  const int nwv = min(NW, n_tiles - (int)blockIdx.x * NW);       // waves of this workgroup that own a tile
+  float *tile = lds + wave * tile_rows * 16;                     // dX tile (swizzled, tile_swz)
+  float *xt = lds + (NW + wave) * tile_rows * 16;                // X tile (row-major)
+  float *xs = lds + 2 * NW * tile_rows * 16 + wave * BW_SCR2;    // transposition scratch
+  float *win = lds + 2 * NW * tile_rows * 16 + NW * BW_SCR2;     // [NG][WIN_GS][256] fragment order
+  int *state = reinterpret_cast<int *>(win + NG * WIN_GS * 256); // [NG]
+  const int row0 = t * tile_rows;
+  const int nrows = valid ? min(tile_rows, n_dst - row0) : 0;
+  for (int i = lane; i < nrows * 4; i += 64) {
+    reinterpret_cast<float4 *>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4 *>(xt)[i] = reinterpret_cast<const float4 *>(X + (size_t)row0 * 16)[i];
+  }
+  if (tid < NG) state[tid] = tid << 16;                           // slot group q serves relation group q first
+  __syncthreads();                                                // the only workgroup barrier
+  if (!valid) return;
+
+  const int my0 = run_ptr[(size_t)t * (R + 1)], my1 = run_ptr[(size_t)t * (R + 1) + R];
+  const int m = lane & 15, k = lane >> 4;
+  unsigned long long t_wave0 = 0, t_contrib = 0, t_wait = 0, n_contrib = 0;
+  unsigned n_spin_tag = 0, n_spin_lock = 0, n_cas_fail = 0;     // ABL & 256: how often a hand-over finds the slot not ready / taken
+  if (ABL & 128) t_wave0 = __builtin_amdgcn_s_memtime();
+  const int n_groups = (R + WIN_GS - 1) / WIN_GS;
+  int doneg = 0;                // relation groups [0, doneg) have been contributed by this wave
+  int curg = -1;                // group whose partials are held (-1: none)
+  int hasmask = 0;              // which of the group's relations have data in hold[]
+  f32x4 hold[WIN_GS];
+#pragma unroll
+  for (int q = 0; q < WIN_GS; ++q) hold[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int xrd = (int)((xt - lds) * 4) + m * 4;       // byte address of X_lds[0][m]
+  float *xs_wr = xs + m * 16 + 4 * ((k + (m >> 1)) & 3);                                  // this lane's float4 of slot m
+  const float *xs_rd0 = xs + k * 16 + 4 * (((m >> 2) + (k >> 1)) & 3) + (m & 3);          // feature m of slot 4 t + k, t even: + 128 t
+  const float *xs_rd1 = xs + (4 + k) * 16 + 4 * (((m >> 2) + 2 + (k >> 1)) & 3) + (m & 3); // t odd: + 128 (t - 1)
+
+  // hand this wave's partials of relation group g to the shared window (mask: which relations carry data)
+  auto contribute = [&](int g, const f32x4 (&part)[WIN_GS], int mask) {
+    const int gq = (int)((unsigned)g % (unsigned)NG);
+    int *st = state + gq;
+    f32x4 *slot = reinterpret_cast<f32x4 *>(win + gq * (WIN_GS * 256)) + lane;
+    int s;
+    unsigned long long tc0 = 0;
+    if (ABL & 128) tc0 = __builtin_amdgcn_s_memtime();
+    if (ATOMIC) {
+      for (;;) {
+        s = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (((ABL & 32) || (s >> 16) == g) && !(s & 1)) {
+          int ok = 0;
+          if (lane == 0) {
+            int e = s;
+            ok = __hip_atomic_compare_exchange_strong(st, &e, s | 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          if (__builtin_amdgcn_readfirstlane(ok)) break;
+          if (ABL & 256) ++n_cas_fail;
+        } else if (ABL & 256) {
+          if ((s >> 16) != g) ++n_spin_tag; else ++n_spin_lock;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    } else {
+      for (;;) {      // fixed order: wave 0, 1, ... (bit-reproducible sums)
+        s = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if ((s >> 16) == g && ((s >> 1) & 31) == wave) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (ABL & 128) t_wait += __builtin_amdgcn_s_memtime() - tc0;
+    const int c = (s >> 1) & 31;
+    const int dirty = (s >> 8) & 15;                             // slots somebody added data to
+    const bool last = c + 1 == nwv;
+    const int touch = last ? (dirty | mask) : mask;              // slots this wave reads / writes
+    f32x4 v[WIN_GS];
+#pragma unroll
+    for (int q = 0; q < WIN_GS; ++q) {
+      v[q] = part[q];
+      if ((touch & dirty) >> q & 1) v[q] = slot[q * 64];
+    }
+#pragma unroll
+    for (int q = 0; q < WIN_GS; ++q)
+      if (((touch & dirty) >> q & 1) && (mask >> q & 1)) v[q] += part[q];
+    if (!last) {
+#pragma unroll
+      for (int q = 0; q < WIN_GS; ++q)
+        if (mask >> q & 1) slot[q * 64] = v[q];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0)
+        __hip_atomic_store(st, (g << 16) | ((dirty | mask) << 8) | ((c + 1) << 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(st, (g + NG) << 16, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+      for (int q = 0; q < WIN_GS; ++q) {
+        const int r = g * WIN_GS + q;
+        if (r >= R) break;
+        if (ABL & 64) {
+          asm volatile("" :: "v"(v[q][0]), "v"(v[q][1]), "v"(v[q][2]), "v"(v[q][3]));
+        } else if (ATOMIC) {
+          if (touch >> q & 1) {  // D: lane 16q+j holds rows 4q..4q+3 (input feature), column j (output feature)
+            float *wr = dWout + (size_t)r * 256 + (4 * k) * 16 + m;
+            atomicAdd(wr, v[q][0]); atomicAdd(wr + 16, v[q][1]); atomicAdd(wr + 32, v[q][2]); atomicAdd(wr + 48, v[q][3]);
+          }
+        } else {
+          reinterpret_cast<f32x4 *>(dWout + ((size_t)r * n_blocks + blockIdx.x) * 256)[lane] = (touch >> q & 1) ? v[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    if (ABL & 128) { t_contrib += __builtin_amdgcn_s_memtime() - tc0; ++n_contrib; }
+    if (ABL & 256) ++n_contrib;
+  };
+  // leave the held group: groups before it that this wave never saw pass empty, then the group itself
+  auto flush_group = [&]() {
+    if (ABL & 4) return;
+    const f32x4 zero[WIN_GS] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (; doneg < curg; ++doneg) contribute(doneg, zero, 0);
+    contribute(curg, hold, hasmask);
+    doneg = curg + 1;
+  };
+
+  if (my0 < my1) {
+    const int last = my1 - 1;
+    int2 pk_n[U];
+    int relv_n;
+    auto request_idx = [&](int c) {
+      relv_n = chunk_rel[min(c + (lane & (U - 1)), last)];
+#pragma unroll
+      for (int j = 0; j < U; ++j) pk_n[j] = p_pack[min(c + j, last) * RGCN_CHUNK + m];
+    };
+    request_idx(my0);
+    for (int c = my0; c < my1; c += U) {
+      int s_[U], dl_[U], d_[U], r_[U];
+      float v_[U];
+      float4 g_[U], w_[U];
+      const int relv = relv_n;
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const int2 pk = pk_n[j];
+        s_[j] = pk.x & 0xFFFFFF;
+        dl_[j] = (int)((unsigned)pk.x >> 24);
+        d_[j] = dl_[j] == 0xFF ? -1 : dl_[j];                  // row inside the tile (the fold only compares them)
+        v_[j] = (c + j <= last) ? __builtin_bit_cast(float, pk.y) : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) r_[j] = __builtin_amdgcn_readlane(relv, j);
+#pragma unroll
+      for (int j = 0; j < U; ++j) asm volatile("" : "+v"(d_[j]), "+v"(v_[j]));   // pin the index data here
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const unsigned og = (ABL & 1) ? (((unsigned)(row0 + (s_[j] & 63)) << 6) | ((unsigned)k << 4))
+                                      : (((unsigned)s_[j] << 6) | ((unsigned)k << 4));
+        g_[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(G) + og);
+        w_[j] = reinterpret_cast<const float4 *>(Wtp)[(size_t)r_[j] * 64 + lane];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      request_idx(c + U);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ABL & 16) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) asm volatile("" :: "v"(g_[j].x), "v"(g_[j].y), "v"(g_[j].z), "v"(g_[j].w), "v"(w_[j].x), "v"(w_[j].w), "v"(d_[j]), "v"(v_[j]));
+        continue;
+      }
+      // ---- phase 1: scaled rows (0 * anything = 0: pads and slots past the range stay exactly zero), dX products
+      f32x4 sc[U], acc[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        sc[j] = f32x4{mul0(g_[j].x, v_[j]), mul0(g_[j].y, v_[j]),
+                      mul0(g_[j].z, v_[j]), mul0(g_[j].w, v_[j])};
+        acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].x, sc[j][0], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].y, sc[j][1], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].z, sc[j][2], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].w, sc[j][3], acc[j], 0, 0, 0);
+      // ---- phase 2: dW products, two chunks at a time: B[mu][j'] = val G[s_mu][j'] through the scratch (written as rows of a
+      // slot, read as one feature of four slots), A[i][mu] = X[o_mu][i] from the LDS copy of the tile's rows
+      if (!(ABL & 2)) {
+        f32x4 aw[U];
+#pragma unroll
+        for (int h = 0; h < U; h += 2) {
+          float bv[2][4], av[2][4];
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int j = h + jj;
+            const int dlc = dl_[j] == 0xFF ? 0 : dl_[j];            // pads: B is 0, keep A finite and inside the tile
+            int rot = dlc;                                          // lane (k, m) <- dl of slot (m + k) & 15
+            rot = __builtin_amdgcn_update_dpp(rot, rot, 0x120 + 15, 0x2, 0xF, false);
+            rot = __builtin_amdgcn_update_dpp(rot, rot, 0x120 + 14, 0x4, 0xF, false);
+            rot = __builtin_amdgcn_update_dpp(rot, rot, 0x120 + 13, 0x8, 0xF, false);
+            asm volatile("" ::: "memory");
+            *reinterpret_cast<f32x4 *>(xs_wr) = sc[j];
+            asm volatile("" ::: "memory");
+            bv[jj][0] = xs_rd0[0]; bv[jj][1] = xs_rd1[0]; bv[jj][2] = xs_rd0[128]; bv[jj][3] = xs_rd1[128];
+            int rowk[4];                                            // row_share: destination row of slot 4 t4 + k
+            rowk[0] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 0, 0xF, 0xF, false);
+            rowk[1] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 4, 0xF, 0xF, false);
+            rowk[2] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 8, 0xF, 0xF, false);
+            rowk[3] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 12, 0xF, 0xF, false);
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4)
+              av[jj][t4] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(lds) + (xrd + (rowk[t4] << 6)));
+            asm volatile("" ::: "memory");
+          }
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) aw[h + jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+              aw[h + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj][t4], bv[jj][t4], aw[h + jj], 0, 0, 0);
+        }
+        // relation bookkeeping (wave-uniform): add each chunk's product to the held partial of its relation
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          const int rj = __builtin_amdgcn_readfirstlane(r_[j]);
+          const int gj = rj >> 2, qj = rj & 3;
+          if (gj != curg) {
+            if (curg >= 0) {
+              flush_group();
+#pragma unroll
+              for (int q = 0; q < WIN_GS; ++q) hold[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            curg = gj;
+            hasmask = 0;
+          }
+          hasmask |= 1 << qj;
+          if (qj == 0) hold[0] += aw[j];
+          else if (qj == 1) hold[1] += aw[j];
+          else if (qj == 2) hold[2] += aw[j];
+          else hold[3] += aw[j];
+        }
+      }
+      // ---- phase 3: fold equal destinations (the four chunks in step), one LDS update per segment, chunk after chunk (two
+      // chunks of a tile may end in the same row)
+      if (ABL & 8) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) asm volatile("" :: "v"(acc[j][0]), "v"(acc[j][1]), "v"(acc[j][2]), "v"(acc[j][3]));
+      } else {
+        bool tail[U];
+        fold_segments_multi<U>(acc, d_, tail);
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          if (tail[j]) {
+            f32x4 *p = reinterpret_cast<f32x4 *>(tile + dl_[j] * 16 + 4 * (k ^ ((dl_[j] >> 2) & 3)));   // swizzled: see tile_swz
+            *p += acc[j];
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (!(ABL & (2 | 4 | 16))) {
+    if (curg >= 0) flush_group();
+    const f32x4 zero[WIN_GS] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (; doneg < n_groups; ++doneg) contribute(doneg, zero, 0);
+  } else {
+#pragma unroll
+    for (int q = 0; q < WIN_GS; ++q) asm volatile("" :: "v"(hold[q][0]), "v"(hold[q][1]), "v"(hold[q][2]), "v"(hold[q][3]));
+  }
+
+  if ((ABL & 256) && lane == 0 && (t & 15) == 0) {
+    atomicAdd(&g_bwd_prof[3], 1ull);
+    atomicAdd(&g_bwd_prof[4], n_contrib);
+    atomicAdd(&g_bwd_prof[5], (unsigned long long)n_spin_tag);
+    atomicAdd(&g_bwd_prof[6], (unsigned long long)n_spin_lock);
+    atomicAdd(&g_bwd_prof[7], (unsigned long long)n_cas_fail);
+  }
+  if ((ABL & 128) && lane == 0) {
+    atomicAdd(&g_bwd_prof[0], __builtin_amdgcn_s_memtime() - t_wave0);
+    atomicAdd(&g_bwd_prof[1], t_contrib);
+    atomicAdd(&g_bwd_prof[2], t_wait);
+    atomicAdd(&g_bwd_prof[3], 1ull);
+    atomicAdd(&g_bwd_prof[4], n_contrib);
+  }
   float4 *o4 = reinterpret_cast<float4 *>(dX + (size_t)row0 * 16);
   for (int i = lane; i < nrows * 4; i += 64) {
     float4 a = reinterpret_cast<const float4 *>(tile)[tile_swz(i)];
@@ -552,6 +974,15 @@ __global__ __launch_bounds__(WG) void pack_w16t_kernel(const float *__restrict__
   Wp[i] = W[r * 256 + o * 16 + (4 * kk + c)];
 }
 
+// both fragment orders of W in one launch (forward: Wp[r][lane = 16k+o][c] = W[r][4k+c][o]; backward: Wtp[r][lane = 16k+f][c] = W[r][f][4k+c])
+__global__ __launch_bounds__(WG) void pack_w16_pair_kernel(const float *__restrict__ W, float *__restrict__ Wp, float *__restrict__ Wtp, int n) {
+  const int i = blockIdx.x * WG + threadIdx.x;
+  if (i >= n) return;
+  const int c = i & 3, o = (i >> 2) & 15, kk = (i >> 6) & 3, r = i >> 8;
+  Wp[i] = W[r * 256 + (4 * kk + c) * 16 + o];
+  Wtp[i] = W[r * 256 + o * 16 + (4 * kk + c)];
+}
+
 struct BwdLaunch {
   const float *G, *X, *Wtp;
   float *dX, *dWout;
@@ -584,13 +1015,13 @@ hipError_t launch_bwd8(const BwdLaunch &a) {
 }
 
 // window kernel (round 3): NW waves per workgroup, DW window slots; needs more than 64 KiB of LDS at 64-row tiles
-template <int NW, int DW>
+template <int NW, int DW, int SG = NW>
 size_t bwd_win_lds(int tile_rows) {
-  return ((size_t)2 * NW * tile_rows * 16 + NW * BW_SCR + DW * 256) * sizeof(float) + DW * sizeof(int);
+  return ((size_t)2 * NW * tile_rows * 16 + NW * BW_SCR + (NW / SG) * DW * 256) * sizeof(float) + (NW / SG) * DW * sizeof(int);
 }
-template <int NW, int DW, bool AT, bool RELU, bool BPERM>
+template <int NW, int DW, bool AT, bool RELU, bool BPERM, int ABL = 0, bool PIPE = false, int SG = NW>
 hipError_t launch_bwd_win(const BwdLaunch &a) {
-  auto kern = bwd_win_d16_kernel<4, NW, DW, AT, RELU, BPERM>;
+  auto kern = bwd_win_d16_kernel<4, NW, DW, AT, RELU, BPERM, ABL, PIPE, SG>;
   static bool raised = false;                    // once per process and instantiation (not a stream operation)
   if (a.lds > 64 * 1024 && !raised) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -603,8 +1034,89 @@ hipError_t launch_bwd_win(const BwdLaunch &a) {
 }
 template <int NW, int DW, bool AT>
 hipError_t launch_bwd_win_f(const BwdLaunch &a, bool relu, bool bperm) {
+  static const int ABL = getenv("RGCN_BWD_ABL") ? atoi(getenv("RGCN_BWD_ABL")) : 0;     // timing experiments (wrong results)
+  static const int SGSEL = getenv("RGCN_BWD_SG") ? atoi(getenv("RGCN_BWD_SG")) : 0;      // waves per window (experiments)
+  if (NW == 16 && AT && SGSEL == 8) {
+    BwdLaunch b = a; b.lds = bwd_win_lds<16, 4, 8>(a.tile_rows);
+    return ABL == 256 ? launch_bwd_win<16, 4, true, false, false, 256, false, 8>(b) : launch_bwd_win<16, 4, true, false, false, 0, false, 8>(b);
+  }
+  if (NW == 16 && AT && SGSEL == 4) {
+    BwdLaunch b = a; b.lds = bwd_win_lds<16, 2, 4>(a.tile_rows);
+    return ABL == 256 ? launch_bwd_win<16, 2, true, false, false, 256, false, 4>(b) : launch_bwd_win<16, 2, true, false, false, 0, false, 4>(b);
+  }
+  if (NW == 16 && AT && SGSEL == 43) {
+    BwdLaunch b = a; b.lds = bwd_win_lds<16, 3, 4>(a.tile_rows);
+    return launch_bwd_win<16, 3, true, false, false, 0, false, 4>(b);
+  }
+  static const bool PIPE = getenv("RGCN_BWD_PIPE") && atoi(getenv("RGCN_BWD_PIPE"));
+  if (NW == 16 && AT && PIPE) {
+    switch (ABL) {
+      case 0: return launch_bwd_win<16, 8, true, false, false, 0, true>(a);
+      case 1: return launch_bwd_win<16, 8, true, false, false, 1, true>(a);
+      case 4: return launch_bwd_win<16, 8, true, false, false, 4, true>(a);
+      case 5: return launch_bwd_win<16, 8, true, false, false, 5, true>(a);
+      case 16: return launch_bwd_win<16, 8, true, false, false, 16, true>(a);
+      default: break;
+    }
+  }
+  if (NW == 16 && AT && ABL) {
+    switch (ABL) {
+      case 256: return launch_bwd_win<16, 8, true, false, false, 256>(a);
+      case 1: return launch_bwd_win<16, 8, true, false, false, 1>(a);
+      case 2: return launch_bwd_win<16, 8, true, false, false, 2>(a);
+      case 3: return launch_bwd_win<16, 8, true, false, false, 3>(a);
+      case 4: return launch_bwd_win<16, 8, true, false, false, 4>(a);
+      case 5: return launch_bwd_win<16, 8, true, false, false, 5>(a);
+      case 8: return launch_bwd_win<16, 8, true, false, false, 8>(a);
+      case 10: return launch_bwd_win<16, 8, true, false, false, 10>(a);
+      case 11: return launch_bwd_win<16, 8, true, false, false, 11>(a);
+      case 16: return launch_bwd_win<16, 8, true, false, false, 16>(a);
+      default: break;
+    }
+  }
   if (bperm) return launch_bwd_win<NW, DW, AT, false, true>(a);
   return relu ? launch_bwd_win<NW, DW, AT, true, false>(a) : launch_bwd_win<NW, DW, AT, false, false>(a);
+}
+
+template <int NW, int NG>
+size_t bwd_win2_lds(int tile_rows) {
+  return ((size_t)2 * NW * tile_rows * 16 + NW * BW_SCR2 + NG * WIN_GS * 256) * sizeof(float) + NG * sizeof(int);
+}
+template <int NW, int NG, bool AT, bool RELU, int ABL = 0>
+hipError_t launch_bwd_win2(const BwdLaunch &a) {
+  auto kern = bwd_win2_d16_kernel<NW, NG, AT, RELU, ABL>;
+  static bool raised = false;                    // once per process and instantiation (not a stream operation)
+  if (a.lds > 64 * 1024 && !raised) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    raised = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.n_blocks), dim3(64 * NW), a.lds, a.st, a.G, a.X, a.Wtp, a.dX, a.dWout, a.pk, a.chunk_rel,
+                     a.run_ptr, a.n_tiles, a.n_blocks, a.tile_rows, a.n_dst, a.R);
+  return hipGetLastError();
+}
+template <int NW, int NG, bool AT>
+hipError_t launch_bwd_win2_f(const BwdLaunch &a, bool relu) {
+  static const int ABL = getenv("RGCN_BWD_ABL") ? atoi(getenv("RGCN_BWD_ABL")) : 0;     // timing experiments (wrong results)
+  if (NW == 16 && AT && ABL) {
+    switch (ABL) {
+      case 1: return launch_bwd_win2<16, 3, true, false, 1>(a);
+      case 2: return launch_bwd_win2<16, 3, true, false, 2>(a);
+      case 3: return launch_bwd_win2<16, 3, true, false, 3>(a);
+      case 4: return launch_bwd_win2<16, 3, true, false, 4>(a);
+      case 5: return launch_bwd_win2<16, 3, true, false, 5>(a);
+      case 8: return launch_bwd_win2<16, 3, true, false, 8>(a);
+      case 11: return launch_bwd_win2<16, 3, true, false, 11>(a);
+      case 16: return launch_bwd_win2<16, 3, true, false, 16>(a);
+      case 32: return launch_bwd_win2<16, 3, true, false, 32>(a);
+      case 64: return launch_bwd_win2<16, 3, true, false, 64>(a);
+      case 96: return launch_bwd_win2<16, 3, true, false, 96>(a);
+      case 128: return launch_bwd_win2<16, 3, true, false, 128>(a);
+      case 256: return launch_bwd_win2<16, 3, true, false, 256>(a);
+      default: break;
+    }
+  }
+  return relu ? launch_bwd_win2<NW, NG, AT, true>(a) : launch_bwd_win2<NW, NG, AT, false>(a);
 }
 
 template <int U, bool AT>
@@ -616,10 +1128,27 @@ void launch_bwd_d(const BwdLaunch &a, int D) {
 
 }  // namespace
 
+extern "C" int rgcn_debug_bwd_prof(uint64_t *out8, int32_t reset) {
+  if (out8) HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bwd_prof), 8 * sizeof(uint64_t)));
+  if (reset) {
+    const uint64_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_prof), z, sizeof(z)));
+  }
+  return RGCN_OK;
+}
+
 extern "C" int rgcn_pack_w16t_f32(const float *W, float *Wp, int32_t R, void *stream) {
   if (!W || !Wp || R <= 0) { rgcn_set_error("pack_w16t: bad argument"); return RGCN_EINVAL; }
   const int n = R * 256;
   hipLaunchKernelGGL(pack_w16t_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, (hipStream_t)stream, W, Wp, n);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_pack_w16_pair_f32(const float *W, float *Wp, float *Wtp, int32_t R, void *stream) {
+  if (!W || !Wp || !Wtp || R <= 0) { rgcn_set_error("pack_w16_pair: bad argument"); return RGCN_EINVAL; }
+  const int n = R * 256;
+  hipLaunchKernelGGL(pack_w16_pair_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, (hipStream_t)stream, W, Wp, Wtp, n);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
@@ -647,6 +1176,33 @@ extern "C" int rgcn_bwd_fused_f32(const float *G, const float *X, const float *W
   static const bool WANT_WIN = !(getenv("RGCN_BWD_KERNEL") && !strcmp(getenv("RGCN_BWD_KERNEL"), "stage"));
   static const int WIN_NW = getenv("RGCN_BWD_NW") ? atoi(getenv("RGCN_BWD_NW")) : 16;
   static const bool WIN_BPERM = getenv("RGCN_BWD_BPERM") && atoi(getenv("RGCN_BWD_BPERM"));
+  static const bool WANT_WIN1 = getenv("RGCN_BWD_KERNEL") && !strcmp(getenv("RGCN_BWD_KERNEL"), "win1");
+  if (WANT_WIN && !WANT_WIN1) {      // second form of the window kernel (phases over 4 chunks, window per group of 4 relations)
+    const bool nw16 = WIN_NW >= 16 && bwd_win2_lds<16, 3>(tile_rows) <= 160 * 1024;
+    const bool nw8 = !nw16 && bwd_win2_lds<8, 1>(tile_rows) <= 160 * 1024;
+    if (nw16 || nw8) {
+      const int NWv = nw16 ? 16 : 8;
+      const int n_blocks = (int)((n_tiles + NWv - 1) / NWv);
+      hipStream_t st = (hipStream_t)stream;
+      static const size_t LDS_PAD = getenv("RGCN_BWD_LDS_PAD") ? (size_t)atoi(getenv("RGCN_BWD_LDS_PAD")) : 0;   // occupancy experiments
+      const BwdLaunch L{G, X, Wt_packed, dX, atomic ? dW : scratch, reinterpret_cast<const int2 *>(p_pack), chunk_rel, run_ptr,
+                        (int)n_tiles, n_blocks, tile_rows, (int)n_dst, R, (nw16 ? bwd_win2_lds<16, 3>(tile_rows) : bwd_win2_lds<8, 1>(tile_rows)) + LDS_PAD, st};
+      if (atomic) {
+        HIP_TRY(zero_async(dW, (size_t)R * 256 * sizeof(float), st));
+        if (nw16) HIP_TRY((launch_bwd_win2_f<16, 3, true>(L, relu)));
+        else HIP_TRY((launch_bwd_win2_f<8, 1, true>(L, relu)));
+      } else {
+        if (nw16) HIP_TRY((launch_bwd_win2_f<16, 3, false>(L, relu)));
+        else HIP_TRY((launch_bwd_win2_f<8, 1, false>(L, relu)));
+        const int S = (int)std::max<int64_t>(1, std::min<int64_t>(16, n_blocks / 64));
+        float *tmp = scratch + (size_t)n_blocks * R * 256;
+        hipLaunchKernelGGL(dw_reduce_a_kernel, dim3((unsigned)R, (unsigned)S), dim3(WG), 0, st, scratch, tmp, n_blocks, S);
+        hipLaunchKernelGGL(dw_reduce_b_kernel, dim3((unsigned)R), dim3(WG), 0, st, tmp, dW, S);
+        HIP_TRY(hipGetLastError());
+      }
+      return RGCN_OK;
+    }
+  }
   if (WANT_WIN) {
     const bool nw16 = WIN_NW >= 16 && bwd_win_lds<16, 8>(tile_rows) <= 160 * 1024;
     const bool nw8 = !nw16 && bwd_win_lds<8, 4>(tile_rows) <= 160 * 1024;

@@ -101,4 +101,44 @@ __device__ __forceinline__ bool fold_segments(f32x4 (&acc)[NV], int dst) {
 }
 
 
+// The same fold for NC chunks at once (each with its own destinations): the chunks' steps are interleaved and share the
+// wave-uniform early exits -- a step is taken by all chunks when any of them needs it (independent dependency chains for the
+// scheduler instead of NC chains one after the other).  tail[c] = last lane of every run of real slots of chunk c.
+template <int NC>
+__device__ __forceinline__ void fold_segments_multi(f32x4 (&acc)[NC], const int (&dst)[NC], bool (&tail)[NC]) {
+#define RGCN_FOLDM_STEP(N, SAME)                                                       \
+  _Pragma("unroll") for (int c = 0; c < NC; ++c) {                                     \
+    const float sf = (SAME)[c] ? 1.f : 0.f;                                            \
+    acc[c][0] = fmaf(dpp_shr0<N>(acc[c][0]), sf, acc[c][0]);                           \
+    acc[c][1] = fmaf(dpp_shr0<N>(acc[c][1]), sf, acc[c][1]);                           \
+    acc[c][2] = fmaf(dpp_shr0<N>(acc[c][2]), sf, acc[c][2]);                           \
+    acc[c][3] = fmaf(dpp_shr0<N>(acc[c][3]), sf, acc[c][3]);                           \
+  }
+  bool s1[NC], any = false;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { s1[c] = dpp_i<ROW_SHR + 1>(-1, dst[c]) == dst[c] && dst[c] >= 0; any |= s1[c]; }
+  if (__builtin_amdgcn_ballot_w64(any)) {
+    RGCN_FOLDM_STEP(1, s1)
+    bool s2[NC]; any = false;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { s2[c] = dpp_i<ROW_SHR + 2>(-1, dst[c]) == dst[c] && dst[c] >= 0; any |= s2[c]; }
+    if (__builtin_amdgcn_ballot_w64(any)) {
+      RGCN_FOLDM_STEP(2, s2)
+      bool s4[NC]; any = false;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) { s4[c] = dpp_i<ROW_SHR + 4>(-1, dst[c]) == dst[c] && dst[c] >= 0; any |= s4[c]; }
+      if (__builtin_amdgcn_ballot_w64(any)) {
+        RGCN_FOLDM_STEP(4, s4)
+        bool s8[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) s8[c] = dpp_i<ROW_SHR + 8>(-1, dst[c]) == dst[c] && dst[c] >= 0;
+        RGCN_FOLDM_STEP(8, s8)
+      }
+    }
+  }
+#undef RGCN_FOLDM_STEP
+#pragma unroll
+  for (int c = 0; c < NC; ++c) tail[c] = dpp_i<ROW_SHL + 1>(-2, dst[c]) != dst[c] && dst[c] >= 0;
+}
+
 }  // namespace

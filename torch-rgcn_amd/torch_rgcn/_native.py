@@ -691,12 +691,36 @@ def _req(t, name, dtype=torch.float32):
 F_RELU, F_WPACKED = 1, 2
 
 
-def pack_w16(W):
-    """[R,16,16] weights -> MFMA fragment order (one float4 per lane), see rgcn_pack_w16_f32"""
-    Wp = torch.empty_like(W)
+# (weak reference to the weight tensor, its version counter) -> (Wp, Wtp): both fragment orders of a [R,16,16] weight, packed
+# in ONE launch the first time either is asked for and reused until the tensor is written to (in-place optimiser updates
+# bump `_version`) or dies.  Keyed by object identity, never by address: a new tensor at a recycled address is a new entry.
+_PACKED_W16 = {}
+
+
+def _packed_w16(W):
+    import weakref
+    key = id(W)
+    capturing = torch.cuda.is_current_stream_capturing()      # a captured step packs inside the graph: replays see the weights of THEIR step
+    hit = None if capturing else _PACKED_W16.get(key)
+    if hit is not None and hit[0]() is W and hit[1] == W._version:
+        return hit[2], hit[3]
+    if len(_PACKED_W16) >= 16:                      # dead or stale entries: drop them all (a model holds a handful of layers)
+        for k in [k for k, v in _PACKED_W16.items() if v[0]() is None or k == key]:
+            del _PACKED_W16[k]
+        if len(_PACKED_W16) >= 16:
+            _PACKED_W16.clear()
+    Wp, Wtp = torch.empty_like(W), torch.empty_like(W)
     with _on(W.device):
-        _check(lib().rgcn_pack_w16_f32(_dp(W), _dp(Wp), c_i32(W.shape[0]), _stream(W.device)), "pack_w16")
-    return Wp
+        _check(lib().rgcn_pack_w16_pair_f32(_dp(W), _dp(Wp), _dp(Wtp), c_i32(W.shape[0]), _stream(W.device)), "pack_w16_pair")
+    if not capturing:
+        _PACKED_W16[key] = (weakref.ref(W), W._version, Wp, Wtp)
+    return Wp, Wtp
+
+
+def pack_w16(W):
+    """[R,16,16] weights -> MFMA fragment order (one float4 per lane), see rgcn_pack_w16_f32 (cached with the transposed
+    fragments, rgcn_pack_w16_pair_f32)"""
+    return _packed_w16(W)[0]
 
 
 def _spmm_launch(X, W, bias, plan, out, flags, u0, u1, n_split, tag):
@@ -904,11 +928,9 @@ F_TRANSPOSE_W = 8
 
 
 def pack_w16t(W):
-    """[R,16,16] weights -> fragments of W^T (what the feature-gradient kernels multiply by), see rgcn_pack_w16t_f32"""
-    Wp = torch.empty_like(W)
-    with _on(W.device):
-        _check(lib().rgcn_pack_w16t_f32(_dp(W), _dp(Wp), c_i32(W.shape[0]), _stream(W.device)), "pack_w16t")
-    return Wp
+    """[R,16,16] weights -> fragments of W^T (what the feature-gradient kernels multiply by), see rgcn_pack_w16t_f32 (cached
+    with the forward fragments)"""
+    return _packed_w16(W)[1]
 
 
 def bwd_fused_ok(plan):
@@ -921,7 +943,7 @@ def bwd_fused_relu_ok(plan):
     """RGCN_F_RELU of rgcn_bwd_fused_f32 (dX masked with X > 0 in the epilogue) exists in the window kernel only: its LDS
     (dX tile + X tile + scratch per wave, 8 waves at least) has to fit"""
     return os.environ.get("RGCN_BWD_KERNEL", "win") != "stage" and \
-        (2 * 8 * plan.tile_rows * 16 + 8 * 320 + 4 * 256) * 4 + 16 <= 160 * 1024
+        (2 * 8 * plan.tile_rows * 16 + 8 * 256 + 4 * 256) * 4 + 4 <= 160 * 1024
 
 
 def bwd_fused(G, X, W, plan, atomic=False, relu=False):

@@ -77,7 +77,21 @@ _SUMMED_PARAMS = ("bases",)
 _PER_RELATION_PARAMS = ("weights", "comps", "blocks")
 
 
-def shard_layer(layer, group=None, keep="all"):
+TRANSPORTS = ("allreduce", "rs_ag", "a2a", "none")
+
+
+def set_transport(layer, comm="allreduce", slabs=0):
+    """How a sharded layer sums its partial N x d matrices over the group (functional._join_shards): "allreduce", "rs_ag"
+    (reduce-scatter + all-gather), "a2a" (direct exchange: all-to-all of row blocks + local sum + all-gather); slabs > 0
+    (with "allreduce"): the partial is produced slab by slab and every slab is reduced asynchronously while the next one's
+    kernels run.  "none" skips the collective -- TIMING ONLY (bench.py's compute-alone leg), the numbers are wrong.
+    State of the layer, not of the process."""
+    assert comm in TRANSPORTS, f"unknown transport {comm!r}"
+    layer._shard_transport = (comm, int(slabs))
+    return layer
+
+
+def shard_layer(layer, group=None, keep="all", comm=None, slabs=None):
     """Turn a RelationalGraphConvolutionNC into one shard of a relation-sharded layer.
 
     keep="all"  : the layer's triples already ARE this rank's relations (weak scaling: every rank
@@ -87,15 +101,23 @@ def shard_layer(layer, group=None, keep="all"):
 
     Parameter gradients: `bias` is computed from the replicated upstream gradient (identical on every rank);
     `bases` (basis decomposition: W_r = sum_b comps[r,b] bases[b]) receives contributions from every relation, so its
-    gradient is all-reduced here (a hook; B x d_in x d_out floats) and the replicas stay in step; `weights` / `comps` /
-    `blocks` have one row per relation and the row's gradient exists on the owner only -- rows of relations a rank does
-    not own keep their values there, `gather_owned_parameters()` assembles the complete tensors (checkpoints).
+    gradient is all-reduced here (a hook; B x d_in x d_out floats; both keep modes) and the replicas stay in step;
+    `weights` / `comps` / `blocks` have one row per relation and the row's gradient exists on the owner only.  Rows of
+    relations a rank does not own get a ZERO gradient there, but an optimiser with weight decay or momentum still moves
+    them: they are not authoritative -- CHECKPOINTS MUST GO THROUGH `gather_owned_parameters()` (a plain state_dict()
+    of one rank holds stale rows for the relations it does not own), and `sync_owned_parameters()` copies the owners'
+    rows back into every replica (call it before evaluation on a single rank or every few hundred steps).
     """
     group = group if group is not None else dist.group.WORLD
     layer._shard_group = group
     layer._shard_keep = keep
     layer._graph = None  # rebuild with the filter
-    if keep == "lpt" and not getattr(layer, "_shard_hooks", None):
+    # transport: argument, else the environment's default read ONCE here (RGCN_DIST_COMM / RGCN_DIST_SLABS), else all-reduce
+    import os
+    set_transport(layer, comm if comm is not None else os.environ.get("RGCN_DIST_COMM", "allreduce"),
+                  slabs if slabs is not None else int(os.environ.get("RGCN_DIST_SLABS", "0")))
+    # `bases` sums over ALL relations whichever way the relations were split: its gradient is all-reduced in both modes
+    if not getattr(layer, "_shard_hooks", None):
         layer._shard_hooks = [getattr(layer, n).register_hook(_sum_over_group(group))
                               for n in _SUMMED_PARAMS if getattr(layer, n, None) is not None]
     return layer
@@ -121,6 +143,14 @@ def gather_owned_parameters(layer):
         dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
         out[name] = full
     return out
+
+
+@torch.no_grad()
+def sync_owned_parameters(layer):
+    """Overwrite every replica's per-relation parameters with the owners' rows (collective).  After it, state_dict() is
+    the same, complete model on every rank."""
+    for name, full in gather_owned_parameters(layer).items():
+        getattr(layer, name).copy_(full)
 
 
 def filter_graph_for_rank(graph, group):

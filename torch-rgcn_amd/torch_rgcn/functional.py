@@ -106,16 +106,40 @@ def _dense_buckets(plan):
     return plan.m_pad > 0 and plan.n_messages >= 0.5 * plan.m_pad
 
 
-def _fused_backward(X, W, g, graph):
+class _ReluToken:
+    """Links a layer whose kernel applied ReLU in its epilogue (the producer of H = relu(pre)) with the layer that consumes
+    H.  The consumer's fused backward can mask its feature gradient with H > 0 in the kernel's epilogue -- that IS the ReLU's
+    backward -- and then records here WHICH tensor it returned; the producer's backward skips its own masking launch
+    (aten.threshold_backward) only when the gradient it receives is that very tensor object, unmodified (same Python object
+    through a weak reference, same version counter).  Anything else -- H had other consumers and autograd summed their
+    gradients (a new tensor, or an in-place add that bumps the version), a hook replaced the tensor, the consumer took
+    another route -- falls back to masking, which is idempotent on the pre-masked part: always exact."""
+    __slots__ = ("ref", "version")
+
+    def __init__(self):
+        self.ref, self.version = None, -1
+
+    def mark(self, dX):
+        import weakref
+        self.ref, self.version = weakref.ref(dX), dX._version
+
+    def premasked(self, g):
+        return self.ref is not None and self.ref() is g and g._version == self.version
+
+
+def _fused_backward(X, W, g, graph, relu_in=False):
     """hidden 16, both gradients wanted: ONE walk of the transposed plan gathers G[s] once per message and produces dX
     and dW together (csrc/rgcn_bwd.hip).  None when the plan does not qualify (hub-split tiles, unpacked slots) or
-    RGCN_BWD=split asks for round 1's two-pass backward."""
+    RGCN_BWD=split asks for round 1's two-pass backward.  relu_in: X is the output of a ReLU and dX is wanted before it
+    (masked with X > 0 in the kernel's epilogue); returns (dX, dW, masked)."""
     if W.shape[1] != 16 or W.shape[2] != 16 or os.environ.get("RGCN_BWD", "fused") == "split":
         return None
     bp = graph.bwd_plan(16)
     if not _native.bwd_fused_ok(bp):
         return None
-    return _native.bwd_fused(g, X, W, bp, atomic=not deterministic())
+    masked = relu_in and _native.bwd_fused_relu_ok(bp)
+    dX, dW = _native.bwd_fused(g, X, W, bp, atomic=not deterministic(), relu=masked)
+    return dX, dW, masked
 
 
 def _weight_gradient(X, W, g, graph):
@@ -135,7 +159,9 @@ def _weight_gradient(X, W, g, graph):
 
 class _RelationalMP(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, X, W, bias, graph, relu=False, blocks=None):
+    def forward(ctx, X, W, bias, graph, relu=False, blocks=None, in_token=None):
+        ctx.in_token = in_token                      # X = relu(...) of a layer that fused the activation (see _ReluToken)
+        ctx.out_token = _ReluToken() if relu else None
         X, W, bias, ctx.dims = _pad_blocks(X, W, bias, graph)
         X = X.contiguous()
         W = W.contiguous()
@@ -170,13 +196,16 @@ class _RelationalMP(torch.autograd.Function):
         if ctx.dims is not None and ctx.dims[1] % 16:
             g = torch.nn.functional.pad(g, (0, -ctx.dims[1] % 16))
         g = g.contiguous()   # after the pad: a zero-width pad keeps the strides of a non-contiguous upstream gradient
-        if ctx.relu:         # out = relu(pre): the gradient passes where the stored output is positive
+        if ctx.relu and not ctx.out_token.premasked(g):     # out = relu(pre): the gradient passes where the stored output is positive
             g = torch.ops.aten.threshold_backward(g, ctx.saved_tensors[2], 0.0)
         dX = dW = db = None
         sparse = _sparse_buckets(graph, W)
         both = None
+        masked = False
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not sparse:
-            both = _fused_backward(X, W, g, graph)
+            both = _fused_backward(X, W, g, graph, relu_in=ctx.in_token is not None and ctx.dims is None)
+            if both is not None:
+                both, masked = both[:2], both[2]
         elif ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and os.environ.get("RGCN_BWD", "fused") != "split" \
                 and os.environ.get("RGCN_TWOPASS", "gather") == "gather" and not deterministic():
             # sparse buckets: relation-major walk, G[s] and X[o] gathered once each for dX's rows and dW together
@@ -194,11 +223,14 @@ class _RelationalMP(torch.autograd.Function):
                 dW = _weight_gradient(X, W, g, graph)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _native.colsum(g)
-        return (*_unpad_blocks(ctx.dims, dX, dW, db), None, None, None)
+        if masked:
+            ctx.in_token.mark(dX)                     # dX already is the gradient BEFORE the producer's ReLU
+        return (*_unpad_blocks(ctx.dims, dX, dW, db), None, None, None, None)
 
 
-def _join_shards(partial, group, works=None):
-    """Sum the ranks' partial N x d matrices (in place; returns the tensor to use).  RGCN_DIST_COMM:
+def _join_shards(partial, group, mode="allreduce"):
+    """Sum the ranks' partial N x d matrices (in place; returns the tensor to use).  mode (an argument -- the sharded
+    layer's transport, torch_rgcn.dist.set_transport -- not process-global state):
       allreduce (default)  one RCCL all-reduce of the whole matrix
       rs_ag                reduce-scatter of row blocks + all-gather (the two halves of an all-reduce as separate
                            collectives: lets RCCL pick its direct algorithms per half; same bytes on every link)
@@ -207,7 +239,7 @@ def _join_shards(partial, group, works=None):
                            through every link in turn), local sum of the world_size received blocks, all-gather
       none                 no collective at all -- TIMING ONLY (bench.py's compute-alone leg); results are wrong"""
     import torch.distributed as dist
-    mode = os.environ.get("RGCN_DIST_COMM", "allreduce")
+    assert mode in ("allreduce", "rs_ag", "a2a", "none"), f"unknown transport {mode!r}"
     if mode == "none":
         return partial
     if mode == "a2a":
@@ -242,21 +274,21 @@ class _ShardedRelationalMP(torch.autograd.Function):
     (strong scaling at 8 GPUs: the kernel is ~8x shorter than the collective, nothing to hide behind)."""
 
     @staticmethod
-    def forward(ctx, X, W, bias, graph, group, n_slabs):
+    def forward(ctx, X, W, bias, graph, group, n_slabs, comm="allreduce"):
         import torch.distributed as dist
         X, W, bias, ctx.dims = _pad_blocks(X, W, bias)
         X, W = X.contiguous(), W.contiguous()
         rank = dist.get_rank(group)
         b = bias.contiguous() if (bias is not None and rank == 0) else None
-        if n_slabs > 0 and os.environ.get("RGCN_DIST_COMM", "allreduce") == "allreduce":
+        if n_slabs > 0 and comm == "allreduce":
             works = []
             out = _native.spmm_slabs(X, W, b, graph.fwd_plan(W.shape[2]), n_slabs,
                                      lambda o, r0, r1: works.append(dist.all_reduce(o[r0:r1], group=group, async_op=True)))
             for w in works:
                 w.wait()
         else:
-            out = _join_shards(_native.spmm(X, W, b, graph.fwd_plan(W.shape[2])), group)
-        ctx.graph, ctx.group, ctx.n_slabs, ctx.has_bias = graph, group, n_slabs, bias is not None
+            out = _join_shards(_native.spmm(X, W, b, graph.fwd_plan(W.shape[2])), group, comm)
+        ctx.graph, ctx.group, ctx.n_slabs, ctx.has_bias, ctx.comm = graph, group, n_slabs, bias is not None, comm
         ctx.save_for_backward(X, W)
         return out if ctx.dims is None else out[:, :ctx.dims[1]]
 
@@ -270,12 +302,12 @@ class _ShardedRelationalMP(torch.autograd.Function):
         g = g.contiguous()   # after the pad: a zero-width pad keeps the strides of a non-contiguous upstream gradient
         dX = dW = db = None
         works = []
-        slabbed = ctx.n_slabs > 0 and os.environ.get("RGCN_DIST_COMM", "allreduce") == "allreduce"
+        slabbed = ctx.n_slabs > 0 and ctx.comm == "allreduce"
         both = None
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not slabbed:
             both = _fused_backward(X, W, g, graph)
         if both is not None:
-            dX, dW = both
+            dX, dW = both[:2]
         else:
             if ctx.needs_input_grad[0]:
                 Wt = W.transpose(1, 2).contiguous()
@@ -289,14 +321,14 @@ class _ShardedRelationalMP(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _native.colsum(g)
         if dX is not None and not slabbed:
-            dX = _join_shards(dX, ctx.group)
+            dX = _join_shards(dX, ctx.group, ctx.comm)
         for w in works:
             w.wait()
-        return (*_unpad_blocks(ctx.dims, dX, dW, db), None, None, None)
+        return (*_unpad_blocks(ctx.dims, dX, dW, db), None, None, None, None)
 
 
-def sharded_relational_mp(features, weights, bias, graph, group, n_slabs=4):
-    return _ShardedRelationalMP.apply(features, weights, bias, graph, group, n_slabs)
+def sharded_relational_mp(features, weights, bias, graph, group, n_slabs=0, comm="allreduce"):
+    return _ShardedRelationalMP.apply(features, weights, bias, graph, group, n_slabs, comm)
 
 
 class _FeaturelessMP(torch.autograd.Function):
@@ -548,7 +580,9 @@ def relational_mp(features, weights, bias, graph, relu=False, blocks=None):
     """features [N, d_in], weights [R, d_in, d_out] (dense), bias [d_out] or None -> [N, d_out]; relu=True applies the
     activation in the kernel's epilogue (the backward masks the upstream gradient with the stored output); blocks: the
     [R, nb, bi, bo] parameter when weights = block_diag(blocks) (a hint: lets the forward skip the zero entries)"""
-    return _RelationalMP.apply(features, weights, bias, graph, relu, blocks)
+    # features = the output of a layer that applied ReLU in its kernel's epilogue: its backward node carries the token
+    in_token = getattr(getattr(features, "grad_fn", None), "out_token", None)
+    return _RelationalMP.apply(features, weights, bias, graph, relu, blocks, in_token)
 
 
 def featureless_mp(table, bias, graph):

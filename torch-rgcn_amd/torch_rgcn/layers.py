@@ -295,9 +295,9 @@ class RelationalGraphConvolutionNC(_RGCBase):
         if group is None:
             output = local(features, self.bias)
         elif self.in_features is not None and not block_table and weights is not None:
-            # relation-sharded: partial sums joined by the collective picked with RGCN_DIST_COMM / RGCN_DIST_SLABS
-            output = F_.sharded_relational_mp(features, weights, self.bias, graph, group,
-                                              int(os.environ.get("RGCN_DIST_SLABS", "0")))
+            # relation-sharded: partial sums joined by the layer's transport (torch_rgcn.dist.shard_layer / set_transport)
+            comm, slabs = getattr(self, "_shard_transport", ("allreduce", 0))
+            output = F_.sharded_relational_mp(features, weights, self.bias, graph, group, slabs, comm)
         else:  # relation-sharded: partial sums joined by an all-reduce, bias added once afterwards
             from .dist import sharded_apply
             output = sharded_apply(lambda x: local(x, None), features, group)
