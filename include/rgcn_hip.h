@@ -264,6 +264,23 @@ RGCN_API int rgcn_bwd_fused_f32(const float *G, const float *X, const float *Wt_
                                 float *scratch, const int32_t *p_pack, const int32_t *chunk_rel,
                                 const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R,
                                 int32_t flags, void *stream);
+/* The same backward on a reformatted plan (round 3, "lean" kernel): per-chunk bookkeeping -- unpacking, duplicate / tail flags of the
+ * fold, LDS row offsets -- is done once per plan instead of once per launch.
+ *   rgcn_bwd_lean_slot_bytes(n_chunks)   size of the slot array (12 bytes per slot: source row << 6 | flags, val, tile row << 6)
+ *   rgcn_bwd_lean_prepare_f32            p_pack / chunk_rel of the transposed plan (n_chunks = m_pad / 16) -> slots, hdr [n_chunks]
+ *                                        (relation | fold flags); once per static graph, per call for per-call graphs
+ *   rgcn_bwd_lean_supported(tile_rows)   1 when the kernel's LDS (dX tile + X tile + scratch per wave, 8 or 16 waves) fits
+ *   rgcn_bwd_lean_f32                    arguments as rgcn_bwd_fused_f32 with (slots, hdr) in place of (p_pack, chunk_rel);
+ *                                        flags RGCN_F_DW_ATOMIC, RGCN_F_RELU (dX masked with X > 0: X is a ReLU's output and
+ *                                        dX is wanted before it -- the caller's F.relu backward, models.py:196 / autograd)
+ * Same autograd duals of layers.py:293-301 as above; R < 65536. */
+RGCN_API int64_t rgcn_bwd_lean_slot_bytes(int64_t n_chunks);
+RGCN_API int rgcn_bwd_lean_prepare_f32(const int32_t *p_pack, const int32_t *chunk_rel, int64_t n_chunks, void *slots, int32_t *hdr,
+                                       void *stream);
+RGCN_API int rgcn_bwd_lean_supported(int32_t tile_rows);
+RGCN_API int rgcn_bwd_lean_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, float *scratch,
+                               const void *slots, const int32_t *hdr, const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows,
+                               int64_t n_dst, int32_t R, int32_t flags, void *stream);
 /* Debug / tuning aid (tools/kbench.py with RGCN_BWD_ABL=128): shader-cycle totals the instrumented window kernel adds up --
  * out8[0] all waves, [1] inside the window hand-over, [2] of that waiting for the slot, [3] waves, [4] hand-overs.
  * reset != 0 clears the counters.  No reference counterpart. */

@@ -861,6 +861,345 @@ __global__ __launch_bounds__(64 * NW, 4) void bwd_win2_d16_kernel(
   }
 }
 
+// ---- window kernel, third form ("lean"): the same algorithm with the per-chunk instruction count cut to what the data flow needs.
+// What bounds the second form (profiles/r03_bwd_ablation.txt, r03_pmc_sq.json): with 4 waves per SIMD the kernel's time follows
+// the SIMD's issue cycles -- 8 MFMAs (32 cycles each) + ~90 VALU + ~70 SALU + 15 LDS instructions per chunk; removing the fold
+// and the tile update (25 VALU) takes 13 % off, removing the window hand-over (53 SALU, 20 VALU) 17 %, removing the random
+// gathers nothing.  So the chunk's bookkeeping moves into a one-off reformatting of the plan (rgcn_bwd_lean_prepare_f32):
+//   slot (12 bytes)   word 0 = source row << 6 | same destination as the previous slot (bit 0) | last slot of its destination
+//                     (bit 1): the gather offset is ONE v_and_or; word 1 = val; word 2 = destination row inside the tile << 6 (pads: 0):
+//                     the LDS addresses of the tile update and of the X rows are ONE v_and_or / v_or each
+//   chunk header      relation | some slot repeats its predecessor's destination (bit 16) | some run is 3 slots or longer (bit 17):
+//                     the fold's wave-uniform exits come from a scalar register; the flags replace the DPP compare chains
+//   slots, headers and W fragments are addressed as scalar base (advanced per chunk on the scalar unit) + a constant lane offset.
+// The dX tile is no longer swizzled (the update address is base | row << 6 | k << 4; measured in round 2: the swizzle moved the LDS
+// conflict counter, not the time).
+struct LeanSlot { unsigned w0; float val; unsigned w2; };
+
+// p_pack / chunk_rel (the packed transposed plan) -> lean slots + chunk headers; one lane per slot, one wave per 4 chunks
+__global__ __launch_bounds__(WG) void bwd_lean_prep_kernel(const int2 *__restrict__ p_pack, const int *__restrict__ chunk_rel,
+                                                           LeanSlot *__restrict__ slots, int *__restrict__ hdr, long long n_chunks) {
+  const long long e = (long long)blockIdx.x * WG + threadIdx.x;          // slot index
+  const long long c = e >> 4;
+  const bool in = c < n_chunks;
+  const int2 pk = in ? p_pack[e] : make_int2((int)0xFF000000u, 0);
+  const int dl = (int)((unsigned)pk.x >> 24);
+  const bool pad = dl == 0xFF;
+  const int key = pad ? -1 : dl;
+  const int prev1 = dpp_i<ROW_SHR + 1>(-2, key), prev2 = dpp_i<ROW_SHR + 2>(-2, key), next1 = dpp_i<ROW_SHL + 1>(-3, key);
+  const bool dup1 = !pad && prev1 == key, dup2 = !pad && prev2 == key, tail = !pad && next1 != key;
+  const unsigned long long b1 = __builtin_amdgcn_ballot_w64(dup1), b2 = __builtin_amdgcn_ballot_w64(dup2);
+  if (in) {
+    LeanSlot o;
+    o.w0 = ((unsigned)(pk.x & 0xFFFFFF) << 6) | (dup1 ? 1u : 0u) | (tail ? 2u : 0u);
+    o.val = pad ? 0.f : __builtin_bit_cast(float, pk.y);
+    o.w2 = pad ? 0u : ((unsigned)dl << 6);
+    slots[e] = o;
+    if ((threadIdx.x & 15) == 0) {
+      const int row = (threadIdx.x & 63) >> 4;                           // this chunk's 16 lanes inside the wave
+      const unsigned m1 = (unsigned)(b1 >> (16 * row)) & 0xFFFFu, m2 = (unsigned)(b2 >> (16 * row)) & 0xFFFFu;
+      hdr[c] = chunk_rel[c] | (m1 ? 1 << 16 : 0) | (m2 ? 1 << 17 : 0);
+    }
+  }
+}
+
+template <int NW, int NG, bool ATOMIC, bool RELU, int ABL = 0>
+__global__ __launch_bounds__(64 * NW, 4) void bwd_lean_d16_kernel(
+    const float *__restrict__ G, const float *__restrict__ X, const float *__restrict__ Wtp, float *__restrict__ dX,
+    float *__restrict__ dWout, const LeanSlot *__restrict__ slots, const int *__restrict__ hdr,
+    const int *__restrict__ run_ptr, int n_tiles, int n_blocks, int tile_rows, int n_dst, int R) {
+  constexpr int U = 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int t = blockIdx.x * NW + wave;
+  const bool valid = t < n_tiles;
+  const int nwv = min(NW, n_tiles - (int)blockIdx.x * NW);       // waves of this workgroup that own a tile
+  float *tile = lds + wave * tile_rows * 16;                     // dX tile (row-major)
+  float *xt = lds + (NW + wave) * tile_rows * 16;                // X tile (row-major)
+  float *xs = lds + 2 * NW * tile_rows * 16 + wave * BW_SCR2;    // transposition scratch
+  float *win = lds + 2 * NW * tile_rows * 16 + NW * BW_SCR2;     // [NG][WIN_GS][256] fragment order
+  int *state = reinterpret_cast<int *>(win + NG * WIN_GS * 256); // [NG]
+  const int row0 = t * tile_rows;
+  const int nrows = valid ? min(tile_rows, n_dst - row0) : 0;
+  for (int i = lane; i < nrows * 4; i += 64) {
+    reinterpret_cast<float4 *>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4 *>(xt)[i] = reinterpret_cast<const float4 *>(X + (size_t)row0 * 16)[i];
+  }
+  if (tid < NG) state[tid] = tid << 16;                           // slot group q serves relation group q first
+  __syncthreads();                                                // the only workgroup barrier
+  if (!valid) return;
+
+  const int my0 = __builtin_amdgcn_readfirstlane(run_ptr[(size_t)t * (R + 1)]);
+  const int my1 = __builtin_amdgcn_readfirstlane(run_ptr[(size_t)t * (R + 1) + R]);
+  const int m = lane & 15, k = lane >> 4;
+  const int n_groups = (R + WIN_GS - 1) / WIN_GS;
+  int doneg = 0;                // relation groups [0, doneg) have been contributed by this wave
+  int curg = -1;                // group whose partials are held (-1: none)
+  int hasmask = 0;              // which of the group's relations have data in hold[]
+  f32x4 hold[WIN_GS];
+#pragma unroll
+  for (int q = 0; q < WIN_GS; ++q) hold[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned kofs = (unsigned)k << 4;
+  const unsigned tile_k = (unsigned)((tile - lds) * 4) + kofs;       // LDS byte address of tile[0][4k]
+  const unsigned xrd = (unsigned)((xt - lds) * 4) + (unsigned)m * 4;   // LDS byte address of X_lds[0][m]
+  float *xs_wr = xs + m * 16 + 4 * ((k + (m >> 1)) & 3);                                  // this lane's float4 of slot m
+  const float *xs_rd0 = xs + k * 16 + 4 * (((m >> 2) + (k >> 1)) & 3) + (m & 3);          // feature m of slot 4 t + k, t even: + 128 t
+  const float *xs_rd1 = xs + (4 + k) * 16 + 4 * (((m >> 2) + 2 + (k >> 1)) & 3) + (m & 3); // t odd: + 128 (t - 1)
+  const unsigned slot_lane = (unsigned)m * 12u;                       // this lane's slot inside a chunk (bytes)
+  const unsigned w_lane = (unsigned)lane * 16u;                       // this lane's float4 inside a W fragment (bytes)
+
+  // hand this wave's partials of relation group g to the shared window (mask: which relations carry data)
+  auto contribute = [&](int g, const f32x4 (&part)[WIN_GS], int mask) {
+    const int gq = (int)((unsigned)g % (unsigned)NG);
+    int *st = state + gq;
+    f32x4 *slot = reinterpret_cast<f32x4 *>(win + gq * (WIN_GS * 256)) + lane;
+    int s;
+    if (ATOMIC) {
+      for (;;) {
+        s = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if ((s >> 16) == g && !(s & 1)) {
+          int ok = 0;
+          if (lane == 0) {
+            int e = s;
+            ok = __hip_atomic_compare_exchange_strong(st, &e, s | 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          if (__builtin_amdgcn_readfirstlane(ok)) break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    } else {
+      for (;;) {      // fixed order: wave 0, 1, ... (bit-reproducible sums)
+        s = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if ((s >> 16) == g && ((s >> 1) & 31) == wave) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int c = (s >> 1) & 31;
+    const int dirty = (s >> 8) & 15;                             // slots somebody added data to
+    const bool last = c + 1 == nwv;
+    const int touch = last ? (dirty | mask) : mask;              // slots this wave reads / writes
+    f32x4 v[WIN_GS];
+#pragma unroll
+    for (int q = 0; q < WIN_GS; ++q) {
+      v[q] = part[q];
+      if ((touch & dirty) >> q & 1) v[q] = slot[q * 64];
+    }
+#pragma unroll
+    for (int q = 0; q < WIN_GS; ++q)
+      if (((touch & dirty) >> q & 1) && (mask >> q & 1)) v[q] += part[q];
+    if (!last) {
+#pragma unroll
+      for (int q = 0; q < WIN_GS; ++q)
+        if (mask >> q & 1) slot[q * 64] = v[q];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0)
+        __hip_atomic_store(st, (g << 16) | ((dirty | mask) << 8) | ((c + 1) << 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(st, (g + NG) << 16, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+      for (int q = 0; q < WIN_GS; ++q) {
+        const int r = g * WIN_GS + q;
+        if (r >= R) break;
+        if (ATOMIC) {
+          if (touch >> q & 1) {  // D: lane 16q+j holds rows 4q..4q+3 (input feature), column j (output feature)
+            float *wr = dWout + (size_t)r * 256 + (4 * k) * 16 + m;
+            atomicAdd(wr, v[q][0]); atomicAdd(wr + 16, v[q][1]); atomicAdd(wr + 32, v[q][2]); atomicAdd(wr + 48, v[q][3]);
+          }
+        } else {
+          reinterpret_cast<f32x4 *>(dWout + ((size_t)r * n_blocks + blockIdx.x) * 256)[lane] = (touch >> q & 1) ? v[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+  };
+  auto flush_group = [&]() {
+    if (ABL & 4) return;
+    const f32x4 zero[WIN_GS] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (; doneg < curg; ++doneg) contribute(doneg, zero, 0);
+    contribute(curg, hold, hasmask);
+    doneg = curg + 1;
+  };
+
+  if (my0 < my1) {
+    const int last = my1 - 1;
+    const char *sl_base = reinterpret_cast<const char *>(slots);
+    LeanSlot sl_n[U];
+    int hd_n[U];
+    auto request_idx = [&](int c) {
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const int cc = min(c + j, last);                          // scalar: chunks past the range re-read the last chunk (val forced to 0)
+        sl_n[j] = *reinterpret_cast<const LeanSlot *>(sl_base + (size_t)cc * (RGCN_CHUNK * 12) + slot_lane);
+        hd_n[j] = hdr[cc];
+      }
+    };
+    request_idx(my0);
+    for (int c = my0; c < my1; c += U) {
+      unsigned w0_[U], w2_[U];
+      float v_[U];
+      int hd_[U];
+      float4 g_[U], w_[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        w0_[j] = sl_n[j].w0;
+        w2_[j] = sl_n[j].w2;
+        v_[j] = (c + j <= last) ? sl_n[j].val : 0.f;
+        hd_[j] = __builtin_amdgcn_readfirstlane(hd_n[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) asm volatile("" : "+v"(w0_[j]), "+v"(v_[j]));   // pin the index data here
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const unsigned og = (ABL & 1) ? ((((unsigned)row0 << 6) + (w2_[j])) | kofs) : ((w0_[j] & ~63u) | kofs);
+        g_[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(G) + og);
+        w_[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Wtp) + (size_t)(hd_[j] & 0xFFFF) * 1024 + w_lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      request_idx(c + U);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ABL & 16) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) asm volatile("" :: "v"(g_[j].x), "v"(g_[j].y), "v"(g_[j].z), "v"(g_[j].w), "v"(w_[j].x), "v"(w_[j].w), "v"(w2_[j]), "v"(v_[j]));
+        continue;
+      }
+      // ---- phase 1: scaled rows, dX products (four independent MFMA chains)
+      f32x4 sc[U], acc[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        sc[j] = f32x4{g_[j].x * v_[j], g_[j].y * v_[j], g_[j].z * v_[j], g_[j].w * v_[j]};
+        acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].x, sc[j][0], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].y, sc[j][1], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].z, sc[j][2], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].w, sc[j][3], acc[j], 0, 0, 0);
+      // ---- phase 2: dW products, two chunks at a time
+      if (!(ABL & 2)) {
+        f32x4 aw[U];
+#pragma unroll
+        for (int h = 0; h < U; h += 2) {
+          float bv[2][4], av[2][4];
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int j = h + jj;
+            int rot = (int)w2_[j];                                  // lane (k, m) <- (row << 6) of slot (m + k) & 15
+            rot = __builtin_amdgcn_update_dpp(rot, rot, 0x120 + 15, 0x2, 0xF, false);
+            rot = __builtin_amdgcn_update_dpp(rot, rot, 0x120 + 14, 0x4, 0xF, false);
+            rot = __builtin_amdgcn_update_dpp(rot, rot, 0x120 + 13, 0x8, 0xF, false);
+            int rowk[4];                                            // row_share: slot 4 t4 + k
+            rowk[0] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 0, 0xF, 0xF, false);
+            rowk[1] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 4, 0xF, 0xF, false);
+            rowk[2] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 8, 0xF, 0xF, false);
+            rowk[3] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 12, 0xF, 0xF, false);
+            asm volatile("" ::: "memory");
+            *reinterpret_cast<f32x4 *>(xs_wr) = sc[j];
+            asm volatile("" ::: "memory");
+            bv[jj][0] = xs_rd0[0]; bv[jj][1] = xs_rd1[0]; bv[jj][2] = xs_rd0[128]; bv[jj][3] = xs_rd1[128];
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4)
+              av[jj][t4] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(lds) + (xrd + (unsigned)rowk[t4]));
+            asm volatile("" ::: "memory");
+          }
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) aw[h + jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+              aw[h + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj][t4], bv[jj][t4], aw[h + jj], 0, 0, 0);
+        }
+        // relation bookkeeping (wave-uniform): add each chunk's product to the held partial of its relation
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          if (c + j > last) break;
+          const int rj = hd_[j] & 0xFFFF;
+          const int gj = rj >> 2, qj = rj & 3;
+          if (gj != curg) {
+            if (curg >= 0) {
+              flush_group();
+#pragma unroll
+              for (int q = 0; q < WIN_GS; ++q) hold[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            curg = gj;
+            hasmask = 0;
+          }
+          hasmask |= 1 << qj;
+          if (qj == 0) hold[0] += aw[j];
+          else if (qj == 1) hold[1] += aw[j];
+          else if (qj == 2) hold[2] += aw[j];
+          else hold[3] += aw[j];
+        }
+      }
+      // ---- phase 3: fold equal destinations (flags from the plan), one LDS update per segment, chunk after chunk
+      if (ABL & 8) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) asm volatile("" :: "v"(acc[j][0]), "v"(acc[j][1]), "v"(acc[j][2]), "v"(acc[j][3]));
+      } else {
+        const int any1 = (hd_[0] | hd_[1] | hd_[2] | hd_[3]) & (1 << 16), any2 = (hd_[0] | hd_[1] | hd_[2] | hd_[3]) & (1 << 17);
+        if (any1) {
+#pragma unroll
+          for (int j = 0; j < U; ++j) {
+            const float sf = (w0_[j] & 1u) ? 1.f : 0.f;
+            acc[j][0] = fmaf(dpp_shr0<1>(acc[j][0]), sf, acc[j][0]);
+            acc[j][1] = fmaf(dpp_shr0<1>(acc[j][1]), sf, acc[j][1]);
+            acc[j][2] = fmaf(dpp_shr0<1>(acc[j][2]), sf, acc[j][2]);
+            acc[j][3] = fmaf(dpp_shr0<1>(acc[j][3]), sf, acc[j][3]);
+          }
+          if (any2) {     // runs of 3 and more (rare): the general fold on the destination rows
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+              const int dst = (v_[j] != 0.f || (w0_[j] & 3u)) ? (int)(w2_[j] >> 6) : -1;     // pads: no flag, val 0
+              const bool s2 = dpp_i<ROW_SHR + 2>(-1, dst) == dst && dst >= 0;
+              const bool s4 = dpp_i<ROW_SHR + 4>(-1, dst) == dst && dst >= 0;
+              const bool s8 = dpp_i<ROW_SHR + 8>(-1, dst) == dst && dst >= 0;
+              const float f2 = s2 ? 1.f : 0.f, f4 = s4 ? 1.f : 0.f, f8 = s8 ? 1.f : 0.f;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(dpp_shr0<2>(acc[j][e]), f2, acc[j][e]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(dpp_shr0<4>(acc[j][e]), f4, acc[j][e]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(dpp_shr0<8>(acc[j][e]), f8, acc[j][e]);
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          if (w0_[j] & 2u) {
+            f32x4 *p = reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(lds) + (tile_k + w2_[j]));
+            *p += acc[j];
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (!(ABL & (2 | 4 | 16))) {
+    if (curg >= 0) flush_group();
+    const f32x4 zero[WIN_GS] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (; doneg < n_groups; ++doneg) contribute(doneg, zero, 0);
+  } else {
+#pragma unroll
+    for (int q = 0; q < WIN_GS; ++q) asm volatile("" :: "v"(hold[q][0]), "v"(hold[q][1]), "v"(hold[q][2]), "v"(hold[q][3]));
+  }
+
+  float4 *o4 = reinterpret_cast<float4 *>(dX + (size_t)row0 * 16);
+  for (int i = lane; i < nrows * 4; i += 64) {
+    float4 a = reinterpret_cast<const float4 *>(tile)[i];
+    if (RELU) {
+      const float4 x = reinterpret_cast<const float4 *>(xt)[i];
+      a.x = x.x > 0.f ? a.x : 0.f; a.y = x.y > 0.f ? a.y : 0.f; a.z = x.z > 0.f ? a.z : 0.f; a.w = x.w > 0.f ? a.w : 0.f;
+    }
+    o4[i] = a;
+  }
+}
+
 // ---- sparse (tile, relation) buckets (AM: 267 relations): backward of the two-pass path with ONE relation-major walk.
 // Round 1: pass 1 of the feature gradient gathers G[s] per message (relation-major chunks, dense), and the weight gradient
 // walks the same relation-major plan again gathering G[dst] AND X[src] -- three random row reads per message.  Here one
@@ -1119,6 +1458,49 @@ hipError_t launch_bwd_win2_f(const BwdLaunch &a, bool relu) {
   return relu ? launch_bwd_win2<NW, NG, AT, true>(a) : launch_bwd_win2<NW, NG, AT, false>(a);
 }
 
+template <int NW, int NG>
+size_t bwd_lean_lds(int tile_rows) {
+  return ((size_t)2 * NW * tile_rows * 16 + NW * BW_SCR2 + NG * WIN_GS * 256) * sizeof(float) + 4 * NG * sizeof(int);
+}
+struct LeanLaunch {
+  const float *G, *X, *Wtp;
+  float *dX, *dWout;
+  const LeanSlot *slots;
+  const int *hdr, *run_ptr;
+  int n_tiles, n_blocks, tile_rows, n_dst, R;
+  size_t lds;
+  hipStream_t st;
+};
+template <int NW, int NG, bool AT, bool RELU, int ABL = 0>
+hipError_t launch_bwd_lean(const LeanLaunch &a) {
+  auto kern = bwd_lean_d16_kernel<NW, NG, AT, RELU, ABL>;
+  static bool raised = false;                    // once per process and instantiation (not a stream operation)
+  if (a.lds > 64 * 1024 && !raised) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    raised = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.n_blocks), dim3(64 * NW), a.lds, a.st, a.G, a.X, a.Wtp, a.dX, a.dWout, a.slots, a.hdr,
+                     a.run_ptr, a.n_tiles, a.n_blocks, a.tile_rows, a.n_dst, a.R);
+  return hipGetLastError();
+}
+template <int NW, int NG, bool AT>
+hipError_t launch_bwd_lean_f(const LeanLaunch &a, bool relu) {
+  static const int ABL = getenv("RGCN_BWD_ABL") ? atoi(getenv("RGCN_BWD_ABL")) : 0;     // timing experiments (wrong results)
+  if (NW == 16 && AT && ABL) {
+    switch (ABL) {
+      case 1: return launch_bwd_lean<16, 3, true, false, 1>(a);
+      case 2: return launch_bwd_lean<16, 3, true, false, 2>(a);
+      case 4: return launch_bwd_lean<16, 3, true, false, 4>(a);
+      case 5: return launch_bwd_lean<16, 3, true, false, 5>(a);
+      case 8: return launch_bwd_lean<16, 3, true, false, 8>(a);
+      case 16: return launch_bwd_lean<16, 3, true, false, 16>(a);
+      default: break;
+    }
+  }
+  return relu ? launch_bwd_lean<NW, NG, AT, true>(a) : launch_bwd_lean<NW, NG, AT, false>(a);
+}
+
 template <int U, bool AT>
 void launch_bwd_d(const BwdLaunch &a, int D) {
   if (D == 4) launch_bwd<U, AT, 4>(a);
@@ -1157,6 +1539,58 @@ extern "C" int64_t rgcn_bwd_fused_scratch_floats(int64_t n_tiles, int32_t R) {
   const int64_t n_blocks = (n_tiles + 3) / 4;
   const int64_t S = std::max<int64_t>(1, std::min<int64_t>(16, n_blocks / 64));
   return (n_blocks * R + (int64_t)R * S) * 256;
+}
+
+extern "C" int64_t rgcn_bwd_lean_slot_bytes(int64_t n_chunks) { return n_chunks * RGCN_CHUNK * (int64_t)sizeof(LeanSlot); }
+
+extern "C" int rgcn_bwd_lean_prepare_f32(const int32_t *p_pack, const int32_t *chunk_rel, int64_t n_chunks, void *slots, int32_t *hdr,
+                                         void *stream) {
+  if (n_chunks < 0 || (n_chunks && (!p_pack || !chunk_rel || !slots || !hdr))) { rgcn_set_error("bwd_lean_prepare: bad argument"); return RGCN_EINVAL; }
+  if (!n_chunks) return RGCN_OK;
+  const long long n = n_chunks * RGCN_CHUNK;
+  hipLaunchKernelGGL(bwd_lean_prep_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, (hipStream_t)stream,
+                     reinterpret_cast<const int2 *>(p_pack), chunk_rel, reinterpret_cast<LeanSlot *>(slots), hdr, (long long)n_chunks);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_bwd_lean_supported(int32_t tile_rows) {
+  return bwd_lean_lds<16, 3>(tile_rows) <= 160 * 1024 || bwd_lean_lds<8, 1>(tile_rows) <= 160 * 1024;
+}
+
+extern "C" int rgcn_bwd_lean_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, float *scratch,
+                                 const void *slots, const int32_t *hdr, const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows,
+                                 int64_t n_dst, int32_t R, int32_t flags, void *stream) {
+  if (!G || !X || !Wt_packed || !dX || !dW || !slots || !hdr || !run_ptr || n_tiles <= 0 || tile_rows <= 0 || n_dst <= 0 || R <= 0 ||
+      R > 0xFFFF) {
+    rgcn_set_error("bwd_lean: bad argument");
+    return RGCN_EINVAL;
+  }
+  const bool atomic = (flags & RGCN_F_DW_ATOMIC) != 0, relu = (flags & RGCN_F_RELU) != 0;
+  if (!atomic && !scratch) { rgcn_set_error("bwd_lean: the deterministic reduction needs a scratch buffer"); return RGCN_EINVAL; }
+  static const int WIN_NW = getenv("RGCN_BWD_NW") ? atoi(getenv("RGCN_BWD_NW")) : 16;
+  const bool nw16 = WIN_NW >= 16 && bwd_lean_lds<16, 3>(tile_rows) <= 160 * 1024;
+  const bool nw8 = !nw16 && bwd_lean_lds<8, 1>(tile_rows) <= 160 * 1024;
+  if (!nw16 && !nw8) { rgcn_set_error("bwd_lean: tile_rows = %d does not fit the LDS of a CU", tile_rows); return RGCN_EUNSUPPORTED; }
+  const int NWv = nw16 ? 16 : 8;
+  const int n_blocks = (int)((n_tiles + NWv - 1) / NWv);
+  hipStream_t st = (hipStream_t)stream;
+  const LeanLaunch L{G, X, Wt_packed, dX, atomic ? dW : scratch, reinterpret_cast<const LeanSlot *>(slots), hdr, run_ptr, (int)n_tiles, n_blocks,
+                     tile_rows, (int)n_dst, R, nw16 ? bwd_lean_lds<16, 3>(tile_rows) : bwd_lean_lds<8, 1>(tile_rows), st};
+  if (atomic) {
+    HIP_TRY(zero_async(dW, (size_t)R * 256 * sizeof(float), st));
+    if (nw16) HIP_TRY((launch_bwd_lean_f<16, 3, true>(L, relu)));
+    else HIP_TRY((launch_bwd_lean_f<8, 1, true>(L, relu)));
+  } else {
+    if (nw16) HIP_TRY((launch_bwd_lean_f<16, 3, false>(L, relu)));
+    else HIP_TRY((launch_bwd_lean_f<8, 1, false>(L, relu)));
+    const int S = (int)std::max<int64_t>(1, std::min<int64_t>(16, n_blocks / 64));
+    float *tmp = scratch + (size_t)n_blocks * R * 256;
+    hipLaunchKernelGGL(dw_reduce_a_kernel, dim3((unsigned)R, (unsigned)S), dim3(WG), 0, st, scratch, tmp, n_blocks, S);
+    hipLaunchKernelGGL(dw_reduce_b_kernel, dim3((unsigned)R), dim3(WG), 0, st, tmp, dW, S);
+    HIP_TRY(hipGetLastError());
+  }
+  return RGCN_OK;
 }
 
 extern "C" int rgcn_bwd_fused_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW,

@@ -33,6 +33,7 @@ def lib():
         L = ctypes.CDLL(_LIB_PATH)
         L.rgcn_version.restype = ctypes.c_char_p
         L.rgcn_bwd_fused_scratch_floats.restype = ctypes.c_int64
+        L.rgcn_bwd_lean_slot_bytes.restype = ctypes.c_int64
         L.rgcn_colsum_scratch_floats.restype = ctypes.c_int64
         L.rgcn_gemm_scratch_floats.restype = ctypes.c_int64
         L.rgcn_last_error.restype = ctypes.c_char_p
@@ -939,10 +940,26 @@ def bwd_fused_ok(plan):
             and plan.tile_rows <= 160 and plan.n_tiles > 0)      # 160 rows: dX tiles + scratch + staging within 64 KiB of LDS
 
 
+def _lean_plan(plan):
+    """(slots, hdr) of the lean backward kernel: the packed transposed plan reformatted once (rgcn_bwd_lean_prepare_f32), cached
+    on the plan object -- static (NC) graphs pay it once, per-call (LP) graphs one small launch per step"""
+    lean = getattr(plan, "_lean", None)
+    if lean is None:
+        n_chunks = plan.chunk_rel.shape[0]
+        dev = plan.chunk_rel.device
+        slots = torch.empty(int(lib().rgcn_bwd_lean_slot_bytes(c_i64(n_chunks))) + 16, device=dev, dtype=torch.uint8)
+        hdr = torch.empty(max(n_chunks, 1), device=dev, dtype=torch.int32)
+        with _on(dev):
+            _check(lib().rgcn_bwd_lean_prepare_f32(_dp(plan.pack), _dp(plan.chunk_rel), c_i64(n_chunks), _dp(slots), _dp(hdr), _stream(dev)),
+                   "bwd_lean_prepare")
+        lean = plan._lean = (slots, hdr)
+    return lean
+
+
 def bwd_fused_relu_ok(plan):
     """RGCN_F_RELU of rgcn_bwd_fused_f32 (dX masked with X > 0 in the epilogue) exists in the window kernel only: its LDS
     (dX tile + X tile + scratch per wave, 8 waves at least) has to fit"""
-    return os.environ.get("RGCN_BWD_KERNEL", "win") != "stage" and \
+    return os.environ.get("RGCN_BWD_KERNEL", "lean") != "stage" and \
         (2 * 8 * plan.tile_rows * 16 + 8 * 256 + 4 * 256) * 4 + 4 <= 160 * 1024
 
 
@@ -960,6 +977,14 @@ def bwd_fused(G, X, W, plan, atomic=False, relu=False):
     if not atomic:
         n = int(lib().rgcn_bwd_fused_scratch_floats(c_i64(plan.n_tiles), c_i32(W.shape[0])))
         scratch = torch.empty(n, device=dev, dtype=torch.float32)
+    if os.environ.get("RGCN_BWD_KERNEL", "lean") == "lean" and lib().rgcn_bwd_lean_supported(c_i32(plan.tile_rows)) and W.shape[0] < 65536:
+        slots, hdr = _lean_plan(plan)
+        with _on(dev), _timed("bwd_fused"):
+            _check(lib().rgcn_bwd_lean_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(scratch), _dp(slots), _dp(hdr),
+                                           _dp(plan.run_ptr), c_i64(plan.n_tiles), c_i32(plan.tile_rows), c_i64(plan.n_dst),
+                                           c_i32(W.shape[0]), c_i32((F_DW_ATOMIC if atomic else 0) | (1 if relu else 0)),
+                                           _stream(dev)), "bwd_lean")
+        return dX, dW
     with _on(dev), _timed("bwd_fused"):
         _check(lib().rgcn_bwd_fused_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(scratch), _dp(plan.pack),
                                         _dp(plan.chunk_rel), _dp(plan.run_ptr), c_i64(plan.n_tiles), c_i32(plan.tile_rows),
