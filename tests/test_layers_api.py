@@ -152,3 +152,19 @@ def test_utils_block_diag_and_inits():
     assert select_b_init('zeros') is torch.nn.init.zeros_
     with pytest.raises(NotImplementedError):
         select_w_init('he')
+
+
+def test_forward_activated_goes_through_module_call_hooks():
+    """the fused-activation entry the models use must fire forward hooks like `F.relu(self.rgc1(...))` does
+    (checked on the CPU: the hook fires before the layer refuses CPU parameters)."""
+    import torch
+    from torch_rgcn.layers import RelationalGraphConvolutionNC
+    tp = torch.tensor([[0, 0, 1], [1, 1, 0], [0, 2, 0], [1, 2, 1]])
+    layer = RelationalGraphConvolutionNC(triples=tp, num_nodes=2, num_relations=3, in_features=4, out_features=4)
+    seen = []
+    layer.register_forward_pre_hook(lambda mod, args, kwargs: seen.append(("pre", kwargs.get("features") is not None)), with_kwargs=True)
+    try:
+        layer.forward_activated(torch.zeros(2, 4), "relu")
+    except RuntimeError:
+        pass          # no GPU here: the layer has no CPU path -- the hook must have fired first
+    assert seen == [("pre", True)] and "_fused_activation" not in layer.__dict__

@@ -41,8 +41,10 @@ __global__ void split_triples_kernel(const long long *__restrict__ tp, long long
                                      int *__restrict__ s, int *__restrict__ p, int *__restrict__ o,
                                      int *__restrict__ err) {
   for (long long e = (long long)blockIdx.x * TB + threadIdx.x; e < M; e += (long long)gridDim.x * TB) {
-    const long long a = tp[3 * e], b = tp[3 * e + 1], c = tp[3 * e + 2];
-    if (a < 0 || a >= N || c < 0 || c >= N || b < 0 || b >= R) atomicMax(err, 1);
+    long long a = tp[3 * e], b = tp[3 * e + 1], c = tp[3 * e + 2];
+    // an id out of range raises the flag (the caller turns it into the reference's AssertionError) AND is clamped: with deferred
+    // checks the flag is looked at after the step, and nothing downstream (degree tables, plan counters) may index with it
+    if (a < 0 || a >= N || c < 0 || c >= N || b < 0 || b >= R) { atomicMax(err, 1); a = b = c = 0; }
     s[e] = (int)a; p[e] = (int)b; o[e] = (int)c;
   }
 }
@@ -55,11 +57,14 @@ __global__ void lp_expand_kernel(const long long *__restrict__ t, long long E, l
   for (long long e = (long long)blockIdx.x * TB + threadIdx.x; e < M; e += (long long)gridDim.x * TB) {
     if (e < 3 * E) {
       const long long j = e % E, blk = e / E;
-      const long long a = t[3 * j], b = t[3 * j + 1], c = t[3 * j + 2];
-      if (a < 0 || a >= N || c < 0 || c >= N || b < 0 || b >= R0) atomicMax(err, 1);
+      long long a = t[3 * j], b = t[3 * j + 1], c = t[3 * j + 2];
+      // a bad triple raises the flag, is clamped to (0, 0, 0) and marked DEAD: in deferred-check mode (RGCN_DEFERRED_CHECKS=1, hipGraph
+      // replays) the flag is only read after the step, so the message must not reach the degree tables / plan counters as it is
+      const bool bad = a < 0 || a >= N || c < 0 || c >= N || b < 0 || b >= R0;
+      if (bad) { atomicMax(err, 1); a = b = c = 0; }
       if (blk == 1) { s[e] = (int)c; p[e] = (int)b + R0; o[e] = (int)a; }
       else { s[e] = (int)a; p[e] = (int)b; o[e] = (int)c; }
-      alive[e] = 1;
+      alive[e] = bad ? 0 : 1;
     } else {
       const long long n = e - 3 * E;
       s[e] = (int)n; p[e] = 2 * R0; o[e] = (int)n;

@@ -27,6 +27,13 @@ OPTIMISERS = {"adam": torch.optim.Adam, "adamw": torch.optim.AdamW, "adagrad": t
 
 
 def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None, synthetic=None, hipgraph=False):
+    """see _run; process-wide settings a run changes (RGCN_DEFERRED_CHECKS for --hipgraph) are restored on every way out"""
+    import contextlib
+    with contextlib.ExitStack() as cleanup:
+        return _run(cfg, data_dir, epochs, quiet, max_test, synthetic, hipgraph, cleanup)
+
+
+def _run(cfg, data_dir, epochs, quiet, max_test, synthetic, hipgraph, _cleanup):
     """-> (loss per epoch, {"mrr", "hits@1", "hits@3", "hits@10"} of the final evaluation).
     hipgraph=True: the training step (per-step graph build, encoder, decoder, loss, backward, optimiser) is captured once in
     a hipGraph and replayed every epoch on freshly sampled inputs copied into static buffers; needs the sync-free plan
@@ -83,8 +90,20 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None, synthetic=N
     extra = {"fused": True} if opt_cfg["algorithm"] in ("adam", "adamw") else {}
     deferred_before = os.environ.get("RGCN_DEFERRED_CHECKS")
     if hipgraph:
+        # a captured step cannot read the device-side range-check flags back: validate the triples the sampler draws from HERE,
+        # once, on the host (the kernels additionally clamp and kill out-of-range triples, csrc/rgcn_build.hip)
+        tr = np.asarray(train)
+        assert tr.size == 0 or (tr[:, [0, 2]].min() >= 0 and tr[:, [0, 2]].max() < num_nodes and tr[:, 1].min() >= 0
+                                and tr[:, 1].max() < num_relations), "training triples: node or relation index out of range"
         os.environ["RGCN_DEFERRED_CHECKS"] = "1"            # no device -> host reads inside the captured step
         extra = {"capturable": True} if opt_cfg["algorithm"] in ("adam", "adamw") else {}
+
+        def _restore_env():                                  # also when the run raises (registered below)
+            if deferred_before is None:
+                os.environ.pop("RGCN_DEFERRED_CHECKS", None)
+            else:
+                os.environ["RGCN_DEFERRED_CHECKS"] = deferred_before
+        _cleanup.callback(_restore_env)
     optimiser = OPTIMISERS[opt_cfg["algorithm"]](model.parameters(), lr=opt_cfg["learn_rate"],
                                                   weight_decay=opt_cfg["weight_decay"], **extra)
 
@@ -128,6 +147,9 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None, synthetic=N
         # into them.  (Round 2 history: replays used to fault whenever eager kernels ran between them -- the HIP runtime replays
         # hipMemsetAsync NODES with stale arguments; the library zero-fills with kernels now, tools/hipgraph_repro/.)
         static = [t.clone() for t in sample_inputs()]
+        # the warm-up steps below are real optimiser steps: parameters and optimiser state are put back afterwards (in place -- the
+        # captured graph holds their addresses), so that a --hipgraph run starts epoch 1 from the same state as the eager run
+        saved_params = [p.detach().clone() for p in model.parameters()]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                        # warm-up off the capture: allocator pools, lazy inits
@@ -137,6 +159,14 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None, synthetic=N
         captured = torch.cuda.CUDAGraph()
         with torch.cuda.graph(captured):
             static_loss = train_step(*static)
+        with torch.no_grad():
+            for p, q in zip(model.parameters(), saved_params):
+                p.copy_(q)
+            for st in optimiser.state.values():              # Adam / SGD-momentum state after zero steps: all zeros
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        del saved_params
 
     losses = []
     for epoch in range(1, max_epochs + 1):
@@ -174,11 +204,6 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None, synthetic=N
                                 num_nodes=num_nodes, **eval_kw)
     if not quiet:
         report(f"[Final Scores] Total Epoch {max_epochs} ({len(test)} test triples ranked in {time.time() - t0:.2f}s)", mrr, hits)
-    if hipgraph:
-        if deferred_before is None:
-            os.environ.pop("RGCN_DEFERRED_CHECKS", None)
-        else:
-            os.environ["RGCN_DEFERRED_CHECKS"] = deferred_before
     return losses, {"mrr": mrr, "hits@1": hits[0], "hits@3": hits[1], "hits@10": hits[2]}
 
 

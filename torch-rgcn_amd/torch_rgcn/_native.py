@@ -687,6 +687,10 @@ def _req(t, name, dtype=torch.float32):
         raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
     if not t.is_contiguous():
         raise ValueError(f"{name} must be contiguous")
+    if t.data_ptr() % 16:
+        # the kernels pick their 16-byte load / store forms from the row width alone; a contiguous view at an odd storage offset
+        # (a slice of a flattened tensor) would hand them a misaligned base -- functional.py's dense() copies such views
+        raise ValueError(f"{name} must be 16-byte aligned (got a view at storage offset {t.storage_offset()}): pass x.clone()")
 
 
 F_RELU, F_WPACKED = 1, 2
@@ -959,7 +963,7 @@ def _lean_plan(plan):
 def bwd_fused_relu_ok(plan):
     """RGCN_F_RELU of rgcn_bwd_fused_f32 (dX masked with X > 0 in the epilogue) exists in the window kernel only: its LDS
     (dX tile + X tile + scratch per wave, 8 waves at least) has to fit"""
-    return os.environ.get("RGCN_BWD_KERNEL", "lean") != "stage" and \
+    return os.environ.get("RGCN_BWD_KERNEL", "win") != "stage" and \
         (2 * 8 * plan.tile_rows * 16 + 8 * 256 + 4 * 256) * 4 + 4 <= 160 * 1024
 
 
@@ -977,7 +981,7 @@ def bwd_fused(G, X, W, plan, atomic=False, relu=False):
     if not atomic:
         n = int(lib().rgcn_bwd_fused_scratch_floats(c_i64(plan.n_tiles), c_i32(W.shape[0])))
         scratch = torch.empty(n, device=dev, dtype=torch.float32)
-    if os.environ.get("RGCN_BWD_KERNEL", "lean") == "lean" and lib().rgcn_bwd_lean_supported(c_i32(plan.tile_rows)) and W.shape[0] < 65536:
+    if os.environ.get("RGCN_BWD_KERNEL", "win") == "lean" and lib().rgcn_bwd_lean_supported(c_i32(plan.tile_rows)) and W.shape[0] < 65536:
         slots, hdr = _lean_plan(plan)
         with _on(dev), _timed("bwd_fused"):
             _check(lib().rgcn_bwd_lean_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(scratch), _dp(slots), _dp(hdr),

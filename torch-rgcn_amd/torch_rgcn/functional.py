@@ -106,6 +106,12 @@ def _dense_buckets(plan):
     return plan.m_pad > 0 and plan.n_messages >= 0.5 * plan.m_pad
 
 
+def dense(t):
+    """contiguous AND 16-byte aligned (what the C ABI asks for): a contiguous view at an odd storage offset is copied"""
+    t = t.contiguous()
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
 class _ReluToken:
     """Links a layer whose kernel applied ReLU in its epilogue (the producer of H = relu(pre)) with the layer that consumes
     H.  The consumer's fused backward can mask its feature gradient with H > 0 in the kernel's epilogue -- that IS the ReLU's
@@ -163,9 +169,9 @@ class _RelationalMP(torch.autograd.Function):
         ctx.in_token = in_token                      # X = relu(...) of a layer that fused the activation (see _ReluToken)
         ctx.out_token = _ReluToken() if relu else None
         X, W, bias, ctx.dims = _pad_blocks(X, W, bias, graph)
-        X = X.contiguous()
-        W = W.contiguous()
-        b = None if bias is None else bias.contiguous()
+        X = dense(X)
+        W = dense(W)
+        b = None if bias is None else dense(bias)
         fused_relu = relu and (max(W.shape[1], W.shape[2]) <= 64 or _wide_gemm_path(graph, W.shape[1], W.shape[2]))   # kernel epilogues
         if _sparse_buckets(graph, W) and blocks is not None and ctx.dims is None and tuple(blocks.shape[2:]) == (4, 4) and \
                 os.environ.get("RGCN_BLOCK_FWD", "1") != "0":
@@ -195,7 +201,7 @@ class _RelationalMP(torch.autograd.Function):
         graph = ctx.graph
         if ctx.dims is not None and ctx.dims[1] % 16:
             g = torch.nn.functional.pad(g, (0, -ctx.dims[1] % 16))
-        g = g.contiguous()   # after the pad: a zero-width pad keeps the strides of a non-contiguous upstream gradient
+        g = dense(g)   # after the pad: a zero-width pad keeps the strides of a non-contiguous upstream gradient
         if ctx.relu and not ctx.out_token.premasked(g):     # out = relu(pre): the gradient passes where the stored output is positive
             g = torch.ops.aten.threshold_backward(g, ctx.saved_tensors[2], 0.0)
         dX = dW = db = None
@@ -277,9 +283,9 @@ class _ShardedRelationalMP(torch.autograd.Function):
     def forward(ctx, X, W, bias, graph, group, n_slabs, comm="allreduce"):
         import torch.distributed as dist
         X, W, bias, ctx.dims = _pad_blocks(X, W, bias)
-        X, W = X.contiguous(), W.contiguous()
+        X, W = dense(X), dense(W)
         rank = dist.get_rank(group)
-        b = bias.contiguous() if (bias is not None and rank == 0) else None
+        b = dense(bias) if (bias is not None and rank == 0) else None
         if n_slabs > 0 and comm == "allreduce":
             works = []
             out = _native.spmm_slabs(X, W, b, graph.fwd_plan(W.shape[2]), n_slabs,
@@ -299,7 +305,7 @@ class _ShardedRelationalMP(torch.autograd.Function):
         graph = ctx.graph
         if ctx.dims is not None and ctx.dims[1] % 16:
             g = torch.nn.functional.pad(g, (0, -ctx.dims[1] % 16))
-        g = g.contiguous()   # after the pad: a zero-width pad keeps the strides of a non-contiguous upstream gradient
+        g = dense(g)   # after the pad: a zero-width pad keeps the strides of a non-contiguous upstream gradient
         dX = dW = db = None
         works = []
         slabbed = ctx.n_slabs > 0 and ctx.comm == "allreduce"
@@ -334,8 +340,8 @@ def sharded_relational_mp(features, weights, bias, graph, group, n_slabs=0, comm
 class _FeaturelessMP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, bias, graph):
-        table = table.contiguous()
-        b = None if bias is None else bias.contiguous()
+        table = dense(table)
+        b = None if bias is None else dense(bias)
         out = _native.featureless_fwd(table, b, graph.fwd_plan(table.shape[2]))
         ctx.graph = graph
         ctx.has_bias = bias is not None
@@ -345,7 +351,7 @@ class _FeaturelessMP(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        g = g.contiguous()
+        g = dense(g)
         dT = db = None
         if ctx.needs_input_grad[0]:
             dT = _native.featureless_wgrad(g, ctx.graph.fwd_plan(ctx.width), ctx.num_rels)
@@ -361,8 +367,8 @@ class _BlockMP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, blocks, bias, graph, relu):
-        X, blocks = X.contiguous(), blocks.contiguous()
-        b = None if bias is None else bias.contiguous()
+        X, blocks = dense(X), dense(blocks)
+        b = None if bias is None else dense(bias)
         out = _native.block_spmm(X, blocks, b, graph.csr("fwd"), relu=relu)
         ctx.save_for_backward(X, blocks, out if relu else None)
         ctx.graph = graph
@@ -373,7 +379,7 @@ class _BlockMP(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         X, blocks, out = ctx.saved_tensors
-        g = g.contiguous()
+        g = dense(g)
         if ctx.relu:
             g = torch.ops.aten.threshold_backward(g, out, 0.0)
         graph = ctx.graph
@@ -410,8 +416,8 @@ class _DiagMP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, w, bias, graph):
-        X, w = X.contiguous(), w.contiguous()
-        b = None if bias is None else bias.contiguous()
+        X, w = dense(X), dense(w)
+        b = None if bias is None else dense(bias)
         out = _native.diag_spmm(X, w, b, graph.csr("fwd"))
         ctx.save_for_backward(X, w)
         ctx.graph = graph
@@ -421,7 +427,7 @@ class _DiagMP(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         X, w = ctx.saved_tensors
-        g = g.contiguous()
+        g = dense(g)
         graph = ctx.graph
         dX = dw = db = None
         if ctx.needs_input_grad[0]:
@@ -455,14 +461,14 @@ class _MatmulMFMA(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, A, B):
-        A, B = A.contiguous(), B.contiguous()
+        A, B = dense(A), dense(B)
         ctx.save_for_backward(A, B)
         return _native.gemm(A, B)
 
     @staticmethod
     def backward(ctx, g):
         A, B = ctx.saved_tensors
-        g = g.contiguous()
+        g = dense(g)
         dA = _native.gemm(g, B, trans_b=True) if ctx.needs_input_grad[0] else None          # g B^T
         # A^T g: K = the rows of A (nodes) -- split so that a small M x N output still fills the chip (fixed-order reduction)
         dB = _native.gemm(A, g, trans_a=True, split_k=_split_k(A.shape[0], A.shape[1], g.shape[1])) \
@@ -484,9 +490,9 @@ class _BasisMP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, bases, comps, bias, graph):
-        X, bases, comps = X.contiguous(), bases.contiguous(), comps.contiguous()
+        X, bases, comps = dense(X), dense(bases), dense(comps)
         B, d_in, d_out = bases.shape
-        b = None if bias is None else bias.contiguous()
+        b = None if bias is None else dense(bias)
         need_bwd = any(ctx.needs_input_grad[:4])
         if _native.basis_fused_supported(B, d_in) and os.environ.get("RGCN_BASIS_FUSED", "0") == "1":
             out, ag = _native.basis_fused_fwd(X, comps, bases, b, graph.csr("fwd"), keep_ag=need_bwd and ctx.needs_input_grad[1])
@@ -501,7 +507,7 @@ class _BasisMP(torch.autograd.Function):
     def backward(ctx, g):
         X, bases, comps, ag = ctx.saved_tensors
         B, d_in, d_out = bases.shape
-        g = g.contiguous()
+        g = dense(g)
         flat = bases.view(B * d_in, d_out)
         dX = dB = dC = db = None
         d_ag = _native.gemm(g, flat, trans_b=True) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[2]) else None   # [N, B*d_in]
@@ -526,11 +532,11 @@ class _FeaturelessBasisMP(torch.autograd.Function):
         ctx.src_major = _native.fbasis_supported(B, d) and os.environ.get("RGCN_FBASIS", "src") == "src"
         table = bases.permute(1, 0, 2).contiguous()                   # [N, B, d]: one contiguous block per source node
         if ctx.src_major:   # every node's B x d block is read once
-            comps = comps.contiguous()
+            comps = dense(comps)
             ctx.graph, ctx.has_bias = graph, bias is not None
             ctx.save_for_backward(table, comps)
             return _native.fbasis_fwd(table, comps, bias, graph.fbasis_plan())
-        comps = comps.contiguous()
+        comps = dense(comps)
         out = _native.basis_aggregate(table.view(N, B * d), comps, graph.csr("fwd"), B, d, B)
         if bias is not None:
             out += bias
@@ -540,7 +546,7 @@ class _FeaturelessBasisMP(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        g = g.contiguous()
+        g = dense(g)
         if ctx.src_major:
             table, comps = ctx.saved_tensors
             dB, dC = _native.fbasis_bwd(table, comps, g, ctx.graph.fbasis_plan(), ctx.needs_input_grad[0],
@@ -595,8 +601,8 @@ class _DistMultScore(torch.autograd.Function):
     def forward(ctx, triples, nodes, relations, sbias, pbias, obias):
         shape = triples.shape[:-1]
         tr = triples.reshape(-1, 3).contiguous()
-        nodes = nodes.contiguous()
-        relations = relations.contiguous()
+        nodes = dense(nodes)
+        relations = dense(relations)
         scores = _native.distmult_fwd(tr, nodes, relations, sbias, pbias, obias)
         ctx.save_for_backward(tr, nodes, relations)
         ctx.with_bias = sbias is not None
@@ -607,7 +613,7 @@ class _DistMultScore(torch.autograd.Function):
     def backward(ctx, gs):
         tr, nodes, relations = ctx.saved_tensors
         gs = gs.reshape(-1)
-        gs = gs.contiguous()
+        gs = dense(gs)
         mode = os.environ.get("RGCN_DISTMULT_BWD", "csr")
         scatter = mode == "atomic" or tr.shape[0] == 0
         if not scatter and mode != "split" and _native.distmult_bwd_all_supported(relations.shape[0], nodes.shape[1]):

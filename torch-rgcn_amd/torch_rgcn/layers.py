@@ -222,12 +222,22 @@ class RelationalGraphConvolutionNC(_RGCBase):
         return self._graph
 
     def forward(self, features=None):
-        return self.forward_activated(features, None)
+        return self._forward_impl(features, self.__dict__.pop("_fused_activation", None))
 
     def forward_activated(self, features=None, activation=None):
         """forward() plus the activation the models apply right after this layer (reference models.py:194,235,290
         `F.relu(self.rgc1(...))`), run in the kernel's epilogue.  activation: None or "relu".  A separate method so that
-        forward() keeps the reference's exact signature."""
+        forward() keeps the reference's exact signature; it goes through nn.Module.__call__ (forward / pre-forward hooks
+        registered on the layer fire exactly as for `F.relu(self.rgc1(...))`), the activation rides along as a transient
+        attribute."""
+        assert activation in (None, "relu"), f"unknown activation {activation!r}"
+        self._fused_activation = activation
+        try:
+            return self(features=features)
+        finally:
+            self.__dict__.pop("_fused_activation", None)
+
+    def _forward_impl(self, features, activation):
         assert (features is None) == (self.in_features is None), "in_features not provided!"
         assert activation in (None, "relu"), f"unknown activation {activation!r}"
         any_param = self.weights if (self.diag_weight_matrix or self.weight_decomp is None) else \
