@@ -7,12 +7,12 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=${1:-gpurun_out/pmc}
 mkdir -p "$OUT"
 i=0
-for SET in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum" \
+for SET in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_HIT_sum TCC_MISS_sum" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "GRBM_GUI_ACTIVE GRBM_TA_BUSY" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/k$i" -o p -- python tools/kbench.py --what spmm,bwd,wtiled --iters 3 > "$OUT/k$i.log" 2>&1
+  timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/k$i" -o p -- python tools/kbench.py --what spmm,bwd --iters 3 > "$OUT/k$i.log" 2>&1
 done
 python - "$OUT" <<'PY'
 import collections, csv, glob, json, sys
@@ -22,6 +22,7 @@ for f in glob.glob(out + "/k*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         per[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 keys = {"spmm": "spmm_d16_kernel", "bwd_fused": "bwd_fused_d16_kernel<4, true", "bwd_fused_deterministic": "bwd_fused_d16_kernel<4, false",
+        "bwd_win": "bwd_win2_d16_kernel<16, 3, true, false", "bwd_win_deterministic": "bwd_win2_d16_kernel<16, 3, false, false",
         "wgrad_tiled": "wgrad_tiled_d16_kernel"}
 detail = {"_how": "tools/pmc_passes.sh: separate rocprofv3 --pmc passes over tools/kbench.py --what spmm,bwd,wtiled (S1 launches); means per launch. "
                   "GRBM_GUI_ACTIVE is summed over the 8 XCDs: MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)"}
