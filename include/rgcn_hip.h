@@ -226,6 +226,11 @@ RGCN_API int rgcn_segment_sum_f32(const float *Y, const int32_t *rowptr, const f
  * gathers a destination's rows through perm[destination-major position] = slot. */
 RGCN_API int rgcn_segment_gather_sum_f32(const float *Y, const int32_t *perm, const int32_t *rowptr, const float *bias,
                                          float *out, int64_t n_rows, int32_t d, int32_t flags, void *stream);
+/* Pass 2 over work units (int32 [n_units][4] = {row, first entry, end entry, flags}, as rgcn_block_spmm_f32's): hub rows are cut into
+ * pieces that merge with fp32 atomics (n_split = number of such pieces; out is zeroed first; RGCN_F_RELU only with n_split = 0). */
+RGCN_API int rgcn_segment_gather_sum_units_f32(const float *Y, const int32_t *perm, const int32_t *units, int64_t n_units,
+                                               int64_t n_split, const float *bias, float *out, int64_t n_rows, int32_t d,
+                                               int32_t flags, void *stream);
 
 /* dW[rel] += sum over slots val * X[src,:]^T G[dst,:]  for every work item; dW
  * ([R, d_in, d_out]) is zeroed first.  Autograd dual of the einsum / sparse mm pair

@@ -162,6 +162,15 @@ def _dominant(step, iters=3):
     return name, float(np.mean(prof[name])), len(prof[name]) / iters, {k: round(float(np.mean(v)), 4) for k, v in prof.items()}
 
 
+def _launch_counts(step, iters=2):
+    """launches per step of every timed kernel name"""
+    _native.profile_start()
+    for _ in range(iters):
+        step()
+    prof = _native.profile_stop()
+    return {k: len(v) / iters for k, v in prof.items()}
+
+
 def _roof(name, ms, alg_bytes, note):
     if not name or not ms:
         return None
@@ -249,13 +258,53 @@ def line_featured(tag, N, R0, E, d, decomposition, seed, baseline_config):
     ms = timed(step, iters=10, warm=3)
     name, kms, per_step, allk = _dominant(step)
     M = 2 * E + N
-    alg = {"spmm": M * (4 * d + 8) + N * 4 * d, "spmm_scatter": M * (4 * d + 8) + M * 4 * d, "segment_sum": M * (4 * d + 4) + N * 4 * d,
-           "bwd_fused": M * (4 * d + 8) + 2 * N * 4 * d, "wgrad": M * (4 * d + 8) + N * 4 * d,
-           "bwd_scatter_dw": M * (2 * 4 * d + 12) + M * 4 * d, "block_spmm": M * (4 * d + 12) + N * 4 * d,
-           "block_wgrad": M * (2 * 4 * d + 12)}.get(name, M * (4 * d + 8) + N * 4 * d)
+    # SURVEY 8(d), literally: forward of one layer M (4 d + 8) + N 4 d; backward M (4 d + 8) + 2 N 4 d (X needs a gradient).  The
+    # forward / backward of a layer may be ONE kernel (tile path) or TWO (sparse buckets: transform + per-destination sum): the
+    # fraction is taken over the SUM of the kernels that make up the pass, never over one of them with its own byte model.
+    fwd_alg, bwd_alg = M * (4 * d + 8) + N * 4 * d, M * (4 * d + 8) + 2 * N * 4 * d
+    fwd_kernels = [k for k in ("spmm", "block_spmm", "spmm_scatter") if k in allk]
+    if "spmm_scatter" in allk and "segment_sum" in allk:
+        fwd_kernels.append("segment_sum")
+    bwd_kernels = [k for k in ("bwd_fused", "bwd_scatter_dw", "wgrad", "block_wgrad") if k in allk]
+    if "bwd_scatter_dw" in allk and "segment_sum" in allk and "segment_sum" not in fwd_kernels:
+        bwd_kernels.append("segment_sum")
+    # per-kernel launch counts per step tell a shared kernel name's passes apart (segment_sum serves both directions on the two-pass path)
+    counts = _launch_counts(step)
+    def pass_ms(kernels, direction):
+        tot = 0.0
+        for k in kernels:
+            per_layer = counts.get(k, 0) / 2.0                 # launches of this kernel per layer and step (both directions together)
+            share = 1.0 if k != "segment_sum" else (0.5 if ("spmm_scatter" in allk and "bwd_scatter_dw" in allk) else 1.0)
+            tot += allk[k] * per_layer * share
+        return tot
+    fwd_ms, bwd_ms = pass_ms(fwd_kernels, "fwd"), pass_ms(bwd_kernels, "bwd")
+
+    def blk(kernels, t, alg, model):
+        if not kernels or not t:
+            return None
+        ach = alg / (t * 1e-3) / 1e9
+        return {"kernels": " + ".join(kernels), "ms_per_layer": round(t, 4), "algorithmic_bytes_per_layer": int(alg), "achieved": round(ach, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "bound": "hbm", "bytes_model": model}
+    fwd = blk(fwd_kernels, fwd_ms, fwd_alg, "SURVEY 8(d) forward, one layer: M (4 d_in + 8) + N 4 d_out")
+    bwd = blk(bwd_kernels, bwd_ms, bwd_alg, "SURVEY 8(d) backward, one layer: M (4 d_out + 8) + 2 N 4 d_in")
+    dom = bwd if (bwd and (not fwd or bwd_ms >= fwd_ms)) else fwd
+    roof = dict(dom) if dom else None
+    if roof:
+        roof["kernel"] = roof.pop("kernels")
+        roof["avg_launch_ms"] = roof["ms_per_layer"]
+        roof["forward"], roof["backward"] = fwd, bwd
+        step_alg = 2 * (fwd_alg + bwd_alg)
+        roof["step_frac"] = round(step_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        # the dominant kernel with its OWN access pattern's bytes, as a separately named figure (not the roofline fraction)
+        own = {"spmm": M * (4 * d + 8) + N * 4 * d, "spmm_scatter": M * (4 * d + 8) + M * 4 * d, "segment_sum": M * (4 * d + 4) + N * 4 * d,
+               "bwd_fused": bwd_alg, "wgrad": M * (4 * d + 8) + N * 4 * d, "bwd_scatter_dw": M * (2 * 4 * d + 12) + M * 4 * d,
+               "block_spmm": M * (4 * d + 12) + N * 4 * d, "block_wgrad": M * (2 * 4 * d + 12)}.get(name)
+        if own and kms:
+            roof["dominant_kernel_own_access_pattern"] = {"kernel": name, "avg_launch_ms": round(kms, 4), "bytes_per_launch": int(own),
+                                                          "GBs": round(own / (kms * 1e-3) / 1e9, 1),
+                                                          "note": "what this kernel itself moves (two gathered rows / the transformed rows once more), NOT SURVEY 8(d)"}
     return {"baseline_config": baseline_config, "workload": tag, "N": N, "R0": R0, "E": E, "step": "2 featured layers, forward + backward",
-            "ms_per_step": round(ms, 3), "edges_per_s": round(E / ms * 1e3), "kernels_ms": allk,
-            "roofline": _roof(name, kms, alg, "SURVEY 8(d): M (4 d + 8) + N 4 d (two-pass: the transformed rows once more; bwd_scatter_dw: two gathered rows + indices + one written row per message)")}
+            "ms_per_step": round(ms, 3), "edges_per_s": round(E / ms * 1e3), "kernels_ms": allk, "roofline": roof}
 
 
 def line_wn18(baseline_config):

@@ -365,6 +365,42 @@ __global__ __launch_bounds__(WG) void segment_gather_sum_d16_kernel(const float 
   }
 }
 
+// The same over work UNITS {row, first entry, end entry, flags}: one unit per row, hub rows cut into pieces whose partial sums are
+// added to `out` with fp32 atomics (RGCN_U_SHARED; `out` zeroed by the launcher; the RGCN_U_FIRST piece adds the bias).  Without
+// the cut a row with 184 k entries (Zipf(0.9) AM-shaped graph) is one 4-lane loop: 50 ms per launch against 0.5.
+__global__ __launch_bounds__(WG) void segment_gather_sum_units_d16_kernel(const float *__restrict__ Y, const int *__restrict__ perm,
+                                                                          const int4 *__restrict__ units, const float *__restrict__ bias,
+                                                                          float *__restrict__ out, long long n_units, int relu_out) {
+  const int q = threadIdx.x & 3;
+  for (long long u = ((long long)blockIdx.x * WG + threadIdx.x) >> 2; u < n_units; u += ((long long)gridDim.x * WG) >> 2) {
+    const int4 unit = units[u];
+    const bool shared = unit.w & RGCN_U_SHARED;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias && (!shared || (unit.w & RGCN_U_FIRST))) a = reinterpret_cast<const float4 *>(bias)[q];
+    int e = unit.y;
+    const int e1 = unit.z;
+    for (; e + 1 < e1; e += 2) {
+      const int p0 = perm[e], p1 = perm[e + 1];
+      const float4 y0 = *reinterpret_cast<const float4 *>(Y + (size_t)p0 * 16 + 4 * q);
+      const float4 y1 = *reinterpret_cast<const float4 *>(Y + (size_t)p1 * 16 + 4 * q);
+      a.x += y0.x; a.y += y0.y; a.z += y0.z; a.w += y0.w;
+      b.x += y1.x; b.y += y1.y; b.z += y1.z; b.w += y1.w;
+    }
+    if (e < e1) {
+      const float4 y0 = *reinterpret_cast<const float4 *>(Y + (size_t)perm[e] * 16 + 4 * q);
+      a.x += y0.x; a.y += y0.y; a.z += y0.z; a.w += y0.w;
+    }
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    float *o = out + (size_t)unit.x * 16 + 4 * q;
+    if (shared) {
+      atomicAdd(o, a.x); atomicAdd(o + 1, a.y); atomicAdd(o + 2, a.z); atomicAdd(o + 3, a.w);
+    } else {
+      if (relu_out) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+      *reinterpret_cast<float4 *>(o) = a;
+    }
+  }
+}
+
 // ---- any d_in / d_out.  NJT = 16-wide output column tiles kept in accumulators per pass over d_in;
 // the LDS tile rows are padded to ldt = round_up(d_out, 4) floats so every update is one aligned b128.
 template <int NJT>
@@ -1422,6 +1458,21 @@ extern "C" int rgcn_segment_gather_sum_f32(const float *Y, const int32_t *perm, 
   const unsigned gx = (unsigned)std::min<int64_t>((n_rows * 4 + WG - 1) / WG, 256 * 64);
   hipLaunchKernelGGL(segment_gather_sum_d16_kernel, dim3(gx), dim3(WG), 0, (hipStream_t)stream, Y, perm, rowptr, bias, out,
                      (long long)n_rows, flags & RGCN_F_RELU);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_segment_gather_sum_units_f32(const float *Y, const int32_t *perm, const int32_t *units, int64_t n_units, int64_t n_split,
+                                                 const float *bias, float *out, int64_t n_rows, int32_t d, int32_t flags, void *stream) {
+  if (!Y || !perm || !units || !out || n_rows < 0 || n_units < 0) { rgcn_set_error("segment_gather_sum_units: bad argument"); return RGCN_EINVAL; }
+  if (d != 16) { rgcn_set_error("segment_gather_sum_units: only d = 16"); return RGCN_EUNSUPPORTED; }
+  if ((flags & RGCN_F_RELU) && n_split) { rgcn_set_error("segment_gather_sum_units: RGCN_F_RELU with shared units"); return RGCN_EINVAL; }
+  if (!n_rows || !n_units) return RGCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (n_split) HIP_TRY(zero_async(out, (size_t)n_rows * 16 * sizeof(float), st));
+  const unsigned gx = (unsigned)std::min<int64_t>((n_units * 4 + WG - 1) / WG, 256 * 64);
+  hipLaunchKernelGGL(segment_gather_sum_units_d16_kernel, dim3(gx), dim3(WG), 0, st, Y, perm, reinterpret_cast<const int4 *>(units), bias, out,
+                     (long long)n_units, flags & RGCN_F_RELU);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

@@ -816,6 +816,19 @@ def _slot_perm(p, n_msg, dev):
     return p._inv
 
 
+def _segment_gather_sum(Y, perm, csr, bias, out, relu):
+    """pass 2 of the two-pass routes: out[row] = bias + sum of the row's Y rows (through perm).  Static graphs with hub rows (longer
+    than 512 entries) go over work units -- the pieces of a hub row merge with atomics; returns whether a ReLU is still owed"""
+    units, n_units, n_split = _csr_units(csr)
+    if units is not None and n_split:
+        _check(lib().rgcn_segment_gather_sum_units_f32(_dp(Y), _dp(perm), _dp(units), c_i64(n_units), c_i64(n_split), _dp(bias), _dp(out),
+                                                       c_i64(csr.n_rows), c_i32(16), c_i32(0), _stream(Y.device)), "segment_gather_sum_units")
+        return relu
+    _check(lib().rgcn_segment_gather_sum_f32(_dp(Y), _dp(perm), _dp(csr.rowptr), _dp(bias), _dp(out), c_i64(csr.n_rows), c_i32(16),
+                                             c_i32(F_RELU if relu else 0), _stream(Y.device)), "segment_gather_sum")
+    return False
+
+
 def spmm_two_pass(X, W, bias, scatter_plan, csr, relu=False):
     """sparse-bucket path (d = 16): relation-major transform, then per-destination sum.  Default: pass 1 writes its rows
     in slot order (sequential, full lines) and pass 2 gathers them through a permutation; RGCN_TWOPASS=scatter: pass 1
@@ -837,13 +850,12 @@ def spmm_two_pass(X, W, bias, scatter_plan, csr, relu=False):
                "spmm_scatter")
     with _on(X.device), _timed("segment_sum"):
         if gather:
-            _check(lib().rgcn_segment_gather_sum_f32(_dp(Y), _dp(p._inv), _dp(csr.rowptr), _dp(bias), _dp(out),
-                                                     c_i64(csr.n_rows), c_i32(16), c_i32(F_RELU if relu else 0),
-                                                     _stream(X.device)), "segment_gather_sum")
+            relu = _segment_gather_sum(Y, p._inv, csr, bias, out, relu)
         else:
             _check(lib().rgcn_segment_sum_f32(_dp(Y), _dp(csr.rowptr), _dp(bias), _dp(out), c_i64(csr.n_rows), c_i32(16),
                                               c_i32(F_RELU if relu else 0), _stream(X.device)), "segment_sum")
-    return out
+            relu = False
+    return out.relu_() if relu else out
 
 
 def spmm_wide_two_pass(X, W, bias, scatter_plan, csr, relu=False):
@@ -895,8 +907,7 @@ def bwd_two_pass_fused(G, X, W, scatter_plan, csr):
                                              _dp(p.chunk_rel), _dp(p.items), c_i64(p.n_items), c_i32(W.shape[0]), c_i32(16),
                                              _stream(dev)), "bwd_scatter_dw")
     with _on(dev), _timed("segment_sum"):
-        _check(lib().rgcn_segment_gather_sum_f32(_dp(Y), _dp(p._inv), _dp(csr.rowptr), None, _dp(dX), c_i64(csr.n_rows),
-                                                 c_i32(16), c_i32(0), _stream(dev)), "segment_gather_sum")
+        _segment_gather_sum(Y, p._inv, csr, None, dX, False)
     return dX, dW
 
 

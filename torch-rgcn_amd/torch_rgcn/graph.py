@@ -53,6 +53,7 @@ class RelGraph:
                                       f"{4 * self.num_nodes * self.num_rels / 2**30:.0f} GiB counting table (limit {_MAX_CELLS:,} cells)")
         self._dev = None
         self._plans = {}
+        self.perm = self.inv = None   # locality relabelling of the nodes (graph_from_nc_triples(relabel=...)): perm[old] = new, inv[new] = old
         self.sync_free = False      # True: plans are sized by upper bounds and finished on the device (no host read-back)
         if triples_plus is None:
             return
@@ -188,8 +189,55 @@ def _device_build_enabled():
     return os.environ.get("RGCN_GRAPH_BUILD", "device") == "device"
 
 
-def graph_from_nc_triples(triples_plus, num_nodes, num_rels, vertical, device):
-    """NC layer: n = int((M - N) / 2), i = N  (torch_rgcn/layers.py:235-236, :269-271)."""
+def node_order(s, o, num_nodes, how):
+    """Locality relabelling of the nodes (SURVEY 8d / DESIGN: every gathered 64-byte row costs a 128-byte line, and a line is only
+    shared when its two rows are wanted close together in time).  s, o: int arrays of the messages' endpoints.  Returns
+    perm (int64 [N]): new id of every old id.
+      "degree"  nodes by descending message count (in + out): hub rows become neighbours, a handful of lines carries most gathers
+                and stays in L2 (pays on skewed graphs; on a uniform graph every row is as cold as every other)
+      "rcm"     reverse Cuthill-McKee on the symmetrised adjacency (scipy): neighbours get nearby ids, so a destination tile's
+                sources cluster (pays when the graph has community structure / small separators; a uniform random graph has none)
+      "bfs"     breadth-first order from the highest-degree node"""
+    s = np.asarray(s, dtype=np.int64)
+    o = np.asarray(o, dtype=np.int64)
+    if how == "degree":
+        deg = np.bincount(s, minlength=num_nodes) + np.bincount(o, minlength=num_nodes)
+        order = np.argsort(-deg, kind="stable")                      # order[new] = old
+    elif how in ("rcm", "bfs"):
+        import scipy.sparse as sp
+        from scipy.sparse import csgraph
+        keep = s != o
+        A = sp.coo_matrix((np.ones(int(keep.sum()), np.int8), (s[keep], o[keep])), shape=(num_nodes, num_nodes)).tocsr()
+        A = ((A + A.T) > 0).astype(np.int8).tocsr()
+        if how == "rcm":
+            order = np.asarray(csgraph.reverse_cuthill_mckee(A, symmetric_mode=True), dtype=np.int64)
+        else:
+            deg = np.asarray(A.sum(axis=1)).ravel()
+            seen = np.zeros(num_nodes, bool)
+            parts = []
+            for start in np.argsort(-deg, kind="stable"):
+                if seen[start]:
+                    continue
+                comp = csgraph.breadth_first_order(A, int(start), directed=False, return_predecessors=False)
+                seen[comp] = True
+                parts.append(comp)
+                if seen.all():
+                    break
+            order = np.concatenate(parts).astype(np.int64)
+    else:
+        raise NotImplementedError(f"node order {how!r} (degree, rcm, bfs)")
+    perm = np.empty(num_nodes, dtype=np.int64)
+    perm[order] = np.arange(num_nodes, dtype=np.int64)
+    return perm
+
+
+def graph_from_nc_triples(triples_plus, num_nodes, num_rels, vertical, device, relabel=None):
+    """NC layer: n = int((M - N) / 2), i = N  (torch_rgcn/layers.py:235-236, :269-271).
+    relabel ("degree" / "rcm" / "bfs", default: RGCN_RELABEL or none): the plans are built on locality-relabelled node ids
+    (node_order); graph.perm[old] = new, graph.inv[new] = old on the device -- the layer reads its features through inv and
+    returns its output through perm, so callers never see the relabelling.  The normalisation is computed on the original
+    ids first (it only counts equal (relation, node) keys: invariant under a relabelling)."""
+    relabel = relabel if relabel is not None else (os.environ.get("RGCN_RELABEL") or None)
     if _device_build_enabled() and num_nodes * num_rels < _MAX_CELLS:
         t = torch.as_tensor(triples_plus, dtype=torch.long).reshape(-1, 3).to(device)
         M = t.shape[0]
@@ -199,7 +247,17 @@ def graph_from_nc_triples(triples_plus, num_nodes, num_rels, vertical, device):
         s, p, o, err = _native.dev_split_triples(t, num_nodes, num_rels)
         _native.dev_check_err(err, "stack_matrices")
         val = _native.dev_edge_norm(s, p, o, None, num_nodes, num_rels, vertical, max(n_swap, 0))
-        return RelGraph.on_device(s, p, o, val, None, M, num_nodes, num_rels)
+        perm = None
+        if relabel and relabel != "none":
+            perm = torch.from_numpy(node_order(s.cpu().numpy(), o.cpu().numpy(), num_nodes, relabel)).to(device)
+            p32 = perm.to(torch.int32)
+            s, o = p32[s.long()].contiguous(), p32[o.long()].contiguous()
+        g = RelGraph.on_device(s, p, o, val, None, M, num_nodes, num_rels)
+        if perm is not None:
+            g.perm = perm
+            g.inv = torch.empty_like(perm)
+            g.inv[perm] = torch.arange(num_nodes, device=perm.device)
+        return g
     tp = triples_plus.detach().cpu().numpy() if torch.is_tensor(triples_plus) else np.asarray(triples_plus)
     tp = np.ascontiguousarray(tp, dtype=np.int64).reshape(-1, 3)
     M = tp.shape[0]

@@ -246,6 +246,11 @@ class RelationalGraphConvolutionNC(_RGCBase):
         N, R, out_dim = self.num_nodes, self.num_relations, self.out_features
         in_dim = N if self.in_features is None else self.in_features
         graph = self._graph_on(any_param.device)
+        relabelled = graph.perm is not None
+        if relabelled:      # plans on locality-relabelled ids (RGCN_RELABEL): features in through inv, output back through perm
+            if features is None:
+                raise NotImplementedError("RGCN_RELABEL with a featureless layer (the R x N x d weight table is indexed by node id)")
+            features = features.index_select(0, graph.inv)
 
         fl_basis = (self.in_features is None and self.weight_decomp == 'basis' and not self.vertical_stacking and
                     getattr(graph, "_dev", None) is not None and os.environ.get("RGCN_BASIS_PATH") != "0")
@@ -314,6 +319,8 @@ class RelationalGraphConvolutionNC(_RGCBase):
             if self.bias is not None:
                 output = output + self.bias
         assert output.size() == (N, out_dim)
+        if relabelled:
+            output = output.index_select(0, graph.perm)
         return torch.relu(output) if activation == "relu" else output
 
 
