@@ -403,11 +403,12 @@ def main():
             bwd = None
             if "bwd_fused" in launches:
                 bms = launches["bwd_fused"][0] + launches.get("dw_reduce", (0.0, 0))[0]
-                win = os.environ.get("RGCN_BWD_KERNEL", "win") != "stage"
-                bwd = kernel_roofline(("bwd_win_d16_kernel" if win else "bwd_fused_d16_kernel") + " (dX + dW of one layer from one gather per message"
+                route = os.environ.get("RGCN_BWD_KERNEL", "lean")
+                kname, kkey = {"lean": ("bwd_lean_d16_kernel", "bwd_lean"), "win": ("bwd_win2_d16_kernel", "bwd_win"),
+                               "pc": ("bwd_pc_d16_kernel", "bwd_pc")}.get(route, ("bwd_fused_d16_kernel", "bwd_fused"))
+                bwd = kernel_roofline(kname + " (dX + dW of one layer from one gather per message"
                                       + (" + dw_reduce)" if "dw_reduce" in launches else ")"), bms, balg, bmodel, ms, 2,
-                                      ("bwd_win_d16_kernel", "bwd_fused_d16_kernel") if win else ("bwd_fused_d16_kernel",),
-                                      "bwd_win" if win else "bwd_fused")
+                                      (kname, "bwd_fused_d16_kernel") if kname != "bwd_fused_d16_kernel" else (kname,), kkey)
             elif "wgrad" in launches and not slabbed:
                 bms = spmm_ms + launches["wgrad"][0]
                 bwd = kernel_roofline("spmm_d16_kernel (dX) + wgrad_tiled_d16_kernel (dW)", bms, balg, bmodel, ms, 2, (), None)

@@ -974,7 +974,7 @@ def _lean_plan(plan):
 def bwd_fused_relu_ok(plan):
     """RGCN_F_RELU of rgcn_bwd_fused_f32 (dX masked with X > 0 in the epilogue) exists in the window kernel only: its LDS
     (dX tile + X tile + scratch per wave, 8 waves at least) has to fit"""
-    return os.environ.get("RGCN_BWD_KERNEL", "win") != "stage" and \
+    return os.environ.get("RGCN_BWD_KERNEL", "lean") != "stage" and \
         (2 * 8 * plan.tile_rows * 16 + 8 * 256 + 4 * 256) * 4 + 4 <= 160 * 1024
 
 
@@ -992,7 +992,15 @@ def bwd_fused(G, X, W, plan, atomic=False, relu=False):
     if not atomic:
         n = int(lib().rgcn_bwd_fused_scratch_floats(c_i64(plan.n_tiles), c_i32(W.shape[0])))
         scratch = torch.empty(n, device=dev, dtype=torch.float32)
-    if os.environ.get("RGCN_BWD_KERNEL", "win") == "lean" and lib().rgcn_bwd_lean_supported(c_i32(plan.tile_rows)) and W.shape[0] < 65536:
+    route = os.environ.get("RGCN_BWD_KERNEL", "lean")    # lean (default) | win | stage | pc: see DESIGN.md 4.2
+    if route == "pc" and atomic and lib().rgcn_bwd_pc_supported(c_i32(plan.tile_rows)) and W.shape[0] < 0x7FFF:
+        slots, hdr = _lean_plan(plan)
+        with _on(dev), _timed("bwd_fused"):
+            _check(lib().rgcn_bwd_pc_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(slots), _dp(hdr), _dp(plan.run_ptr),
+                                         c_i64(plan.n_tiles), c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i32(W.shape[0]),
+                                         c_i32(1 if relu else 0), _stream(dev)), "bwd_pc")
+        return dX, dW
+    if route == "lean" and lib().rgcn_bwd_lean_supported(c_i32(plan.tile_rows)) and W.shape[0] < 65536:
         slots, hdr = _lean_plan(plan)
         with _on(dev), _timed("bwd_fused"):
             _check(lib().rgcn_bwd_lean_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(scratch), _dp(slots), _dp(hdr),
