@@ -294,6 +294,16 @@ RGCN_API int rgcn_bwd_pc_supported(int32_t tile_rows);
 RGCN_API int rgcn_bwd_pc_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, const void *slots,
                              const int32_t *hdr, const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R,
                              int32_t flags, void *stream);
+/* The same backward, block-tile form (round 3, the default when it applies): ONE destination tile of up to 255 rows per workgroup
+ * (plan built with that tile height: 15 % bucket padding instead of 42 %), its chunks dealt to the 16 waves from an LDS counter,
+ * dX tile / X tile shared (LDS float atomics), dW of ALL relations resident in LDS for the workgroup's life and flushed once
+ * (dirty relations only).  Needs R * 1 KiB + 48 KiB of LDS (R <= 111) and tile_rows <= 255: rgcn_bwd_blk_supported.  Atomic
+ * flush only, dX sums in arrival order (not bit-reproducible: RGCN_DETERMINISTIC=1 takes the lean kernel on 64-row tiles).
+ * flags: RGCN_F_RELU.  Plan arrays as rgcn_bwd_lean_f32. */
+RGCN_API int rgcn_bwd_blk_supported(int32_t tile_rows, int32_t R);
+RGCN_API int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, const void *slots,
+                              const int32_t *hdr, const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R,
+                              int32_t flags, void *stream);
 /* Debug / tuning aid (tools/kbench.py with RGCN_BWD_ABL=128): shader-cycle totals the instrumented window kernel adds up --
  * out8[0] all waves, [1] inside the window hand-over, [2] of that waiting for the slot, [3] waves, [4] hand-overs.
  * reset != 0 clears the counters.  No reference counterpart. */

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of window-kernel variants.  usage: tools/r3_pmc2.sh <outdir> "ENV=.. ENV=.." tag   (repeatable via wrapper)
+# SQ counters of backward-kernel variants.  usage: CHUNKS=1.52e6 tools/r3_pmc2.sh <outdir> <tag> ENV=.. ENV=..
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=$1; TAG=$2; shift; shift
@@ -12,14 +12,15 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   i=$((i+1))
   env "$@" timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/${TAG}_$i" -o p -- python tools/kbench.py --what bwd --iters 2 > "$OUT/${TAG}_$i.log" 2>&1
 done
-python - "$OUT" "$TAG" <<'PY'
+python - "$OUT" "$TAG" "${CHUNKS:-1.863e6}" <<'PY'
 import collections, csv, glob, json, sys
 out, tag = sys.argv[1:3]
+nchunks = float(sys.argv[3])
 per = collections.defaultdict(list)
 for f in glob.glob(f"{out}/{tag}_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if ("bwd_win" in n or "bwd_lean_d16" in n or "bwd_fused_d16" in n) and "true" in n.split("<")[1][:30]:
+        if "bwd_blk_d16" in n or (("bwd_win" in n or "bwd_lean_d16" in n or "bwd_fused_d16" in n) and "true" in n.split("<")[1][:30]):
             per[r["Counter_Name"]].append(float(r["Counter_Value"]))
 d = {k: sum(v) / len(v) for k, v in per.items()}
 json.dump(d, open(f"{out}/{tag}.json", "w"), indent=1, sort_keys=True)
@@ -30,5 +31,5 @@ print(tag, "cycles/XCD %.0f" % g, "wave-cyc(quad) %.3g" % wc, "| of wave time: a
     "| per SIMD busy: VALU %.2f MFMA %.2f LDS(perCU) %.2f SALU(perCU) %.2f" % (
     d.get("SQ_ACTIVE_INST_VALU", 0) * 4 / 1024 / max(g, 1), d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / max(g, 1),
     d.get("SQ_LDS_IDX_ACTIVE", 0) / 256 / max(g, 1), d.get("SQ_INSTS_SALU", 0) / 256 / max(g, 1)),
-    "| insts/chunk VALU %.0f SALU %.0f LDS %.1f MFMA %.1f VMEM %.1f" % tuple(d.get(k, 0) / 1.863e6 for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_MFMA", "SQ_INSTS_VMEM_RD")))
+    "| insts/chunk VALU %.0f SALU %.0f LDS %.1f MFMA %.1f VMEM %.1f" % tuple(d.get(k, 0) / nchunks for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_MFMA", "SQ_INSTS_VMEM_RD")))
 PY

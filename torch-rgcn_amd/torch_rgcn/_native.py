@@ -949,10 +949,36 @@ def pack_w16t(W):
     return _packed_w16(W)[1]
 
 
+def bwd_route():
+    """RGCN_BWD_KERNEL: blk (default: block-tile kernel where it applies, else lean) | lean | win | stage | pc -- DESIGN.md 4.2"""
+    return os.environ.get("RGCN_BWD_KERNEL", "blk")
+
+
+_BLK_MIN_NODES = 32768      # below: a tile per workgroup leaves most CUs idle; the wave-owned 64-row (or smaller) tiles stay
+
+
+def bwd_blk_rows(n_nodes, num_rels, deterministic=False, device=None):
+    """tile height of the transposed plan for the block-tile backward kernel (rgcn_bwd_blk_f32), 0 when it does not apply:
+    the tallest tile <= 255 rows that gives every CU the same number of tiles (S1: 245 rows, 4082 tiles, 15.95 per CU)"""
+    if bwd_route() != "blk" or deterministic or n_nodes < _BLK_MIN_NODES or not lib().rgcn_bwd_blk_supported(c_i32(255), c_i32(num_rels)):
+        return 0
+    n_cu = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).multi_processor_count
+    per_cu = -(-n_nodes // (n_cu * 255))
+    return -(-n_nodes // (n_cu * per_cu))
+
+
+def _bwd_blk_plan(plan):
+    return (plan.tile_rows > 160 or (plan.tile_rows > 64 and bwd_route() == "blk")) and \
+        bool(lib().rgcn_bwd_blk_supported(c_i32(plan.tile_rows), c_i32(plan.num_rels)))
+
+
 def bwd_fused_ok(plan):
-    """the fused backward kernel walks the transposed plan tile by tile: packed slots, run pointers, no hub-split tiles"""
-    return (plan.pack is not None and plan.run_ptr is not None and plan.n_split == 0 and plan.n_units == plan.n_tiles
-            and plan.tile_rows <= 160 and plan.n_tiles > 0)      # 160 rows: dX tiles + scratch + staging within 64 KiB of LDS
+    """the fused backward kernels walk the transposed plan tile by tile: packed slots and run pointers.  The wave-owned forms
+    take a whole tile per wave (no hub-split work units, at most 160 rows: dX tiles + scratch + staging within the LDS); the
+    block-tile form deals a tile's chunks to 16 waves itself and ignores the work units"""
+    if plan.pack is None or plan.run_ptr is None or plan.n_tiles <= 0:
+        return False
+    return _bwd_blk_plan(plan) or (plan.n_split == 0 and plan.n_units == plan.n_tiles and plan.tile_rows <= 160)
 
 
 def _lean_plan(plan):
@@ -974,8 +1000,8 @@ def _lean_plan(plan):
 def bwd_fused_relu_ok(plan):
     """RGCN_F_RELU of rgcn_bwd_fused_f32 (dX masked with X > 0 in the epilogue) exists in the window kernel only: its LDS
     (dX tile + X tile + scratch per wave, 8 waves at least) has to fit"""
-    return os.environ.get("RGCN_BWD_KERNEL", "lean") != "stage" and \
-        (2 * 8 * plan.tile_rows * 16 + 8 * 256 + 4 * 256) * 4 + 4 <= 160 * 1024
+    return _bwd_blk_plan(plan) or (bwd_route() != "stage" and
+                                   (2 * 8 * plan.tile_rows * 16 + 8 * 256 + 4 * 256) * 4 + 4 <= 160 * 1024)
 
 
 def bwd_fused(G, X, W, plan, atomic=False, relu=False):
@@ -992,7 +1018,16 @@ def bwd_fused(G, X, W, plan, atomic=False, relu=False):
     if not atomic:
         n = int(lib().rgcn_bwd_fused_scratch_floats(c_i64(plan.n_tiles), c_i32(W.shape[0])))
         scratch = torch.empty(n, device=dev, dtype=torch.float32)
-    route = os.environ.get("RGCN_BWD_KERNEL", "lean")    # lean (default) | win | stage | pc: see DESIGN.md 4.2
+    route = bwd_route()
+    if _bwd_blk_plan(plan):     # a plan of tall tiles (graph.bwd_plan asked bwd_blk_rows): one tile per workgroup
+        if not atomic:
+            raise NativeLibraryError("bwd_fused: the block-tile plan (tall tiles) has no bit-reproducible kernel")
+        slots, hdr = _lean_plan(plan)
+        with _on(dev), _timed("bwd_fused"):
+            _check(lib().rgcn_bwd_blk_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(slots), _dp(hdr), _dp(plan.run_ptr),
+                                          c_i64(plan.n_tiles), c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i32(W.shape[0]),
+                                          c_i32(1 if relu else 0), _stream(dev)), "bwd_blk")
+        return dX, dW
     if route == "pc" and atomic and lib().rgcn_bwd_pc_supported(c_i32(plan.tile_rows)) and W.shape[0] < 0x7FFF:
         slots, hdr = _lean_plan(plan)
         with _on(dev), _timed("bwd_fused"):
@@ -1000,7 +1035,7 @@ def bwd_fused(G, X, W, plan, atomic=False, relu=False):
                                          c_i64(plan.n_tiles), c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i32(W.shape[0]),
                                          c_i32(1 if relu else 0), _stream(dev)), "bwd_pc")
         return dX, dW
-    if route == "lean" and lib().rgcn_bwd_lean_supported(c_i32(plan.tile_rows)) and W.shape[0] < 65536:
+    if route in ("lean", "blk") and lib().rgcn_bwd_lean_supported(c_i32(plan.tile_rows)) and W.shape[0] < 65536:
         slots, hdr = _lean_plan(plan)
         with _on(dev), _timed("bwd_fused"):
             _check(lib().rgcn_bwd_lean_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(scratch), _dp(slots), _dp(hdr),

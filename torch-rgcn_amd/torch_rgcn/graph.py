@@ -107,7 +107,11 @@ class RelGraph:
         if d_in == 16 and "RGCN_TILE_ROWS" not in os.environ:
             # hidden 16: the fused backward kernel (dX + dW in one walk) keeps a dX tile, a transposition scratch and the
             # dW staging slots in LDS; 64-row tiles keep 4 workgroups per CU resident (measured: 0.71 ms at 64 rows, 0.80 at 128)
-            rows = min(rows, int(os.environ.get("RGCN_BWD_TILE_ROWS", "64")))
+            rows = int(os.environ["RGCN_BWD_TILE_ROWS"]) if "RGCN_BWD_TILE_ROWS" in os.environ else min(rows, 64)
+            # large graphs with few relations: ONE tall tile per workgroup (block-tile kernel, dW of all relations in LDS)
+            if "RGCN_BWD_TILE_ROWS" not in os.environ:
+                rows = _native.bwd_blk_rows(self.num_nodes, self.num_rels, os.environ.get("RGCN_DETERMINISTIC", "0") == "1",
+                                            self.device) or rows
         return self._plan("bwd", rows)
 
     def wgt_plan(self):
