@@ -299,11 +299,13 @@ RGCN_API int rgcn_bwd_pc_f32(const float *G, const float *X, const float *Wt_pac
  * dX tile / X tile shared (LDS float atomics), dW of ALL relations resident in LDS for the workgroup's life and flushed once
  * (dirty relations only).  Needs R * 1 KiB + 48 KiB of LDS (R <= 111) and tile_rows <= 255: rgcn_bwd_blk_supported.  Atomic
  * flush only, dX sums in arrival order (not bit-reproducible: RGCN_DETERMINISTIC=1 takes the lean kernel on 64-row tiles).
- * flags: RGCN_F_RELU.  Plan arrays as rgcn_bwd_lean_f32. */
+ * flags: RGCN_F_RELU.  Plan arrays as rgcn_bwd_lean_f32.  dbias (may be NULL): 16 floats, the bias gradient = column sums of
+ * G's n_src rows, read on the side of the tile walk (replaces an rgcn_colsum_f32 launch; one fill zeroes dW and dbias when
+ * dbias == dW + R * 256). */
 RGCN_API int rgcn_bwd_blk_supported(int32_t tile_rows, int32_t R);
 RGCN_API int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, const void *slots,
                               const int32_t *hdr, const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R,
-                              int32_t flags, void *stream);
+                              int32_t flags, float *dbias, int64_t n_src, void *stream);
 /* Debug / tuning aid (tools/kbench.py with RGCN_BWD_ABL=128): shader-cycle totals the instrumented window kernel adds up --
  * out8[0] all waves, [1] inside the window hand-over, [2] of that waiting for the slot, [3] waves, [4] hand-overs.
  * reset != 0 clears the counters.  No reference counterpart. */

@@ -952,7 +952,7 @@ template <bool RELU, int ABL>
 __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
     const float *__restrict__ G, const float *__restrict__ X, const float *__restrict__ Wtp, float *__restrict__ dX,
     float *__restrict__ dWout, const LeanSlot *__restrict__ slots, const int *__restrict__ hdr,
-    const int *__restrict__ run_ptr, int n_tiles, int tile_rows, int n_dst, int R) {
+    const int *__restrict__ run_ptr, int n_tiles, int tile_rows, int n_dst, int R, float *__restrict__ dbias, int n_src) {
   constexpr int U = 4, NW = BLK_NW;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -971,6 +971,11 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
   int c0 = __builtin_amdgcn_readfirstlane(run_ptr[(size_t)t * (R + 1)]);
   int c1 = __builtin_amdgcn_readfirstlane(run_ptr[(size_t)t * (R + 1) + R]);
   int nq = (c1 - c0 + U - 1) / U;
+  // bias gradient (column sums of G) on the side: every tile switch a thread adds one float4 of G's rows, the workgroups striding
+  // through G together (S1: 16 stripes of 16 KiB per workgroup = its 16 tiles); what is left after the last tile is read at the end
+  float4 gs = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long long g_n4 = dbias ? (long long)n_src * 4 : 0, g_step = (long long)gridDim.x * (64 * NW);
+  long long g_i = (long long)blockIdx.x * (64 * NW) + tid;
   {
     float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < nrows * 4) x0 = reinterpret_cast<const float4 *>(X + (size_t)row0 * 16)[tid];
@@ -1176,7 +1181,11 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
       if (tid < nrn * 4) xn = reinterpret_cast<const float4 *>(X + (size_t)row0n * 16)[tid];
       if (wave < nqn) request_idx(c0n + wave * U, c1n - 1);
     }
+    float4 gn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g_i < g_n4) gn = reinterpret_cast<const float4 *>(G)[g_i];
+    g_i += g_step;
     __syncthreads();                                               // every wave has finished adding to the dX tile
+    gs.x += gn.x; gs.y += gn.y; gs.z += gn.z; gs.w += gn.w;
     if (tid < nrows * 4) {
       float4 a = dxt4[tid];
       if (RELU) {
@@ -1192,6 +1201,32 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
     __syncthreads();                                               // the next tile is installed
     t = tn; row0 = row0n; nrows = nrn; c0 = c0n; c1 = c1n; nq = nqn;
     q_cur = wave; q_nxt = wave + NW;
+  }
+  if (dbias) {
+    for (; g_i < g_n4; g_i += g_step) {
+      const float4 gn = reinterpret_cast<const float4 *>(G)[g_i];
+      gs.x += gn.x; gs.y += gn.y; gs.z += gn.z; gs.w += gn.w;
+    }
+    __syncthreads();                                               // the last tile has been stored: the dX tile's LDS is free
+    dxt4[tid] = gs;                                                // thread tid holds features 4 (tid & 3) .. + 3
+    __syncthreads();
+    if (tid < 64) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < NW; ++i) {
+        const float4 b = dxt4[((tid >> 2) * NW + i) * 4 + (tid & 3)];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      xt4[tid] = a;
+    }
+    __syncthreads();
+    if (tid < 4) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < 16; ++i) {
+        const float4 b = xt4[i * 4 + tid];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      atomicAdd(dbias + 4 * tid, a.x); atomicAdd(dbias + 4 * tid + 1, a.y); atomicAdd(dbias + 4 * tid + 2, a.z); atomicAdd(dbias + 4 * tid + 3, a.w);
+    }
   }
   // one flush of the workgroup's dW: dirty relations only.  D fragment: lane 16k + m, element e = row 4k + e (input feature), column m
   if (!(ABL & 4)) {
@@ -1919,7 +1954,7 @@ extern "C" int rgcn_bwd_blk_supported(int32_t tile_rows, int32_t R) {
 /* block-tile form (atomic flush only; dX sums are LDS float atomics: not bit-reproducible): arguments as rgcn_bwd_pc_f32 */
 extern "C" int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, const void *slots,
                                 const int32_t *hdr, const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R,
-                                int32_t flags, void *stream) {
+                                int32_t flags, float *dbias, int64_t n_src, void *stream) {
   if (!G || !X || !Wt_packed || !dX || !dW || !slots || !hdr || !run_ptr || n_tiles <= 0 || tile_rows <= 0 || n_dst <= 0 || R <= 0) {
     rgcn_set_error("bwd_blk: bad argument");
     return RGCN_EINVAL;
@@ -1938,7 +1973,13 @@ extern "C" int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_
     HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
     n_cu = v > 0 ? v : 256;
   }
-  HIP_TRY(zero_async(dW, (size_t)R * 256 * sizeof(float), st));
+  if (dbias && (n_src <= 0 || n_src >= (int64_t(1) << 29))) { rgcn_set_error("bwd_blk: dbias needs 0 < n_src < 2^29"); return RGCN_EINVAL; }
+  if (dbias == dW + (size_t)R * 256) {     // one fill for both when the caller laid them out back to back
+    HIP_TRY(zero_async(dW, ((size_t)R * 256 + 16) * sizeof(float), st));
+  } else {
+    HIP_TRY(zero_async(dW, (size_t)R * 256 * sizeof(float), st));
+    if (dbias) HIP_TRY(zero_async(dbias, 16 * sizeof(float), st));
+  }
   const unsigned n_blocks = (unsigned)std::min<int64_t>(n_tiles, n_cu);
   static const int ABL = getenv("RGCN_BWD_ABL") ? atoi(getenv("RGCN_BWD_ABL")) : 0;     // timing experiments (wrong results)
   auto launch = [&](auto kern, bool &raised) -> hipError_t {
@@ -1948,7 +1989,7 @@ extern "C" int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_
       raised = true;
     }
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64 * BLK_NW), lds, st, G, X, Wt_packed, dX, dW, reinterpret_cast<const LeanSlot *>(slots),
-                       hdr, run_ptr, (int)n_tiles, tile_rows, (int)n_dst, R);
+                       hdr, run_ptr, (int)n_tiles, tile_rows, (int)n_dst, R, dbias, (int)n_src);
     return hipGetLastError();
   };
   static bool r0 = false, r1 = false, r2 = false, r3 = false, r4 = false, r5 = false;

@@ -1004,37 +1004,45 @@ def bwd_fused_relu_ok(plan):
                                    (2 * 8 * plan.tile_rows * 16 + 8 * 256 + 4 * 256) * 4 + 4 <= 160 * 1024)
 
 
-def bwd_fused(G, X, W, plan, atomic=False, relu=False):
+def bwd_fused(G, X, W, plan, atomic=False, relu=False, want_db=False):
     """(dX [n, 16], dW [R, 16, 16]) of the hidden-16 layer from one walk of the transposed plan (rgcn_bwd_fused_f32):
     G upstream gradient, X the layer's input, W [R, 16, 16].  relu: X is the output of a ReLU and dX is wanted BEFORE it
-    (rows masked with X > 0 in the kernel's epilogue)."""
+    (rows masked with X > 0 in the kernel's epilogue).  want_db: returns (dX, dW, db) -- db [16] = column sums of G when the
+    kernel that ran computes them on the side (block-tile kernel), else None (the caller launches colsum)."""
     _req(G, "grad_output"); _req(X, "features"); _req(W, "weights")
     assert W.shape[1:] == (16, 16) and G.shape == (plan.n_src, 16) and X.shape == (plan.n_dst, 16)
     dev = G.device
     Wtp = pack_w16t(W)
     dX = torch.empty((plan.n_dst, 16), device=dev, dtype=torch.float32)
-    dW = torch.empty_like(W)
+    blk = _bwd_blk_plan(plan)
+    db = None
+    if blk and want_db:      # dW and db back to back: one fill zeroes both
+        buf = torch.empty(W.numel() + 16, device=dev, dtype=torch.float32)
+        dW, db = buf[:W.numel()].view_as(W), buf[W.numel():]
+    else:
+        dW = torch.empty_like(W)
+    ret = (lambda: (dX, dW, db)) if want_db else (lambda: (dX, dW))
     scratch = None
     if not atomic:
         n = int(lib().rgcn_bwd_fused_scratch_floats(c_i64(plan.n_tiles), c_i32(W.shape[0])))
         scratch = torch.empty(n, device=dev, dtype=torch.float32)
     route = bwd_route()
-    if _bwd_blk_plan(plan):     # a plan of tall tiles (graph.bwd_plan asked bwd_blk_rows): one tile per workgroup
+    if blk:     # a plan of tall tiles (graph.bwd_plan asked bwd_blk_rows): one tile per workgroup
         if not atomic:
             raise NativeLibraryError("bwd_fused: the block-tile plan (tall tiles) has no bit-reproducible kernel")
         slots, hdr = _lean_plan(plan)
         with _on(dev), _timed("bwd_fused"):
             _check(lib().rgcn_bwd_blk_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(slots), _dp(hdr), _dp(plan.run_ptr),
                                           c_i64(plan.n_tiles), c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i32(W.shape[0]),
-                                          c_i32(1 if relu else 0), _stream(dev)), "bwd_blk")
-        return dX, dW
+                                          c_i32(1 if relu else 0), _dp(db), c_i64(plan.n_src), _stream(dev)), "bwd_blk")
+        return ret()
     if route == "pc" and atomic and lib().rgcn_bwd_pc_supported(c_i32(plan.tile_rows)) and W.shape[0] < 0x7FFF:
         slots, hdr = _lean_plan(plan)
         with _on(dev), _timed("bwd_fused"):
             _check(lib().rgcn_bwd_pc_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(slots), _dp(hdr), _dp(plan.run_ptr),
                                          c_i64(plan.n_tiles), c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i32(W.shape[0]),
                                          c_i32(1 if relu else 0), _stream(dev)), "bwd_pc")
-        return dX, dW
+        return ret()
     if route in ("lean", "blk") and lib().rgcn_bwd_lean_supported(c_i32(plan.tile_rows)) and W.shape[0] < 65536:
         slots, hdr = _lean_plan(plan)
         with _on(dev), _timed("bwd_fused"):
@@ -1042,13 +1050,13 @@ def bwd_fused(G, X, W, plan, atomic=False, relu=False):
                                            _dp(plan.run_ptr), c_i64(plan.n_tiles), c_i32(plan.tile_rows), c_i64(plan.n_dst),
                                            c_i32(W.shape[0]), c_i32((F_DW_ATOMIC if atomic else 0) | (1 if relu else 0)),
                                            _stream(dev)), "bwd_lean")
-        return dX, dW
+        return ret()
     with _on(dev), _timed("bwd_fused"):
         _check(lib().rgcn_bwd_fused_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(scratch), _dp(plan.pack),
                                         _dp(plan.chunk_rel), _dp(plan.run_ptr), c_i64(plan.n_tiles), c_i32(plan.tile_rows),
                                         c_i64(plan.n_dst), c_i32(W.shape[0]), c_i32((F_DW_ATOMIC if atomic else 0) | (1 if relu else 0)),
                                         _stream(dev)), "bwd_fused")
-    return dX, dW
+    return ret()
 
 
 def featureless_fwd(table, bias, plan):

@@ -133,19 +133,20 @@ class _ReluToken:
         return self.ref is not None and self.ref() is g and g._version == self.version
 
 
-def _fused_backward(X, W, g, graph, relu_in=False):
+def _fused_backward(X, W, g, graph, relu_in=False, want_db=False):
     """hidden 16, both gradients wanted: ONE walk of the transposed plan gathers G[s] once per message and produces dX
     and dW together (csrc/rgcn_bwd.hip).  None when the plan does not qualify (hub-split tiles, unpacked slots) or
     RGCN_BWD=split asks for round 1's two-pass backward.  relu_in: X is the output of a ReLU and dX is wanted before it
-    (masked with X > 0 in the kernel's epilogue); returns (dX, dW, masked)."""
+    (masked with X > 0 in the kernel's epilogue); returns (dX, dW, masked, db) -- db: the bias gradient when want_db and the kernel
+    sums G's columns on the side (block-tile kernel), else None."""
     if W.shape[1] != 16 or W.shape[2] != 16 or os.environ.get("RGCN_BWD", "fused") == "split":
         return None
     bp = graph.bwd_plan(16)
     if not _native.bwd_fused_ok(bp):
         return None
     masked = relu_in and _native.bwd_fused_relu_ok(bp)
-    dX, dW = _native.bwd_fused(g, X, W, bp, atomic=not deterministic(), relu=masked)
-    return dX, dW, masked
+    dX, dW, db = _native.bwd_fused(g, X, W, bp, atomic=not deterministic(), relu=masked, want_db=True)
+    return dX, dW, masked, (db if want_db else None)
 
 
 def _weight_gradient(X, W, g, graph):
@@ -209,9 +210,10 @@ class _RelationalMP(torch.autograd.Function):
         both = None
         masked = False
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not sparse:
-            both = _fused_backward(X, W, g, graph, relu_in=ctx.in_token is not None and ctx.dims is None)
+            both = _fused_backward(X, W, g, graph, relu_in=ctx.in_token is not None and ctx.dims is None,
+                                   want_db=ctx.has_bias and ctx.needs_input_grad[2])
             if both is not None:
-                both, masked = both[:2], both[2]
+                both, masked, db = both[:2], both[2], both[3]
         elif ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and os.environ.get("RGCN_BWD", "fused") != "split" \
                 and os.environ.get("RGCN_TWOPASS", "gather") == "gather" and not deterministic():
             # sparse buckets: relation-major walk, G[s] and X[o] gathered once each for dX's rows and dW together
@@ -227,7 +229,7 @@ class _RelationalMP(torch.autograd.Function):
                     dX = _spmm_blocked(g, Wt, None, graph.bwd_plan, graph=graph, kind="bwd")
             if ctx.needs_input_grad[1]:
                 dW = _weight_gradient(X, W, g, graph)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
             db = _native.colsum(g)
         if masked:
             ctx.in_token.mark(dX)                     # dX already is the gradient BEFORE the producer's ReLU
