@@ -264,6 +264,7 @@ RGCN_API int rgcn_wgrad_tiled_f32(const float *X, const float *G, float *dW, con
  *                fp32 atomics instead and scratch may be NULL. */
 #define RGCN_F_DW_ATOMIC 4
 #define RGCN_F_TRANSPOSE_W 8   /* rgcn_block_spmm_f32: multiply by the transposed blocks */
+#define RGCN_F_DIAG4 16        /* rgcn_bwd_blk_f32: W_r is block-diagonal with 4 x 4 blocks; only the diagonal blocks of dW_r are computed */
 RGCN_API int64_t rgcn_bwd_fused_scratch_floats(int64_t n_tiles, int32_t R);
 RGCN_API int rgcn_bwd_fused_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW,
                                 float *scratch, const int32_t *p_pack, const int32_t *chunk_rel,
@@ -299,10 +300,12 @@ RGCN_API int rgcn_bwd_pc_f32(const float *G, const float *X, const float *Wt_pac
  * dX tile / X tile shared (LDS float atomics), dW of ALL relations resident in LDS for the workgroup's life and flushed once
  * (dirty relations only).  Needs R * 1 KiB + 48 KiB of LDS (R <= 111) and tile_rows <= 255: rgcn_bwd_blk_supported.  Atomic
  * flush only, dX sums in arrival order (not bit-reproducible: RGCN_DETERMINISTIC=1 takes the lean kernel on 64-row tiles).
- * flags: RGCN_F_RELU.  Plan arrays as rgcn_bwd_lean_f32.  dbias (may be NULL): 16 floats, the bias gradient = column sums of
+ * flags: RGCN_F_RELU; RGCN_F_DIAG4: the weights are block_diag() of 4 x 4 blocks (layers.py:243-244 at width 16) -- only the
+ * diagonal blocks of dW_r are accumulated (the rest of dW stays zero), 256 bytes of LDS per relation instead of 1 KiB (R <= 447:
+ * AM's 267 relations fit).  Plan arrays as rgcn_bwd_lean_f32.  dbias (may be NULL): 16 floats, the bias gradient = column sums of
  * G's n_src rows, read on the side of the tile walk (replaces an rgcn_colsum_f32 launch; one fill zeroes dW and dbias when
  * dbias == dW + R * 256). */
-RGCN_API int rgcn_bwd_blk_supported(int32_t tile_rows, int32_t R);
+RGCN_API int rgcn_bwd_blk_supported(int32_t tile_rows, int32_t R, int32_t flags);
 RGCN_API int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, const void *slots,
                               const int32_t *hdr, const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R,
                               int32_t flags, float *dbias, int64_t n_src, void *stream);

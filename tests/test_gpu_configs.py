@@ -22,27 +22,31 @@ MUTAG = dict(N=23_644, R0=23, E=74_227)
 
 
 @pytest.mark.parametrize("vertical", [False, True])
-@pytest.mark.parametrize("route", ["block", "hybrid", "twopass", "tile"])
+@pytest.mark.parametrize("route", ["block", "hybrid", "hybrid_r2", "twopass", "tile"])
 def test_am_tenth_scale_block_diagonal_layer_vs_oracle(monkeypatch, route, vertical):
     """1/10 of AM, block-diagonal nb = 4, d = 16, both stackings, every route: out / dX / dblocks / db against the oracle.
       hybrid   the default for sparse (tile, relation) buckets (267 relations): forward on the block CSR kernel (4 x 4 blocks as
-               they are), backward on the expanded 16 x 16 weights (relation-major fused pass + row sums)
-      twopass  forward too on the expanded weights (transform in relation-major order, sum per destination)
+               they are), backward on the block-tile kernel (round 3: one 255-row tile per workgroup, dX + the DIAGONAL blocks of
+               dW + db from one gather per message; RGCN_F_DIAG4)
+      hybrid_r2  round 2's default: the backward on the expanded 16 x 16 weights, relation-major fused pass + row sums
+      twopass  forward too on the expanded weights (transform in relation-major order, sum per destination), round 2's backward
       tile     the (tile, relation) kernels of dense-bucket graphs
       block    forward and backward on the block kernels (RGCN_BLOCK_PATH=2; at width 16 not the default)"""
     from torch_rgcn import _native
     monkeypatch.setenv("RGCN_BLOCK_PATH", "2" if route == "block" else "0")
-    monkeypatch.setenv("RGCN_BLOCK_FWD", "1" if route == "hybrid" else "0")
+    monkeypatch.setenv("RGCN_BLOCK_FWD", "1" if route in ("hybrid", "hybrid_r2") else "0")
+    if route in ("hybrid_r2", "twopass"):
+        monkeypatch.setenv("RGCN_BWD_KERNEL", "lean")       # no block-tile kernel: the sparse graph's backward is the two-pass one
     if route in ("twopass", "tile"):
         monkeypatch.setenv("RGCN_SPARSE_PATH", "1" if route == "twopass" else "0")
     _native.profile_start()
     run_layer_vs_oracle(N=166_676, R0=133, E=598_832, d_in=16, d_out=16, mode="block", num_blocks=4, vertical=vertical,
                         seed=301 + int(vertical))
     prof = _native.profile_stop()
-    assert ("block_spmm" in prof) == (route in ("block", "hybrid")) and ("block_wgrad" in prof) == (route == "block")
+    assert ("block_spmm" in prof) == (route in ("block", "hybrid", "hybrid_r2")) and ("block_wgrad" in prof) == (route == "block")
     assert ("spmm_scatter" in prof) == (route == "twopass")
     # backward: relation-major fused pass (dX rows + dW from one walk) on the sparse path, tile-walk fused kernel otherwise
-    assert ("bwd_scatter_dw" in prof) == (route in ("hybrid", "twopass")) and ("bwd_fused" in prof) == (route == "tile")
+    assert ("bwd_scatter_dw" in prof) == (route in ("hybrid_r2", "twopass")) and ("bwd_fused" in prof) == (route in ("tile", "hybrid"))
 
 
 def test_am_tenth_scale_default_path_is_the_sparse_one():

@@ -18,7 +18,7 @@ from torch_rgcn import _native  # noqa: E402
 from torch_rgcn.layers import RelationalGraphConvolutionLP, RelationalGraphConvolutionNC  # noqa: E402
 
 dev = torch.device("cuda")
-ROUTES = {"block_kernels": ("2", "1"), "table": ("0", "1"), "dense": ("0", "0")}     # RGCN_BLOCK_PATH, RGCN_BLOCK_TABLE
+ROUTES = {"block_kernels": ("2", "1"), "dense": ("0", "0")}     # RGCN_BLOCK_PATH (the einsum message-table route was removed in round 3)
 
 
 def timed(fn, iters=7, warm=3):

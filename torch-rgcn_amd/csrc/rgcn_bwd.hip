@@ -946,9 +946,11 @@ __global__ __launch_bounds__(64 * NW, 4) void bwd_lean_d16_kernel(
 // kernel serves everything else and the bit-reproducible mode (LDS float atomics have no fixed order).
 constexpr int BLK_NW = 16;
 constexpr int BLK_TILE_FLOATS = 256 * 16;
-static size_t bwd_blk_lds(int R) { return ((size_t)2 * BLK_TILE_FLOATS + BLK_NW * BW_SCR2 + (size_t)R * 256) * 4 + (4 + (size_t)R) * 4; }
+// DIAG4: W is block-diagonal with 4 x 4 blocks (decomposition {type: block}, width 16): only the four diagonal blocks of dW_r are
+// wanted (64 floats per relation instead of 256: hundreds of relations fit, AM has 267)
+static size_t bwd_blk_lds(int R, bool diag4) { return ((size_t)2 * BLK_TILE_FLOATS + BLK_NW * BW_SCR2 + (size_t)R * (diag4 ? 64 : 256)) * 4 + (4 + (size_t)R) * 4; }
 
-template <bool RELU, int ABL>
+template <bool RELU, int ABL, bool DIAG4 = false>
 __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
     const float *__restrict__ G, const float *__restrict__ X, const float *__restrict__ Wtp, float *__restrict__ dX,
     float *__restrict__ dWout, const LeanSlot *__restrict__ slots, const int *__restrict__ hdr,
@@ -960,8 +962,9 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
   float *dxt = lds;                                               // dX tile [256][16]
   float *xt = lds + BLK_TILE_FLOATS;                              // X tile  [256][16]
   float *xs = lds + 2 * BLK_TILE_FLOATS + wave * BW_SCR2;         // transposition scratch of this wave
-  float *dwl = lds + 2 * BLK_TILE_FLOATS + NW * BW_SCR2;          // dW [R][64 lanes][4] (fragment order, a lane's four elements adjacent)
-  int *ctl = reinterpret_cast<int *>(dwl + (size_t)R * 256);      // [0]: next quad of the tile; [4 + r]: relation r has data
+  constexpr int DWR = DIAG4 ? 64 : 256;                           // floats of dW kept per relation
+  float *dwl = lds + 2 * BLK_TILE_FLOATS + NW * BW_SCR2;          // dW [R][64 lanes][4] (fragment order, a lane's four elements adjacent); DIAG4: [R][16 lanes][4]
+  int *ctl = reinterpret_cast<int *>(dwl + (size_t)R * DWR);      // [0]: next quad of the tile; [4 + r]: relation r has data
   int *dirty = ctl + 4;
   float4 *dxt4 = reinterpret_cast<float4 *>(dxt), *xt4 = reinterpret_cast<float4 *>(xt);
 
@@ -981,7 +984,7 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
     if (tid < nrows * 4) x0 = reinterpret_cast<const float4 *>(X + (size_t)row0 * 16)[tid];
     xt4[tid] = x0;
     dxt4[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = tid; i < R * 64; i += 64 * NW) reinterpret_cast<float4 *>(dwl)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < R * (DWR / 4); i += 64 * NW) reinterpret_cast<float4 *>(dwl)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < R + 4; i += 64 * NW) ctl[i] = i == 0 ? 2 * NW : 0;
   }
   __syncthreads();
@@ -1001,7 +1004,11 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
   int cur_r = -1;
   auto flush_hold = [&]() {
     if (cur_r >= 0 && !(ABL & 4)) {
-      lds_cas_add4(dwl + (size_t)cur_r * 256 + lane * 4, hold);
+      if (DIAG4) {       // D: lane 16 k + m holds rows 4k .. 4k + 3, column m: the diagonal block k lives in the lanes with m >> 2 == k
+        if ((m >> 2) == k) lds_cas_add4(dwl + (size_t)cur_r * 64 + (4 * k + (m & 3)) * 4, hold);
+      } else {
+        lds_cas_add4(dwl + (size_t)cur_r * 256 + lane * 4, hold);
+      }
       if (lane == 0) lds_st(dirty + cur_r, 1);
     }
   };
@@ -1230,8 +1237,9 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
   }
   // one flush of the workgroup's dW: dirty relations only.  D fragment: lane 16k + m, element e = row 4k + e (input feature), column m
   if (!(ABL & 4)) {
-    for (int i = tid; i < R * 256; i += 64 * NW) {
-      const int r = i >> 8, ln = (i >> 2) & 63, e = i & 3;
+    for (int i = tid; i < R * DWR; i += 64 * NW) {
+      const int r = i / DWR, e = i & 3;
+      const int ln = DIAG4 ? 16 * ((i >> 4) & 3) + 4 * ((i >> 4) & 3) + ((i >> 2) & 3) : (i >> 2) & 63;     // DIAG4: k = (i >> 4) & 3, m = 4 k + ((i >> 2) & 3)
       if (lds_ld(dirty + r)) atomicAdd(dWout + (size_t)r * 256 + (4 * (ln >> 4) + e) * 16 + (ln & 15), dwl[i]);
     }
   }
@@ -1947,8 +1955,8 @@ extern "C" int rgcn_bwd_pc_f32(const float *G, const float *X, const float *Wt_p
   return RGCN_OK;
 }
 
-extern "C" int rgcn_bwd_blk_supported(int32_t tile_rows, int32_t R) {
-  return tile_rows > 0 && tile_rows <= 255 && R > 0 && bwd_blk_lds(R) <= 160 * 1024;
+extern "C" int rgcn_bwd_blk_supported(int32_t tile_rows, int32_t R, int32_t flags) {
+  return tile_rows > 0 && tile_rows <= 255 && R > 0 && R < 0xFFFF && bwd_blk_lds(R, (flags & RGCN_F_DIAG4) != 0) <= 160 * 1024;
 }
 
 /* block-tile form (atomic flush only; dX sums are LDS float atomics: not bit-reproducible): arguments as rgcn_bwd_pc_f32 */
@@ -1959,12 +1967,12 @@ extern "C" int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_
     rgcn_set_error("bwd_blk: bad argument");
     return RGCN_EINVAL;
   }
-  if (!rgcn_bwd_blk_supported(tile_rows, R)) {
-    rgcn_set_error("bwd_blk: tile_rows = %d (<= 255) / R = %d (R KiB + 48 KiB of LDS) not supported", tile_rows, R);
+  if (!rgcn_bwd_blk_supported(tile_rows, R, flags)) {
+    rgcn_set_error("bwd_blk: tile_rows = %d (<= 255) / R = %d (R KiB, or R / 4 KiB with RGCN_F_DIAG4, + 48 KiB of LDS) not supported", tile_rows, R);
     return RGCN_EUNSUPPORTED;
   }
-  const size_t lds = bwd_blk_lds(R);
-  const bool relu = (flags & RGCN_F_RELU) != 0;
+  const bool relu = (flags & RGCN_F_RELU) != 0, diag4 = (flags & RGCN_F_DIAG4) != 0;
+  const size_t lds = bwd_blk_lds(R, diag4);
   hipStream_t st = (hipStream_t)stream;
   static int n_cu = 0;
   if (!n_cu) {
@@ -1992,8 +2000,10 @@ extern "C" int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_
                        hdr, run_ptr, (int)n_tiles, tile_rows, (int)n_dst, R, dbias, (int)n_src);
     return hipGetLastError();
   };
-  static bool r0 = false, r1 = false, r2 = false, r3 = false, r4 = false, r5 = false;
-  if (ABL == 2) HIP_TRY(launch(bwd_blk_d16_kernel<false, 2>, r2));
+  static bool r0 = false, r1 = false, r2 = false, r3 = false, r4 = false, r5 = false, r6 = false, r7 = false;
+  if (diag4 && relu) HIP_TRY(launch(bwd_blk_d16_kernel<true, 0, true>, r6));
+  else if (diag4) HIP_TRY(launch(bwd_blk_d16_kernel<false, 0, true>, r7));
+  else if (ABL == 2) HIP_TRY(launch(bwd_blk_d16_kernel<false, 2>, r2));
   else if (ABL == 4) HIP_TRY(launch(bwd_blk_d16_kernel<false, 4>, r3));
   else if (ABL == 8) HIP_TRY(launch(bwd_blk_d16_kernel<false, 8>, r4));
   else if (ABL == 16) HIP_TRY(launch(bwd_blk_d16_kernel<false, 16>, r5));

@@ -694,6 +694,7 @@ def _req(t, name, dtype=torch.float32):
 
 
 F_RELU, F_WPACKED = 1, 2
+F_DIAG4 = 16      # rgcn_bwd_blk_f32: block-diagonal weights, 4 x 4 blocks
 
 
 # (weak reference to the weight tensor, its version counter) -> (Wp, Wtp): both fragment orders of a [R,16,16] weight, packed
@@ -957,28 +958,30 @@ def bwd_route():
 _BLK_MIN_NODES = 32768      # below: a tile per workgroup leaves most CUs idle; the wave-owned 64-row (or smaller) tiles stay
 
 
-def bwd_blk_rows(n_nodes, num_rels, deterministic=False, device=None):
+def bwd_blk_rows(n_nodes, num_rels, deterministic=False, device=None, diag4=False):
     """tile height of the transposed plan for the block-tile backward kernel (rgcn_bwd_blk_f32), 0 when it does not apply:
-    the tallest tile <= 255 rows that gives every CU the same number of tiles (S1: 245 rows, 4082 tiles, 15.95 per CU)"""
-    if bwd_route() != "blk" or deterministic or n_nodes < _BLK_MIN_NODES or not lib().rgcn_bwd_blk_supported(c_i32(255), c_i32(num_rels)):
+    the tallest tile <= 255 rows that gives every CU the same number of tiles (S1: 245 rows, 4082 tiles, 15.95 per CU).
+    diag4: the weights are block_diag() of 4 x 4 blocks (only the diagonal blocks of dW are kept: up to 447 relations)"""
+    if bwd_route() != "blk" or deterministic or n_nodes < _BLK_MIN_NODES or \
+            not lib().rgcn_bwd_blk_supported(c_i32(255), c_i32(num_rels), c_i32(F_DIAG4 if diag4 else 0)):
         return 0
     n_cu = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).multi_processor_count
     per_cu = -(-n_nodes // (n_cu * 255))
     return -(-n_nodes // (n_cu * per_cu))
 
 
-def _bwd_blk_plan(plan):
+def _bwd_blk_plan(plan, diag4=False):
     return (plan.tile_rows > 160 or (plan.tile_rows > 64 and bwd_route() == "blk")) and \
-        bool(lib().rgcn_bwd_blk_supported(c_i32(plan.tile_rows), c_i32(plan.num_rels)))
+        bool(lib().rgcn_bwd_blk_supported(c_i32(plan.tile_rows), c_i32(plan.num_rels), c_i32(F_DIAG4 if diag4 else 0)))
 
 
-def bwd_fused_ok(plan):
+def bwd_fused_ok(plan, diag4=False):
     """the fused backward kernels walk the transposed plan tile by tile: packed slots and run pointers.  The wave-owned forms
     take a whole tile per wave (no hub-split work units, at most 160 rows: dX tiles + scratch + staging within the LDS); the
     block-tile form deals a tile's chunks to 16 waves itself and ignores the work units"""
     if plan.pack is None or plan.run_ptr is None or plan.n_tiles <= 0:
         return False
-    return _bwd_blk_plan(plan) or (plan.n_split == 0 and plan.n_units == plan.n_tiles and plan.tile_rows <= 160)
+    return _bwd_blk_plan(plan, diag4) or (plan.n_split == 0 and plan.n_units == plan.n_tiles and plan.tile_rows <= 160)
 
 
 def _lean_plan(plan):
@@ -997,24 +1000,27 @@ def _lean_plan(plan):
     return lean
 
 
-def bwd_fused_relu_ok(plan):
+def bwd_fused_relu_ok(plan, diag4=False):
     """RGCN_F_RELU of rgcn_bwd_fused_f32 (dX masked with X > 0 in the epilogue) exists in the window kernel only: its LDS
     (dX tile + X tile + scratch per wave, 8 waves at least) has to fit"""
-    return _bwd_blk_plan(plan) or (bwd_route() != "stage" and
+    return _bwd_blk_plan(plan, diag4) or (bwd_route() != "stage" and
                                    (2 * 8 * plan.tile_rows * 16 + 8 * 256 + 4 * 256) * 4 + 4 <= 160 * 1024)
 
 
-def bwd_fused(G, X, W, plan, atomic=False, relu=False, want_db=False):
+def bwd_fused(G, X, W, plan, atomic=False, relu=False, want_db=False, diag4=False):
     """(dX [n, 16], dW [R, 16, 16]) of the hidden-16 layer from one walk of the transposed plan (rgcn_bwd_fused_f32):
     G upstream gradient, X the layer's input, W [R, 16, 16].  relu: X is the output of a ReLU and dX is wanted BEFORE it
     (rows masked with X > 0 in the kernel's epilogue).  want_db: returns (dX, dW, db) -- db [16] = column sums of G when the
-    kernel that ran computes them on the side (block-tile kernel), else None (the caller launches colsum)."""
+    kernel that ran computes them on the side (block-tile kernel), else None (the caller launches colsum).  diag4: W is
+    block_diag() of 4 x 4 blocks and only the diagonal blocks of dW are wanted (block-tile kernel only: up to 447 relations)."""
     _req(G, "grad_output"); _req(X, "features"); _req(W, "weights")
     assert W.shape[1:] == (16, 16) and G.shape == (plan.n_src, 16) and X.shape == (plan.n_dst, 16)
     dev = G.device
     Wtp = pack_w16t(W)
     dX = torch.empty((plan.n_dst, 16), device=dev, dtype=torch.float32)
-    blk = _bwd_blk_plan(plan)
+    blk = _bwd_blk_plan(plan, diag4)
+    if diag4 and not blk:
+        raise NativeLibraryError("bwd_fused: diag4 needs the block-tile kernel (plan of tall tiles, non-deterministic mode)")
     db = None
     if blk and want_db:      # dW and db back to back: one fill zeroes both
         buf = torch.empty(W.numel() + 16, device=dev, dtype=torch.float32)
@@ -1034,7 +1040,8 @@ def bwd_fused(G, X, W, plan, atomic=False, relu=False, want_db=False):
         with _on(dev), _timed("bwd_fused"):
             _check(lib().rgcn_bwd_blk_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(slots), _dp(hdr), _dp(plan.run_ptr),
                                           c_i64(plan.n_tiles), c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i32(W.shape[0]),
-                                          c_i32(1 if relu else 0), _dp(db), c_i64(plan.n_src), _stream(dev)), "bwd_blk")
+                                          c_i32((F_RELU if relu else 0) | (F_DIAG4 if diag4 else 0)), _dp(db), c_i64(plan.n_src),
+                                          _stream(dev)), "bwd_blk")
         return ret()
     if route == "pc" and atomic and lib().rgcn_bwd_pc_supported(c_i32(plan.tile_rows)) and W.shape[0] < 0x7FFF:
         slots, hdr = _lean_plan(plan)

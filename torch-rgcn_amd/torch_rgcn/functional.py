@@ -133,7 +133,7 @@ class _ReluToken:
         return self.ref is not None and self.ref() is g and g._version == self.version
 
 
-def _fused_backward(X, W, g, graph, relu_in=False, want_db=False):
+def _fused_backward(X, W, g, graph, relu_in=False, want_db=False, diag4=False):
     """hidden 16, both gradients wanted: ONE walk of the transposed plan gathers G[s] once per message and produces dX
     and dW together (csrc/rgcn_bwd.hip).  None when the plan does not qualify (hub-split tiles, unpacked slots) or
     RGCN_BWD=split asks for round 1's two-pass backward.  relu_in: X is the output of a ReLU and dX is wanted before it
@@ -141,11 +141,12 @@ def _fused_backward(X, W, g, graph, relu_in=False, want_db=False):
     sums G's columns on the side (block-tile kernel), else None."""
     if W.shape[1] != 16 or W.shape[2] != 16 or os.environ.get("RGCN_BWD", "fused") == "split":
         return None
-    bp = graph.bwd_plan(16)
-    if not _native.bwd_fused_ok(bp):
+    bp = graph.bwd_plan(16, diag4)
+    diag4 = diag4 and _native._bwd_blk_plan(bp, True)       # block-diagonal W (4 x 4 blocks): only on the block-tile kernel
+    if not _native.bwd_fused_ok(bp, diag4):
         return None
-    masked = relu_in and _native.bwd_fused_relu_ok(bp)
-    dX, dW, db = _native.bwd_fused(g, X, W, bp, atomic=not deterministic(), relu=masked, want_db=True)
+    masked = relu_in and _native.bwd_fused_relu_ok(bp, diag4)
+    dX, dW, db = _native.bwd_fused(g, X, W, bp, atomic=not deterministic(), relu=masked, want_db=True, diag4=diag4)
     return dX, dW, masked, (db if want_db else None)
 
 
@@ -190,6 +191,8 @@ class _RelationalMP(torch.autograd.Function):
         ctx.graph = graph
         ctx.has_bias = bias is not None
         ctx.relu = relu
+        # W = block_diag(4 x 4 blocks) at width 16: the backward may keep only dW's diagonal blocks (block-tile kernel, R <= 447)
+        ctx.diag4 = blocks is not None and ctx.dims is None and tuple(blocks.shape[2:]) == (4, 4) and W.shape[1] == 16 and W.shape[2] == 16
         if relu:
             ctx.save_for_backward(X, W, out)
         else:
@@ -209,12 +212,16 @@ class _RelationalMP(torch.autograd.Function):
         sparse = _sparse_buckets(graph, W)
         both = None
         masked = False
-        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not sparse:
+        # sparse (tile, relation) buckets normally leave the tile plan -- except block-diagonal weights on a graph the block-tile
+        # kernel takes (255-row tiles halve the padding of the sparse buckets; dW's diagonal blocks of all relations fit its LDS)
+        blk_diag = sparse and ctx.diag4 and os.environ.get("RGCN_BWD", "fused") != "split" and \
+            _native.bwd_blk_rows(graph.num_nodes, graph.num_rels, deterministic(), graph.device, True) > 0
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and (not sparse or blk_diag):
             both = _fused_backward(X, W, g, graph, relu_in=ctx.in_token is not None and ctx.dims is None,
-                                   want_db=ctx.has_bias and ctx.needs_input_grad[2])
+                                   want_db=ctx.has_bias and ctx.needs_input_grad[2], diag4=ctx.diag4)
             if both is not None:
                 both, masked, db = both[:2], both[2], both[3]
-        elif ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and os.environ.get("RGCN_BWD", "fused") != "split" \
+        if both is None and sparse and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and os.environ.get("RGCN_BWD", "fused") != "split" \
                 and os.environ.get("RGCN_TWOPASS", "gather") == "gather" and not deterministic():
             # sparse buckets: relation-major walk, G[s] and X[o] gathered once each for dX's rows and dW together
             both = _native.bwd_two_pass_fused(g, X, W, graph.scatter_plan("bwd"), graph.csr("bwd"))

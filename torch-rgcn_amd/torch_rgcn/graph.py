@@ -102,7 +102,7 @@ class RelGraph:
     def fwd_plan(self, d_out):
         return self._plan("fwd", pick_tile_rows(d_out, self.num_nodes))
 
-    def bwd_plan(self, d_in):
+    def bwd_plan(self, d_in, diag4=False):
         rows = pick_tile_rows(d_in, self.num_nodes)
         if d_in == 16 and "RGCN_TILE_ROWS" not in os.environ:
             # hidden 16: the fused backward kernel (dX + dW in one walk) keeps a dX tile, a transposition scratch and the
@@ -111,7 +111,7 @@ class RelGraph:
             # large graphs with few relations: ONE tall tile per workgroup (block-tile kernel, dW of all relations in LDS)
             if "RGCN_BWD_TILE_ROWS" not in os.environ:
                 rows = _native.bwd_blk_rows(self.num_nodes, self.num_rels, os.environ.get("RGCN_DETERMINISTIC", "0") == "1",
-                                            self.device) or rows
+                                            self.device, diag4) or rows
         return self._plan("bwd", rows)
 
     def wgt_plan(self):

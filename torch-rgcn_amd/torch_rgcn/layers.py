@@ -135,28 +135,6 @@ class _RGCBase(Module):
         raise NotImplementedError(f'{kind} decomposition has not been implemented')
 
 
-def _block_messages(features, blocks):
-    """Block-diagonal weights at a width above 16: transform, then aggregate (what the reference does, layers.py:536-541:
-    `einsum('nbi, rbio -> rnbo')`).  The per-relation transform of ALL nodes costs N * d * (d_out / nb) MACs per relation on
-    rocBLAS -- 1/nb of a dense product -- and the R x N x d_out table it produces is aggregated by the featureless gather
-    kernels; expanding the blocks to dense R x d x d weights (1 MB per relation at d = 500) and multiplying per message
-    is what it replaces (FB-toy, d = 500, 100 blocks: 23 ms -> well under 1 ms per layer call)."""
-    n, (r, nb, bi, bo) = features.shape[0], blocks.shape
-    return torch.einsum('nbi,rbio->rnbo', features.reshape(n, nb, bi), blocks).reshape(r, n, nb * bo)
-
-
-def _wide_block(weight_decomp, in_dim, out_dim, num_relations, num_nodes):
-    """Block-diagonal weights above width 16: which route?  Small graphs: transform first (`_block_messages`: the
-    R x N x d_out message table, 1/nb of a dense product) and aggregate with the featureless gather kernels.  The table grows
-    with R N: at FB15k-237 shape (R = 475, N = 14,545, d = 500) it is 13.8 GB (27.9 GB peak with its gradient) and the
-    step takes 56 ms -- there the blocks are expanded to dense R x d x d weights and the relation-grouped gather-GEMM of
-    csrc/rgcn_gemm.hip does the per-message products on the matrix cores: 6.3 ms, 1.7 GB (tools/block_probe.py)."""
-    if weight_decomp != 'block' or (in_dim <= 16 and out_dim <= 16) or os.environ.get("RGCN_BLOCK_TABLE", "1") == "0":
-        return False
-    limit_mb = float(os.environ.get("RGCN_BLOCK_TABLE_MAX_MB", "256"))
-    return num_relations * num_nodes * out_dim * 4 <= limit_mb * (1 << 20)
-
-
 class RelationalGraphConvolutionNC(_RGCBase):
     """R-GCN layer for node classification; the (already augmented) graph is fixed at construction."""
 
@@ -254,12 +232,12 @@ class RelationalGraphConvolutionNC(_RGCBase):
 
         fl_basis = (self.in_features is None and self.weight_decomp == 'basis' and not self.vertical_stacking and
                     getattr(graph, "_dev", None) is not None and os.environ.get("RGCN_BASIS_PATH") != "0")
-        # block-diagonal weights: the blocks are applied as they are (csrc/rgcn_block.hip); only blocks above 8 x 8, or a
-        # host-built graph, fall back to the message table / the expanded dense weights
+        # block-diagonal weights: the blocks are applied as they are (csrc/rgcn_block.hip); blocks above 8 x 8, or a host-built
+        # graph, are expanded to dense R x d x d weights and multiplied per message by the relation-grouped gather-GEMM of
+        # csrc/rgcn_gemm.hip (hand-written MFMA).  Round 1-2 had a third route for small graphs -- einsum('nbi,rbio->rnbo') on
+        # rocBLAS into an R x N x d_out message table -- removed in round 3: no path arithmetic on a vendor BLAS.
         block_path = self.in_features is not None and self.weight_decomp == 'block' and not self.diag_weight_matrix and \
             F_.use_block_path(graph, self.blocks)
-        block_table = self.in_features is not None and not self.diag_weight_matrix and not block_path and \
-            _wide_block(self.weight_decomp, in_dim, out_dim, R, N)
         diag_path = self.diag_weight_matrix and self.in_features is not None and not self.vertical_stacking and \
             getattr(self, "_shard_group", None) is None and F_.use_diag_path(graph, in_dim)
         if self.diag_weight_matrix:
@@ -269,7 +247,7 @@ class RelationalGraphConvolutionNC(_RGCBase):
         elif fl_basis:
             weights = None                                     # never materialise the R x N x d_out table
             assert self.bases.size() == (self.num_bases, in_dim, out_dim) and self.comps.size() == (R, self.num_bases)
-        elif block_table or block_path:
+        elif block_path:
             weights = None                                     # never expand the blocks to R x d x d
         elif self.in_features is not None and self.weight_decomp == 'basis' and \
                 F_.use_basis_path(self.num_bases, in_dim, out_dim, graph):
@@ -298,8 +276,6 @@ class RelationalGraphConvolutionNC(_RGCBase):
                     activation = None
             elif self.weight_decomp == 'basis' and not self.diag_weight_matrix and weights is None:
                 local = lambda x, b: F_.basis_mp(x, self.bases, self.comps, b, graph)
-            elif block_table:
-                local = lambda x, b: F_.featureless_mp(_block_messages(x, self.blocks), b, graph)
             else:
                 fuse_act = activation == "relu" and getattr(self, "_shard_group", None) is None
                 hint = self.blocks if (self.weight_decomp == 'block' and not self.diag_weight_matrix) else None
@@ -309,7 +285,7 @@ class RelationalGraphConvolutionNC(_RGCBase):
         group = getattr(self, "_shard_group", None)
         if group is None:
             output = local(features, self.bias)
-        elif self.in_features is not None and not block_table and weights is not None:
+        elif self.in_features is not None and weights is not None:
             # relation-sharded: partial sums joined by the layer's transport (torch_rgcn.dist.shard_layer / set_transport)
             comm, slabs = getattr(self, "_shard_transport", ("allreduce", 0))
             output = F_.sharded_relational_mp(features, weights, self.bias, graph, group, slabs, comm)
@@ -396,17 +372,12 @@ class RelationalGraphConvolutionLP(_RGCBase):
         assert features.size() == (N, in_dim)
         self_drop = None
         block_path = self.weight_decomp == 'block' and F_.use_block_path(graph, self.blocks)
-        block_table = not block_path and _wide_block(self.weight_decomp, in_dim, out_dim, R, N)
         if self.weight_decomp == 'block':
             if training_dropout and self.edge_dropout["self_loop"] > 0:
                 # dense dropout on the self-loop messages X @ blocks_self before aggregation (added below)
                 self_drop = self.edge_dropout["self_loop"]
             if block_path:      # blocks applied as they are; the dense self-loop relation is added below
                 weights = None
-            elif block_table:   # messages of every relation, transformed first: [R, N, d_out]
-                own = torch.zeros(N, out_dim, device=device) if self_drop is not None else F_.matmul_mfma(features, self.blocks_self)
-                weights = None
-                table = torch.cat([_block_messages(features, self.blocks), own[None]], dim=0)
             else:
                 own = torch.zeros_like(self.blocks_self) if self_drop is not None else self.blocks_self
                 weights = torch.cat([block_diag(self.blocks), own[None]], dim=0)
@@ -426,8 +397,6 @@ class RelationalGraphConvolutionLP(_RGCBase):
             if self_drop is None:
                 own = F_.matmul_mfma(features, self.blocks_self)
                 output = output + (own if (mask is None or keep == 1) else own * mask[:, None].to(own.dtype))
-        elif block_table:
-            output = F_.featureless_mp(table, self.bias, graph)
         else:
             output = F_.relational_mp(features, weights, self.bias, graph)
         if self_drop is not None:
