@@ -279,7 +279,8 @@ def main():
     for layer in (l1, l2):
         g = layer._graph_on(device)
         g.fwd_plan(d)
-        g.bwd_plan(d)
+        if group is not None or g.bwd_blk_plan() is None:      # (sharded ranks may fall back to spmm on the wave-owned plan)
+            g.bwd_plan(d)
     torch.cuda.synchronize()
     graph_build_ms = 1e3 * (time.perf_counter() - t_b)
     my_messages = l1._graph.num_messages

@@ -283,6 +283,10 @@ RGCN_API int rgcn_bwd_fused_f32(const float *G, const float *X, const float *Wt_
 RGCN_API int64_t rgcn_bwd_lean_slot_bytes(int64_t n_chunks);
 RGCN_API int rgcn_bwd_lean_prepare_f32(const int32_t *p_pack, const int32_t *chunk_rel, int64_t n_chunks, void *slots, int32_t *hdr,
                                        void *stream);
+/* The same from a plan WITHOUT packed slots (tiles taller than 255 rows, up to 512): p_src / p_dst (global destination row, < 0 = pad) /
+ * p_val as rgcn_dev_plan_fill wrote them. */
+RGCN_API int rgcn_bwd_lean_prepare_unpacked_f32(const int32_t *p_src, const int32_t *p_dst, const float *p_val, int32_t tile_rows,
+                                                const int32_t *chunk_rel, int64_t n_chunks, void *slots, int32_t *hdr, void *stream);
 RGCN_API int rgcn_bwd_lean_supported(int32_t tile_rows);
 RGCN_API int rgcn_bwd_lean_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, float *scratch,
                                const void *slots, const int32_t *hdr, const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows,
@@ -298,7 +302,8 @@ RGCN_API int rgcn_bwd_pc_f32(const float *G, const float *X, const float *Wt_pac
 /* The same backward, block-tile form (round 3, the default when it applies): ONE destination tile of up to 255 rows per workgroup
  * (plan built with that tile height: 15 % bucket padding instead of 42 %), its chunks dealt to the 16 waves from an LDS counter,
  * dX tile / X tile shared (LDS float atomics), dW of ALL relations resident in LDS for the workgroup's life and flushed once
- * (dirty relations only).  Needs R * 1 KiB + 48 KiB of LDS (R <= 111) and tile_rows <= 255: rgcn_bwd_blk_supported.  Atomic
+ * (dirty relations only).  Needs R * 1 KiB + 48 KiB of LDS (R <= 111) and tile_rows <= 255 (tiles of up to 512 rows on an unpacked
+ * plan: + 32 KiB; with RGCN_F_DIAG4 up to 319 relations): rgcn_bwd_blk_supported.  Atomic
  * flush only, dX sums in arrival order (not bit-reproducible: RGCN_DETERMINISTIC=1 takes the lean kernel on 64-row tiles).
  * flags: RGCN_F_RELU; RGCN_F_DIAG4: the weights are block_diag() of 4 x 4 blocks (layers.py:243-244 at width 16) -- only the
  * diagonal blocks of dW_r are accumulated (the rest of dW stays zero), 256 bytes of LDS per relation instead of 1 KiB (R <= 447:

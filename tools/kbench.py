@@ -99,7 +99,7 @@ if "wtiled" in a.what:
     med, mn = timeit(lambda: _native.wgrad_tiled(X, G, plan, R, tpi), a.iters)
     print(f"[{tag}] wgrad_tiled tiles/item={tpi} relerr_vs_relmajor={err:.2e} med {med:.3f} ms min {mn:.3f} ms", flush=True)
 if "bwd" in a.what:
-    bp, fp = g.bwd_plan(d), g.fwd_plan(d)
+    bp, fp = g.bwd_blk_plan() or g.bwd_plan(d), g.fwd_plan(d)
     Wt = W.transpose(1, 2).contiguous()
     bp64 = g._plan("bwd", min(64, bp.tile_rows))
     ref_dx = _native.spmm(G, Wt, None, bp64)

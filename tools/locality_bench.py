@@ -70,7 +70,7 @@ for how in a.orders.split(","):
     if dense:
         out = _native.spmm(Xp, W, b, fp)
         res["spmm_ms"] = round(timeit(lambda: _native.spmm(Xp, W, b, fp), a.iters), 4)
-        bp = g.bwd_plan(d)
+        bp = g.bwd_blk_plan() or g.bwd_plan(d)
         if _native.bwd_fused_ok(bp):
             res["bwd_fused_ms"] = round(timeit(lambda: _native.bwd_fused(Gp, Xp, W, bp, atomic=True), a.iters), 4)
     else:

@@ -609,14 +609,29 @@ __device__ __forceinline__ void lds_cas_add4(float *p, const f32x4 &v) {
 struct LeanSlot { unsigned w0; float val; unsigned w2; };
 
 // p_pack / chunk_rel (the packed transposed plan) -> lean slots + chunk headers; one lane per slot, one wave per 4 chunks
-__global__ __launch_bounds__(WG) void bwd_lean_prep_kernel(const int2 *__restrict__ p_pack, const int *__restrict__ chunk_rel,
+// p_pack == nullptr: the plan's unpacked arrays (tiles taller than 255 rows have no packed slots): source row, GLOBAL destination row
+// (< 0: pad) and val per slot
+__global__ __launch_bounds__(WG) void bwd_lean_prep_kernel(const int2 *__restrict__ p_pack, const int *__restrict__ p_src,
+                                                           const int *__restrict__ p_dst, const float *__restrict__ p_val, int tile_rows,
+                                                           const int *__restrict__ chunk_rel,
                                                            LeanSlot *__restrict__ slots, int *__restrict__ hdr, long long n_chunks) {
   const long long e = (long long)blockIdx.x * WG + threadIdx.x;          // slot index
   const long long c = e >> 4;
   const bool in = c < n_chunks;
-  const int2 pk = in ? p_pack[e] : make_int2((int)0xFF000000u, 0);
-  const int dl = (int)((unsigned)pk.x >> 24);
-  const bool pad = dl == 0xFF;
+  int2 pk = make_int2(0, 0);
+  int dl = 0xFFFF;
+  if (in) {
+    if (p_pack) {
+      pk = p_pack[e];
+      dl = (int)((unsigned)pk.x >> 24);
+      if (dl == 0xFF) dl = 0xFFFF;
+    } else {
+      const int gd = p_dst[e];
+      pk = make_int2(p_src[e] & 0xFFFFFF, __builtin_bit_cast(int, p_val[e]));
+      dl = gd < 0 ? 0xFFFF : gd % tile_rows;
+    }
+  }
+  const bool pad = dl == 0xFFFF;
   const int key = pad ? -1 : dl;
   const int prev1 = dpp_i<ROW_SHR + 1>(-2, key), prev2 = dpp_i<ROW_SHR + 2>(-2, key), next1 = dpp_i<ROW_SHL + 1>(-3, key);
   const bool dup1 = !pad && prev1 == key, dup2 = !pad && prev2 == key, tail = !pad && next1 != key;
@@ -948,9 +963,10 @@ constexpr int BLK_NW = 16;
 constexpr int BLK_TILE_FLOATS = 256 * 16;
 // DIAG4: W is block-diagonal with 4 x 4 blocks (decomposition {type: block}, width 16): only the four diagonal blocks of dW_r are
 // wanted (64 floats per relation instead of 256: hundreds of relations fit, AM has 267)
-static size_t bwd_blk_lds(int R, bool diag4) { return ((size_t)2 * BLK_TILE_FLOATS + BLK_NW * BW_SCR2 + (size_t)R * (diag4 ? 64 : 256)) * 4 + (4 + (size_t)R) * 4; }
+// tq: tile capacity in units of 256 rows (1: tiles of up to 255 rows, packed or unpacked plan; 2: up to 512 rows, unpacked plan)
+static size_t bwd_blk_lds(int R, bool diag4, int tq) { return ((size_t)2 * tq * BLK_TILE_FLOATS + BLK_NW * BW_SCR2 + (size_t)R * (diag4 ? 64 : 256)) * 4 + (4 + (size_t)R) * 4; }
 
-template <bool RELU, int ABL, bool DIAG4 = false>
+template <bool RELU, int ABL, bool DIAG4 = false, int TQ = 1>
 __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
     const float *__restrict__ G, const float *__restrict__ X, const float *__restrict__ Wtp, float *__restrict__ dX,
     float *__restrict__ dWout, const LeanSlot *__restrict__ slots, const int *__restrict__ hdr,
@@ -959,11 +975,12 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  float *dxt = lds;                                               // dX tile [256][16]
-  float *xt = lds + BLK_TILE_FLOATS;                              // X tile  [256][16]
-  float *xs = lds + 2 * BLK_TILE_FLOATS + wave * BW_SCR2;         // transposition scratch of this wave
+  constexpr int TILE_F = TQ * BLK_TILE_FLOATS;                    // TQ = 2: tiles of up to 512 rows (sparse buckets: less padding)
+  float *dxt = lds;                                               // dX tile [256 TQ][16]
+  float *xt = lds + TILE_F;                                       // X tile  [256 TQ][16]
+  float *xs = lds + 2 * TILE_F + wave * BW_SCR2;                  // transposition scratch of this wave
   constexpr int DWR = DIAG4 ? 64 : 256;                           // floats of dW kept per relation
-  float *dwl = lds + 2 * BLK_TILE_FLOATS + NW * BW_SCR2;          // dW [R][64 lanes][4] (fragment order, a lane's four elements adjacent); DIAG4: [R][16 lanes][4]
+  float *dwl = lds + 2 * TILE_F + NW * BW_SCR2;                   // dW [R][64 lanes][4] (fragment order, a lane's four elements adjacent); DIAG4: [R][16 lanes][4]
   int *ctl = reinterpret_cast<int *>(dwl + (size_t)R * DWR);      // [0]: next quad of the tile; [4 + r]: relation r has data
   int *dirty = ctl + 4;
   float4 *dxt4 = reinterpret_cast<float4 *>(dxt), *xt4 = reinterpret_cast<float4 *>(xt);
@@ -980,10 +997,14 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
   const long long g_n4 = dbias ? (long long)n_src * 4 : 0, g_step = (long long)gridDim.x * (64 * NW);
   long long g_i = (long long)blockIdx.x * (64 * NW) + tid;
   {
-    float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < nrows * 4) x0 = reinterpret_cast<const float4 *>(X + (size_t)row0 * 16)[tid];
-    xt4[tid] = x0;
-    dxt4[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < TQ; ++q) {
+      const int idx = tid + q * (64 * NW);
+      float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < nrows * 4) x0 = reinterpret_cast<const float4 *>(X + (size_t)row0 * 16)[idx];
+      xt4[idx] = x0;
+      dxt4[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     for (int i = tid; i < R * (DWR / 4); i += 64 * NW) reinterpret_cast<float4 *>(dwl)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < R + 4; i += 64 * NW) ctl[i] = i == 0 ? 2 * NW : 0;
   }
@@ -992,7 +1013,7 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
   const int m = lane & 15, k = lane >> 4;
   const unsigned kofs = (unsigned)k << 4;
   const unsigned tile_k = kofs;                                        // LDS byte address of dxt[0][4k]
-  const unsigned xrd = (unsigned)(BLK_TILE_FLOATS * 4) + (unsigned)m * 4;   // LDS byte address of xt[0][m]
+  const unsigned xrd = (unsigned)(TILE_F * 4) + (unsigned)m * 4;            // LDS byte address of xt[0][m]
   float *xs_wr = xs + m * 16 + 4 * ((k + (m >> 1)) & 3);                                  // this lane's float4 of slot m
   const float *xs_rd0 = xs + k * 16 + 4 * (((m >> 2) + (k >> 1)) & 3) + (m & 3);          // feature m of slot 4 t + k, t even: + 128 t
   const float *xs_rd1 = xs + (4 + k) * 16 + 4 * (((m >> 2) + 2 + (k >> 1)) & 3) + (m & 3); // t odd: + 128 (t - 1)
@@ -1177,7 +1198,9 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
     cur_r = -1;
     // the next tile of this workgroup: its X rows and this wave's first chunks are requested before the barrier
     const int tn = t + (int)gridDim.x;
-    float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 xn[TQ];
+#pragma unroll
+    for (int q = 0; q < TQ; ++q) xn[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     int c0n = 0, c1n = 0, nqn = 0, row0n = 0, nrn = 0;
     if (tn < n_tiles) {
       row0n = tn * tile_rows;
@@ -1185,7 +1208,9 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
       c0n = __builtin_amdgcn_readfirstlane(run_ptr[(size_t)tn * (R + 1)]);
       c1n = __builtin_amdgcn_readfirstlane(run_ptr[(size_t)tn * (R + 1) + R]);
       nqn = (c1n - c0n + U - 1) / U;
-      if (tid < nrn * 4) xn = reinterpret_cast<const float4 *>(X + (size_t)row0n * 16)[tid];
+#pragma unroll
+      for (int q = 0; q < TQ; ++q)
+        if (tid + q * (64 * NW) < nrn * 4) xn[q] = reinterpret_cast<const float4 *>(X + (size_t)row0n * 16)[tid + q * (64 * NW)];
       if (wave < nqn) request_idx(c0n + wave * U, c1n - 1);
     }
     float4 gn = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1193,17 +1218,24 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
     g_i += g_step;
     __syncthreads();                                               // every wave has finished adding to the dX tile
     gs.x += gn.x; gs.y += gn.y; gs.z += gn.z; gs.w += gn.w;
-    if (tid < nrows * 4) {
-      float4 a = dxt4[tid];
-      if (RELU) {
-        const float4 x = xt4[tid];
-        a.x = x.x > 0.f ? a.x : 0.f; a.y = x.y > 0.f ? a.y : 0.f; a.z = x.z > 0.f ? a.z : 0.f; a.w = x.w > 0.f ? a.w : 0.f;
+#pragma unroll
+    for (int q = 0; q < TQ; ++q) {
+      const int idx = tid + q * (64 * NW);
+      if (idx < nrows * 4) {
+        float4 a = dxt4[idx];
+        if (RELU) {
+          const float4 x = xt4[idx];
+          a.x = x.x > 0.f ? a.x : 0.f; a.y = x.y > 0.f ? a.y : 0.f; a.z = x.z > 0.f ? a.z : 0.f; a.w = x.w > 0.f ? a.w : 0.f;
+        }
+        reinterpret_cast<float4 *>(dX + (size_t)row0 * 16)[idx] = a;
       }
-      reinterpret_cast<float4 *>(dX + (size_t)row0 * 16)[tid] = a;
     }
     if (tn >= n_tiles) break;
-    dxt4[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    xt4[tid] = xn;
+#pragma unroll
+    for (int q = 0; q < TQ; ++q) {
+      dxt4[tid + q * (64 * NW)] = make_float4(0.f, 0.f, 0.f, 0.f);
+      xt4[tid + q * (64 * NW)] = xn[q];
+    }
     if (tid == 0) ctl[0] = 2 * NW;
     __syncthreads();                                               // the next tile is installed
     t = tn; row0 = row0n; nrows = nrn; c0 = c0n; c1 = c1n; nq = nqn;
@@ -1907,7 +1939,22 @@ extern "C" int rgcn_bwd_lean_prepare_f32(const int32_t *p_pack, const int32_t *c
   if (!n_chunks) return RGCN_OK;
   const long long n = n_chunks * RGCN_CHUNK;
   hipLaunchKernelGGL(bwd_lean_prep_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, (hipStream_t)stream,
-                     reinterpret_cast<const int2 *>(p_pack), chunk_rel, reinterpret_cast<LeanSlot *>(slots), hdr, (long long)n_chunks);
+                     reinterpret_cast<const int2 *>(p_pack), nullptr, nullptr, nullptr, 0, chunk_rel, reinterpret_cast<LeanSlot *>(slots), hdr,
+                     (long long)n_chunks);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_bwd_lean_prepare_unpacked_f32(const int32_t *p_src, const int32_t *p_dst, const float *p_val, int32_t tile_rows,
+                                                  const int32_t *chunk_rel, int64_t n_chunks, void *slots, int32_t *hdr, void *stream) {
+  if (n_chunks < 0 || tile_rows <= 0 || tile_rows > 512 || (n_chunks && (!p_src || !p_dst || !p_val || !chunk_rel || !slots || !hdr))) {
+    rgcn_set_error("bwd_lean_prepare_unpacked: bad argument");
+    return RGCN_EINVAL;
+  }
+  if (!n_chunks) return RGCN_OK;
+  const long long n = n_chunks * RGCN_CHUNK;
+  hipLaunchKernelGGL(bwd_lean_prep_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, (hipStream_t)stream,
+                     nullptr, p_src, p_dst, p_val, tile_rows, chunk_rel, reinterpret_cast<LeanSlot *>(slots), hdr, (long long)n_chunks);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
@@ -1956,7 +2003,8 @@ extern "C" int rgcn_bwd_pc_f32(const float *G, const float *X, const float *Wt_p
 }
 
 extern "C" int rgcn_bwd_blk_supported(int32_t tile_rows, int32_t R, int32_t flags) {
-  return tile_rows > 0 && tile_rows <= 255 && R > 0 && R < 0xFFFF && bwd_blk_lds(R, (flags & RGCN_F_DIAG4) != 0) <= 160 * 1024;
+  return tile_rows > 0 && tile_rows <= 512 && R > 0 && R < 0xFFFF &&
+         bwd_blk_lds(R, (flags & RGCN_F_DIAG4) != 0, tile_rows > 256 ? 2 : 1) <= 160 * 1024;
 }
 
 /* block-tile form (atomic flush only; dX sums are LDS float atomics: not bit-reproducible): arguments as rgcn_bwd_pc_f32 */
@@ -1968,11 +2016,12 @@ extern "C" int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_
     return RGCN_EINVAL;
   }
   if (!rgcn_bwd_blk_supported(tile_rows, R, flags)) {
-    rgcn_set_error("bwd_blk: tile_rows = %d (<= 255) / R = %d (R KiB, or R / 4 KiB with RGCN_F_DIAG4, + 48 KiB of LDS) not supported", tile_rows, R);
+    rgcn_set_error("bwd_blk: tile_rows = %d (<= 512) / R = %d (R KiB, or R / 4 KiB with RGCN_F_DIAG4, + 48 KiB -- 80 KiB above 256 rows -- of LDS) not supported", tile_rows, R);
     return RGCN_EUNSUPPORTED;
   }
   const bool relu = (flags & RGCN_F_RELU) != 0, diag4 = (flags & RGCN_F_DIAG4) != 0;
-  const size_t lds = bwd_blk_lds(R, diag4);
+  const int tq = tile_rows > 256 ? 2 : 1;
+  const size_t lds = bwd_blk_lds(R, diag4, tq);
   hipStream_t st = (hipStream_t)stream;
   static int n_cu = 0;
   if (!n_cu) {
@@ -2000,8 +2049,12 @@ extern "C" int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_
                        hdr, run_ptr, (int)n_tiles, tile_rows, (int)n_dst, R, dbias, (int)n_src);
     return hipGetLastError();
   };
-  static bool r0 = false, r1 = false, r2 = false, r3 = false, r4 = false, r5 = false, r6 = false, r7 = false;
-  if (diag4 && relu) HIP_TRY(launch(bwd_blk_d16_kernel<true, 0, true>, r6));
+  static bool r0 = false, r1 = false, r2 = false, r3 = false, r4 = false, r5 = false, r6 = false, r7 = false, r8 = false, r9 = false, r10 = false, r11 = false;
+  if (tq == 2 && diag4 && relu) HIP_TRY(launch(bwd_blk_d16_kernel<true, 0, true, 2>, r8));
+  else if (tq == 2 && diag4) HIP_TRY(launch(bwd_blk_d16_kernel<false, 0, true, 2>, r9));
+  else if (tq == 2 && relu) HIP_TRY(launch(bwd_blk_d16_kernel<true, 0, false, 2>, r10));
+  else if (tq == 2) HIP_TRY(launch(bwd_blk_d16_kernel<false, 0, false, 2>, r11));
+  else if (diag4 && relu) HIP_TRY(launch(bwd_blk_d16_kernel<true, 0, true>, r6));
   else if (diag4) HIP_TRY(launch(bwd_blk_d16_kernel<false, 0, true>, r7));
   else if (ABL == 2) HIP_TRY(launch(bwd_blk_d16_kernel<false, 2>, r2));
   else if (ABL == 4) HIP_TRY(launch(bwd_blk_d16_kernel<false, 4>, r3));

@@ -966,7 +966,10 @@ def bwd_blk_rows(n_nodes, num_rels, deterministic=False, device=None, diag4=Fals
             not lib().rgcn_bwd_blk_supported(c_i32(255), c_i32(num_rels), c_i32(F_DIAG4 if diag4 else 0)):
         return 0
     n_cu = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).multi_processor_count
-    per_cu = -(-n_nodes // (n_cu * 255))
+    # tiles of up to 512 rows (unpacked plan slots, 32 KiB more LDS) when they fit: fewer, fuller (tile, relation) buckets
+    cap = 512 if lib().rgcn_bwd_blk_supported(c_i32(512), c_i32(num_rels), c_i32(F_DIAG4 if diag4 else 0)) and \
+        os.environ.get("RGCN_BWD_BLK_CAP", "512") == "512" else 255
+    per_cu = -(-n_nodes // (n_cu * cap))
     return -(-n_nodes // (n_cu * per_cu))
 
 
@@ -979,9 +982,11 @@ def bwd_fused_ok(plan, diag4=False):
     """the fused backward kernels walk the transposed plan tile by tile: packed slots and run pointers.  The wave-owned forms
     take a whole tile per wave (no hub-split work units, at most 160 rows: dX tiles + scratch + staging within the LDS); the
     block-tile form deals a tile's chunks to 16 waves itself and ignores the work units"""
-    if plan.pack is None or plan.run_ptr is None or plan.n_tiles <= 0:
+    if plan.run_ptr is None or plan.n_tiles <= 0 or plan.n_src >= (1 << 24):
         return False
-    return _bwd_blk_plan(plan, diag4) or (plan.n_split == 0 and plan.n_units == plan.n_tiles and plan.tile_rows <= 160)
+    if _bwd_blk_plan(plan, diag4):
+        return True             # (tiles above 255 rows have no packed slots: the lean slots are made from the unpacked arrays)
+    return plan.pack is not None and plan.n_split == 0 and plan.n_units == plan.n_tiles and plan.tile_rows <= 160
 
 
 def _lean_plan(plan):
@@ -994,8 +999,13 @@ def _lean_plan(plan):
         slots = torch.empty(int(lib().rgcn_bwd_lean_slot_bytes(c_i64(n_chunks))) + 16, device=dev, dtype=torch.uint8)
         hdr = torch.empty(max(n_chunks, 1), device=dev, dtype=torch.int32)
         with _on(dev):
-            _check(lib().rgcn_bwd_lean_prepare_f32(_dp(plan.pack), _dp(plan.chunk_rel), c_i64(n_chunks), _dp(slots), _dp(hdr), _stream(dev)),
-                   "bwd_lean_prepare")
+            if plan.pack is not None:
+                _check(lib().rgcn_bwd_lean_prepare_f32(_dp(plan.pack), _dp(plan.chunk_rel), c_i64(n_chunks), _dp(slots), _dp(hdr), _stream(dev)),
+                       "bwd_lean_prepare")
+            else:
+                _check(lib().rgcn_bwd_lean_prepare_unpacked_f32(_dp(plan.src), _dp(plan.dst), _dp(plan.val), c_i32(plan.tile_rows),
+                                                                _dp(plan.chunk_rel), c_i64(n_chunks), _dp(slots), _dp(hdr), _stream(dev)),
+                       "bwd_lean_prepare_unpacked")
         lean = plan._lean = (slots, hdr)
     return lean
 

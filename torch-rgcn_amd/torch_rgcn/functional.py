@@ -141,8 +141,10 @@ def _fused_backward(X, W, g, graph, relu_in=False, want_db=False, diag4=False):
     sums G's columns on the side (block-tile kernel), else None."""
     if W.shape[1] != 16 or W.shape[2] != 16 or os.environ.get("RGCN_BWD", "fused") == "split":
         return None
-    bp = graph.bwd_plan(16, diag4)
-    diag4 = diag4 and _native._bwd_blk_plan(bp, True)       # block-diagonal W (4 x 4 blocks): only on the block-tile kernel
+    bp = graph.bwd_blk_plan(diag4)                          # tall tiles, one per workgroup -- or the wave-owned 64-row plan
+    diag4 = diag4 and bp is not None and _native._bwd_blk_plan(bp, True)   # block-diagonal W (4 x 4 blocks): only on the block-tile kernel
+    if bp is None or not _native._bwd_blk_plan(bp, diag4):
+        bp = graph.bwd_plan(16)
     if not _native.bwd_fused_ok(bp, diag4):
         return None
     masked = relu_in and _native.bwd_fused_relu_ok(bp, diag4)

@@ -102,17 +102,26 @@ class RelGraph:
     def fwd_plan(self, d_out):
         return self._plan("fwd", pick_tile_rows(d_out, self.num_nodes))
 
-    def bwd_plan(self, d_in, diag4=False):
+    def bwd_plan(self, d_in):
+        """transposed plan with wave-owned tiles (spmm on the transposed graph, the wave-owned fused backward kernels)"""
         rows = pick_tile_rows(d_in, self.num_nodes)
         if d_in == 16 and "RGCN_TILE_ROWS" not in os.environ:
-            # hidden 16: the fused backward kernel (dX + dW in one walk) keeps a dX tile, a transposition scratch and the
-            # dW staging slots in LDS; 64-row tiles keep 4 workgroups per CU resident (measured: 0.71 ms at 64 rows, 0.80 at 128)
+            # hidden 16: the fused backward kernels (dX + dW in one walk) keep a dX tile, an X tile, a transposition scratch and
+            # the dW hand-over slots in LDS: 64-row tiles (measured in round 2: 0.71 ms at 64 rows, 0.80 at 128)
             rows = int(os.environ["RGCN_BWD_TILE_ROWS"]) if "RGCN_BWD_TILE_ROWS" in os.environ else min(rows, 64)
-            # large graphs with few relations: ONE tall tile per workgroup (block-tile kernel, dW of all relations in LDS)
-            if "RGCN_BWD_TILE_ROWS" not in os.environ:
-                rows = _native.bwd_blk_rows(self.num_nodes, self.num_rels, os.environ.get("RGCN_DETERMINISTIC", "0") == "1",
-                                            self.device, diag4) or rows
         return self._plan("bwd", rows)
+
+    def bwd_blk_plan(self, diag4=False):
+        """transposed plan of TALL tiles (one per workgroup, up to 255 / 512 rows) for the block-tile backward kernel, or None
+        when that kernel does not apply (small graph, too many relations, RGCN_DETERMINISTIC=1, RGCN_BWD_KERNEL != blk).
+        Only rgcn_bwd_blk_f32 can walk it -- every other kernel gets bwd_plan()."""
+        if "RGCN_TILE_ROWS" in os.environ:
+            return None
+        if "RGCN_BWD_TILE_ROWS" in os.environ and _native.bwd_route() == "blk":
+            rows = int(os.environ["RGCN_BWD_TILE_ROWS"])         # experiments (tools/r3_blk.sh)
+            return self._plan("bwd", rows) if rows > 64 else None
+        rows = _native.bwd_blk_rows(self.num_nodes, self.num_rels, os.environ.get("RGCN_DETERMINISTIC", "0") == "1", self.device, diag4)
+        return self._plan("bwd", rows) if rows else None
 
     def wgt_plan(self):
         """relation-major (single tile): long runs per relation for the weight gradient"""
