@@ -236,6 +236,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-s1", action="store_true", help="CPU baseline at 1/10 scale only")
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary lines for BASELINE configs 1-4")
+    ap.add_argument("--sustained-steps", type=int, default=400,
+                    help="N = 1: untimed-for-the-headline extra leg after the K timed steps (clocks / thermals over ~1 s); 0: skip")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -381,6 +383,24 @@ def main():
                               "2(G-1)/G x 64 MB over each rank's slowest link, a direct reduce-scatter + all-gather "
                               "2(G-1)/G x 64 MB spread over G-1 links (DESIGN.md section 6)"})
 
+    sustained = None
+    if world == 1 and group is None and args.sustained_steps > 0:
+        # the timed region is K steps (~45 ms at the defaults): a second, longer leg of the SAME step shows whether the figure holds
+        # once clocks and temperature have settled.  Reported next to the headline, never instead of it.
+        n_s = args.sustained_steps
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        fence()
+        for q in range(4):
+            ev[q].record()
+            for _ in range(n_s // 4):
+                step()
+        ev[4].record()
+        fence()
+        quarters = [ev[q].elapsed_time(ev[q + 1]) / (n_s // 4) for q in range(4)]
+        sustained = {"steps": 4 * (n_s // 4), "ms_per_step": round(float(np.mean(quarters)), 4),
+                     "ms_per_step_by_quarter": [round(v, 4) for v in quarters],
+                     "note": "HIP events around four consecutive quarters of the leg, after the timed region; same step, same inputs"}
+
     if rank == 0:
         total_edges = E * (world if mode == "weak" else 1)
         value = total_edges / (ms * 1e-3)
@@ -438,6 +458,7 @@ def main():
                "scaling": "weak" if mode == "weak" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "per_gpu_edges_per_s": value / world,
                "step_ms_median": round(float(np.median(per_step)), 4), "step_ms_min": round(float(np.min(per_step)), 4),
+               "step_ms_p95": round(float(np.percentile(per_step, 95)), 4), "sustained": sustained,
                "graph_build_ms": round(graph_build_ms, 2),
                "config": {"workload": (f"S1: N={N} nodes, E={E} base triples" + ("/GPU" if mode == "weak" else "") +
                                        f", R0={R0} relations" + ("/GPU" if mode == "weak" else "") +
