@@ -56,13 +56,16 @@ __device__ __forceinline__ void block_unit(
     float acc[CAP_OUT];
 #pragma unroll
     for (int o = 0; o < CAP_OUT; ++o) acc[o] = 0.f;
-    if (b < nb)
-      for (int e = unit.y + g; e < e1; e += gpr) {
-        const int rel = e_rel[e];
-        const float v = rel < n_rel_blocks ? e_val[e] : 0.f;        // relations past the block table (LP self loops): not ours
-        if (v == 0.f) continue;
-        const float *xr = X + (size_t)e_src[e] * d_in + (size_t)b * n_in;
-        const float *wr = W + (size_t)rel * rel_stride + (size_t)b * (bi * bo);
+    if (b < nb) {
+      // one message: indices -> feature segment + block -> acc.  Two messages of the unit per lane group are in flight (their
+      // index loads and row gathers are independent: a row of <= 2 gpr messages -- AM: 8 on average, gpr = 4 -- costs ONE chain of
+      // index latency + gather latency instead of two; measured at AM scale: 0.455 -> see DESIGN 4.3)
+      auto one = [&](int e, bool have) {
+        const int ee = have ? e : unit.y;
+        const int rel = e_rel[ee];
+        const float v = (have && rel < n_rel_blocks) ? e_val[ee] : 0.f;        // relations past the block table (LP self loops): not ours
+        const float *xr = X + (size_t)e_src[ee] * d_in + (size_t)b * n_in;
+        const float *wr = W + (size_t)(rel < n_rel_blocks ? rel : 0) * rel_stride + (size_t)b * (bi * bo);
         float x[CAP_IN], w[FIXED ? BI_ * BO_ : MAXB * MAXB];
         if (vec_in) {
 #pragma unroll
@@ -98,7 +101,12 @@ __device__ __forceinline__ void block_unit(
                 if (i < n_in) acc[o] = fmaf(x[i], TR ? wr[o * bo + i] : wr[i * bo + o], acc[o]);
             }
         }
+      };
+      for (int e = unit.y + g; e < e1; e += 2 * gpr) {
+        one(e, true);
+        one(e + gpr, e + gpr < e1);
       }
+    }
     for (int s = lpm; s < lr; s *= 2) {          // sum over the message groups of the unit (same trip count in every lane)
 #pragma unroll
       for (int o = 0; o < CAP_OUT; ++o) acc[o] += __shfl_xor(acc[o], s, 64);
