@@ -427,8 +427,7 @@ def main():
                 route = _native.bwd_route()
                 if route == "blk" and not _native.bwd_blk_rows(N, 2 * R0 + 1, os.environ.get("RGCN_DETERMINISTIC", "0") == "1"):
                     route = "lean"
-                kname, kkey = {"blk": ("bwd_blk_d16_kernel", "bwd_blk"), "lean": ("bwd_lean_d16_kernel", "bwd_lean"), "win": ("bwd_win2_d16_kernel", "bwd_win"),
-                               "pc": ("bwd_pc_d16_kernel", "bwd_pc")}.get(route, ("bwd_fused_d16_kernel", "bwd_fused"))
+                kname, kkey = {"blk": ("bwd_blk_d16_kernel", "bwd_blk"), "lean": ("bwd_lean_d16_kernel", "bwd_lean")}.get(route, ("bwd_fused_d16_kernel", "bwd_fused"))
                 bwd = kernel_roofline(kname + " (dX + dW of one layer from one gather per message"
                                       + (" + dw_reduce)" if "dw_reduce" in launches else ")"), bms, balg, bmodel, ms, 2,
                                       (kname, "bwd_fused_d16_kernel") if kname != "bwd_fused_d16_kernel" else (kname,), kkey)

@@ -291,14 +291,6 @@ RGCN_API int rgcn_bwd_lean_supported(int32_t tile_rows);
 RGCN_API int rgcn_bwd_lean_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, float *scratch,
                                const void *slots, const int32_t *hdr, const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows,
                                int64_t n_dst, int32_t R, int32_t flags, void *stream);
-/* The same backward, producer / consumer form (round 3): 12 waves of a workgroup own a tile each (gather, dX), 4 waves own the
- * relations (r mod 4) and take the dW products of all 12 tiles from the producers' LDS rings -- a relation's partial grows in one
- * wave's registers and leaves the CU once; no merge of partial sums, no locks.  Sums over tiles in arrival order: atomic flush
- * only (flags: RGCN_F_RELU; RGCN_F_DW_ATOMIC implied).  Plan arrays as rgcn_bwd_lean_f32 (rgcn_bwd_lean_prepare_f32). */
-RGCN_API int rgcn_bwd_pc_supported(int32_t tile_rows);
-RGCN_API int rgcn_bwd_pc_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, const void *slots,
-                             const int32_t *hdr, const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R,
-                             int32_t flags, void *stream);
 /* The same backward, block-tile form (round 3, the default when it applies): ONE destination tile of up to 255 rows per workgroup
  * (plan built with that tile height: 15 % bucket padding instead of 42 %), its chunks dealt to the 16 waves from an LDS counter,
  * dX tile / X tile shared (LDS float atomics), dW of ALL relations resident in LDS for the workgroup's life and flushed once
@@ -314,14 +306,6 @@ RGCN_API int rgcn_bwd_blk_supported(int32_t tile_rows, int32_t R, int32_t flags)
 RGCN_API int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, const void *slots,
                               const int32_t *hdr, const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R,
                               int32_t flags, float *dbias, int64_t n_src, void *stream);
-/* Debug / tuning aid (tools/kbench.py with RGCN_BWD_ABL=128): shader-cycle totals the instrumented window kernel adds up --
- * out8[0] all waves, [1] inside the window hand-over, [2] of that waiting for the slot, [3] waves, [4] hand-overs.
- * reset != 0 clears the counters.  No reference counterpart. */
-RGCN_API int rgcn_debug_bwd_prof(uint64_t *out8, int32_t reset);
-/* Occupancy experiment (tools/kbench.py): the window kernel with 12 instead of 16 tile-owning waves per CU; abl as RGCN_BWD_ABL. */
-RGCN_API int rgcn_debug_bwd_nw12(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, const int32_t *p_pack,
-                                 const int32_t *chunk_rel, const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst,
-                                 int32_t R, int32_t abl, void *stream);
 /* The same for graphs whose (tile, relation) buckets are sparse (AM: 267 relations), on the RELATION-major plan of the
  * two-pass path: one wave per work item gathers G[p_src] and X[p_dst] once per message and produces
  *   Y[slot, :] = val G[p_src] W_r^T   (slot order; pass 2 = rgcn_segment_gather_sum_f32 sums them per destination -> dX)

@@ -116,49 +116,6 @@ if "bwd" in a.what:
         balg = M * (4 * d + 8) + 2 * N * 4 * d
         print(f"[{tag} K={os.environ.get('RGCN_BWD_KERNEL', 'blk')} NW={os.environ.get('RGCN_BWD_NW', '-')} BP={os.environ.get('RGCN_BWD_BPERM', '-')}] bwd_fused {'atomic' if atomic else 'partial'} tile={bp.tile_rows} relerr dX {e1:.2e} dW {e2:.2e} "
               f"med {med:.3f} ms min {mn:.3f} ms -> {balg / med / 1e6:.0f} GB/s algorithmic (backward bytes)", flush=True)
-    if os.environ.get("RGCN_BWD_NW12"):
-        from ctypes import c_int32 as ci, c_int64 as cl
-        Wtp = _native.pack_w16t(W)
-        dXn, dWn = torch.empty_like(X), torch.empty_like(W)
-        for abl in (0, 2, 16):
-            f = lambda: _native._check(_native.lib().rgcn_debug_bwd_nw12(_native._dp(G), _native._dp(X), _native._dp(Wtp), _native._dp(dXn), _native._dp(dWn),
-                                                                           _native._dp(bp.pack), _native._dp(bp.chunk_rel), _native._dp(bp.run_ptr), cl(bp.n_tiles),
-                                                                           ci(bp.tile_rows), cl(bp.n_dst), ci(R), ci(abl), _native._stream(dev)), "nw12")
-            med, mn = timeit(f, a.iters)
-            extra = ""
-            if abl == 0:
-                extra = f" relerr dX {((dXn - ref_dx).abs().max() / ref_dx.abs().max()).item():.1e} dW {((dWn - ref_dw).abs().max() / ref_dw.abs().max()).item():.1e}"
-            print(f"NW12 abl={abl} med {med:.3f} ms min {mn:.3f} ms{extra}", flush=True)
-    if int(os.environ.get("RGCN_BWD_ABL", "0")) & 256 and os.environ.get("RGCN_BWD_KERNEL") == "pc":
-        import ctypes
-        buf = (ctypes.c_uint64 * 8)()
-        _native.lib().rgcn_debug_bwd_prof(buf, 1)
-        _native.bwd_fused(G, X, W, bp, atomic=True)
-        torch.cuda.synchronize()
-        _native.lib().rgcn_debug_bwd_prof(buf, 0)
-        nc, npass, nbusy, ntaken, nprod, nfull, nposted = [int(buf[i]) for i in range(7)]
-        print(f"PCPROF consumers {nc}: passes/consumer {npass / max(nc, 1):.0f} busy {nbusy / max(nc, 1):.0f} chunks {ntaken / max(nc, 1):.0f} (per busy pass {ntaken / max(nbusy, 1):.2f}); "
-              f"producers {nprod}: chunks {nposted / max(nprod, 1):.0f} ring-full spins {nfull / max(nprod, 1):.0f}", flush=True)
-    elif int(os.environ.get("RGCN_BWD_ABL", "0")) & 256:
-        import ctypes
-        buf = (ctypes.c_uint64 * 8)()
-        _native.lib().rgcn_debug_bwd_prof(buf, 1)
-        _native.bwd_fused(G, X, W, bp, atomic=True)
-        torch.cuda.synchronize()
-        _native.lib().rgcn_debug_bwd_prof(buf, 0)
-        nw, nc, st, sl, cf = [int(buf[i]) for i in range(3, 8)]
-        print(f"PROF waves {nw} hand-overs/wave {nc / max(nw, 1):.1f}; per hand-over: slot-not-ready spins {st / max(nc, 1):.2f} lock-taken spins {sl / max(nc, 1):.2f} "
-              f"lost CAS {cf / max(nc, 1):.2f}", flush=True)
-    if int(os.environ.get("RGCN_BWD_ABL", "0")) & 128:
-        import ctypes
-        buf = (ctypes.c_uint64 * 8)()
-        _native.lib().rgcn_debug_bwd_prof(buf, 1)
-        _native.bwd_fused(G, X, W, bp, atomic=True)
-        torch.cuda.synchronize()
-        _native.lib().rgcn_debug_bwd_prof(buf, 0)
-        tot, con, wait, nw, nc = [int(buf[i]) for i in range(5)]
-        print(f"PROF waves {nw} cycles/wave {tot / max(nw, 1):.0f} in hand-over {con / max(nw, 1):.0f} ({100 * con / max(tot, 1):.1f} %) waiting "
-              f"{wait / max(nw, 1):.0f} ({100 * wait / max(tot, 1):.1f} %) hand-overs/wave {nc / max(nw, 1):.1f} cycles/hand-over {con / max(nc, 1):.0f}", flush=True)
     if _native.bwd_fused_relu_ok(bp):        # ReLU mask fused into the dX epilogue (window kernel)
         Xr = torch.relu(X)
         dxr, dwr = _native.bwd_fused(G, Xr, W, bp, atomic=True, relu=True)

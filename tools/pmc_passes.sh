@@ -14,7 +14,6 @@ for SET in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_RDREQ_64B_sum TCC
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/k$i" -o p -- python tools/kbench.py --what spmm,bwd --iters 3 > "$OUT/k$i.log" 2>&1
   RGCN_BWD_KERNEL=lean timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/kl$i" -o p -- python tools/kbench.py --what bwd --iters 3 > "$OUT/kl$i.log" 2>&1
-  RGCN_BWD_KERNEL=win timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/kw$i" -o p -- python tools/kbench.py --what bwd --iters 3 > "$OUT/kw$i.log" 2>&1
 done
 python - "$OUT" <<'PY'
 import collections, csv, glob, json, sys
@@ -25,7 +24,6 @@ for f in glob.glob(out + "/k*/*counter_collection.csv"):
         per[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 keys = {"spmm": "spmm_d16_kernel", "bwd_fused": "bwd_fused_d16_kernel<4, true", "bwd_fused_deterministic": "bwd_fused_d16_kernel<4, false",
         "bwd_blk": "bwd_blk_d16_kernel<false, 0>", "bwd_lean": "bwd_lean_d16_kernel<16, 3, true, false", "bwd_lean_deterministic": "bwd_lean_d16_kernel<16, 3, false, false",
-        "bwd_win": "bwd_win2_d16_kernel<16, 3, true, false", "bwd_win_deterministic": "bwd_win2_d16_kernel<16, 3, false, false",
         "wgrad_tiled": "wgrad_tiled_d16_kernel"}
 detail = {"_how": "tools/pmc_passes.sh: separate rocprofv3 --pmc passes over tools/kbench.py --what spmm,bwd,wtiled (S1 launches); means per launch. "
                   "GRBM_GUI_ACTIVE is summed over the 8 XCDs: MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)"}

@@ -235,10 +235,6 @@ __global__ __launch_bounds__(64 * NW, 16 / NW) void bwd_fused_d16_kernel(
 // from the LDS copy (the caller's aten.threshold_backward launch, functional.py, disappears).
 // ABL (timing experiments only, tools/kbench.py; results are wrong): 1 gathers hit the tile's own rows (no random HBM access),
 // 2 no dW part, 4 no window protocol (partials dropped), 8 no fold / dX tile update, 16 no compute at all (loads only)
-// timing instrumentation of the window kernel (ABL & 128, tools/kbench.py only): shader cycles summed over all waves --
-// [0] whole wave, [1] inside contribute(), [2] of that: waiting for the slot / the lock, [3] waves, [4] contribute() calls
-__device__ unsigned long long g_bwd_prof[8];
-
 // ---- window kernel, second form: the U = 4 chunks of an iteration go through each phase TOGETHER, and the window is taken per
 // GROUP of 4 relations.  Measured on the first form (profiles/r03_bwd_ablation.txt): with the random gathers replaced by
 // tile-local rows it runs as long as with them (0.69 ms) -- the kernel is bound by a wave's chain of dependent latencies (4
@@ -254,315 +250,12 @@ __device__ unsigned long long g_bwd_prof[8];
 constexpr int WIN_GS = 4;       // relations per window group
 
 
-// a * b with 0 * anything = 0 (v_mul_legacy_f32): a pad slot (val = 0) stays exactly zero whatever row it gathered
-__device__ __forceinline__ float mul0(float a, float b) {
-  float r;
-  asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
 constexpr int BW_SCR2 = 16 * 16;  // floats of transposition scratch per wave: [16 slots][16 features], the float4 column of features 4k..4k+3 of
                                   // slot m is stored at column (k + (m >> 1)) & 3 (b128 writes of 8 consecutive slots and b32 reads of two
                                   // consecutive slots are conflict-free without the 4-float row padding of the first form: 1 KiB, not 1.25)
 
-template <int NW, int NG, bool ATOMIC, bool RELU, int ABL = 0>
-__global__ __launch_bounds__(64 * NW, 4) void bwd_win2_d16_kernel(
-    const float *__restrict__ G, const float *__restrict__ X, const float *__restrict__ Wtp, float *__restrict__ dX,
-    float *__restrict__ dWout, const int2 *__restrict__ p_pack, const int *__restrict__ chunk_rel,
-    const int *__restrict__ run_ptr, int n_tiles, int n_blocks, int tile_rows, int n_dst, int R) {
-  constexpr int U = 4;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int t = blockIdx.x * NW + wave;
-  const bool valid = t < n_tiles;
-  const int nwv = min(NW, n_tiles - (int)blockIdx.x * NW);       // waves of this workgroup that own a tile
-  float *tile = lds + wave * tile_rows * 16;                     // dX tile (swizzled, tile_swz)
-  float *xt = lds + (NW + wave) * tile_rows * 16;                // X tile (row-major)
-  float *xs = lds + 2 * NW * tile_rows * 16 + wave * BW_SCR2;    // transposition scratch
-  float *win = lds + 2 * NW * tile_rows * 16 + NW * BW_SCR2;     // [NG][WIN_GS][256] fragment order
-  int *state = reinterpret_cast<int *>(win + NG * WIN_GS * 256); // [NG]
-  const int row0 = t * tile_rows;
-  const int nrows = valid ? min(tile_rows, n_dst - row0) : 0;
-  for (int i = lane; i < nrows * 4; i += 64) {
-    reinterpret_cast<float4 *>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    reinterpret_cast<float4 *>(xt)[i] = reinterpret_cast<const float4 *>(X + (size_t)row0 * 16)[i];
-  }
-  if (tid < NG) state[tid] = tid << 16;                           // slot group q serves relation group q first
-  __syncthreads();                                                // the only workgroup barrier
-  if (!valid) return;
-
-  const int my0 = run_ptr[(size_t)t * (R + 1)], my1 = run_ptr[(size_t)t * (R + 1) + R];
-  const int m = lane & 15, k = lane >> 4;
-  unsigned long long t_wave0 = 0, t_contrib = 0, t_wait = 0, n_contrib = 0;
-  unsigned n_spin_tag = 0, n_spin_lock = 0, n_cas_fail = 0;     // ABL & 256: how often a hand-over finds the slot not ready / taken
-  if (ABL & 128) t_wave0 = __builtin_amdgcn_s_memtime();
-  const int n_groups = (R + WIN_GS - 1) / WIN_GS;
-  int doneg = 0;                // relation groups [0, doneg) have been contributed by this wave
-  int curg = -1;                // group whose partials are held (-1: none)
-  int hasmask = 0;              // which of the group's relations have data in hold[]
-  f32x4 hold[WIN_GS];
-#pragma unroll
-  for (int q = 0; q < WIN_GS; ++q) hold[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int xrd = (int)((xt - lds) * 4) + m * 4;       // byte address of X_lds[0][m]
-  float *xs_wr = xs + m * 16 + 4 * ((k + (m >> 1)) & 3);                                  // this lane's float4 of slot m
-  const float *xs_rd0 = xs + k * 16 + 4 * (((m >> 2) + (k >> 1)) & 3) + (m & 3);          // feature m of slot 4 t + k, t even: + 128 t
-  const float *xs_rd1 = xs + (4 + k) * 16 + 4 * (((m >> 2) + 2 + (k >> 1)) & 3) + (m & 3); // t odd: + 128 (t - 1)
-
-  // hand this wave's partials of relation group g to the shared window (mask: which relations carry data)
-  auto contribute = [&](int g, const f32x4 (&part)[WIN_GS], int mask) {
-    const int gq = (int)((unsigned)g % (unsigned)NG);
-    int *st = state + gq;
-    f32x4 *slot = reinterpret_cast<f32x4 *>(win + gq * (WIN_GS * 256)) + lane;
-    int s;
-    unsigned long long tc0 = 0;
-    if (ABL & 128) tc0 = __builtin_amdgcn_s_memtime();
-    if (ABL & 512) __builtin_amdgcn_s_setprio(3);
-    if (ATOMIC) {
-      for (;;) {
-        s = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        if (((ABL & 32) || (s >> 16) == g) && !(s & 1)) {
-          int ok = 0;
-          if (lane == 0) {
-            int e = s;
-            ok = __hip_atomic_compare_exchange_strong(st, &e, s | 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-          if (__builtin_amdgcn_readfirstlane(ok)) break;
-          if (ABL & 256) ++n_cas_fail;
-        } else if (ABL & 256) {
-          if ((s >> 16) != g) ++n_spin_tag; else ++n_spin_lock;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-    } else {
-      for (;;) {      // fixed order: wave 0, 1, ... (bit-reproducible sums)
-        s = __builtin_amdgcn_readfirstlane(__hip_atomic_load(st, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-        if ((s >> 16) == g && ((s >> 1) & 31) == wave) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (ABL & 128) t_wait += __builtin_amdgcn_s_memtime() - tc0;
-    const int c = (s >> 1) & 31;
-    const int dirty = (s >> 8) & 15;                             // slots somebody added data to
-    const bool last = c + 1 == nwv;
-    const int touch = last ? (dirty | mask) : mask;              // slots this wave reads / writes
-    f32x4 v[WIN_GS];
-#pragma unroll
-    for (int q = 0; q < WIN_GS; ++q) {
-      v[q] = part[q];
-      if ((touch & dirty) >> q & 1) v[q] = slot[q * 64];
-    }
-#pragma unroll
-    for (int q = 0; q < WIN_GS; ++q)
-      if (((touch & dirty) >> q & 1) && (mask >> q & 1)) v[q] += part[q];
-    if (!last) {
-#pragma unroll
-      for (int q = 0; q < WIN_GS; ++q)
-        if (mask >> q & 1) slot[q * 64] = v[q];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0)
-        __hip_atomic_store(st, (g << 16) | ((dirty | mask) << 8) | ((c + 1) << 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) __hip_atomic_store(st, (g + NG) << 16, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-      for (int q = 0; q < WIN_GS; ++q) {
-        const int r = g * WIN_GS + q;
-        if (r >= R) break;
-        if (ABL & 64) {
-          asm volatile("" :: "v"(v[q][0]), "v"(v[q][1]), "v"(v[q][2]), "v"(v[q][3]));
-        } else if (ATOMIC) {
-          if (touch >> q & 1) {  // D: lane 16q+j holds rows 4q..4q+3 (input feature), column j (output feature)
-            float *wr = dWout + (size_t)r * 256 + (4 * k) * 16 + m;
-            atomicAdd(wr, v[q][0]); atomicAdd(wr + 16, v[q][1]); atomicAdd(wr + 32, v[q][2]); atomicAdd(wr + 48, v[q][3]);
-          }
-        } else {
-          reinterpret_cast<f32x4 *>(dWout + ((size_t)r * n_blocks + blockIdx.x) * 256)[lane] = (touch >> q & 1) ? v[q] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-    }
-    if (ABL & 128) { t_contrib += __builtin_amdgcn_s_memtime() - tc0; ++n_contrib; }
-    if (ABL & 256) ++n_contrib;
-    if (ABL & 512) __builtin_amdgcn_s_setprio(0);
-  };
-  // leave the held group: groups before it that this wave never saw pass empty, then the group itself
-  auto flush_group = [&]() {
-    if (ABL & 4) return;
-    const f32x4 zero[WIN_GS] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    for (; doneg < curg; ++doneg) contribute(doneg, zero, 0);
-    contribute(curg, hold, hasmask);
-    doneg = curg + 1;
-  };
-
-  if (my0 < my1) {
-    const int last = my1 - 1;
-    int2 pk_n[U];
-    int relv_n;
-    auto request_idx = [&](int c) {
-      relv_n = chunk_rel[min(c + (lane & (U - 1)), last)];
-#pragma unroll
-      for (int j = 0; j < U; ++j) pk_n[j] = p_pack[min(c + j, last) * RGCN_CHUNK + m];
-    };
-    request_idx(my0);
-    for (int c = my0; c < my1; c += U) {
-      int s_[U], dl_[U], d_[U], r_[U];
-      float v_[U];
-      float4 g_[U], w_[U];
-      const int relv = relv_n;
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        const int2 pk = pk_n[j];
-        s_[j] = pk.x & 0xFFFFFF;
-        dl_[j] = (int)((unsigned)pk.x >> 24);
-        d_[j] = dl_[j] == 0xFF ? -1 : dl_[j];                  // row inside the tile (the fold only compares them)
-        v_[j] = (c + j <= last) ? __builtin_bit_cast(float, pk.y) : 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < U; ++j) r_[j] = __builtin_amdgcn_readlane(relv, j);
-#pragma unroll
-      for (int j = 0; j < U; ++j) asm volatile("" : "+v"(d_[j]), "+v"(v_[j]));   // pin the index data here
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        const unsigned og = (ABL & 1) ? (((unsigned)(row0 + (s_[j] & 63)) << 6) | ((unsigned)k << 4))
-                                      : (((unsigned)s_[j] << 6) | ((unsigned)k << 4));
-        g_[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(G) + og);
-        w_[j] = reinterpret_cast<const float4 *>(Wtp)[(size_t)r_[j] * 64 + lane];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      request_idx(c + U);
-      __builtin_amdgcn_sched_barrier(0);
-      if (ABL & 16) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) asm volatile("" :: "v"(g_[j].x), "v"(g_[j].y), "v"(g_[j].z), "v"(g_[j].w), "v"(w_[j].x), "v"(w_[j].w), "v"(d_[j]), "v"(v_[j]));
-        continue;
-      }
-      // ---- phase 1: scaled rows (0 * anything = 0: pads and slots past the range stay exactly zero), dX products
-      f32x4 sc[U], acc[U];
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        sc[j] = f32x4{mul0(g_[j].x, v_[j]), mul0(g_[j].y, v_[j]),
-                      mul0(g_[j].z, v_[j]), mul0(g_[j].w, v_[j])};
-        acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].x, sc[j][0], acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].y, sc[j][1], acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].z, sc[j][2], acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].w, sc[j][3], acc[j], 0, 0, 0);
-      // ---- phase 2: dW products, two chunks at a time: B[mu][j'] = val G[s_mu][j'] through the scratch (written as rows of a
-      // slot, read as one feature of four slots), A[i][mu] = X[o_mu][i] from the LDS copy of the tile's rows
-      if (!(ABL & 2)) {
-        f32x4 aw[U];
-#pragma unroll
-        for (int h = 0; h < U; h += 2) {
-          float bv[2][4], av[2][4];
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            const int j = h + jj;
-            const int dlc = dl_[j] == 0xFF ? 0 : dl_[j];            // pads: B is 0, keep A finite and inside the tile
-            int rot = dlc;                                          // lane (k, m) <- dl of slot (m + k) & 15
-            rot = __builtin_amdgcn_update_dpp(rot, rot, 0x120 + 15, 0x2, 0xF, false);
-            rot = __builtin_amdgcn_update_dpp(rot, rot, 0x120 + 14, 0x4, 0xF, false);
-            rot = __builtin_amdgcn_update_dpp(rot, rot, 0x120 + 13, 0x8, 0xF, false);
-            asm volatile("" ::: "memory");
-            *reinterpret_cast<f32x4 *>(xs_wr) = sc[j];
-            asm volatile("" ::: "memory");
-            bv[jj][0] = xs_rd0[0]; bv[jj][1] = xs_rd1[0]; bv[jj][2] = xs_rd0[128]; bv[jj][3] = xs_rd1[128];
-            int rowk[4];                                            // row_share: destination row of slot 4 t4 + k
-            rowk[0] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 0, 0xF, 0xF, false);
-            rowk[1] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 4, 0xF, 0xF, false);
-            rowk[2] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 8, 0xF, 0xF, false);
-            rowk[3] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 12, 0xF, 0xF, false);
-#pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4)
-              av[jj][t4] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(lds) + (xrd + (rowk[t4] << 6)));
-            asm volatile("" ::: "memory");
-          }
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj) aw[h + jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int t4 = 0; t4 < 4; ++t4)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-              aw[h + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj][t4], bv[jj][t4], aw[h + jj], 0, 0, 0);
-        }
-        // relation bookkeeping (wave-uniform): add each chunk's product to the held partial of its relation
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-          const int rj = __builtin_amdgcn_readfirstlane(r_[j]);
-          const int gj = rj >> 2, qj = rj & 3;
-          if (gj != curg) {
-            if (curg >= 0) {
-              flush_group();
-#pragma unroll
-              for (int q = 0; q < WIN_GS; ++q) hold[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            curg = gj;
-            hasmask = 0;
-          }
-          hasmask |= 1 << qj;
-          if (qj == 0) hold[0] += aw[j];
-          else if (qj == 1) hold[1] += aw[j];
-          else if (qj == 2) hold[2] += aw[j];
-          else hold[3] += aw[j];
-        }
-      }
-      // ---- phase 3: fold equal destinations (the four chunks in step), one LDS update per segment, chunk after chunk (two
-      // chunks of a tile may end in the same row)
-      if (ABL & 8) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) asm volatile("" :: "v"(acc[j][0]), "v"(acc[j][1]), "v"(acc[j][2]), "v"(acc[j][3]));
-      } else {
-        bool tail[U];
-        fold_segments_multi<U>(acc, d_, tail);
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-          if (tail[j]) {
-            f32x4 *p = reinterpret_cast<f32x4 *>(tile + dl_[j] * 16 + 4 * (k ^ ((dl_[j] >> 2) & 3)));   // swizzled: see tile_swz
-            *p += acc[j];
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  if (!(ABL & (2 | 4 | 16))) {
-    if (curg >= 0) flush_group();
-    const f32x4 zero[WIN_GS] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    for (; doneg < n_groups; ++doneg) contribute(doneg, zero, 0);
-  } else {
-#pragma unroll
-    for (int q = 0; q < WIN_GS; ++q) asm volatile("" :: "v"(hold[q][0]), "v"(hold[q][1]), "v"(hold[q][2]), "v"(hold[q][3]));
-  }
-
-  if ((ABL & 256) && lane == 0 && (t & 15) == 0) {
-    atomicAdd(&g_bwd_prof[3], 1ull);
-    atomicAdd(&g_bwd_prof[4], n_contrib);
-    atomicAdd(&g_bwd_prof[5], (unsigned long long)n_spin_tag);
-    atomicAdd(&g_bwd_prof[6], (unsigned long long)n_spin_lock);
-    atomicAdd(&g_bwd_prof[7], (unsigned long long)n_cas_fail);
-  }
-  if ((ABL & 128) && lane == 0) {
-    atomicAdd(&g_bwd_prof[0], __builtin_amdgcn_s_memtime() - t_wave0);
-    atomicAdd(&g_bwd_prof[1], t_contrib);
-    atomicAdd(&g_bwd_prof[2], t_wait);
-    atomicAdd(&g_bwd_prof[3], 1ull);
-    atomicAdd(&g_bwd_prof[4], n_contrib);
-  }
-  float4 *o4 = reinterpret_cast<float4 *>(dX + (size_t)row0 * 16);
-  for (int i = lane; i < nrows * 4; i += 64) {
-    float4 a = reinterpret_cast<const float4 *>(tile)[tile_swz(i)];
-    if (RELU) {
-      const float4 x = reinterpret_cast<const float4 *>(xt)[i];
-      a.x = x.x > 0.f ? a.x : 0.f; a.y = x.y > 0.f ? a.y : 0.f; a.z = x.z > 0.f ? a.z : 0.f; a.w = x.w > 0.f ? a.w : 0.f;
-    }
-    o4[i] = a;
-  }
-}
+// (The kernel of this second form, bwd_win2_d16_kernel, was measured at 0.69 ms and is superseded by the lean form below, which
+// keeps its phases, its window protocol and its LDS layout; it lives in the history of round 3.)
 
 // ---- window kernel, third form ("lean"): the same algorithm with the per-chunk instruction count cut to what the data flow needs.
 // What bounds the second form (profiles/r03_bwd_ablation.txt, r03_pmc_sq.json): with 4 waves per SIMD the kernel's time follows
@@ -1277,381 +970,9 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
   }
 }
 
-// ---- fourth form: producers and consumers.  What the three window kernels could not get rid of is the merge of the dW partials
-// of a workgroup's tiles: 16 waves x 101 relations x (lock + read-modify-write of 1 KiB in LDS, ~1000 cycles of LDS round trips
-// under load) saturates the lock -- 0.10-0.16 ms of a 0.69 ms kernel.  Here nothing is merged: a workgroup is 12 PRODUCER waves
-// (one 64-row tile each: gather, dX products, fold, tile update -- the window kernel without its dW part runs at the fabric floor,
-// 0.47 ms with 12 waves per CU) and 4 CONSUMER waves (one per SIMD; consumer c owns the relations r = c mod 4) that do the dW
-// products of ALL 12 tiles: a relation's partial grows in ONE wave's registers across the tiles and leaves the CU once.
-//   producer, per chunk: the scaled rows it has to write to LDS for the transposition anyway go into a slot of its ring (4 slots
-//     of 1 KiB + the 16 destination-row offsets), then ONE word {sequence, relation, slot} into the queue of the consumer that owns
-//     the relation.  It waits only when its ring is full.
-//   consumer: polls its 12 queues (single-producer / single-consumer, sequence-tagged words: no locks, no atomics), reads the B
-//     operand from the slot and the A operand from the PRODUCER's X tile (same workgroup: same LDS), 4 MFMAs into the accumulator of
-//     the relation (a window of 8 accumulators = 32 relations ahead of the slowest producer; chunks further ahead stay queued and
-//     back-pressure their producer), frees the slot.  Producers publish the relation they are working on; a relation every producer
-//     has passed is flushed (256 fp32 atomics per workgroup and relation: 1,303 x 101 KiB = 132 MB per launch).
-// The sums over tiles are taken in arrival order: this form serves the atomic-flush mode only (RGCN_DETERMINISTIC=1 keeps the
-// ordered window kernel).
-constexpr int PC_NP = 12, PC_NC = 4, PC_D = 4, PC_WIN = 8;
-constexpr int PC_DONE = 0x7FFF;
-
-template <bool RELU, int ABL = 0>
-__global__ __launch_bounds__(64 * (PC_NP + PC_NC), 4) void bwd_pc_d16_kernel(
-    const float *__restrict__ G, const float *__restrict__ X, const float *__restrict__ Wtp, float *__restrict__ dX,
-    float *__restrict__ dW, const LeanSlot *__restrict__ slots, const int *__restrict__ hdr,
-    const int *__restrict__ run_ptr, int n_tiles, int tile_rows, int n_dst, int R) {
-  constexpr int U = 4;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int m = lane & 15, k = lane >> 4;
-  // LDS: [dX tiles NP][X tiles NP][ring data NP x D x 256][ring row offsets NP x D x 16][slot flags NP x D][queues NC x NP x D][prog NP][fin NC x NP]
-  float *ring = lds + 2 * PC_NP * tile_rows * 16;
-  int *ring_dl = reinterpret_cast<int *>(ring + PC_NP * PC_D * 256);
-  int *flags = ring_dl + PC_NP * PC_D * 16;
-  int *queue = flags + PC_NP * PC_D;
-  int *prog = queue + PC_NC * PC_NP * PC_D;
-  int *fin = prog + PC_NP;
-  const int n_ctrl = PC_NP * PC_D + PC_NC * PC_NP * PC_D + PC_NP + PC_NC * PC_NP;
-  for (int i = tid; i < n_ctrl; i += 64 * (PC_NP + PC_NC)) flags[i] = 0;      // flags 0 = free, queue words 0 = no entry (sequence 0 is never expected first), prog 0
-  // swizzled transposition layout of a 16 x 16 slot (see BW_SCR2)
-  const int xs_wr = m * 16 + 4 * ((k + (m >> 1)) & 3);
-  const int xs_rd0 = k * 16 + 4 * (((m >> 2) + (k >> 1)) & 3) + (m & 3);
-  const int xs_rd1 = (4 + k) * 16 + 4 * (((m >> 2) + 2 + (k >> 1)) & 3) + (m & 3);
-
-  if (wave < PC_NP) {
-    // ------------------------------------------------------------------ producer
-    const int t = blockIdx.x * PC_NP + wave;
-    const bool valid = t < n_tiles;
-    float *tile = lds + wave * tile_rows * 16;
-    float *xt = lds + (PC_NP + wave) * tile_rows * 16;
-    const int row0 = t * tile_rows;
-    const int nrows = valid ? min(tile_rows, n_dst - row0) : 0;
-    for (int i = lane; i < nrows * 4; i += 64) {
-      reinterpret_cast<float4 *>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      reinterpret_cast<float4 *>(xt)[i] = reinterpret_cast<const float4 *>(X + (size_t)row0 * 16)[i];
-    }
-    __syncthreads();                                              // the only workgroup barrier (control words zeroed, X tiles in place)
-    float *my_ring = ring + wave * (PC_D * 256);
-    int *my_dl = ring_dl + wave * (PC_D * 16);
-    int *my_flags = flags + wave * PC_D;
-    unsigned tails = 0;                                           // entries posted to consumer c: byte c (mod 256)
-    unsigned n_full = 0;
-    int n_posted = 0;                                             // chunks posted = ring position
-    int cur_rel = -1;
-    if (valid) {
-      const int my0 = __builtin_amdgcn_readfirstlane(run_ptr[(size_t)t * (R + 1)]);
-      const int my1 = __builtin_amdgcn_readfirstlane(run_ptr[(size_t)t * (R + 1) + R]);
-      const unsigned kofs = (unsigned)k << 4;
-      const unsigned tile_k = (unsigned)((tile - lds) * 4) + kofs;
-      const unsigned slot_lane = (unsigned)m * 12u, w_lane = (unsigned)lane * 16u;
-      if (my0 < my1) {
-        const int last = my1 - 1;
-        const char *sl_base = reinterpret_cast<const char *>(slots);
-        LeanSlot sl_n[U];
-        int hd_n[U];
-        auto request_idx = [&](int c) {
-#pragma unroll
-          for (int j = 0; j < U; ++j) {
-            const int cc = min(c + j, last);
-            sl_n[j] = *reinterpret_cast<const LeanSlot *>(sl_base + (size_t)cc * (RGCN_CHUNK * 12) + slot_lane);
-            hd_n[j] = hdr[cc];
-          }
-        };
-        request_idx(my0);
-        for (int c = my0; c < my1; c += U) {
-          unsigned w0_[U], w2_[U];
-          float v_[U];
-          int hd_[U];
-          float4 g_[U], w_[U];
-#pragma unroll
-          for (int j = 0; j < U; ++j) {
-            w0_[j] = sl_n[j].w0;
-            w2_[j] = sl_n[j].w2;
-            v_[j] = (c + j <= last) ? sl_n[j].val : 0.f;
-            hd_[j] = __builtin_amdgcn_readfirstlane(hd_n[j]);
-          }
-#pragma unroll
-          for (int j = 0; j < U; ++j) asm volatile("" : "+v"(w0_[j]), "+v"(v_[j]));
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < U; ++j) {
-            const unsigned og = (ABL & 1) ? ((((unsigned)row0 << 6) + (w2_[j])) | kofs) : ((w0_[j] & ~63u) | kofs);
-            g_[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(G) + og);
-            w_[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Wtp) + (size_t)(hd_[j] & 0xFFFF) * 1024 + w_lane);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          request_idx(c + U);
-          __builtin_amdgcn_sched_barrier(0);
-          // scaled rows, dX products (four independent MFMA chains)
-          f32x4 sc[U], acc[U];
-#pragma unroll
-          for (int j = 0; j < U; ++j) {
-            sc[j] = f32x4{g_[j].x * v_[j], g_[j].y * v_[j], g_[j].z * v_[j], g_[j].w * v_[j]};
-            acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-          }
-#pragma unroll
-          for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].x, sc[j][0], acc[j], 0, 0, 0);
-#pragma unroll
-          for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].y, sc[j][1], acc[j], 0, 0, 0);
-#pragma unroll
-          for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].z, sc[j][2], acc[j], 0, 0, 0);
-#pragma unroll
-          for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].w, sc[j][3], acc[j], 0, 0, 0);
-          // hand the chunks to the consumers
-          if (!(ABL & 2)) {
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-              if (c + j > last) break;
-              const int rj = hd_[j] & 0xFFFF;
-              if (rj != cur_rel) {                                 // every chunk of the relations before rj has been posted
-                cur_rel = rj;
-                asm volatile("" ::: "memory");
-                if (lane == 0) lds_st(prog + wave, rj);
-              }
-              const int sidx = n_posted & (PC_D - 1);
-              while (__builtin_amdgcn_readfirstlane(lds_ld(my_flags + sidx)) != 0) { if (ABL & 256) ++n_full; __builtin_amdgcn_s_sleep(1); }      // ring full: its consumer is behind
-              asm volatile("" ::: "memory");
-              *reinterpret_cast<f32x4 *>(my_ring + sidx * 256 + xs_wr) = sc[j];
-              if (k == 0) my_dl[sidx * 16 + m] = (int)w2_[j];
-              asm volatile("" ::: "memory");
-              const int cc = rj & (PC_NC - 1);
-              const unsigned tl = (tails >> (8 * cc)) & 0xFFu;
-              if (lane == 0) {
-                lds_st(my_flags + sidx, 1);
-                lds_st(queue + (cc * PC_NP + wave) * PC_D + (tl & (PC_D - 1)), (int)((((tl + 1) & 0xFFu) << 24) | ((unsigned)rj << 8) | (unsigned)sidx));
-              }
-              asm volatile("" ::: "memory");
-              tails = (tails & ~(0xFFu << (8 * cc))) | (((tl + 1) & 0xFFu) << (8 * cc));
-              ++n_posted;
-            }
-          }
-          // fold equal destinations (flags from the plan), one LDS update per segment, chunk after chunk
-          if (ABL & 8) {
-#pragma unroll
-            for (int j = 0; j < U; ++j) asm volatile("" :: "v"(acc[j][0]), "v"(acc[j][1]), "v"(acc[j][2]), "v"(acc[j][3]));
-          } else {
-            const int any1 = (hd_[0] | hd_[1] | hd_[2] | hd_[3]) & (1 << 16), any2 = (hd_[0] | hd_[1] | hd_[2] | hd_[3]) & (1 << 17);
-            if (any1) {
-#pragma unroll
-              for (int j = 0; j < U; ++j) {
-                const float sf = (w0_[j] & 1u) ? 1.f : 0.f;
-                acc[j][0] = fmaf(dpp_shr0<1>(acc[j][0]), sf, acc[j][0]);
-                acc[j][1] = fmaf(dpp_shr0<1>(acc[j][1]), sf, acc[j][1]);
-                acc[j][2] = fmaf(dpp_shr0<1>(acc[j][2]), sf, acc[j][2]);
-                acc[j][3] = fmaf(dpp_shr0<1>(acc[j][3]), sf, acc[j][3]);
-              }
-              if (any2) {
-#pragma unroll
-                for (int j = 0; j < U; ++j) {
-                  const int dst = (v_[j] != 0.f || (w0_[j] & 3u)) ? (int)(w2_[j] >> 6) : -1;
-                  const bool s2 = dpp_i<ROW_SHR + 2>(-1, dst) == dst && dst >= 0;
-                  const bool s4 = dpp_i<ROW_SHR + 4>(-1, dst) == dst && dst >= 0;
-                  const bool s8 = dpp_i<ROW_SHR + 8>(-1, dst) == dst && dst >= 0;
-                  const float f2 = s2 ? 1.f : 0.f, f4 = s4 ? 1.f : 0.f, f8 = s8 ? 1.f : 0.f;
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(dpp_shr0<2>(acc[j][e]), f2, acc[j][e]);
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(dpp_shr0<4>(acc[j][e]), f4, acc[j][e]);
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(dpp_shr0<8>(acc[j][e]), f8, acc[j][e]);
-                }
-              }
-            }
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-              if (w0_[j] & 2u) {
-                f32x4 *pp = reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(lds) + (tile_k + w2_[j]));
-                *pp += acc[j];
-              }
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-    if ((ABL & 256) && lane == 0 && (blockIdx.x & 15) == 0) { atomicAdd(&g_bwd_prof[4], 1ull); atomicAdd(&g_bwd_prof[5], (unsigned long long)n_full); atomicAdd(&g_bwd_prof[6], (unsigned long long)n_posted); }
-    // this producer is through: final queue lengths, then "done"
-    asm volatile("" ::: "memory");
-    if (lane < PC_NC) lds_st(fin + lane * PC_NP + wave, (int)((tails >> (8 * lane)) & 0xFFu));
-    asm volatile("" ::: "memory");
-    if (lane == 0) lds_st(prog + wave, PC_DONE);
-    if (valid) {
-      float4 *o4 = reinterpret_cast<float4 *>(dX + (size_t)row0 * 16);
-      for (int i = lane; i < nrows * 4; i += 64) {
-        float4 a = reinterpret_cast<const float4 *>(tile)[i];
-        if (RELU) {
-          const float4 x = reinterpret_cast<const float4 *>(xt)[i];
-          a.x = x.x > 0.f ? a.x : 0.f; a.y = x.y > 0.f ? a.y : 0.f; a.z = x.z > 0.f ? a.z : 0.f; a.w = x.w > 0.f ? a.w : 0.f;
-        }
-        o4[i] = a;
-      }
-    }
-    return;
-  }
-
-  // ------------------------------------------------------------------ consumer c: relations r = c mod 4, local index j = r >> 2
-  __syncthreads();
-  if (ABL & 2) return;
-  // the consumers are the last-dispatched (youngest) waves of their SIMDs and would lose every issue arbitration against the three
-  // producers beside them; their work is short and everybody waits for it: highest priority
-  __builtin_amdgcn_s_setprio(3);
-  const int cons = wave - PC_NP;
-  const int n_local = (R - cons + PC_NC - 1) / PC_NC;            // relations this consumer owns
-  int *my_q = queue + cons * PC_NP * PC_D;
-  unsigned n_pass = 0, n_busy = 0, n_taken = 0;
-  int head = 0;                                                  // lane p < 12: entries read from producer p's queue
-  f32x4 acc[PC_WIN];
-#pragma unroll
-  for (int q = 0; q < PC_WIN; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int jbase = 0;                                                 // local relations [0, jbase) are flushed
-  auto flush = [&](int j) {
-    const int r = j * PC_NC + cons;
-    f32x4 v;
-    switch (j & (PC_WIN - 1)) {
-      case 0: v = acc[0]; acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; break;
-      case 1: v = acc[1]; acc[1] = f32x4{0.f, 0.f, 0.f, 0.f}; break;
-      case 2: v = acc[2]; acc[2] = f32x4{0.f, 0.f, 0.f, 0.f}; break;
-      case 3: v = acc[3]; acc[3] = f32x4{0.f, 0.f, 0.f, 0.f}; break;
-      case 4: v = acc[4]; acc[4] = f32x4{0.f, 0.f, 0.f, 0.f}; break;
-      case 5: v = acc[5]; acc[5] = f32x4{0.f, 0.f, 0.f, 0.f}; break;
-      case 6: v = acc[6]; acc[6] = f32x4{0.f, 0.f, 0.f, 0.f}; break;
-      default: v = acc[7]; acc[7] = f32x4{0.f, 0.f, 0.f, 0.f}; break;
-    }
-    if (r < R && __builtin_amdgcn_ballot_w64(v[0] != 0.f || v[1] != 0.f || v[2] != 0.f || v[3] != 0.f)) {
-      float *wr = dW + (size_t)r * 256 + (4 * k) * 16 + m;       // D: lane 16q+j holds rows 4q..4q+3 (input feature), column j (output feature)
-      atomicAdd(wr, v[0]); atomicAdd(wr + 16, v[1]); atomicAdd(wr + 32, v[2]); atomicAdd(wr + 48, v[3]);
-    }
-  };
-  constexpr int PC_B = 4;                                        // chunks per pass: their LDS reads are issued together (three round trips per pass)
-  for (;;) {
-    // the slowest producer's relation, read BEFORE the queues: every chunk of an earlier relation is in a queue by now
-    asm volatile("" ::: "memory");
-    int pr = PC_DONE, qw = 0;
-    if (lane < PC_NP) pr = lds_ld(prog + lane);
-    asm volatile("" ::: "memory");
-    if (lane < PC_NP) qw = lds_ld(my_q + lane * PC_D + (head & (PC_D - 1)));
-    asm volatile("" ::: "memory");
-    // minimum over lanes 0 .. 11 (one DPP row): shifts by 1, 2, 4, 8 -> lane 15 holds the row's minimum (lanes 12 .. 15 carry PC_DONE)
-    auto row_min = [&](int v) {
-      v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x110 + 1, 0xF, 0xF, false));
-      v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x110 + 2, 0xF, 0xF, false));
-      v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x110 + 4, 0xF, 0xF, false));
-      v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x110 + 8, 0xF, 0xF, false));
-      return __builtin_amdgcn_readlane(v, 15);
-    };
-    const int rmin = row_min(lane < PC_NP ? pr : PC_DONE);
-    const bool fresh = lane < PC_NP && ((unsigned)qw >> 24) == (((unsigned)head + 1u) & 0xFFu);
-    const int jq = ((qw >> 8) & 0xFFFF) >> 2;
-    const bool inwin = fresh && jq < jbase + PC_WIN;
-    // chunks too far ahead of the slowest producer stay queued, and their relations are not flushed
-    int jdefer = row_min((fresh && !inwin) ? jq : 0x7FFFFFFF);
-    unsigned long long ready = __builtin_amdgcn_ballot_w64(inwin);
-    // up to PC_B of the ready producers
-    int bp[PC_B], bs[PC_B], bj[PC_B], nb = 0;
-    unsigned long long taken = 0;
-#pragma unroll
-    for (int i = 0; i < PC_B; ++i) {
-      bp[i] = 0; bs[i] = 0; bj[i] = 0;
-      if (ready) {
-        const int p = __builtin_ctzll(ready);
-        ready &= ready - 1;
-        taken |= 1ull << p;
-        const int w = __builtin_amdgcn_readlane(qw, p);
-        bp[i] = p; bs[i] = w & 0xFF; bj[i] = ((w >> 8) & 0xFFFF) >> 2;
-        nb = i + 1;
-      }
-    }
-    if (nb) {
-      float bv[PC_B][4], av[PC_B][4];
-      int rowm[PC_B];
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < PC_B; ++i) {
-        if (i < nb) {
-          const float *sd = ring + (bp[i] * PC_D + bs[i]) * 256;
-          rowm[i] = ring_dl[(bp[i] * PC_D + bs[i]) * 16 + m];      // row << 6 of slot m
-          bv[i][0] = sd[xs_rd0]; bv[i][1] = sd[xs_rd1]; bv[i][2] = sd[xs_rd0 + 128]; bv[i][3] = sd[xs_rd1 + 128];
-        }
-      }
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < PC_B; ++i) {
-        if (i < nb) {
-          int rot = rowm[i];                                      // lane (k, m) <- row of slot (m + k) & 15
-          rot = __builtin_amdgcn_update_dpp(rot, rot, 0x120 + 15, 0x2, 0xF, false);
-          rot = __builtin_amdgcn_update_dpp(rot, rot, 0x120 + 14, 0x4, 0xF, false);
-          rot = __builtin_amdgcn_update_dpp(rot, rot, 0x120 + 13, 0x8, 0xF, false);
-          int rowk[4];
-          rowk[0] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 0, 0xF, 0xF, false);
-          rowk[1] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 4, 0xF, 0xF, false);
-          rowk[2] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 8, 0xF, 0xF, false);
-          rowk[3] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 12, 0xF, 0xF, false);
-          const unsigned xrd = (unsigned)((PC_NP + bp[i]) * tile_rows * 16 * 4) + (unsigned)m * 4;     // producer's X tile, feature m
-#pragma unroll
-          for (int t4 = 0; t4 < 4; ++t4)
-            av[i][t4] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(lds) + (xrd + (unsigned)rowk[t4]));
-        }
-      }
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < PC_B; ++i)                              // the operand reads are queued ahead of these writes (in-order LDS): the slots are free
-        if (i < nb && lane == 0) lds_st(flags + bp[i] * PC_D + bs[i], 0);
-      asm volatile("" ::: "memory");
-      f32x4 aw[PC_B];
-#pragma unroll
-      for (int i = 0; i < PC_B; ++i) aw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4)
-#pragma unroll
-        for (int i = 0; i < PC_B; ++i)
-          if (i < nb) aw[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][t4], bv[i][t4], aw[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < PC_B; ++i) {
-        if (i < nb) {
-          switch (bj[i] & (PC_WIN - 1)) {
-            case 0: acc[0] += aw[i]; break;
-            case 1: acc[1] += aw[i]; break;
-            case 2: acc[2] += aw[i]; break;
-            case 3: acc[3] += aw[i]; break;
-            case 4: acc[4] += aw[i]; break;
-            case 5: acc[5] += aw[i]; break;
-            case 6: acc[6] += aw[i]; break;
-            default: acc[7] += aw[i]; break;
-          }
-        }
-      }
-      if ((taken >> lane) & 1ull) ++head;
-    }
-    // fresh entries that did not fit this pass count as "still queued" for the flush below
-    if (ready) jdefer = min(jdefer, row_min(((ready >> lane) & 1ull) ? jq : 0x7FFFFFFF));
-    // relations every producer has passed: nothing more will come for them
-    // (only after a pass that found nothing to do: the queues were read after the producers' relations, so every chunk of a relation
-    // below rmin has been consumed or is accounted for in jdefer; a pass that took chunks has not looked behind them)
-    const int rdone = min(rmin, R + PC_NC);
-    while (!nb && jbase < n_local && jbase < jdefer && jbase * PC_NC + cons < rdone) {
-      flush(jbase);
-      ++jbase;
-    }
-    if (ABL & 256) { ++n_pass; if (nb) ++n_busy; n_taken += nb; }
-    if (rmin >= PC_DONE && !nb) {
-      // every producer is through: finished when every queue has been read to its end
-      int fv = 0;
-      if (lane < PC_NP) fv = lds_ld(fin + cons * PC_NP + lane);
-      const bool mine_drained = lane >= PC_NP || ((unsigned)head & 0xFFu) == (unsigned)fv;
-      if (__builtin_amdgcn_ballot_w64(!mine_drained) == 0) break;
-    }
-    if (!nb) __builtin_amdgcn_s_sleep(1);
-  }
-  for (; jbase < n_local; ++jbase) flush(jbase);
-  if ((ABL & 256) && lane == 0 && (blockIdx.x & 15) == 0) {
-    atomicAdd(&g_bwd_prof[0], 1ull);
-    atomicAdd(&g_bwd_prof[1], (unsigned long long)n_pass);
-    atomicAdd(&g_bwd_prof[2], (unsigned long long)n_busy);
-    atomicAdd(&g_bwd_prof[3], (unsigned long long)n_taken);
-  }
-}
+// ---- fourth form (measured, not kept): producers and consumers -- 12 waves of a workgroup own a tile each (gather, dX) and post
+// their dW operands to LDS rings, 4 consumer waves own the relations (r mod 4) and accumulate a relation's dW in registers: no merge
+// of partial sums, no locks.  Correct, 1.20 ms at S1: a consumer wave's chain of dependent LDS reads + MFMAs bounds the CU.
 
 // ---- sparse (tile, relation) buckets (AM: 267 relations): backward of the two-pass path with ONE relation-major walk.
 // Round 1: pass 1 of the feature gradient gathers G[s] per message (relation-major chunks, dense), and the weight gradient
@@ -1807,48 +1128,6 @@ hipError_t launch_bwd8(const BwdLaunch &a) {
 }
 
 template <int NW, int NG>
-size_t bwd_win2_lds(int tile_rows) {
-  return ((size_t)2 * NW * tile_rows * 16 + NW * BW_SCR2 + NG * WIN_GS * 256) * sizeof(float) + NG * sizeof(int);
-}
-template <int NW, int NG, bool AT, bool RELU, int ABL = 0>
-hipError_t launch_bwd_win2(const BwdLaunch &a) {
-  auto kern = bwd_win2_d16_kernel<NW, NG, AT, RELU, ABL>;
-  static bool raised = false;                    // once per process and instantiation (not a stream operation)
-  if (a.lds > 64 * 1024 && !raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    raised = true;
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)a.n_blocks), dim3(64 * NW), a.lds, a.st, a.G, a.X, a.Wtp, a.dX, a.dWout, a.pk, a.chunk_rel,
-                     a.run_ptr, a.n_tiles, a.n_blocks, a.tile_rows, a.n_dst, a.R);
-  return hipGetLastError();
-}
-template <int NW, int NG, bool AT>
-hipError_t launch_bwd_win2_f(const BwdLaunch &a, bool relu) {
-  static const int ABL = getenv("RGCN_BWD_ABL") ? atoi(getenv("RGCN_BWD_ABL")) : 0;     // timing experiments (wrong results)
-  if (NW == 16 && AT && ABL) {
-    switch (ABL) {
-      case 1: return launch_bwd_win2<16, 3, true, false, 1>(a);
-      case 2: return launch_bwd_win2<16, 3, true, false, 2>(a);
-      case 3: return launch_bwd_win2<16, 3, true, false, 3>(a);
-      case 4: return launch_bwd_win2<16, 3, true, false, 4>(a);
-      case 5: return launch_bwd_win2<16, 3, true, false, 5>(a);
-      case 8: return launch_bwd_win2<16, 3, true, false, 8>(a);
-      case 11: return launch_bwd_win2<16, 3, true, false, 11>(a);
-      case 16: return launch_bwd_win2<16, 3, true, false, 16>(a);
-      case 32: return launch_bwd_win2<16, 3, true, false, 32>(a);
-      case 64: return launch_bwd_win2<16, 3, true, false, 64>(a);
-      case 96: return launch_bwd_win2<16, 3, true, false, 96>(a);
-      case 128: return launch_bwd_win2<16, 3, true, false, 128>(a);
-      case 256: return launch_bwd_win2<16, 3, true, false, 256>(a);
-      case 512: return launch_bwd_win2<16, 3, true, false, 512>(a);
-      default: break;
-    }
-  }
-  return relu ? launch_bwd_win2<NW, NG, AT, true>(a) : launch_bwd_win2<NW, NG, AT, false>(a);
-}
-
-template <int NW, int NG>
 size_t bwd_lean_lds(int tile_rows) {
   return ((size_t)2 * NW * tile_rows * 16 + NW * BW_SCR2 + NG * WIN_GS * 256) * sizeof(float) + 4 * NG * sizeof(int);
 }
@@ -1900,15 +1179,6 @@ void launch_bwd_d(const BwdLaunch &a, int D) {
 
 }  // namespace
 
-extern "C" int rgcn_debug_bwd_prof(uint64_t *out8, int32_t reset) {
-  if (out8) HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bwd_prof), 8 * sizeof(uint64_t)));
-  if (reset) {
-    const uint64_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_prof), z, sizeof(z)));
-  }
-  return RGCN_OK;
-}
-
 extern "C" int rgcn_pack_w16t_f32(const float *W, float *Wp, int32_t R, void *stream) {
   if (!W || !Wp || R <= 0) { rgcn_set_error("pack_w16t: bad argument"); return RGCN_EINVAL; }
   const int n = R * 256;
@@ -1956,49 +1226,6 @@ extern "C" int rgcn_bwd_lean_prepare_unpacked_f32(const int32_t *p_src, const in
   hipLaunchKernelGGL(bwd_lean_prep_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, (hipStream_t)stream,
                      nullptr, p_src, p_dst, p_val, tile_rows, chunk_rel, reinterpret_cast<LeanSlot *>(slots), hdr, (long long)n_chunks);
   HIP_TRY(hipGetLastError());
-  return RGCN_OK;
-}
-
-static size_t bwd_pc_lds(int tile_rows) {
-  return ((size_t)2 * PC_NP * tile_rows * 16 + PC_NP * PC_D * 256) * sizeof(float) +
-         ((size_t)PC_NP * PC_D * 16 + PC_NP * PC_D + PC_NC * PC_NP * PC_D + PC_NP + PC_NC * PC_NP) * sizeof(int);
-}
-
-extern "C" int rgcn_bwd_pc_supported(int32_t tile_rows) { return bwd_pc_lds(tile_rows) <= 160 * 1024; }
-
-/* producer / consumer form (atomic flush only): arguments as rgcn_bwd_lean_f32 without scratch */
-extern "C" int rgcn_bwd_pc_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, const void *slots,
-                               const int32_t *hdr, const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R,
-                               int32_t flags, void *stream) {
-  if (!G || !X || !Wt_packed || !dX || !dW || !slots || !hdr || !run_ptr || n_tiles <= 0 || tile_rows <= 0 || n_dst <= 0 || R <= 0 ||
-      R >= PC_DONE) {
-    rgcn_set_error("bwd_pc: bad argument");
-    return RGCN_EINVAL;
-  }
-  const size_t lds = bwd_pc_lds(tile_rows);
-  if (lds > 160 * 1024) { rgcn_set_error("bwd_pc: tile_rows = %d does not fit the LDS of a CU", tile_rows); return RGCN_EUNSUPPORTED; }
-  const bool relu = (flags & RGCN_F_RELU) != 0;
-  hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(zero_async(dW, (size_t)R * 256 * sizeof(float), st));
-  const unsigned n_blocks = (unsigned)((n_tiles + PC_NP - 1) / PC_NP);
-  static const int ABL = getenv("RGCN_BWD_ABL") ? atoi(getenv("RGCN_BWD_ABL")) : 0;     // timing experiments (wrong results)
-  auto launch = [&](auto kern, bool &raised) -> hipError_t {
-    if (lds > 64 * 1024 && !raised) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return e;
-      raised = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64 * (PC_NP + PC_NC)), lds, st, G, X, Wt_packed, dX, dW, reinterpret_cast<const LeanSlot *>(slots),
-                       hdr, run_ptr, (int)n_tiles, tile_rows, (int)n_dst, R);
-    return hipGetLastError();
-  };
-  static bool r0 = false, r1 = false, r2 = false, r3 = false, r4 = false, r5 = false;
-  if (ABL == 1) HIP_TRY(launch(bwd_pc_d16_kernel<false, 1>, r2));
-  else if (ABL == 2) HIP_TRY(launch(bwd_pc_d16_kernel<false, 2>, r3));
-  else if (ABL == 8) HIP_TRY(launch(bwd_pc_d16_kernel<false, 8>, r4));
-  else if (ABL == 256) HIP_TRY(launch(bwd_pc_d16_kernel<false, 256>, r5));
-  else if (relu) HIP_TRY(launch(bwd_pc_d16_kernel<true, 0>, r1));
-  else HIP_TRY(launch(bwd_pc_d16_kernel<false, 0>, r0));
   return RGCN_OK;
 }
 
@@ -2104,21 +1331,6 @@ extern "C" int rgcn_bwd_lean_f32(const float *G, const float *X, const float *Wt
   return RGCN_OK;
 }
 
-// occupancy experiment (tools only): the window kernel with 12 tile-owning waves per CU (one 768-thread workgroup), full and without the dW part
-extern "C" int rgcn_debug_bwd_nw12(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, const int32_t *p_pack,
-                                   const int32_t *chunk_rel, const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst,
-                                   int32_t R, int32_t abl, void *stream) {
-  const int n_blocks = (int)((n_tiles + 11) / 12);
-  hipStream_t st = (hipStream_t)stream;
-  const BwdLaunch L{G, X, Wt_packed, dX, dW, reinterpret_cast<const int2 *>(p_pack), chunk_rel, run_ptr, (int)n_tiles, n_blocks, tile_rows,
-                    (int)n_dst, R, (size_t)150 * 1024, st};
-  HIP_TRY(zero_async(dW, (size_t)R * 256 * sizeof(float), st));
-  if (abl == 2) HIP_TRY((launch_bwd_win2<12, 3, true, false, 2>(L)));
-  else if (abl == 16) HIP_TRY((launch_bwd_win2<12, 3, true, false, 16>(L)));
-  else HIP_TRY((launch_bwd_win2<12, 3, true, false, 0>(L)));
-  return RGCN_OK;
-}
-
 extern "C" int rgcn_bwd_fused_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW,
                                   float *scratch, const int32_t *p_pack, const int32_t *chunk_rel,
                                   const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R,
@@ -2131,37 +1343,9 @@ extern "C" int rgcn_bwd_fused_f32(const float *G, const float *X, const float *W
   const bool atomic = (flags & RGCN_F_DW_ATOMIC) != 0;
   const bool relu = (flags & RGCN_F_RELU) != 0;
   if (!atomic && !scratch) { rgcn_set_error("bwd_fused: the deterministic reduction needs a scratch buffer"); return RGCN_EINVAL; }
-  // round 3: the window kernel (X tile in LDS, dW partials summed across 16 tiles on the CU, no barrier in the loop) whenever
-  // its LDS fits (64-row tiles at 16 waves); RGCN_BWD_KERNEL=stage keeps round 2's staging kernel, which also serves taller tiles
-  static const bool WANT_WIN = !(getenv("RGCN_BWD_KERNEL") && !strcmp(getenv("RGCN_BWD_KERNEL"), "stage"));
-  static const int WIN_NW = getenv("RGCN_BWD_NW") ? atoi(getenv("RGCN_BWD_NW")) : 16;
-  if (WANT_WIN) {      // second form of the window kernel (phases over 4 chunks, window per group of 4 relations)
-    const bool nw16 = WIN_NW >= 16 && bwd_win2_lds<16, 3>(tile_rows) <= 160 * 1024;
-    const bool nw8 = !nw16 && bwd_win2_lds<8, 1>(tile_rows) <= 160 * 1024;
-    if (nw16 || nw8) {
-      const int NWv = nw16 ? 16 : 8;
-      const int n_blocks = (int)((n_tiles + NWv - 1) / NWv);
-      hipStream_t st = (hipStream_t)stream;
-      static const size_t LDS_PAD = getenv("RGCN_BWD_LDS_PAD") ? (size_t)atoi(getenv("RGCN_BWD_LDS_PAD")) : 0;   // occupancy experiments
-      const BwdLaunch L{G, X, Wt_packed, dX, atomic ? dW : scratch, reinterpret_cast<const int2 *>(p_pack), chunk_rel, run_ptr,
-                        (int)n_tiles, n_blocks, tile_rows, (int)n_dst, R, (nw16 ? bwd_win2_lds<16, 3>(tile_rows) : bwd_win2_lds<8, 1>(tile_rows)) + LDS_PAD, st};
-      if (atomic) {
-        HIP_TRY(zero_async(dW, (size_t)R * 256 * sizeof(float), st));
-        if (nw16) HIP_TRY((launch_bwd_win2_f<16, 3, true>(L, relu)));
-        else HIP_TRY((launch_bwd_win2_f<8, 1, true>(L, relu)));
-      } else {
-        if (nw16) HIP_TRY((launch_bwd_win2_f<16, 3, false>(L, relu)));
-        else HIP_TRY((launch_bwd_win2_f<8, 1, false>(L, relu)));
-        const int S = (int)std::max<int64_t>(1, std::min<int64_t>(16, n_blocks / 64));
-        float *tmp = scratch + (size_t)n_blocks * R * 256;
-        hipLaunchKernelGGL(dw_reduce_a_kernel, dim3((unsigned)R, (unsigned)S), dim3(WG), 0, st, scratch, tmp, n_blocks, S);
-        hipLaunchKernelGGL(dw_reduce_b_kernel, dim3((unsigned)R), dim3(WG), 0, st, tmp, dW, S);
-        HIP_TRY(hipGetLastError());
-      }
-      return RGCN_OK;
-    }
-  }
-  if (relu) { rgcn_set_error("bwd_fused: RGCN_F_RELU needs the window kernel (tile_rows = %d)", tile_rows); return RGCN_EUNSUPPORTED; }
+  // round 2's staging kernel: the fallback for wave-owned tiles the lean kernel's LDS does not hold (65..160 rows) and
+  // RGCN_BWD_KERNEL=stage; rgcn_bwd_blk_f32 / rgcn_bwd_lean_f32 are the round-3 kernels
+  if (relu) { rgcn_set_error("bwd_fused: RGCN_F_RELU is implemented by rgcn_bwd_blk_f32 / rgcn_bwd_lean_f32 only (tile_rows = %d)", tile_rows); return RGCN_EUNSUPPORTED; }
   static const int DSEL = getenv("RGCN_BWD_D") ? atoi(getenv("RGCN_BWD_D")) : 4;
   const int Dv = DSEL >= 4 ? 4 : (DSEL >= 2 ? 2 : 1);
   // tiles per workgroup: 8 halve the number of dW partials -- measured at S1 (profiles/r02_bwd_fused_ablation.txt): atomic flush

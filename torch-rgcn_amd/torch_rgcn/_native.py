@@ -951,7 +951,7 @@ def pack_w16t(W):
 
 
 def bwd_route():
-    """RGCN_BWD_KERNEL: blk (default: block-tile kernel where it applies, else lean) | lean | win | stage | pc -- DESIGN.md 4.2"""
+    """RGCN_BWD_KERNEL: blk (default: block-tile kernel where it applies, else lean) | lean | stage -- DESIGN.md 4.2"""
     return os.environ.get("RGCN_BWD_KERNEL", "blk")
 
 
@@ -1052,13 +1052,6 @@ def bwd_fused(G, X, W, plan, atomic=False, relu=False, want_db=False, diag4=Fals
                                           c_i64(plan.n_tiles), c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i32(W.shape[0]),
                                           c_i32((F_RELU if relu else 0) | (F_DIAG4 if diag4 else 0)), _dp(db), c_i64(plan.n_src),
                                           _stream(dev)), "bwd_blk")
-        return ret()
-    if route == "pc" and atomic and lib().rgcn_bwd_pc_supported(c_i32(plan.tile_rows)) and W.shape[0] < 0x7FFF:
-        slots, hdr = _lean_plan(plan)
-        with _on(dev), _timed("bwd_fused"):
-            _check(lib().rgcn_bwd_pc_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(slots), _dp(hdr), _dp(plan.run_ptr),
-                                         c_i64(plan.n_tiles), c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i32(W.shape[0]),
-                                         c_i32(1 if relu else 0), _stream(dev)), "bwd_pc")
         return ret()
     if route in ("lean", "blk") and lib().rgcn_bwd_lean_supported(c_i32(plan.tile_rows)) and W.shape[0] < 65536:
         slots, hdr = _lean_plan(plan)
