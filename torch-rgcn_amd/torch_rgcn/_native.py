@@ -956,13 +956,14 @@ def bwd_route():
 
 
 _BLK_MIN_NODES = 32768      # below: a tile per workgroup leaves most CUs idle; the wave-owned 64-row (or smaller) tiles stay
+_BLK_MIN_NODES_SPARSE = 4096   # graphs with sparse (tile, relation) buckets: the alternative is the two-pass backward (three launches)
 
 
-def bwd_blk_rows(n_nodes, num_rels, deterministic=False, device=None, diag4=False):
+def bwd_blk_rows(n_nodes, num_rels, deterministic=False, device=None, diag4=False, sparse=False):
     """tile height of the transposed plan for the block-tile backward kernel (rgcn_bwd_blk_f32), 0 when it does not apply:
     the tallest tile <= 255 rows that gives every CU the same number of tiles (S1: 245 rows, 4082 tiles, 15.95 per CU).
     diag4: the weights are block_diag() of 4 x 4 blocks (only the diagonal blocks of dW are kept: up to 447 relations)"""
-    if bwd_route() != "blk" or deterministic or n_nodes < _BLK_MIN_NODES or \
+    if bwd_route() != "blk" or deterministic or n_nodes < (_BLK_MIN_NODES_SPARSE if sparse else _BLK_MIN_NODES) or \
             not lib().rgcn_bwd_blk_supported(c_i32(255), c_i32(num_rels), c_i32(F_DIAG4 if diag4 else 0)):
         return 0
     n_cu = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).multi_processor_count
@@ -970,7 +971,8 @@ def bwd_blk_rows(n_nodes, num_rels, deterministic=False, device=None, diag4=Fals
     cap = 512 if lib().rgcn_bwd_blk_supported(c_i32(512), c_i32(num_rels), c_i32(F_DIAG4 if diag4 else 0)) and \
         os.environ.get("RGCN_BWD_BLK_CAP", "512") == "512" else 255
     per_cu = -(-n_nodes // (n_cu * cap))
-    return -(-n_nodes // (n_cu * per_cu))
+    rows = -(-n_nodes // (n_cu * per_cu))
+    return max(rows, min(cap, 128))      # small graphs: fewer, taller tiles (fuller buckets, fewer dW flushes) rather than one per CU
 
 
 def _bwd_blk_plan(plan, diag4=False):

@@ -133,7 +133,7 @@ class _ReluToken:
         return self.ref is not None and self.ref() is g and g._version == self.version
 
 
-def _fused_backward(X, W, g, graph, relu_in=False, want_db=False, diag4=False):
+def _fused_backward(X, W, g, graph, relu_in=False, want_db=False, diag4=False, sparse=False):
     """hidden 16, both gradients wanted: ONE walk of the transposed plan gathers G[s] once per message and produces dX
     and dW together (csrc/rgcn_bwd.hip).  None when the plan does not qualify (hub-split tiles, unpacked slots) or
     RGCN_BWD=split asks for round 1's two-pass backward.  relu_in: X is the output of a ReLU and dX is wanted before it
@@ -141,7 +141,7 @@ def _fused_backward(X, W, g, graph, relu_in=False, want_db=False, diag4=False):
     sums G's columns on the side (block-tile kernel), else None."""
     if W.shape[1] != 16 or W.shape[2] != 16 or os.environ.get("RGCN_BWD", "fused") == "split":
         return None
-    bp = graph.bwd_blk_plan(diag4)                          # tall tiles, one per workgroup -- or the wave-owned 64-row plan
+    bp = graph.bwd_blk_plan(diag4, sparse)                  # tall tiles, one per workgroup -- or the wave-owned 64-row plan
     diag4 = diag4 and bp is not None and _native._bwd_blk_plan(bp, True)   # block-diagonal W (4 x 4 blocks): only on the block-tile kernel
     if bp is None or not _native._bwd_blk_plan(bp, diag4):
         bp = graph.bwd_plan(16)
@@ -214,13 +214,14 @@ class _RelationalMP(torch.autograd.Function):
         sparse = _sparse_buckets(graph, W)
         both = None
         masked = False
-        # sparse (tile, relation) buckets normally leave the tile plan -- except block-diagonal weights on a graph the block-tile
-        # kernel takes (255-row tiles halve the padding of the sparse buckets; dW's diagonal blocks of all relations fit its LDS)
-        blk_diag = sparse and ctx.diag4 and os.environ.get("RGCN_BWD", "fused") != "split" and \
-            _native.bwd_blk_rows(graph.num_nodes, graph.num_rels, deterministic(), graph.device, True) > 0
-        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and (not sparse or blk_diag):
+        # sparse (tile, relation) buckets normally leave the tile plan -- except on a graph the block-tile kernel takes: its tall tiles
+        # (128 .. 512 rows) hold several messages per bucket where a 64-row tile holds one or two, and dW of all relations (block-diagonal
+        # weights: its diagonal blocks) fits the workgroup's LDS.  One launch instead of the two-pass backward's three.
+        blk_sparse = sparse and os.environ.get("RGCN_BWD", "fused") != "split" and \
+            _native.bwd_blk_rows(graph.num_nodes, graph.num_rels, deterministic(), graph.device, ctx.diag4, True) > 0
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and (not sparse or blk_sparse):
             both = _fused_backward(X, W, g, graph, relu_in=ctx.in_token is not None and ctx.dims is None,
-                                   want_db=ctx.has_bias and ctx.needs_input_grad[2], diag4=ctx.diag4)
+                                   want_db=ctx.has_bias and ctx.needs_input_grad[2], diag4=ctx.diag4, sparse=sparse)
             if both is not None:
                 both, masked, db = both[:2], both[2], both[3]
         if both is None and sparse and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and os.environ.get("RGCN_BWD", "fused") != "split" \

@@ -111,7 +111,7 @@ class RelGraph:
             rows = int(os.environ["RGCN_BWD_TILE_ROWS"]) if "RGCN_BWD_TILE_ROWS" in os.environ else min(rows, 64)
         return self._plan("bwd", rows)
 
-    def bwd_blk_plan(self, diag4=False):
+    def bwd_blk_plan(self, diag4=False, sparse=False):
         """transposed plan of TALL tiles (one per workgroup, up to 255 / 512 rows) for the block-tile backward kernel, or None
         when that kernel does not apply (small graph, too many relations, RGCN_DETERMINISTIC=1, RGCN_BWD_KERNEL != blk).
         Only rgcn_bwd_blk_f32 can walk it -- every other kernel gets bwd_plan()."""
@@ -120,7 +120,8 @@ class RelGraph:
         if "RGCN_BWD_TILE_ROWS" in os.environ and _native.bwd_route() == "blk":
             rows = int(os.environ["RGCN_BWD_TILE_ROWS"])         # experiments (tools/r3_blk.sh)
             return self._plan("bwd", rows) if rows > 64 else None
-        rows = _native.bwd_blk_rows(self.num_nodes, self.num_rels, os.environ.get("RGCN_DETERMINISTIC", "0") == "1", self.device, diag4)
+        rows = _native.bwd_blk_rows(self.num_nodes, self.num_rels, os.environ.get("RGCN_DETERMINISTIC", "0") == "1", self.device, diag4,
+                                    sparse)
         return self._plan("bwd", rows) if rows else None
 
     def wgt_plan(self):
