@@ -371,6 +371,16 @@ RGCN_API int rgcn_featureless_wgrad_f32(const float *G, float *dtable, const int
                                         const int32_t *p_dst, const float *p_val, const int32_t *chunk_rel,
                                         int64_t n_chunks, int64_t n_dst, int64_t n_src, int32_t R,
                                         int32_t d_out, void *stream);
+/* The featureless layer on a destination-major CSR (graphs whose (tile, relation) buckets are sparse: the tile plan of an AIFB-sized
+ * graph with 91 relations is 23 padded slots per message).  Same results as rgcn_featureless_fwd_f32 / rgcn_featureless_wgrad_f32
+ * (reference layers.py:293-301 with the one-hot input folded into the weight table).  units: [n_units][4] = {row, e0, e1, flags}
+ * (hub rows cut into pieces, RGCN_U_SHARED); the weight-gradient form walks the n_entries CSR entries, rowptr gives an entry's row. */
+RGCN_API int rgcn_featureless_csr_fwd_f32(const float *table, const float *bias, float *out, const int32_t *units, int64_t n_units,
+                                          int64_t n_split, const int32_t *e_src, const int32_t *e_rel, const float *e_val,
+                                          int64_t n_rows, int64_t n_src, int32_t R, int32_t d, void *stream);
+RGCN_API int rgcn_featureless_csr_wgrad_f32(const float *G, float *dtable, const int32_t *rowptr, const int32_t *e_src,
+                                            const int32_t *e_rel, const float *e_val, int64_t n_entries, int64_t n_rows, int64_t n_src,
+                                            int32_t R, int32_t d, void *stream);
 
 /* db[j] = sum_n G[n, j]  (bias gradient: autograd dual of the `+ bias` of layers.py:305-306).  Two stages through
  * `scratch` (rgcn_colsum_scratch_floats(n, d) floats), no atomics, fixed summation order: bit-reproducible. */

@@ -848,10 +848,13 @@ __global__ __launch_bounds__(WG) void featureless_wgrad_kernel(
 // diagonal, and nothing materialised.  Destination-major CSR (no (tile, relation) buckets: with hundreds of relations and
 // wide rows those are nearly all padding); work units = rows, long rows cut into pieces (RGCN_U_SHARED: fp32 atomics into
 // the zeroed output).  `lr` lanes per unit = lr / lpm messages in flight x lpm lanes x float4; unrolled by two.
+// TABLE (featureless layer on a graph with sparse (tile, relation) buckets): X is the weight table [R][n_src][d] itself, the message's
+// row is table[rel][src] and there is no w -- out[row, :] = bias + the sum of val * table[rel, src, :].
+template <bool TABLE>
 __global__ __launch_bounds__(WG) void diag_csr_kernel(
     const float *__restrict__ X, const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ out,
     const int4 *__restrict__ units, long long n_units, const int *__restrict__ e_src, const int *__restrict__ e_rel,
-    const float *__restrict__ e_val, int d, int lpm, int lr) {
+    const float *__restrict__ e_val, int d, int lpm, int lr, long long n_src) {
   const long long u = ((long long)blockIdx.x * WG + threadIdx.x) / lr;
   const int sub = threadIdx.x % lr, g = sub / lpm, j = sub % lpm, gpr = lr / lpm;
   const bool on = u < n_units;
@@ -868,17 +871,24 @@ __global__ __launch_bounds__(WG) void diag_csr_kernel(
         const int eb = e + gpr;
         const bool hb = eb < e1;
         const float va = e_val[e], vb = hb ? e_val[eb] : 0.f;
-        const float *xa = X + (size_t)e_src[e] * d + f, *wa = w + (size_t)e_rel[e] * d + f;
-        const float *xb = X + (size_t)e_src[hb ? eb : e] * d + f, *wb = w + (size_t)e_rel[hb ? eb : e] * d + f;
+        const long long ra = e_rel[e], rb = e_rel[hb ? eb : e];
+        const float *xa = X + ((TABLE ? ra * n_src : 0) + e_src[e]) * (size_t)d + f;
+        const float *xb = X + ((TABLE ? rb * n_src : 0) + e_src[hb ? eb : e]) * (size_t)d + f;
+        const float *wa = TABLE ? xa : w + (size_t)ra * d + f, *wb = TABLE ? xb : w + (size_t)rb * d + f;
         if (vec) {
           const f32x4 x0 = *reinterpret_cast<const f32x4 *>(xa), x1 = *reinterpret_cast<const f32x4 *>(xb);
-          const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wa), w1 = *reinterpret_cast<const f32x4 *>(wb);
-          a += x0 * w0 * va;
-          b += x1 * w1 * vb;
+          if (TABLE) {
+            a += x0 * va;
+            b += x1 * vb;
+          } else {
+            const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wa), w1 = *reinterpret_cast<const f32x4 *>(wb);
+            a += x0 * w0 * va;
+            b += x1 * w1 * vb;
+          }
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            if (f + q < d) { a[q] += xa[q] * wa[q] * va; b[q] += xb[q] * wb[q] * vb; }
+            if (f + q < d) { a[q] += xa[q] * (TABLE ? 1.f : wa[q]) * va; b[q] += xb[q] * (TABLE ? 1.f : wb[q]) * vb; }
         }
       }
     a += b;
@@ -902,6 +912,40 @@ __global__ __launch_bounds__(WG) void diag_csr_kernel(
           }
       }
     }
+  }
+}
+
+// Featureless layer, gradient of the weight table on the destination-major CSR: dtable[rel, src, :] += val * G[row, :] for every
+// message of row `row` -- `lpm` lanes per message (a float4 each), WG / lpm messages of consecutive rows' entries in flight; one
+// lane group per CSR ENTRY (not per padded plan slot: on a graph with sparse (tile, relation) buckets the tile plan is 10-20x
+// padding).  fp32 atomics: several messages may share (relation, source).
+__global__ __launch_bounds__(WG) void featureless_csr_wgrad_kernel(
+    const float *__restrict__ G, float *__restrict__ dtable, const int *__restrict__ rowptr, const int *__restrict__ e_row,
+    const int *__restrict__ e_src, const int *__restrict__ e_rel, const float *__restrict__ e_val, long long n_entries, long long n_rows,
+    long long n_src, int d, int lpm) {
+  const long long e = ((long long)blockIdx.x * WG + threadIdx.x) / lpm;
+  const int j = threadIdx.x % lpm;
+  if (e >= n_entries) return;
+  // the entry's row: e_row when the caller has it, else a binary search in rowptr
+  long long row;
+  if (e_row) {
+    row = e_row[e];
+  } else {
+    long long lo = 0, hi = n_rows;
+    while (hi - lo > 1) {
+      const long long mid = (lo + hi) >> 1;
+      if (rowptr[mid] <= e) lo = mid; else hi = mid;
+    }
+    row = lo;
+  }
+  const float v = e_val[e];
+  if (v == 0.f) return;
+  float *t = dtable + ((long long)e_rel[e] * n_src + e_src[e]) * (size_t)d;
+  const float *g = G + (size_t)row * d;
+  for (int f = 4 * j; f < d; f += 4 * lpm) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (f + q < d) atomicAdd(t + f + q, v * g[f + q]);
   }
 }
 
@@ -1588,8 +1632,48 @@ extern "C" int rgcn_diag_spmm_f32(const float *X, const float *w, const float *b
   const int lr = std::min(64, std::max(16, 2 * lpm));   // lanes per unit: >= 2 messages of a row in flight
   const int upw = WG / lr;                      // units per workgroup
   const unsigned gx = (unsigned)((n_units + upw - 1) / upw);
-  hipLaunchKernelGGL(diag_csr_kernel, dim3(gx), dim3(WG), 0, (hipStream_t)stream, X, w, bias, out,
-                     reinterpret_cast<const int4 *>(rowptr_units), (long long)n_units, e_src, e_rel, e_val, d, lpm, lr);
+  hipLaunchKernelGGL(diag_csr_kernel<false>, dim3(gx), dim3(WG), 0, (hipStream_t)stream, X, w, bias, out,
+                     reinterpret_cast<const int4 *>(rowptr_units), (long long)n_units, e_src, e_rel, e_val, d, lpm, lr, 0LL);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_featureless_csr_fwd_f32(const float *table, const float *bias, float *out, const int32_t *units, int64_t n_units,
+                                            int64_t n_split, const int32_t *e_src, const int32_t *e_rel, const float *e_val,
+                                            int64_t n_rows, int64_t n_src, int32_t R, int32_t d, void *stream) {
+  if (!table || !out || d <= 0 || n_rows < 0 || n_src <= 0 || R <= 0 || n_units < 0 || n_split < 0 ||
+      (n_units && (!units || !e_src || !e_rel || !e_val))) {
+    rgcn_set_error("featureless_csr_fwd: bad argument");
+    return RGCN_EINVAL;
+  }
+  if (n_rows == 0 || n_units == 0) return RGCN_OK;
+  if (n_split) HIP_TRY(zero_async(out, (size_t)n_rows * d * sizeof(float), (hipStream_t)stream));
+  int lpm = 1;                                  // lanes per message: float4 each, a power of two
+  while (lpm < 64 && 4 * lpm < d) lpm *= 2;
+  const int lr = std::min(64, std::max(16, 2 * lpm));
+  const int upw = WG / lr;
+  const unsigned gx = (unsigned)((n_units + upw - 1) / upw);
+  hipLaunchKernelGGL(diag_csr_kernel<true>, dim3(gx), dim3(WG), 0, (hipStream_t)stream, table, nullptr, bias, out,
+                     reinterpret_cast<const int4 *>(units), (long long)n_units, e_src, e_rel, e_val, d, lpm, lr, (long long)n_src);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_featureless_csr_wgrad_f32(const float *G, float *dtable, const int32_t *rowptr, const int32_t *e_src, const int32_t *e_rel,
+                                              const float *e_val, int64_t n_entries, int64_t n_rows, int64_t n_src, int32_t R, int32_t d,
+                                              void *stream) {
+  if (!G || !dtable || d <= 0 || n_rows < 0 || n_src <= 0 || R <= 0 || n_entries < 0 || (n_entries && (!rowptr || !e_src || !e_rel || !e_val))) {
+    rgcn_set_error("featureless_csr_wgrad: bad argument");
+    return RGCN_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(zero_async(dtable, (size_t)R * n_src * d * sizeof(float), st));
+  if (!n_entries) return RGCN_OK;
+  int lpm = 1;
+  while (lpm < 64 && 4 * lpm < d) lpm *= 2;
+  const long long threads = (long long)n_entries * lpm;
+  hipLaunchKernelGGL(featureless_csr_wgrad_kernel, dim3((unsigned)((threads + WG - 1) / WG)), dim3(WG), 0, st, G, dtable, rowptr, nullptr,
+                     e_src, e_rel, e_val, (long long)n_entries, (long long)n_rows, (long long)n_src, d, lpm);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

@@ -1086,6 +1086,35 @@ def featureless_fwd(table, bias, plan):
     return out
 
 
+def featureless_csr_fwd(table, bias, csr):
+    """out[n_rows, d] = bias + sum over the row's CSR entries of val * table[rel, src, :] (rgcn_featureless_csr_fwd_f32): the
+    featureless layer on graphs whose (tile, relation) buckets are sparse -- one lane group per MESSAGE, not per padded plan slot"""
+    _req(table, "weights"); _req(bias, "bias")
+    R, n_src, d = table.shape
+    units, n_units, n_split = _csr_units(csr)
+    assert units is not None, "the CSR featureless kernels serve static graphs"
+    out = torch.empty((csr.n_rows, d), device=table.device, dtype=torch.float32)
+    with _on(table.device), _timed("featureless_csr_fwd"):
+        _check(lib().rgcn_featureless_csr_fwd_f32(_dp(table), _dp(bias), _dp(out), _dp(units), c_i64(n_units), c_i64(n_split),
+                                                  _dp(csr.src), _dp(csr.rel), _dp(csr.val), c_i64(csr.n_rows), c_i64(n_src),
+                                                  c_i32(R), c_i32(d), _stream(table.device)), "featureless_csr_fwd")
+    return out
+
+
+def featureless_csr_wgrad(G, csr, num_rels, n_src):
+    """dtable[R, n_src, d]: += val * G[row, :] at [rel, src] for every CSR entry (rgcn_featureless_csr_wgrad_f32)"""
+    _req(G, "grad_output")
+    d = G.shape[1]
+    if getattr(csr, "n_entries", None) is None:
+        csr.n_entries = int(csr.rowptr[-1].item())       # static graph: read once
+    dT = torch.empty((num_rels, n_src, d), device=G.device, dtype=torch.float32)
+    with _on(G.device), _timed("featureless_csr_wgrad"):
+        _check(lib().rgcn_featureless_csr_wgrad_f32(_dp(G), _dp(dT), _dp(csr.rowptr), _dp(csr.src), _dp(csr.rel), _dp(csr.val),
+                                                    c_i64(csr.n_entries), c_i64(csr.n_rows), c_i64(n_src), c_i32(num_rels), c_i32(d),
+                                                    _stream(G.device)), "featureless_csr_wgrad")
+    return dT
+
+
 def _csr_units(csr):
     """(units, n_units, n_split) of a CSR: one unit per row, hub rows cut into 512-entry pieces -- computed once per static
     graph (host statistics); a CSR of a per-call LP graph has none: (None, n_rows, 0) = every row is one unit"""

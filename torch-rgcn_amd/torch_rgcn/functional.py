@@ -349,15 +349,32 @@ def sharded_relational_mp(features, weights, bias, graph, group, n_slabs=0, comm
     return _ShardedRelationalMP.apply(features, weights, bias, graph, group, n_slabs, comm)
 
 
+def _featureless_csr(graph, width):
+    """the featureless layer's route: destination-major CSR kernels (one lane group per message) when the (tile, relation) buckets
+    of the tile plan are mostly padding (AIFB: 91 relations on 8-row tiles, 23 slots per message) and the graph is static"""
+    if getattr(graph, "_dev", None) is None or getattr(graph, "sync_free", False) or getattr(graph, "per_call", False) or \
+            os.environ.get("RGCN_FEATURELESS_CSR", "auto") == "0":
+        return False
+    if os.environ.get("RGCN_FEATURELESS_CSR", "auto") == "1":
+        return True
+    fp = graph.fwd_plan(width)
+    return not _dense_buckets(fp) and graph.max_degree() <= 4096
+
+
 class _FeaturelessMP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, bias, graph):
         table = dense(table)
         b = None if bias is None else dense(bias)
-        out = _native.featureless_fwd(table, b, graph.fwd_plan(table.shape[2]))
+        ctx.csr = _featureless_csr(graph, table.shape[2])
+        if ctx.csr:
+            out = _native.featureless_csr_fwd(table, b, graph.csr("fwd"))
+        else:
+            out = _native.featureless_fwd(table, b, graph.fwd_plan(table.shape[2]))
         ctx.graph = graph
         ctx.has_bias = bias is not None
         ctx.num_rels = table.shape[0]
+        ctx.n_src = table.shape[1]
         ctx.width = table.shape[2]
         return out
 
@@ -366,7 +383,10 @@ class _FeaturelessMP(torch.autograd.Function):
         g = dense(g)
         dT = db = None
         if ctx.needs_input_grad[0]:
-            dT = _native.featureless_wgrad(g, ctx.graph.fwd_plan(ctx.width), ctx.num_rels)
+            if ctx.csr:
+                dT = _native.featureless_csr_wgrad(g, ctx.graph.csr("fwd"), ctx.num_rels, ctx.n_src)
+            else:
+                dT = _native.featureless_wgrad(g, ctx.graph.fwd_plan(ctx.width), ctx.num_rels)
         if ctx.has_bias and ctx.needs_input_grad[1]:
             db = _native.colsum(g)
         return dT, db, None
