@@ -23,7 +23,7 @@ for f in glob.glob(out + "/k*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         per[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 keys = {"spmm": "spmm_d16_kernel", "bwd_fused": "bwd_fused_d16_kernel<4, true", "bwd_fused_deterministic": "bwd_fused_d16_kernel<4, false",
-        "bwd_blk": "bwd_blk_d16_kernel<false, 0>", "bwd_lean": "bwd_lean_d16_kernel<16, 3, true, false", "bwd_lean_deterministic": "bwd_lean_d16_kernel<16, 3, false, false",
+        "bwd_blk": "bwd_blk_d16_kernel<false, 0, false, 1>", "bwd_lean": "bwd_lean_d16_kernel<16, 3, true, false", "bwd_lean_deterministic": "bwd_lean_d16_kernel<16, 3, false, false",
         "wgrad_tiled": "wgrad_tiled_d16_kernel"}
 detail = {"_how": "tools/pmc_passes.sh: separate rocprofv3 --pmc passes over tools/kbench.py --what spmm,bwd,wtiled (S1 launches); means per launch. "
                   "GRBM_GUI_ACTIVE is summed over the 8 XCDs: MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)"}
