@@ -162,6 +162,91 @@ __global__ __launch_bounds__(BIG_WG) void block_csr_lds_kernel(
                              bo_rt, n_rel_blocks, lpm, lr, relu, rel_stride);
 }
 
+// The common case by hand: 4 blocks of 4 x 4 (width 16), block table in LDS, work units given.  Same arithmetic as
+// block_csr_lds_kernel<4, 4, TR> with the dependent load chain of a row -- unit -> (rel, src, val) -> feature segment -- software
+// pipelined across the persistent loop: the unit of the row after next and the indices of the next row are requested while the
+// current row's four feature segments (four messages per lane group in flight: rows of up to 16 messages in one pass) are on
+// their way.  16 lanes per row: lane (g, j) = message group g (0..3), block j (0..3).
+template <bool TR>
+__global__ __launch_bounds__(BIG_WG) void block44_csr_kernel(
+    const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ out,
+    const int4 *__restrict__ units, long long n_units, const int *__restrict__ e_src, const int *__restrict__ e_rel,
+    const float *__restrict__ e_val, int n_rel_blocks, int relu, int table_floats) {
+  extern __shared__ __attribute__((aligned(16))) float wt[];
+  constexpr int PER_REL = 64, REL_STRIDE = 68;          // (the 4-float pad: see block_csr_lds_kernel)
+  for (int i = threadIdx.x; i < table_floats; i += BIG_WG) wt[(i / PER_REL) * REL_STRIDE + i % PER_REL] = W[i];
+  __syncthreads();
+  constexpr int UPW = BIG_WG / 16, MF = 4;              // rows per workgroup pass, messages in flight per lane group
+  const int sub = threadIdx.x & 15, g = sub >> 2, j = sub & 3;
+  const long long stride = (long long)gridDim.x * UPW;
+  long long u = (long long)blockIdx.x * UPW + (threadIdx.x >> 4);
+  struct Idx { int rel[MF], src[MF]; float v[MF]; };
+  auto load_unit = [&](long long uu) { return uu < n_units ? units[uu] : int4{0, 0, 0, 0}; };
+  auto load_idx = [&](const int4 &un, Idx &ix) {
+#pragma unroll
+    for (int q = 0; q < MF; ++q) {
+      const int e = un.y + g + 4 * q;
+      const bool have = e < un.z;
+      const int ee = have ? e : 0;
+      const int r = e_rel[ee];
+      ix.rel[q] = r < n_rel_blocks ? r : 0;
+      ix.src[q] = e_src[ee];
+      ix.v[q] = (have && r < n_rel_blocks) ? e_val[ee] : 0.f;   // relations past the block table (LP self loops): not ours
+    }
+  };
+  auto mac = [&](f32x4 &acc, const f32x4 &x, float v, int rel) {
+    const f32x4 *w = reinterpret_cast<const f32x4 *>(wt + rel * REL_STRIDE + j * 16);
+    const f32x4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];     // block rows i = 0..3: w_i[o]
+    const float x0 = x[0] * v, x1 = x[1] * v, x2 = x[2] * v, x3 = x[3] * v;
+    if (TR) {       // out[i] += sum_o x[o] * w[i][o]
+      acc[0] += x0 * w0[0] + x1 * w0[1] + x2 * w0[2] + x3 * w0[3];
+      acc[1] += x0 * w1[0] + x1 * w1[1] + x2 * w1[2] + x3 * w1[3];
+      acc[2] += x0 * w2[0] + x1 * w2[1] + x2 * w2[2] + x3 * w2[3];
+      acc[3] += x0 * w3[0] + x1 * w3[1] + x2 * w3[2] + x3 * w3[3];
+    } else {        // out[o] += sum_i x[i] * w[i][o]
+      acc += w0 * x0 + w1 * x1 + w2 * x2 + w3 * x3;
+    }
+  };
+  int4 un_c = load_unit(u), un_n = load_unit(u + stride);
+  Idx ix_c, ix_n;
+  load_idx(un_c, ix_c);
+  const long long u_first = (long long)blockIdx.x * UPW;      // uniform loop bound for the whole workgroup (shuffles below)
+  for (long long base = u_first; base < n_units; base += stride, u += stride) {
+    f32x4 x[MF];
+#pragma unroll
+    for (int q = 0; q < MF; ++q) x[q] = *reinterpret_cast<const f32x4 *>(X + (size_t)ix_c.src[q] * 16 + 4 * j);
+    const int4 un_nn = load_unit(u + 2 * stride);
+    load_idx(un_n, ix_n);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < MF; ++q) mac(acc, x[q], ix_c.v[q], ix_c.rel[q]);
+    for (int e = un_c.y + g + 4 * MF; e < un_c.z; e += 4) {      // rows of more than 16 messages: the rest, unpipelined
+      const int r = e_rel[e];
+      const float v = r < n_rel_blocks ? e_val[e] : 0.f;
+      const f32x4 xx = *reinterpret_cast<const f32x4 *>(X + (size_t)e_src[e] * 16 + 4 * j);
+      mac(acc, xx, v, r < n_rel_blocks ? r : 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { acc[q] += __shfl_xor(acc[q], 4, 64); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { acc[q] += __shfl_xor(acc[q], 8, 64); }
+    if (u < n_units && g == 0) {
+      const bool shared = un_c.w & RGCN_U_SHARED;
+      const bool add_bias = bias && (!shared || (un_c.w & RGCN_U_FIRST));
+      float *orow = out + (size_t)un_c.x * 16 + 4 * j;
+      if (add_bias) acc += *reinterpret_cast<const f32x4 *>(bias + 4 * j);
+      if (shared) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) atomicAdd(orow + q, acc[q]);
+      } else {
+        if (relu) { acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f); acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f); }
+        *reinterpret_cast<f32x4 *>(orow) = acc;
+      }
+    }
+    un_c = un_n; un_n = un_nn; ix_c = ix_n;
+  }
+}
+
 // One wave per work item (a chunk range of ONE relation in the relation-major plan; pads carry val = 0).
 template <int BI_, int BO_>
 __global__ __launch_bounds__(WG) void block_wgrad_kernel(
@@ -296,7 +381,24 @@ extern "C" int rgcn_block_spmm_f32(const float *X, const float *blocks, const fl
                          e_rel, e_val, nb, bi, bo, n_rel_blocks, lpm, lr, (int)relu, (int)(table_bytes / sizeof(float)));
       return hipGetLastError();
     };
-    static bool raised_t = false, raised_n = false;
+    static bool raised_t = false, raised_n = false, raised_pt = false, raised_pn = false;
+    static const int pipe = getenv("RGCN_BLOCK_PIPE") ? atoi(getenv("RGCN_BLOCK_PIPE")) : 1;
+    if (pipe && nb == 4 && un) {          // width 16: the software-pipelined form
+      const dim3 pg((unsigned)std::min<int64_t>(512, (n_units + BIG_WG / 16 - 1) / (BIG_WG / 16)));
+      auto launch_p = [&](auto kern, bool &raised) -> hipError_t {
+        if (lds_bytes > 64 * 1024 && !raised) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TABLE_BYTES);
+          if (e != hipSuccess) return e;
+          raised = true;
+        }
+        hipLaunchKernelGGL(kern, pg, dim3(BIG_WG), lds_bytes, st, X, blocks, bias, out, un, (long long)n_units, e_src, e_rel, e_val,
+                           n_rel_blocks, (int)relu, (int)(table_bytes / sizeof(float)));
+        return hipGetLastError();
+      };
+      if (tr) HIP_TRY(launch_p(block44_csr_kernel<true>, raised_pt));
+      else HIP_TRY(launch_p(block44_csr_kernel<false>, raised_pn));
+      return RGCN_OK;
+    }
     if (tr) HIP_TRY(launch(block_csr_lds_kernel<4, 4, true>, raised_t));
     else HIP_TRY(launch(block_csr_lds_kernel<4, 4, false>, raised_n));
     return RGCN_OK;
