@@ -96,9 +96,11 @@ def _unpad_blocks(dims, dX, dW, db):
 
 
 def deterministic():
-    """RGCN_DETERMINISTIC=1: bit-reproducible gradients.  The fused hidden-16 backward then writes its per-workgroup dW
-    partials with plain stores and two small kernels sum them in a fixed order (+0.11 ms per layer at S1) instead of
-    adding them to dW with fp32 atomics.  Outputs, feature gradients and bias gradients are reproducible either way."""
+    """RGCN_DETERMINISTIC=1: bit-reproducible gradients.  The hidden-16 backward then runs the lean window kernel on 64-row tiles
+    (wave-owned dX tiles: a fixed summation order), writes its per-workgroup dW partials with plain stores and two small kernels
+    sum them in a fixed order (+0.1-0.15 ms per layer at S1) -- instead of the block-tile kernel, whose waves add to the shared
+    dX tile, to dW and to the bias gradient in arrival order (fp32 sums differ in the last bits from run to run).  Outputs are
+    reproducible either way."""
     return os.environ.get("RGCN_DETERMINISTIC", "0") == "1"
 
 
