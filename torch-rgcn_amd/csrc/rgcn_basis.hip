@@ -121,10 +121,25 @@ __global__ __launch_bounds__(WG) void fbasis_bwd_kernel(
   const long long o = unit.x;
   const bool has_b = lane < B;
   float blk[DP], dblk[DP];
+  const bool vec = DP % 4 == 0 && d == DP;              // a lane's d floats are one aligned run: 16-byte loads / stores
 #pragma unroll
   for (int i = 0; i < DP; ++i) {
-    blk[i] = (has_b && i < d && T) ? bases[((size_t)o * B + lane) * d + i] : 0.f;
+    blk[i] = 0.f;
     dblk[i] = 0.f;
+  }
+  if (has_b && T) {
+    const float *bp = bases + ((size_t)o * B + lane) * d;
+    if (vec) {
+#pragma unroll
+      for (int i = 0; i < DP / 4; ++i) {
+        const f32x4 t4 = reinterpret_cast<const f32x4 *>(bp)[i];
+        blk[4 * i] = t4[0]; blk[4 * i + 1] = t4[1]; blk[4 * i + 2] = t4[2]; blk[4 * i + 3] = t4[3];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < DP; ++i)
+        if (i < d) blk[i] = bp[i];
+    }
   }
   constexpr int MB = 4;                                 // messages whose row loads fly together (8 measured slower)
   for (int e0 = unit.y; e0 < unit.z; e0 += 64) {
@@ -155,12 +170,18 @@ __global__ __launch_bounds__(WG) void fbasis_bwd_kernel(
     }
   }
   if (dbases && has_b) {
+    float *dp_ = dbases + ((size_t)o * B + lane) * d;
+    if (vec && !(unit.w & U_SHARED)) {
 #pragma unroll
-    for (int i = 0; i < DP; ++i)
-      if (i < d) {
-        float *p = dbases + ((size_t)o * B + lane) * d + i;
-        if (unit.w & U_SHARED) atomicAdd(p, dblk[i]); else *p = dblk[i];
-      }
+      for (int i = 0; i < DP / 4; ++i)
+        reinterpret_cast<f32x4 *>(dp_)[i] = f32x4{dblk[4 * i], dblk[4 * i + 1], dblk[4 * i + 2], dblk[4 * i + 3]};
+    } else {
+#pragma unroll
+      for (int i = 0; i < DP; ++i)
+        if (i < d) {
+          if (unit.w & U_SHARED) atomicAdd(dp_ + i, dblk[i]); else dp_[i] = dblk[i];
+        }
+    }
   }
 }
 
