@@ -388,8 +388,8 @@ RGCN_API int64_t rgcn_colsum_scratch_floats(int64_t n, int32_t d);
 RGCN_API int rgcn_colsum_f32(const float *G, float *db, float *scratch, int64_t n, int32_t d, void *stream);
 
 /* Featureless layer with basis decomposition, source-major (layers.py:241-242 + :286-288 without the R x N x d_out
- * table): out[s,:] = sum_{e=(s,r,o)} val_e sum_b comps[r,b] bases[b,o,:].  `bases` / `dbases` here are NODE-major
- * copies [N, B, d] (the caller transposes the [B, N, d] parameter: one streaming pass), comps [R, B].  Messages in SOURCE-major CSR order: e_dst / e_rel / e_val [M]; `units` = int32 [n_units][4]
+ * table): out[s,:] = sum_{e=(s,r,o)} val_e sum_b comps[r,b] bases[b,o,:].  `bases` / `dbases`: basis_major != 0 -- the parameter's
+ * own [B, N, d] layout (round 3: no transposed copy of the table, no transposed gradient); 0 -- node-major [N, B, d].  comps [R, B].  Messages in SOURCE-major CSR order: e_dst / e_rel / e_val [M]; `units` = int32 [n_units][4]
  * {row, first entry, end entry, flags (RGCN_U_SHARED | RGCN_U_FIRST)}: one unit per source node, long rows cut into
  * several (n_split = number of shared units; their results merge with fp32 atomics into a zeroed output).
  *   rgcn_fbasis_fwd_f32:  Y[e,:] = val_e * comps[r_e,:] . bases[o,:,:]            (d <= 64, ceil(B / (64/pow2(d))) <= 16)
@@ -400,11 +400,11 @@ RGCN_API int rgcn_colsum_f32(const float *G, float *db, float *scratch, int64_t 
  * RGCN_EUNSUPPORTED outside the stated limits (the caller falls back to rgcn_basis_aggregate_f32). */
 RGCN_API int rgcn_fbasis_fwd_f32(const float *bases, const float *comps, float *Y, const int32_t *e_rel,
                                  const float *e_val, const int32_t *units, int64_t n_units, int64_t n_nodes,
-                                 int32_t R, int32_t B, int32_t d, void *stream);
+                                 int32_t R, int32_t B, int32_t d, int32_t basis_major, void *stream);
 RGCN_API int rgcn_fbasis_bwd_f32(const float *bases, const float *comps, const float *G, float *dbases, float *T,
                                  const int32_t *e_dst, const int32_t *e_rel, const float *e_val,
                                  const int32_t *units, int64_t n_units, int64_t n_split, int64_t n_nodes, int32_t R,
-                                 int32_t B, int32_t d, void *stream);
+                                 int32_t B, int32_t d, int32_t basis_major, void *stream);
 RGCN_API int rgcn_gather_rows_sum_f32(const float *Y, const int32_t *perm, const int32_t *units, int64_t n_units,
                                       int64_t n_split, const float *bias, float *out, int64_t n_rows, int32_t w,
                                       void *stream);

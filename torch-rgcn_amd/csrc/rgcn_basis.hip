@@ -56,7 +56,7 @@ template <int NREG, bool TAB_LDS>
 __global__ __launch_bounds__(FWD_WG) void fbasis_fwd_kernel(
     const float *__restrict__ table, const float *__restrict__ comps, float *__restrict__ Y,
     const int *__restrict__ e_rel, const float *__restrict__ e_val, const int4 *__restrict__ units, int n_units,
-    int R, int B, int d, int dp) {
+    int R, int B, int d, int dp, long long sn, long long sb) {      // element (node, b, i) of the table at node * sn + b * sb + i
   extern __shared__ __attribute__((aligned(16))) float ctab[];
   const int ngrp = 64 / dp, Bp = NREG * ngrp;
   if (TAB_LDS) {
@@ -70,12 +70,12 @@ __global__ __launch_bounds__(FWD_WG) void fbasis_fwd_kernel(
   const int i = lane % dp, bg = lane / dp;
   for (int u = blockIdx.x * (FWD_WG / 64) + wave; u < n_units; u += gridDim.x * (FWD_WG / 64)) {
     const int4 unit = units[u];
-    const float *blk_p = table + (size_t)unit.x * B * d;
+    const float *blk_p = table + (size_t)unit.x * sn;
     float blk[NREG];
 #pragma unroll
     for (int k = 0; k < NREG; ++k) {
       const int b = bg * NREG + k;
-      blk[k] = (b < B && i < d) ? blk_p[b * d + i] : 0.f;          // zero where the lane has no element
+      blk[k] = (b < B && i < d) ? blk_p[(size_t)b * sb + i] : 0.f;          // zero where the lane has no element
     }
     for (int e0 = unit.y; e0 < unit.z; e0 += 64) {
       const int n = min(64, unit.z - e0);
@@ -113,7 +113,8 @@ template <int DP>
 __global__ __launch_bounds__(WG) void fbasis_bwd_kernel(
     const float *__restrict__ bases, const float *__restrict__ comps, const float *__restrict__ G,
     float *__restrict__ dbases, float *__restrict__ T, const int *__restrict__ e_dst, const int *__restrict__ e_rel,
-    const float *__restrict__ e_val, const int4 *__restrict__ units, int n_units, long long N, int B, int d) {
+    const float *__restrict__ e_val, const int4 *__restrict__ units, int n_units, long long N, int B, int d, long long sn,
+    long long sb) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int u = blockIdx.x * WAVES + wave;
   if (u >= n_units) return;
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(WG) void fbasis_bwd_kernel(
     dblk[i] = 0.f;
   }
   if (has_b && T) {
-    const float *bp = bases + ((size_t)o * B + lane) * d;
+    const float *bp = bases + (size_t)o * sn + (size_t)lane * sb;
     if (vec) {
 #pragma unroll
       for (int i = 0; i < DP / 4; ++i) {
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(WG) void fbasis_bwd_kernel(
     }
   }
   if (dbases && has_b) {
-    float *dp_ = dbases + ((size_t)o * B + lane) * d;
+    float *dp_ = dbases + (size_t)o * sn + (size_t)lane * sb;
     if (vec && !(unit.w & U_SHARED)) {
 #pragma unroll
       for (int i = 0; i < DP / 4; ++i)
@@ -234,7 +235,8 @@ inline int pow2_at_least(int v, int lo) {
 
 extern "C" int rgcn_fbasis_fwd_f32(const float *bases, const float *comps, float *Y, const int32_t *e_rel,
                                    const float *e_val, const int32_t *units, int64_t n_units, int64_t n_nodes,
-                                   int32_t R, int32_t B, int32_t d, void *stream) {
+                                   int32_t R, int32_t B, int32_t d, int32_t basis_major, void *stream) {
+  const long long sn = basis_major ? d : (long long)B * d, sb = basis_major ? (long long)n_nodes * d : d;
   if (n_units < 0 || n_nodes <= 0 || R <= 0 || B <= 0 || d <= 0 || (n_units && (!bases || !comps || !Y || !units))) {
     rgcn_set_error("fbasis_fwd: bad argument");
     return RGCN_EINVAL;
@@ -252,10 +254,10 @@ extern "C" int rgcn_fbasis_fwd_f32(const float *bases, const float *comps, float
   {                                                                                                                      \
     if (in_lds)                                                                                                          \
       hipLaunchKernelGGL((fbasis_fwd_kernel<NR, true>), grid, dim3(FWD_WG), tab_bytes, (hipStream_t)stream, bases, comps, Y, \
-                         e_rel, e_val, un, (int)n_units, R, B, d, dp);                                                   \
+                         e_rel, e_val, un, (int)n_units, R, B, d, dp, sn, sb);                                           \
     else                                                                                                                 \
       hipLaunchKernelGGL((fbasis_fwd_kernel<NR, false>), grid, dim3(FWD_WG), 0, (hipStream_t)stream, bases, comps, Y, e_rel,  \
-                         e_val, un, (int)n_units, R, B, d, dp);                                                          \
+                         e_val, un, (int)n_units, R, B, d, dp, sn, sb);                                                  \
   }
   if (nreg <= 4) RGCN_FB_FWD(4) else if (nreg <= 8) RGCN_FB_FWD(8) else if (nreg <= 12) RGCN_FB_FWD(12) else RGCN_FB_FWD(16)
 #undef RGCN_FB_FWD
@@ -266,7 +268,8 @@ extern "C" int rgcn_fbasis_fwd_f32(const float *bases, const float *comps, float
 extern "C" int rgcn_fbasis_bwd_f32(const float *bases, const float *comps, const float *G, float *dbases, float *T,
                                    const int32_t *e_dst, const int32_t *e_rel, const float *e_val,
                                    const int32_t *units, int64_t n_units, int64_t n_split, int64_t n_nodes, int32_t R,
-                                   int32_t B, int32_t d, void *stream) {
+                                   int32_t B, int32_t d, int32_t basis_major, void *stream) {
+  const long long sn = basis_major ? d : (long long)B * d, sb = basis_major ? (long long)n_nodes * d : d;
   if (n_units < 0 || n_nodes <= 0 || R <= 0 || B <= 0 || d <= 0 || (!dbases && !T) ||
       (n_units && (!bases || !comps || !G || !units))) {
     rgcn_set_error("fbasis_bwd: bad argument");
@@ -280,7 +283,7 @@ extern "C" int rgcn_fbasis_bwd_f32(const float *bases, const float *comps, const
   const int4 *un = reinterpret_cast<const int4 *>(units);
 #define RGCN_FB_BWD(DPC)                                                                                          \
   hipLaunchKernelGGL(fbasis_bwd_kernel<DPC>, grid, dim3(WG), 0, st, bases, comps, G, dbases, T, e_dst, e_rel, e_val, un, \
-                     (int)n_units, (long long)n_nodes, B, d)
+                     (int)n_units, (long long)n_nodes, B, d, sn, sb)
   if (d <= 4) RGCN_FB_BWD(4); else if (d <= 8) RGCN_FB_BWD(8); else if (d <= 12) RGCN_FB_BWD(12); else RGCN_FB_BWD(16);
 #undef RGCN_FB_BWD
   HIP_TRY(hipGetLastError());

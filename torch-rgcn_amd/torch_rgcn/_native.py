@@ -564,30 +564,30 @@ def fbasis_supported(B, d):
     return d <= 16 and B <= 64 and 4 * ((B + 4 * ngrp - 1) // (4 * ngrp)) <= 16
 
 
-def fbasis_fwd(table, comps, bias, plan):
-    """table: node-major [N, B, d] copy of the bases"""
+def fbasis_fwd(table, comps, bias, plan, basis_major=False):
+    """table: the bases, node-major [N, B, d] or -- basis_major -- in the parameter's own [B, N, d] layout (no transposed copy)"""
     bases = table
     _req(bases, "bases"); _req(comps, "comps"); _req(bias, "bias")
-    N, B, d = bases.shape
+    N, B, d = (bases.shape[1], bases.shape[0], bases.shape[2]) if basis_major else bases.shape
     dev = bases.device
     Y = torch.empty(max(plan.n_messages, 1), d, device=dev, dtype=torch.float32)
     out = torch.empty(N, d, device=dev, dtype=torch.float32)
     units, n_units, _ = plan.units_src
     with _on(dev), _timed("fbasis_fwd"):
         _check(lib().rgcn_fbasis_fwd_f32(_dp(bases), _dp(comps), _dp(Y), _dp(plan.e_rel), _dp(plan.e_val), _dp(units),
-                                         c_i64(n_units), c_i64(N), c_i32(comps.shape[0]), c_i32(B), c_i32(d), _stream(dev)),
-               "fbasis_fwd")
+                                         c_i64(n_units), c_i64(N), c_i32(comps.shape[0]), c_i32(B), c_i32(d),
+                                         c_i32(1 if basis_major else 0), _stream(dev)), "fbasis_fwd")
         units, n_units, n_split = plan.units_dst
         _check(lib().rgcn_gather_rows_sum_f32(_dp(Y), _dp(plan.perm_dst), _dp(units), c_i64(n_units), c_i64(n_split),
                                               _dp(bias), _dp(out), c_i64(N), c_i32(d), _stream(dev)), "gather_rows_sum")
     return out
 
 
-def fbasis_bwd(table, comps, g, plan, need_bases=True, need_comps=True):
-    """-> (d table [N, B, d] node-major, dcomps [R, B])"""
+def fbasis_bwd(table, comps, g, plan, need_bases=True, need_comps=True, basis_major=False):
+    """-> (d table in the layout of `table`: node-major [N, B, d] or, basis_major, [B, N, d]; dcomps [R, B])"""
     bases = table
     _req(bases, "bases"); _req(comps, "comps"); _req(g, "grad")
-    N, B, d = bases.shape
+    N, B, d = (bases.shape[1], bases.shape[0], bases.shape[2]) if basis_major else bases.shape
     R = comps.shape[0]
     dev = bases.device
     dB = torch.empty_like(bases) if need_bases else None
@@ -597,7 +597,7 @@ def fbasis_bwd(table, comps, g, plan, need_bases=True, need_comps=True):
     with _on(dev), _timed("fbasis_bwd"):
         _check(lib().rgcn_fbasis_bwd_f32(_dp(bases), _dp(comps), _dp(g), _dp(dB), _dp(T), _dp(plan.e_dst), _dp(plan.e_rel),
                                          _dp(plan.e_val), _dp(units), c_i64(n_units), c_i64(n_split), c_i64(N), c_i32(R),
-                                         c_i32(B), c_i32(d), _stream(dev)), "fbasis_bwd")
+                                         c_i32(B), c_i32(d), c_i32(1 if basis_major else 0), _stream(dev)), "fbasis_bwd")
         if need_comps:
             units, n_units, n_split = plan.units_rel
             _check(lib().rgcn_gather_rows_sum_f32(_dp(T), _dp(plan.perm_rel), _dp(units), c_i64(n_units), c_i64(n_split),
