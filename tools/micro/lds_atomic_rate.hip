@@ -24,6 +24,24 @@ __global__ __launch_bounds__(1024) void k(float *out, long long *cyc, int iters)
         unsigned long long ex = 0, de = (unsigned long long)i;
         __hip_atomic_compare_exchange_strong(q, &ex, de, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         v += (float)ex;
+      } else if (MODE == 8 || MODE == 9) {   // double-precision LDS atomic add: contiguous (8), dX-tile-like pattern (9: rows 5 m, 4 lanes per row)
+        double *q = MODE == 8 ? reinterpret_cast<double *>(buf + (SHARED ? 0 : wave * 256)) + lane + 64 * (e & 1)
+                              : reinterpret_cast<double *>(buf) + ((lane & 15) * 5) * 8 + (lane >> 4) * 2 + (e & 1);
+        __hip_atomic_fetch_add(q, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else if (MODE == 10) {               // 16 active lanes only, conflicting CAS (does the conflict cost scale with active lanes?)
+        if ((lane & 3) == 0) {
+          unsigned long long *q = reinterpret_cast<unsigned long long *>(buf + ((lane & 15) * 4) * 16 + (lane >> 4) * 4) + (e & 1);
+          unsigned long long ex = 0, de = (unsigned long long)i;
+          __hip_atomic_compare_exchange_strong(q, &ex, de, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          v += (float)ex;
+        }
+      } else if (MODE == 11 || MODE == 12) {   // conflict-FREE compare-and-swap with few active lanes: 16 (11), 32 (12)
+        if ((MODE == 11 && (lane & 3) == 0) || (MODE == 12 && (lane & 1) == 0)) {
+          unsigned long long *q = reinterpret_cast<unsigned long long *>(buf) + (MODE == 11 ? (lane >> 2) * 2 : (lane >> 1)) + 32 * (e & 1);
+          unsigned long long ex = 0, de = (unsigned long long)i;
+          __hip_atomic_compare_exchange_strong(q, &ex, de, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          v += (float)ex;
+        }
       } else if (MODE == 6) {
         unsigned *q = reinterpret_cast<unsigned *>(p + 64 * e);
         unsigned ex = 0, de = (unsigned)i;
@@ -66,5 +84,10 @@ int main() {
   run<5, true>("cas_b64 rows 5m (tile pattern)");
   run<7, true>("cas_b64 rows 4m (16-way)");
   run<6, false>("cas_b32 contiguous private");
+  run<8, false>("ds_add_f64 contiguous private");
+  run<9, true>("ds_add_f64 tile pattern");
+  run<10, true>("cas_b64 conflicting, 16 active lanes");
+  run<11, true>("cas_b64 conflict-free, 16 active lanes");
+  run<12, true>("cas_b64 conflict-free, 32 active lanes");
   return 0;
 }
