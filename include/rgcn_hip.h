@@ -336,6 +336,14 @@ RGCN_API int rgcn_featureless_fwd_f32(const float *table, const float *bias, flo
  * Messages with rel >= n_rel_blocks are skipped (the LP layer's dense self-loop relation, layers.py:514-527, is the
  * caller's).  flags: RGCN_F_TRANSPOSE_W = multiply by the transposed blocks (X is [.][nb*bo], out [.][nb*bi]: the feature
  * gradient on the transposed CSR), RGCN_F_RELU (not with shared units).  bi, bo <= 8 (rgcn_block_supported). */
+/* Dense 16 x 16 weights W [R][16][16] on the same destination-major CSR, one pass: out[row, :] = bias + sum over the row's messages of
+ * val * X[src, :] W[rel] (layers.py:293-301 at hidden 16) for graphs whose (tile, relation) buckets are sparse -- messages of MIXED
+ * relations, the weight table (transposed, padded) resident in LDS: R <= 120 (rgcn_spmm_csr_d16_supported).  flags: RGCN_F_RELU
+ * (not with shared units).  The two-pass route it replaces: rgcn_spmm_scatter_f32 + rgcn_segment_gather_sum_f32. */
+RGCN_API int rgcn_spmm_csr_d16_supported(int32_t R);
+RGCN_API int rgcn_spmm_csr_d16_f32(const float *X, const float *W, const float *bias, float *out, const int32_t *units, int64_t n_units,
+                                   int64_t n_split, const int32_t *e_src, const int32_t *e_rel, const float *e_val, int64_t n_rows,
+                                   int32_t R, int32_t flags, void *stream);
 RGCN_API int rgcn_block_supported(int32_t bi, int32_t bo);
 RGCN_API int rgcn_block_spmm_f32(const float *X, const float *blocks, const float *bias, float *out, const int32_t *units,
                                  const int32_t *rowptr, int64_t n_units, int64_t n_split, const int32_t *e_src,

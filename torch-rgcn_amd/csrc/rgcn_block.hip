@@ -247,6 +247,62 @@ __global__ __launch_bounds__(BIG_WG) void block44_csr_kernel(
   }
 }
 
+// Dense 16 x 16 weights on a destination-major CSR ("chunks of messages with MIXED relations, W fetched per slot from
+// an LDS-resident R x 1 KiB table"): the forward of a hidden-16 layer whose (tile, relation) buckets are sparse, in ONE pass --
+// out[row, j] = bias[j] + sum over the row's messages of val * sum_i X[src, i] W[rel, i, j] -- instead of the two-pass route
+// (transform in relation-major order into an M x 64 B buffer, then sum per destination).  16 lanes per row (lane j = output feature
+// j), the row's messages four at a time: lane i loads X[src][i] (one 64-byte row per message), the 16 products per message are
+// v_fmac with a DPP row_share operand (x_i broadcast inside the 16 lanes) against W[rel][.][j], which sits TRANSPOSED in LDS
+// ([rel][j][i], row stride 20 floats: the four ds_read_b128 of a lane are conflict-free).  R * 1.25 KiB of LDS: R <= 120; the
+// per-message matrix-vector product runs on the vector ALU (256 FMAs; a small graph's few hundred thousand messages are nothing),
+// dense buckets stay on the MFMA tile kernel.  Persistent 1024-thread workgroups, one per CU.
+constexpr int CSRW_LD = 20, CSRW_REL = 16 * CSRW_LD;      // floats per relation in LDS
+__global__ __launch_bounds__(BIG_WG) void spmm_csr_d16_kernel(
+    const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ out,
+    const int4 *__restrict__ units, long long n_units, const int *__restrict__ e_src, const int *__restrict__ e_rel,
+    const float *__restrict__ e_val, int R, int relu) {
+  extern __shared__ __attribute__((aligned(16))) float wt[];
+  for (int t = threadIdx.x; t < R * 256; t += BIG_WG) {       // W[rel][i][j] -> wt[rel][j][i]
+    const int rel = t >> 8, i = (t >> 4) & 15, j = t & 15;
+    wt[rel * CSRW_REL + j * CSRW_LD + i] = W[t];
+  }
+  __syncthreads();
+  constexpr int UPW = BIG_WG / 16, MF = 4;
+  const int j = threadIdx.x & 15;
+  const long long stride = (long long)gridDim.x * UPW;
+  for (long long u = (long long)blockIdx.x * UPW + (threadIdx.x >> 4); u < n_units; u += stride) {
+    const int4 un = units[u];
+    float acc = 0.f;
+    for (int e0 = un.y; e0 < un.z; e0 += MF) {
+      float x[MF];
+      int rel[MF];
+#pragma unroll
+      for (int q = 0; q < MF; ++q) {
+        const int e = min(e0 + q, un.z - 1);
+        rel[q] = e_rel[e];
+        x[q] = X[(size_t)e_src[e] * 16 + j] * (e0 + q < un.z ? e_val[e] : 0.f);
+      }
+#pragma unroll
+      for (int q = 0; q < MF; ++q) {
+        const f32x4 *w4 = reinterpret_cast<const f32x4 *>(wt + rel[q] * CSRW_REL + j * CSRW_LD);
+        const f32x4 w0 = w4[0], w1 = w4[1], w2 = w4[2], w3 = w4[3];
+        const int xi = __builtin_bit_cast(int, x[q]);
+#define RGCN_XS(I) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, xi, 0x150 + (I), 0xF, 0xF, false))
+        acc += RGCN_XS(0) * w0[0] + RGCN_XS(1) * w0[1] + RGCN_XS(2) * w0[2] + RGCN_XS(3) * w0[3];
+        acc += RGCN_XS(4) * w1[0] + RGCN_XS(5) * w1[1] + RGCN_XS(6) * w1[2] + RGCN_XS(7) * w1[3];
+        acc += RGCN_XS(8) * w2[0] + RGCN_XS(9) * w2[1] + RGCN_XS(10) * w2[2] + RGCN_XS(11) * w2[3];
+        acc += RGCN_XS(12) * w3[0] + RGCN_XS(13) * w3[1] + RGCN_XS(14) * w3[2] + RGCN_XS(15) * w3[3];
+#undef RGCN_XS
+      }
+    }
+    const bool shared = un.w & RGCN_U_SHARED;
+    if (bias && (!shared || (un.w & RGCN_U_FIRST))) acc += bias[j];
+    float *o = out + (size_t)un.x * 16 + j;
+    if (shared) atomicAdd(o, acc);
+    else *o = relu ? fmaxf(acc, 0.f) : acc;
+  }
+}
+
 // One wave per work item (a chunk range of ONE relation in the relation-major plan; pads carry val = 0).
 template <int BI_, int BO_>
 __global__ __launch_bounds__(WG) void block_wgrad_kernel(
@@ -416,6 +472,34 @@ extern "C" int rgcn_block_spmm_f32(const float *X, const float *blocks, const fl
   else if (bi == 2 && bo == 2) RGCN_BLOCK_LAUNCH(2, 2);
   else RGCN_BLOCK_LAUNCH(0, 0);
 #undef RGCN_BLOCK_LAUNCH
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_spmm_csr_d16_supported(int32_t R) { return R > 0 && (size_t)R * CSRW_REL * sizeof(float) <= 150 * 1024; }
+
+extern "C" int rgcn_spmm_csr_d16_f32(const float *X, const float *W, const float *bias, float *out, const int32_t *units, int64_t n_units,
+                                     int64_t n_split, const int32_t *e_src, const int32_t *e_rel, const float *e_val, int64_t n_rows,
+                                     int32_t R, int32_t flags, void *stream) {
+  if (!X || !W || !out || n_rows < 0 || n_units < 0 || n_split < 0 || R <= 0 || (n_units && (!units || !e_src || !e_rel || !e_val))) {
+    rgcn_set_error("spmm_csr_d16: bad argument");
+    return RGCN_EINVAL;
+  }
+  if (!rgcn_spmm_csr_d16_supported(R)) { rgcn_set_error("spmm_csr_d16: %d relations x 1.25 KiB exceed the LDS table (150 KiB)", R); return RGCN_EUNSUPPORTED; }
+  const bool relu = flags & RGCN_F_RELU;
+  if (relu && n_split) { rgcn_set_error("spmm_csr_d16: RGCN_F_RELU with shared units"); return RGCN_EINVAL; }
+  if (n_rows == 0 || n_units == 0) return RGCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (n_split) HIP_TRY(zero_async(out, (size_t)n_rows * 16 * sizeof(float), st));
+  const size_t lds = (size_t)R * CSRW_REL * sizeof(float);
+  static bool raised = false;
+  if (lds > 64 * 1024 && !raised) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_csr_d16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    raised = true;
+  }
+  const unsigned gx = (unsigned)std::min<int64_t>(256 * (lds <= 76 * 1024 ? 2 : 1), (n_units + BIG_WG / 16 - 1) / (BIG_WG / 16));
+  hipLaunchKernelGGL(spmm_csr_d16_kernel, dim3(gx), dim3(BIG_WG), lds, st, X, W, bias, out, reinterpret_cast<const int4 *>(units),
+                     (long long)n_units, e_src, e_rel, e_val, R, (int)relu);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

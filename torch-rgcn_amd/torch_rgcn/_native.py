@@ -1149,6 +1149,29 @@ def block_spmm(X, blocks, bias, csr, transposed=False, relu=False):
     return out
 
 
+def spmm_csr_d16_ok(csr, R):
+    """dense 16 x 16 weights on the destination-major CSR in one pass: the table of R relations has to fit the LDS (R <= 120) and
+    the CSR needs its work units (static graphs)"""
+    return not getattr(csr, "sync_free", False) and not getattr(csr, "per_call", False) and \
+        bool(lib().rgcn_spmm_csr_d16_supported(c_i32(R)))
+
+
+def spmm_csr_d16(X, W, bias, csr, relu=False):
+    """out[n_rows, 16] = bias + sum over the row's CSR entries of val * X[src] @ W[rel]   (W: [R, 16, 16]; rgcn_spmm_csr_d16_f32)"""
+    _req(X, "features"); _req(W, "weights"); _req(bias, "bias")
+    assert X.shape[1] == 16 and tuple(W.shape[1:]) == (16, 16)
+    units, n_units, n_split = _csr_units(csr)
+    fuse_relu = relu and n_split == 0
+    out = torch.empty((csr.n_rows, 16), device=X.device, dtype=torch.float32)
+    with _on(X.device), _timed("spmm_csr"):
+        _check(lib().rgcn_spmm_csr_d16_f32(_dp(X), _dp(W), _dp(bias), _dp(out), _dp(units), c_i64(n_units), c_i64(n_split),
+                                           _dp(csr.src), _dp(csr.rel), _dp(csr.val), c_i64(csr.n_rows), c_i32(W.shape[0]),
+                                           c_i32(F_RELU if fuse_relu else 0), _stream(X.device)), "spmm_csr_d16")
+    if relu and not fuse_relu:
+        out.relu_()
+    return out
+
+
 def block_wgrad(X, G, scatter_plan, shape):
     """dblocks[R', nb, bi, bo] = sum_slots val * X[src, b, :]^T G[dst, b, :] grouped by relation (relation-major plan)"""
     _req(X, "features"); _req(G, "grad_output")

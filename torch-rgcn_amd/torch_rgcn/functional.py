@@ -186,6 +186,10 @@ class _RelationalMP(torch.autograd.Function):
             # two passes below.  The backward stays on the dense W (dX rows + dW from one relation-major walk; autograd
             # through block_diag() picks the blocks' gradient out of dW).
             out = _native.block_spmm(X, blocks.detach().contiguous(), b, graph.csr("fwd"), relu=fused_relu)
+        elif _sparse_buckets(graph, W) and os.environ.get("RGCN_SPMM_CSR", "1") != "0" and \
+                _native.spmm_csr_d16_ok(graph.csr("fwd"), W.shape[0]):
+            # sparse buckets, up to 120 relations: ONE pass over the destination-major CSR, messages of mixed relations, W in LDS
+            out = _native.spmm_csr_d16(X, W, b, graph.csr("fwd"), relu=fused_relu)
         elif _sparse_buckets(graph, W):
             out = _native.spmm_two_pass(X, W, b, graph.scatter_plan("fwd"), graph.csr("fwd"), relu=fused_relu)
         else:
