@@ -301,11 +301,14 @@ RGCN_API int rgcn_bwd_lean_f32(const float *G, const float *X, const float *Wt_p
  * diagonal blocks of dW_r are accumulated (the rest of dW stays zero), 256 bytes of LDS per relation instead of 1 KiB (R <= 447:
  * AM's 267 relations fit).  Plan arrays as rgcn_bwd_lean_f32.  dbias (may be NULL): 16 floats, the bias gradient = column sums of
  * G's n_src rows, read on the side of the tile walk (replaces an rgcn_colsum_f32 launch; one fill zeroes dW and dbias when
- * dbias == dW + R * 256). */
+ * dbias == dW + R * 256).  units (may be NULL = one unit per tile): [n_units][4] = {tile, first chunk, end chunk, flags} as
+ * rgcn_plan_units_host makes them from the plan's tile pointer -- tiles of hub rows cut into pieces (RGCN_U_SHARED; n_split of them)
+ * that different workgroups walk and whose dX rows are added to a zeroed dX. */
 RGCN_API int rgcn_bwd_blk_supported(int32_t tile_rows, int32_t R, int32_t flags);
 RGCN_API int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, const void *slots,
                               const int32_t *hdr, const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R,
-                              int32_t flags, float *dbias, int64_t n_src, void *stream);
+                              int32_t flags, float *dbias, int64_t n_src, const int32_t *units, int64_t n_units, int64_t n_split,
+                              void *stream);
 /* The same for graphs whose (tile, relation) buckets are sparse (AM: 267 relations), on the RELATION-major plan of the
  * two-pass path: one wave per work item gathers G[p_src] and X[p_dst] once per message and produces
  *   Y[slot, :] = val G[p_src] W_r^T   (slot order; pass 2 = rgcn_segment_gather_sum_f32 sums them per destination -> dX)

@@ -663,7 +663,9 @@ template <bool RELU, int ABL, bool DIAG4 = false, int TQ = 1>
 __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
     const float *__restrict__ G, const float *__restrict__ X, const float *__restrict__ Wtp, float *__restrict__ dX,
     float *__restrict__ dWout, const LeanSlot *__restrict__ slots, const int *__restrict__ hdr,
-    const int *__restrict__ run_ptr, int n_tiles, int tile_rows, int n_dst, int R, float *__restrict__ dbias, int n_src) {
+    const int *__restrict__ run_ptr, int n_tiles, int tile_rows, int n_dst, int R, float *__restrict__ dbias, int n_src,
+    const int4 *__restrict__ units, int n_units) {      // units: {tile, first chunk, end chunk, flags}: a hub tile arrives in pieces (RGCN_U_SHARED:
+                                                        // their dX rows are ADDED to a zeroed dX); NULL: one unit per tile (n_units = n_tiles)
   constexpr int U = 4, NW = BLK_NW;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -678,11 +680,18 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
   int *dirty = ctl + 4;
   float4 *dxt4 = reinterpret_cast<float4 *>(dxt), *xt4 = reinterpret_cast<float4 *>(xt);
 
-  int t = blockIdx.x;
+  auto unit_of = [&](int u) {
+    if (units) return units[u];
+    return int4{u, run_ptr[(size_t)u * (R + 1)], run_ptr[(size_t)u * (R + 1) + R], 0};
+  };
+  int un = blockIdx.x;
+  int4 unit = unit_of(un);
+  int t = __builtin_amdgcn_readfirstlane(unit.x);
   int row0 = t * tile_rows;
   int nrows = min(tile_rows, n_dst - row0);
-  int c0 = __builtin_amdgcn_readfirstlane(run_ptr[(size_t)t * (R + 1)]);
-  int c1 = __builtin_amdgcn_readfirstlane(run_ptr[(size_t)t * (R + 1) + R]);
+  int c0 = __builtin_amdgcn_readfirstlane(unit.y);
+  int c1 = __builtin_amdgcn_readfirstlane(unit.z);
+  int shared = __builtin_amdgcn_readfirstlane(unit.w) & RGCN_U_SHARED;
   int nq = (c1 - c0 + U - 1) / U;
   // bias gradient (column sums of G) on the side: every tile switch a thread adds one float4 of G's rows, the workgroups striding
   // through G together (S1: 16 stripes of 16 KiB per workgroup = its 16 tiles); what is left after the last tile is read at the end
@@ -890,16 +899,19 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
     flush_hold();
     cur_r = -1;
     // the next tile of this workgroup: its X rows and this wave's first chunks are requested before the barrier
-    const int tn = t + (int)gridDim.x;
+    const int unn = un + (int)gridDim.x;
     float4 xn[TQ];
 #pragma unroll
     for (int q = 0; q < TQ; ++q) xn[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    int c0n = 0, c1n = 0, nqn = 0, row0n = 0, nrn = 0;
-    if (tn < n_tiles) {
+    int c0n = 0, c1n = 0, nqn = 0, row0n = 0, nrn = 0, tn = 0, sharedn = 0;
+    if (unn < n_units) {
+      const int4 unx = unit_of(unn);
+      tn = __builtin_amdgcn_readfirstlane(unx.x);
       row0n = tn * tile_rows;
       nrn = min(tile_rows, n_dst - row0n);
-      c0n = __builtin_amdgcn_readfirstlane(run_ptr[(size_t)tn * (R + 1)]);
-      c1n = __builtin_amdgcn_readfirstlane(run_ptr[(size_t)tn * (R + 1) + R]);
+      c0n = __builtin_amdgcn_readfirstlane(unx.y);
+      c1n = __builtin_amdgcn_readfirstlane(unx.z);
+      sharedn = __builtin_amdgcn_readfirstlane(unx.w) & RGCN_U_SHARED;
       nqn = (c1n - c0n + U - 1) / U;
 #pragma unroll
       for (int q = 0; q < TQ; ++q)
@@ -920,10 +932,15 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
           const float4 x = xt4[idx];
           a.x = x.x > 0.f ? a.x : 0.f; a.y = x.y > 0.f ? a.y : 0.f; a.z = x.z > 0.f ? a.z : 0.f; a.w = x.w > 0.f ? a.w : 0.f;
         }
-        reinterpret_cast<float4 *>(dX + (size_t)row0 * 16)[idx] = a;
+        float4 *o = reinterpret_cast<float4 *>(dX + (size_t)row0 * 16) + idx;
+        if (shared) {       // a piece of a hub tile: the pieces' rows are summed in memory (dX was zeroed)
+          atomicAdd(&o->x, a.x); atomicAdd(&o->y, a.y); atomicAdd(&o->z, a.z); atomicAdd(&o->w, a.w);
+        } else {
+          *o = a;
+        }
       }
     }
-    if (tn >= n_tiles) break;
+    if (unn >= n_units) break;
 #pragma unroll
     for (int q = 0; q < TQ; ++q) {
       dxt4[tid + q * (64 * NW)] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -931,7 +948,7 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
     }
     if (tid == 0) ctl[0] = 2 * NW;
     __syncthreads();                                               // the next tile is installed
-    t = tn; row0 = row0n; nrows = nrn; c0 = c0n; c1 = c1n; nq = nqn;
+    un = unn; t = tn; row0 = row0n; nrows = nrn; c0 = c0n; c1 = c1n; nq = nqn; shared = sharedn;
     q_cur = wave; q_nxt = wave + NW;
   }
   if (dbias) {
@@ -1237,11 +1254,14 @@ extern "C" int rgcn_bwd_blk_supported(int32_t tile_rows, int32_t R, int32_t flag
 /* block-tile form (atomic flush only; dX sums are LDS float atomics: not bit-reproducible): arguments as rgcn_bwd_pc_f32 */
 extern "C" int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, const void *slots,
                                 const int32_t *hdr, const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R,
-                                int32_t flags, float *dbias, int64_t n_src, void *stream) {
-  if (!G || !X || !Wt_packed || !dX || !dW || !slots || !hdr || !run_ptr || n_tiles <= 0 || tile_rows <= 0 || n_dst <= 0 || R <= 0) {
+                                int32_t flags, float *dbias, int64_t n_src, const int32_t *units, int64_t n_units, int64_t n_split,
+                                void *stream) {
+  if (!G || !X || !Wt_packed || !dX || !dW || !slots || !hdr || !run_ptr || n_tiles <= 0 || tile_rows <= 0 || n_dst <= 0 || R <= 0 ||
+      (units && (n_units < n_tiles || n_split < 0 || n_units > INT32_MAX))) {
     rgcn_set_error("bwd_blk: bad argument");
     return RGCN_EINVAL;
   }
+  if (!units) { n_units = n_tiles; n_split = 0; }
   if (!rgcn_bwd_blk_supported(tile_rows, R, flags)) {
     rgcn_set_error("bwd_blk: tile_rows = %d (<= 512) / R = %d (R KiB, or R / 4 KiB with RGCN_F_DIAG4, + 48 KiB -- 80 KiB above 256 rows -- of LDS) not supported", tile_rows, R);
     return RGCN_EUNSUPPORTED;
@@ -1264,7 +1284,8 @@ extern "C" int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_
     HIP_TRY(zero_async(dW, (size_t)R * 256 * sizeof(float), st));
     if (dbias) HIP_TRY(zero_async(dbias, 16 * sizeof(float), st));
   }
-  const unsigned n_blocks = (unsigned)std::min<int64_t>(n_tiles, n_cu);
+  if (n_split) HIP_TRY(zero_async(dX, (size_t)n_dst * 16 * sizeof(float), st));        // pieces of hub tiles add their rows
+  const unsigned n_blocks = (unsigned)std::min<int64_t>(n_units, n_cu);
   static const int ABL = getenv("RGCN_BWD_ABL") ? atoi(getenv("RGCN_BWD_ABL")) : 0;     // timing experiments (wrong results)
   auto launch = [&](auto kern, bool &raised) -> hipError_t {
     if (lds > 64 * 1024 && !raised) {
@@ -1273,7 +1294,8 @@ extern "C" int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_
       raised = true;
     }
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64 * BLK_NW), lds, st, G, X, Wt_packed, dX, dW, reinterpret_cast<const LeanSlot *>(slots),
-                       hdr, run_ptr, (int)n_tiles, tile_rows, (int)n_dst, R, dbias, (int)n_src);
+                       hdr, run_ptr, (int)n_tiles, tile_rows, (int)n_dst, R, dbias, (int)n_src, reinterpret_cast<const int4 *>(units),
+                       (int)n_units);
     return hipGetLastError();
   };
   static bool r0 = false, r1 = false, r2 = false, r3 = false, r4 = false, r5 = false, r6 = false, r7 = false, r8 = false, r9 = false, r10 = false, r11 = false;

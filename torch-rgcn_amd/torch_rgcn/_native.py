@@ -991,6 +991,23 @@ def bwd_fused_ok(plan, diag4=False):
     return plan.pack is not None and plan.n_split == 0 and plan.n_units == plan.n_tiles and plan.tile_rows <= 160
 
 
+def _blk_units(plan):
+    """work units of the block-tile backward: one per tile, tiles holding hub rows (more than 4x the mean chunk count, at least
+    256 chunks) cut into pieces that different workgroups walk -> (units or None, n_units, n_split); plans built without host
+    statistics (sync-free per-call graphs) have none (one unit per tile)"""
+    cached = getattr(plan, "_blk_units", None)
+    if cached is None:
+        if getattr(plan, "units_host", None) is None:
+            cached = (None, plan.n_tiles, 0)
+        else:
+            mean = max(1, plan.n_chunks // max(plan.n_tiles, 1))
+            cached = row_units(plan.tile_ptr, plan.n_tiles, max(256, 4 * mean))
+            if cached[2] == 0:
+                cached = (None, plan.n_tiles, 0)        # no hub tile: the kernel reads the run pointers itself
+        plan._blk_units = cached
+    return cached
+
+
 def _lean_plan(plan):
     """(slots, hdr) of the lean backward kernel: the packed transposed plan reformatted once (rgcn_bwd_lean_prepare_f32), cached
     on the plan object -- static (NC) graphs pay it once, per-call (LP) graphs one small launch per step"""
@@ -1049,11 +1066,12 @@ def bwd_fused(G, X, W, plan, atomic=False, relu=False, want_db=False, diag4=Fals
         if not atomic:
             raise NativeLibraryError("bwd_fused: the block-tile plan (tall tiles) has no bit-reproducible kernel")
         slots, hdr = _lean_plan(plan)
+        units, n_units, n_split = _blk_units(plan)
         with _on(dev), _timed("bwd_fused"):
             _check(lib().rgcn_bwd_blk_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(slots), _dp(hdr), _dp(plan.run_ptr),
                                           c_i64(plan.n_tiles), c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i32(W.shape[0]),
                                           c_i32((F_RELU if relu else 0) | (F_DIAG4 if diag4 else 0)), _dp(db), c_i64(plan.n_src),
-                                          _stream(dev)), "bwd_blk")
+                                          _dp(units), c_i64(n_units), c_i64(n_split), _stream(dev)), "bwd_blk")
         return ret()
     if route in ("lean", "blk") and lib().rgcn_bwd_lean_supported(c_i32(plan.tile_rows)) and W.shape[0] < 65536:
         slots, hdr = _lean_plan(plan)
