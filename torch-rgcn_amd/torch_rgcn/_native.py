@@ -992,7 +992,7 @@ def bwd_fused_ok(plan, diag4=False):
 
 
 def _blk_units(plan):
-    """work units of the block-tile backward: one per tile, tiles holding hub rows (more than 4x the mean chunk count, at least
+    """work units of the block-tile backward: one per tile, tiles holding hub rows (more than 2x the mean chunk count, at least
     256 chunks) cut into pieces that different workgroups walk -> (units or None, n_units, n_split); plans built without host
     statistics (sync-free per-call graphs) have none (one unit per tile)"""
     cached = getattr(plan, "_blk_units", None)
@@ -1001,7 +1001,7 @@ def _blk_units(plan):
             cached = (None, plan.n_tiles, 0)
         else:
             mean = max(1, plan.n_chunks // max(plan.n_tiles, 1))
-            cached = row_units(plan.tile_ptr, plan.n_tiles, max(256, 4 * mean))
+            cached = row_units(plan.tile_ptr, plan.n_tiles, max(256, 2 * mean))   # (pieces of 1 / 2 / 4 / 8 means measured: 2 is best)
             if cached[2] == 0:
                 cached = (None, plan.n_tiles, 0)        # no hub tile: the kernel reads the run pointers itself
         plan._blk_units = cached
