@@ -291,24 +291,36 @@ RGCN_API int rgcn_bwd_lean_supported(int32_t tile_rows);
 RGCN_API int rgcn_bwd_lean_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, float *scratch,
                                const void *slots, const int32_t *hdr, const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows,
                                int64_t n_dst, int32_t R, int32_t flags, void *stream);
-/* The same backward, block-tile form (round 3, the default when it applies): ONE destination tile of up to 255 rows per workgroup
- * (plan built with that tile height: 15 % bucket padding instead of 42 %), its chunks dealt to the 16 waves from an LDS counter,
- * dX tile / X tile shared (LDS float atomics), dW of ALL relations resident in LDS for the workgroup's life and flushed once
- * (dirty relations only).  Needs R * 1 KiB + 48 KiB of LDS (R <= 111) and tile_rows <= 255 (tiles of up to 512 rows on an unpacked
- * plan: + 32 KiB; with RGCN_F_DIAG4 up to 319 relations): rgcn_bwd_blk_supported.  Atomic
- * flush only, dX sums in arrival order (not bit-reproducible: RGCN_DETERMINISTIC=1 takes the lean kernel on 64-row tiles).
+/* The same backward, block-tile form (the default when it applies): ONE destination tile per workgroup (plan built with that tile
+ * height: 15 % bucket padding instead of 42 %), its chunks dealt to the 16 waves from an LDS counter; X tile (fp32) and dX tile (fp64,
+ * updated with ds_add_f64 -- round 4; round 3: fp32 with compare-and-swap loops) shared, dW of ALL relations resident in LDS for the
+ * workgroup's life and flushed once (dirty relations only).  LDS: 192 bytes per tile row + 16 KiB + R KiB (R / 4 KiB with
+ * RGCN_F_DIAG4):
+ *   rgcn_bwd_blk_max_rows(R, flags)      tallest tile that fits (0: none; at most 512) -- S1 (R = 101): 227, AM with diag4 (R = 267): 406
+ *   rgcn_bwd_blk_supported(tile_rows, R, flags)
+ *   rgcn_bwd_blk_rec_bytes(n_chunks)     size of the chunk records (176 bytes per chunk: 16 x {source row << 6, val}, 16 x u16 tile
+ *                                        row << 6, relation)
+ *   rgcn_bwd_blk_prepare_f32             the transposed plan -> records, once per plan: p_pack (tiles of up to 255 rows) or, with
+ *                                        p_pack == NULL, p_src / p_dst (global destination row, < 0 = pad) / p_val as
+ *                                        rgcn_dev_plan_fill wrote them (tiles of up to 512 rows); chunk_rel; n_chunks = m_pad / 16
+ * Atomic flush only, sums in arrival order (dX: fp64 sums rounded once, so run-to-run differences are rare but possible;
+ * RGCN_DETERMINISTIC=1 takes the lean kernel on 64-row tiles).
  * flags: RGCN_F_RELU; RGCN_F_DIAG4: the weights are block_diag() of 4 x 4 blocks (layers.py:243-244 at width 16) -- only the
- * diagonal blocks of dW_r are accumulated (the rest of dW stays zero), 256 bytes of LDS per relation instead of 1 KiB (R <= 447:
- * AM's 267 relations fit).  Plan arrays as rgcn_bwd_lean_f32.  dbias (may be NULL): 16 floats, the bias gradient = column sums of
+ * diagonal blocks of dW_r are accumulated (the rest of dW stays zero), 256 bytes of LDS per relation instead of 1 KiB.
+ * dbias (may be NULL): 16 floats, the bias gradient = column sums of
  * G's n_src rows, read on the side of the tile walk (replaces an rgcn_colsum_f32 launch; one fill zeroes dW and dbias when
  * dbias == dW + R * 256).  units (may be NULL = one unit per tile): [n_units][4] = {tile, first chunk, end chunk, flags} as
  * rgcn_plan_units_host makes them from the plan's tile pointer -- tiles of hub rows cut into pieces (RGCN_U_SHARED; n_split of them)
- * that different workgroups walk and whose dX rows are added to a zeroed dX. */
+ * that different workgroups walk and whose dX rows are added to a zeroed dX.
+ * Same autograd duals of layers.py:293-301 as above. */
+RGCN_API int32_t rgcn_bwd_blk_max_rows(int32_t R, int32_t flags);
 RGCN_API int rgcn_bwd_blk_supported(int32_t tile_rows, int32_t R, int32_t flags);
-RGCN_API int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, const void *slots,
-                              const int32_t *hdr, const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R,
-                              int32_t flags, float *dbias, int64_t n_src, const int32_t *units, int64_t n_units, int64_t n_split,
-                              void *stream);
+RGCN_API int64_t rgcn_bwd_blk_rec_bytes(int64_t n_chunks);
+RGCN_API int rgcn_bwd_blk_prepare_f32(const int32_t *p_pack, const int32_t *p_src, const int32_t *p_dst, const float *p_val,
+                                      int32_t tile_rows, const int32_t *chunk_rel, int64_t n_chunks, void *rec, void *stream);
+RGCN_API int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, const void *rec,
+                              const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R, int32_t flags,
+                              float *dbias, int64_t n_src, const int32_t *units, int64_t n_units, int64_t n_split, void *stream);
 /* The same for graphs whose (tile, relation) buckets are sparse (AM: 267 relations), on the RELATION-major plan of the
  * two-pass path: one wave per work item gathers G[p_src] and X[p_dst] once per message and produces
  *   Y[slot, :] = val G[p_src] W_r^T   (slot order; pass 2 = rgcn_segment_gather_sum_f32 sums them per destination -> dX)

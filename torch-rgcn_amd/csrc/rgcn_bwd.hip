@@ -250,10 +250,6 @@ __global__ __launch_bounds__(64 * NW, 16 / NW) void bwd_fused_d16_kernel(
 constexpr int WIN_GS = 4;       // relations per window group
 
 
-constexpr int BW_SCR2 = 16 * 16;  // floats of transposition scratch per wave: [16 slots][16 features], the float4 column of features 4k..4k+3 of
-                                  // slot m is stored at column (k + (m >> 1)) & 3 (b128 writes of 8 consecutive slots and b32 reads of two
-                                  // consecutive slots are conflict-free without the 4-float row padding of the first form: 1 KiB, not 1.25)
-
 // (The kernel of this second form, bwd_win2_d16_kernel, was measured at 0.69 ms and is superseded by the lean form below, which
 // keeps its phases, its window protocol and its LDS layout; it lives in the history of round 3.)
 
@@ -270,35 +266,6 @@ constexpr int BW_SCR2 = 16 * 16;  // floats of transposition scratch per wave: [
 //   slots, headers and W fragments are addressed as scalar base (advanced per chunk on the scalar unit) + a constant lane offset.
 // The dX tile is no longer swizzled (the update address is base | row << 6 | k << 4; measured in round 2: the swizzle moved the LDS
 // conflict counter, not the time).
-// LDS words other waves write: relaxed workgroup-scope atomics (ds_read_b32 / ds_write_b32).  NOT `volatile`: a volatile access through
-// a generic pointer compiles to flat_load / flat_store sc0 sc1 and a wait for vmcnt(0) -- every poll then drains the wave's global loads.
-__device__ __forceinline__ int lds_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void lds_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-
-// p[0..3] += v, atomically against the other waves of the workgroup (p: LDS, 16-byte aligned).  NOT ds_add_f32: measured on gfx950
-// (tools/micro/lds_atomic_rate.hip) one wave-level ds_add_f32 occupies the CU's LDS for ~190 cycles (3 per lane, serialised) against
-// 4.4 for ds_add_u32 / ds_write_b32 -- float atomics in LDS are 40x slower than integer ones.  So: optimistic read, add in registers,
-// two 64-bit compare-and-swaps (integer rate), each half retried on interference (rare: 16 waves on a 16 KiB tile).
-__device__ __forceinline__ void lds_cas_add4(float *p, const f32x4 &v) {
-  unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
-  const f32x4 o = *reinterpret_cast<const f32x4 *>(p);
-  asm volatile("" ::: "memory");
-  unsigned long long e0 = ((unsigned long long)__float_as_uint(o[1]) << 32) | __float_as_uint(o[0]);
-  unsigned long long e1 = ((unsigned long long)__float_as_uint(o[3]) << 32) | __float_as_uint(o[2]);
-  unsigned long long n0 = ((unsigned long long)__float_as_uint(o[1] + v[1]) << 32) | __float_as_uint(o[0] + v[0]);
-  unsigned long long n1 = ((unsigned long long)__float_as_uint(o[3] + v[3]) << 32) | __float_as_uint(o[2] + v[2]);
-  bool ok0 = __hip_atomic_compare_exchange_strong(q, &e0, n0, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  bool ok1 = __hip_atomic_compare_exchange_strong(q + 1, &e1, n1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  while (!ok0) {
-    n0 = ((unsigned long long)__float_as_uint(__uint_as_float((unsigned)(e0 >> 32)) + v[1]) << 32) | __float_as_uint(__uint_as_float((unsigned)e0) + v[0]);
-    ok0 = __hip_atomic_compare_exchange_strong(q, &e0, n0, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  while (!ok1) {
-    n1 = ((unsigned long long)__float_as_uint(__uint_as_float((unsigned)(e1 >> 32)) + v[3]) << 32) | __float_as_uint(__uint_as_float((unsigned)e1) + v[2]);
-    ok1 = __hip_atomic_compare_exchange_strong(q + 1, &e1, n1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-}
-
 struct LeanSlot { unsigned w0; float val; unsigned w2; };
 
 // p_pack / chunk_rel (the packed transposed plan) -> lean slots + chunk headers; one lane per slot, one wave per 4 chunks
@@ -640,352 +607,9 @@ __global__ __launch_bounds__(64 * NW, 4) void bwd_lean_d16_kernel(
   }
 }
 
-// ---- fifth form ("block tile"): the workgroup, not the wave, owns the destination tile.
-// What the wave-owned forms cannot shed is (a) the padding of the (64-row tile, relation) buckets to 16-slot chunks (x1.42 at S1:
-// 42 % of every chunk's MFMA / VALU issue is spent on empty slots) -- taller tiles do not fit 16 times into the CU's LDS -- and
-// (b) the hand-over of the dW partials between the waves (0.10 ms of lock traffic).  Here ONE tile of up to 255 rows per workgroup
-// (x1.15 padding): its chunks are dealt to the 16 waves four at a time from an LDS counter, the dX tile and the X tile are shared
-// (16 KiB each; tile updates are LDS float atomics, one ds_add_f32 per element instead of read + add + write), and dW lives in LDS
-// for ALL relations for the workgroup's whole life (R KiB, fragment order: lane-contiguous ds_add_f32, no window, no lock, no
-// ordering between waves) and is flushed ONCE per workgroup, dirty relations only (S1: 256 x 101 KiB = 26 MB of atomics per launch;
-// the window forms flush 98 MB).  Workgroups are persistent (one per CU) and walk tiles blockIdx, + gridDim, ...; between two tiles
-// two barriers bracket the epilogue (store dX, re-zero, install the next X tile, which every thread fetched BEFORE the first
-// barrier together with the first slots of its next chunks).  Bound: R * 1 KiB + 48 KiB of LDS, i.e. R <= 111; the lean window
-// kernel serves everything else and the bit-reproducible mode (LDS float atomics have no fixed order).
-constexpr int BLK_NW = 16;
-constexpr int BLK_TILE_FLOATS = 256 * 16;
-// DIAG4: W is block-diagonal with 4 x 4 blocks (decomposition {type: block}, width 16): only the four diagonal blocks of dW_r are
-// wanted (64 floats per relation instead of 256: hundreds of relations fit, AM has 267)
-// tq: tile capacity in units of 256 rows (1: tiles of up to 255 rows, packed or unpacked plan; 2: up to 512 rows, unpacked plan)
-static size_t bwd_blk_lds(int R, bool diag4, int tq) { return ((size_t)2 * tq * BLK_TILE_FLOATS + BLK_NW * BW_SCR2 + (size_t)R * (diag4 ? 64 : 256)) * 4 + (4 + (size_t)R) * 4; }
-
-template <bool RELU, int ABL, bool DIAG4 = false, int TQ = 1>
-__global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
-    const float *__restrict__ G, const float *__restrict__ X, const float *__restrict__ Wtp, float *__restrict__ dX,
-    float *__restrict__ dWout, const LeanSlot *__restrict__ slots, const int *__restrict__ hdr,
-    const int *__restrict__ run_ptr, int n_tiles, int tile_rows, int n_dst, int R, float *__restrict__ dbias, int n_src,
-    const int4 *__restrict__ units, int n_units) {      // units: {tile, first chunk, end chunk, flags}: a hub tile arrives in pieces (RGCN_U_SHARED:
-                                                        // their dX rows are ADDED to a zeroed dX); NULL: one unit per tile (n_units = n_tiles)
-  constexpr int U = 4, NW = BLK_NW;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  constexpr int TILE_F = TQ * BLK_TILE_FLOATS;                    // TQ = 2: tiles of up to 512 rows (sparse buckets: less padding)
-  float *dxt = lds;                                               // dX tile [256 TQ][16]
-  float *xt = lds + TILE_F;                                       // X tile  [256 TQ][16]
-  float *xs = lds + 2 * TILE_F + wave * BW_SCR2;                  // transposition scratch of this wave
-  constexpr int DWR = DIAG4 ? 64 : 256;                           // floats of dW kept per relation
-  float *dwl = lds + 2 * TILE_F + NW * BW_SCR2;                   // dW [R][64 lanes][4] (fragment order, a lane's four elements adjacent); DIAG4: [R][16 lanes][4]
-  int *ctl = reinterpret_cast<int *>(dwl + (size_t)R * DWR);      // [0]: next quad of the tile; [4 + r]: relation r has data
-  int *dirty = ctl + 4;
-  float4 *dxt4 = reinterpret_cast<float4 *>(dxt), *xt4 = reinterpret_cast<float4 *>(xt);
-
-  auto unit_of = [&](int u) {
-    if (units) return units[u];
-    return int4{u, run_ptr[(size_t)u * (R + 1)], run_ptr[(size_t)u * (R + 1) + R], 0};
-  };
-  int un = blockIdx.x;
-  int4 unit = unit_of(un);
-  int t = __builtin_amdgcn_readfirstlane(unit.x);
-  int row0 = t * tile_rows;
-  int nrows = min(tile_rows, n_dst - row0);
-  int c0 = __builtin_amdgcn_readfirstlane(unit.y);
-  int c1 = __builtin_amdgcn_readfirstlane(unit.z);
-  int shared = __builtin_amdgcn_readfirstlane(unit.w) & RGCN_U_SHARED;
-  int nq = (c1 - c0 + U - 1) / U;
-  // bias gradient (column sums of G) on the side: every tile switch a thread adds one float4 of G's rows, the workgroups striding
-  // through G together (S1: 16 stripes of 16 KiB per workgroup = its 16 tiles); what is left after the last tile is read at the end
-  float4 gs = make_float4(0.f, 0.f, 0.f, 0.f);
-  const long long g_n4 = dbias ? (long long)n_src * 4 : 0, g_step = (long long)gridDim.x * (64 * NW);
-  long long g_i = (long long)blockIdx.x * (64 * NW) + tid;
-  {
-#pragma unroll
-    for (int q = 0; q < TQ; ++q) {
-      const int idx = tid + q * (64 * NW);
-      float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < nrows * 4) x0 = reinterpret_cast<const float4 *>(X + (size_t)row0 * 16)[idx];
-      xt4[idx] = x0;
-      dxt4[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    for (int i = tid; i < R * (DWR / 4); i += 64 * NW) reinterpret_cast<float4 *>(dwl)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = tid; i < R + 4; i += 64 * NW) ctl[i] = i == 0 ? 2 * NW : 0;
-  }
-  __syncthreads();
-
-  const int m = lane & 15, k = lane >> 4;
-  const unsigned kofs = (unsigned)k << 4;
-  const unsigned tile_k = kofs;                                        // LDS byte address of dxt[0][4k]
-  const unsigned xrd = (unsigned)(TILE_F * 4) + (unsigned)m * 4;            // LDS byte address of xt[0][m]
-  float *xs_wr = xs + m * 16 + 4 * ((k + (m >> 1)) & 3);                                  // this lane's float4 of slot m
-  const float *xs_rd0 = xs + k * 16 + 4 * (((m >> 2) + (k >> 1)) & 3) + (m & 3);          // feature m of slot 4 t + k, t even: + 128 t
-  const float *xs_rd1 = xs + (4 + k) * 16 + 4 * (((m >> 2) + 2 + (k >> 1)) & 3) + (m & 3); // t odd: + 128 (t - 1)
-  const unsigned slot_lane = (unsigned)m * 12u;
-  const unsigned w_lane = (unsigned)lane * 16u;
-  const char *sl_base = reinterpret_cast<const char *>(slots);
-
-  f32x4 hold = f32x4{0.f, 0.f, 0.f, 0.f};    // dW partial of relation cur_r (this wave's consecutive chunks)
-  int cur_r = -1;
-  auto flush_hold = [&]() {
-    if (cur_r >= 0 && !(ABL & 4)) {
-      if (DIAG4) {       // D: lane 16 k + m holds rows 4k .. 4k + 3, column m: the diagonal block k lives in the lanes with m >> 2 == k
-        if ((m >> 2) == k) lds_cas_add4(dwl + (size_t)cur_r * 64 + (4 * k + (m & 3)) * 4, hold);
-      } else {
-        lds_cas_add4(dwl + (size_t)cur_r * 256 + lane * 4, hold);
-      }
-      if (lane == 0) lds_st(dirty + cur_r, 1);
-    }
-  };
-
-  LeanSlot sl_n[U];
-  int hd_n[U];
-  auto request_idx = [&](int c, int last) {
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
-      const int cc = min(c + j, last);                          // scalar: chunks past the tile re-read its last chunk (val forced to 0)
-      sl_n[j] = *reinterpret_cast<const LeanSlot *>(sl_base + (size_t)cc * (RGCN_CHUNK * 12) + slot_lane);
-      hd_n[j] = hdr[cc];
-    }
-  };
-  int q_cur = wave, q_nxt = wave + NW;
-  if (q_cur < nq) request_idx(c0 + q_cur * U, c1 - 1);
-
-  for (;;) {
-    const int last = c1 - 1;
-    while (q_cur < nq) {
-      const int c = c0 + q_cur * U;
-      unsigned w0_[U], w2_[U];
-      float v_[U];
-      int hd_[U];
-      float4 g_[U], w_[U];
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        w0_[j] = sl_n[j].w0;
-        w2_[j] = sl_n[j].w2;
-        v_[j] = (c + j <= last) ? sl_n[j].val : 0.f;
-        hd_[j] = __builtin_amdgcn_readfirstlane(hd_n[j]);
-      }
-#pragma unroll
-      for (int j = 0; j < U; ++j) asm volatile("" : "+v"(w0_[j]), "+v"(v_[j]));   // pin the index data here
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        const unsigned og = (w0_[j] & ~63u) | kofs;
-        g_[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(G) + og);
-        w_[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Wtp) + (size_t)(hd_[j] & 0xFFFF) * 1024 + w_lane);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (q_nxt < nq) request_idx(c0 + q_nxt * U, last);
-      int q_nn = 0;
-      if (lane == 0) q_nn = __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __builtin_amdgcn_sched_barrier(0);
-      if (ABL & 16) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) asm volatile("" :: "v"(g_[j].x), "v"(g_[j].y), "v"(g_[j].z), "v"(g_[j].w), "v"(w_[j].x), "v"(w_[j].w), "v"(w2_[j]), "v"(v_[j]));
-        q_cur = q_nxt;
-        q_nxt = __builtin_amdgcn_readfirstlane(q_nn);
-        continue;
-      }
-      // ---- phase 1: scaled rows, dX products (four independent MFMA chains)
-      f32x4 sc[U], acc[U];
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        sc[j] = f32x4{g_[j].x * v_[j], g_[j].y * v_[j], g_[j].z * v_[j], g_[j].w * v_[j]};
-        acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].x, sc[j][0], acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].y, sc[j][1], acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].z, sc[j][2], acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_[j].w, sc[j][3], acc[j], 0, 0, 0);
-      // ---- phase 2: dW products, two chunks at a time
-      if (!(ABL & 2)) {
-        f32x4 aw[U];
-#pragma unroll
-        for (int h = 0; h < U; h += 2) {
-          float bv[2][4], av[2][4];
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            const int j = h + jj;
-            int rot = (int)w2_[j];                                  // lane (k, m) <- (row << 6) of slot (m + k) & 15
-            rot = __builtin_amdgcn_update_dpp(rot, rot, 0x120 + 15, 0x2, 0xF, false);
-            rot = __builtin_amdgcn_update_dpp(rot, rot, 0x120 + 14, 0x4, 0xF, false);
-            rot = __builtin_amdgcn_update_dpp(rot, rot, 0x120 + 13, 0x8, 0xF, false);
-            int rowk[4];                                            // row_share: slot 4 t4 + k
-            rowk[0] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 0, 0xF, 0xF, false);
-            rowk[1] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 4, 0xF, 0xF, false);
-            rowk[2] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 8, 0xF, 0xF, false);
-            rowk[3] = __builtin_amdgcn_update_dpp(0, rot, 0x150 + 12, 0xF, 0xF, false);
-            asm volatile("" ::: "memory");
-            *reinterpret_cast<f32x4 *>(xs_wr) = sc[j];
-            asm volatile("" ::: "memory");
-            bv[jj][0] = xs_rd0[0]; bv[jj][1] = xs_rd1[0]; bv[jj][2] = xs_rd0[128]; bv[jj][3] = xs_rd1[128];
-#pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4)
-              av[jj][t4] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(lds) + (xrd + (unsigned)rowk[t4]));
-            asm volatile("" ::: "memory");
-          }
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj) aw[h + jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int t4 = 0; t4 < 4; ++t4)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-              aw[h + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj][t4], bv[jj][t4], aw[h + jj], 0, 0, 0);
-        }
-        // relation bookkeeping (wave-uniform): consecutive chunks of one relation accumulate in registers
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-          if (c + j > last) break;
-          const int rj = hd_[j] & 0xFFFF;
-          if (rj != cur_r) {
-            flush_hold();
-            cur_r = rj;
-            hold = aw[j];
-          } else {
-            hold += aw[j];
-          }
-        }
-      }
-      // ---- phase 3: fold equal destinations (flags from the plan), one LDS atomic update per segment and element
-      if (ABL & 8) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) asm volatile("" :: "v"(acc[j][0]), "v"(acc[j][1]), "v"(acc[j][2]), "v"(acc[j][3]));
-      } else {
-        const int any1 = (hd_[0] | hd_[1] | hd_[2] | hd_[3]) & (1 << 16), any2 = (hd_[0] | hd_[1] | hd_[2] | hd_[3]) & (1 << 17);
-        if (any1) {
-#pragma unroll
-          for (int j = 0; j < U; ++j) {
-            const float sf = (w0_[j] & 1u) ? 1.f : 0.f;
-            acc[j][0] = fmaf(dpp_shr0<1>(acc[j][0]), sf, acc[j][0]);
-            acc[j][1] = fmaf(dpp_shr0<1>(acc[j][1]), sf, acc[j][1]);
-            acc[j][2] = fmaf(dpp_shr0<1>(acc[j][2]), sf, acc[j][2]);
-            acc[j][3] = fmaf(dpp_shr0<1>(acc[j][3]), sf, acc[j][3]);
-          }
-          if (any2) {     // runs of 3 and more: the general fold on the destination rows
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-              const int dst = (v_[j] != 0.f || (w0_[j] & 3u)) ? (int)(w2_[j] >> 6) : -1;     // pads: no flag, val 0
-              const bool s2 = dpp_i<ROW_SHR + 2>(-1, dst) == dst && dst >= 0;
-              const bool s4 = dpp_i<ROW_SHR + 4>(-1, dst) == dst && dst >= 0;
-              const bool s8 = dpp_i<ROW_SHR + 8>(-1, dst) == dst && dst >= 0;
-              const float f2 = s2 ? 1.f : 0.f, f4 = s4 ? 1.f : 0.f, f8 = s8 ? 1.f : 0.f;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(dpp_shr0<2>(acc[j][e]), f2, acc[j][e]);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(dpp_shr0<4>(acc[j][e]), f4, acc[j][e]);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(dpp_shr0<8>(acc[j][e]), f8, acc[j][e]);
-            }
-          }
-        }
-        // (one lock per tile around plain read-add-writes of the quad was measured too: 0.86 ms against 0.61 -- a convoy)
-        // (checking chunk j's compare-and-swaps only after chunk j + 1's read -- one round trip less per chunk -- measured slower,
-        // 0.67 against 0.61 ms: the longer window between a read and its swap loses more races)
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-          if (w0_[j] & 2u) {
-            float *p = reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + (tile_k + w2_[j]));
-            lds_cas_add4(p, acc[j]);
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      q_cur = q_nxt;
-      q_nxt = __builtin_amdgcn_readfirstlane(q_nn);
-    }
-    flush_hold();
-    cur_r = -1;
-    // the next tile of this workgroup: its X rows and this wave's first chunks are requested before the barrier
-    const int unn = un + (int)gridDim.x;
-    float4 xn[TQ];
-#pragma unroll
-    for (int q = 0; q < TQ; ++q) xn[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    int c0n = 0, c1n = 0, nqn = 0, row0n = 0, nrn = 0, tn = 0, sharedn = 0;
-    if (unn < n_units) {
-      const int4 unx = unit_of(unn);
-      tn = __builtin_amdgcn_readfirstlane(unx.x);
-      row0n = tn * tile_rows;
-      nrn = min(tile_rows, n_dst - row0n);
-      c0n = __builtin_amdgcn_readfirstlane(unx.y);
-      c1n = __builtin_amdgcn_readfirstlane(unx.z);
-      sharedn = __builtin_amdgcn_readfirstlane(unx.w) & RGCN_U_SHARED;
-      nqn = (c1n - c0n + U - 1) / U;
-#pragma unroll
-      for (int q = 0; q < TQ; ++q)
-        if (tid + q * (64 * NW) < nrn * 4) xn[q] = reinterpret_cast<const float4 *>(X + (size_t)row0n * 16)[tid + q * (64 * NW)];
-      if (wave < nqn) request_idx(c0n + wave * U, c1n - 1);
-    }
-    float4 gn = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g_i < g_n4) gn = reinterpret_cast<const float4 *>(G)[g_i];
-    g_i += g_step;
-    __syncthreads();                                               // every wave has finished adding to the dX tile
-    gs.x += gn.x; gs.y += gn.y; gs.z += gn.z; gs.w += gn.w;
-#pragma unroll
-    for (int q = 0; q < TQ; ++q) {
-      const int idx = tid + q * (64 * NW);
-      if (idx < nrows * 4) {
-        float4 a = dxt4[idx];
-        if (RELU) {
-          const float4 x = xt4[idx];
-          a.x = x.x > 0.f ? a.x : 0.f; a.y = x.y > 0.f ? a.y : 0.f; a.z = x.z > 0.f ? a.z : 0.f; a.w = x.w > 0.f ? a.w : 0.f;
-        }
-        float4 *o = reinterpret_cast<float4 *>(dX + (size_t)row0 * 16) + idx;
-        if (shared) {       // a piece of a hub tile: the pieces' rows are summed in memory (dX was zeroed)
-          atomicAdd(&o->x, a.x); atomicAdd(&o->y, a.y); atomicAdd(&o->z, a.z); atomicAdd(&o->w, a.w);
-        } else {
-          *o = a;
-        }
-      }
-    }
-    if (unn >= n_units) break;
-#pragma unroll
-    for (int q = 0; q < TQ; ++q) {
-      dxt4[tid + q * (64 * NW)] = make_float4(0.f, 0.f, 0.f, 0.f);
-      xt4[tid + q * (64 * NW)] = xn[q];
-    }
-    if (tid == 0) ctl[0] = 2 * NW;
-    __syncthreads();                                               // the next tile is installed
-    un = unn; t = tn; row0 = row0n; nrows = nrn; c0 = c0n; c1 = c1n; nq = nqn; shared = sharedn;
-    q_cur = wave; q_nxt = wave + NW;
-  }
-  if (dbias) {
-    for (; g_i < g_n4; g_i += g_step) {
-      const float4 gn = reinterpret_cast<const float4 *>(G)[g_i];
-      gs.x += gn.x; gs.y += gn.y; gs.z += gn.z; gs.w += gn.w;
-    }
-    __syncthreads();                                               // the last tile has been stored: the dX tile's LDS is free
-    dxt4[tid] = gs;                                                // thread tid holds features 4 (tid & 3) .. + 3
-    __syncthreads();
-    if (tid < 64) {
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int i = 0; i < NW; ++i) {
-        const float4 b = dxt4[((tid >> 2) * NW + i) * 4 + (tid & 3)];
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-      }
-      xt4[tid] = a;
-    }
-    __syncthreads();
-    if (tid < 4) {
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int i = 0; i < 16; ++i) {
-        const float4 b = xt4[i * 4 + tid];
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-      }
-      atomicAdd(dbias + 4 * tid, a.x); atomicAdd(dbias + 4 * tid + 1, a.y); atomicAdd(dbias + 4 * tid + 2, a.z); atomicAdd(dbias + 4 * tid + 3, a.w);
-    }
-  }
-  // one flush of the workgroup's dW: dirty relations only.  D fragment: lane 16k + m, element e = row 4k + e (input feature), column m
-  if (!(ABL & 4)) {
-    for (int i = tid; i < R * DWR; i += 64 * NW) {
-      const int r = i / DWR, e = i & 3;
-      const int ln = DIAG4 ? 16 * ((i >> 4) & 3) + 4 * ((i >> 4) & 3) + ((i >> 2) & 3) : (i >> 2) & 63;     // DIAG4: k = (i >> 4) & 3, m = 4 k + ((i >> 2) & 3)
-      if (lds_ld(dirty + r)) atomicAdd(dWout + (size_t)r * 256 + (4 * (ln >> 4) + e) * 16 + (ln & 15), dwl[i]);
-    }
-  }
-}
+// ---- fifth form ("block tile", the default on large graphs): the workgroup, not the wave, owns the destination tile -- its own
+// translation unit, csrc/rgcn_bwd_blk.hip (round 4: the dX tile is accumulated in DOUBLES with ds_add_f64, the only LDS float
+// atomic gfx950 runs at full rate).
 
 // ---- fourth form (measured, not kept): producers and consumers -- 12 waves of a workgroup own a tile each (gather, dX) and post
 // their dW operands to LDS rings, 4 consumer waves own the relations (r mod 4) and accumulate a relation's dW in registers: no merge
@@ -1243,74 +867,6 @@ extern "C" int rgcn_bwd_lean_prepare_unpacked_f32(const int32_t *p_src, const in
   hipLaunchKernelGGL(bwd_lean_prep_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, (hipStream_t)stream,
                      nullptr, p_src, p_dst, p_val, tile_rows, chunk_rel, reinterpret_cast<LeanSlot *>(slots), hdr, (long long)n_chunks);
   HIP_TRY(hipGetLastError());
-  return RGCN_OK;
-}
-
-extern "C" int rgcn_bwd_blk_supported(int32_t tile_rows, int32_t R, int32_t flags) {
-  return tile_rows > 0 && tile_rows <= 512 && R > 0 && R < 0xFFFF &&
-         bwd_blk_lds(R, (flags & RGCN_F_DIAG4) != 0, tile_rows > 256 ? 2 : 1) <= 160 * 1024;
-}
-
-/* block-tile form (atomic flush only; dX sums are LDS float atomics: not bit-reproducible): arguments as rgcn_bwd_pc_f32 */
-extern "C" int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, const void *slots,
-                                const int32_t *hdr, const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R,
-                                int32_t flags, float *dbias, int64_t n_src, const int32_t *units, int64_t n_units, int64_t n_split,
-                                void *stream) {
-  if (!G || !X || !Wt_packed || !dX || !dW || !slots || !hdr || !run_ptr || n_tiles <= 0 || tile_rows <= 0 || n_dst <= 0 || R <= 0 ||
-      (units && (n_units < n_tiles || n_split < 0 || n_units > INT32_MAX))) {
-    rgcn_set_error("bwd_blk: bad argument");
-    return RGCN_EINVAL;
-  }
-  if (!units) { n_units = n_tiles; n_split = 0; }
-  if (!rgcn_bwd_blk_supported(tile_rows, R, flags)) {
-    rgcn_set_error("bwd_blk: tile_rows = %d (<= 512) / R = %d (R KiB, or R / 4 KiB with RGCN_F_DIAG4, + 48 KiB -- 80 KiB above 256 rows -- of LDS) not supported", tile_rows, R);
-    return RGCN_EUNSUPPORTED;
-  }
-  const bool relu = (flags & RGCN_F_RELU) != 0, diag4 = (flags & RGCN_F_DIAG4) != 0;
-  const int tq = tile_rows > 256 ? 2 : 1;
-  const size_t lds = bwd_blk_lds(R, diag4, tq);
-  hipStream_t st = (hipStream_t)stream;
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0, v = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
-    n_cu = v > 0 ? v : 256;
-  }
-  if (dbias && (n_src <= 0 || n_src >= (int64_t(1) << 29))) { rgcn_set_error("bwd_blk: dbias needs 0 < n_src < 2^29"); return RGCN_EINVAL; }
-  if (dbias == dW + (size_t)R * 256) {     // one fill for both when the caller laid them out back to back
-    HIP_TRY(zero_async(dW, ((size_t)R * 256 + 16) * sizeof(float), st));
-  } else {
-    HIP_TRY(zero_async(dW, (size_t)R * 256 * sizeof(float), st));
-    if (dbias) HIP_TRY(zero_async(dbias, 16 * sizeof(float), st));
-  }
-  if (n_split) HIP_TRY(zero_async(dX, (size_t)n_dst * 16 * sizeof(float), st));        // pieces of hub tiles add their rows
-  const unsigned n_blocks = (unsigned)std::min<int64_t>(n_units, n_cu);
-  static const int ABL = getenv("RGCN_BWD_ABL") ? atoi(getenv("RGCN_BWD_ABL")) : 0;     // timing experiments (wrong results)
-  auto launch = [&](auto kern, bool &raised) -> hipError_t {
-    if (lds > 64 * 1024 && !raised) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return e;
-      raised = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64 * BLK_NW), lds, st, G, X, Wt_packed, dX, dW, reinterpret_cast<const LeanSlot *>(slots),
-                       hdr, run_ptr, (int)n_tiles, tile_rows, (int)n_dst, R, dbias, (int)n_src, reinterpret_cast<const int4 *>(units),
-                       (int)n_units);
-    return hipGetLastError();
-  };
-  static bool r0 = false, r1 = false, r2 = false, r3 = false, r4 = false, r5 = false, r6 = false, r7 = false, r8 = false, r9 = false, r10 = false, r11 = false;
-  if (tq == 2 && diag4 && relu) HIP_TRY(launch(bwd_blk_d16_kernel<true, 0, true, 2>, r8));
-  else if (tq == 2 && diag4) HIP_TRY(launch(bwd_blk_d16_kernel<false, 0, true, 2>, r9));
-  else if (tq == 2 && relu) HIP_TRY(launch(bwd_blk_d16_kernel<true, 0, false, 2>, r10));
-  else if (tq == 2) HIP_TRY(launch(bwd_blk_d16_kernel<false, 0, false, 2>, r11));
-  else if (diag4 && relu) HIP_TRY(launch(bwd_blk_d16_kernel<true, 0, true>, r6));
-  else if (diag4) HIP_TRY(launch(bwd_blk_d16_kernel<false, 0, true>, r7));
-  else if (ABL == 2) HIP_TRY(launch(bwd_blk_d16_kernel<false, 2>, r2));
-  else if (ABL == 4) HIP_TRY(launch(bwd_blk_d16_kernel<false, 4>, r3));
-  else if (ABL == 8) HIP_TRY(launch(bwd_blk_d16_kernel<false, 8>, r4));
-  else if (ABL == 16) HIP_TRY(launch(bwd_blk_d16_kernel<false, 16>, r5));
-  else if (relu) HIP_TRY(launch(bwd_blk_d16_kernel<true, 0>, r1));
-  else HIP_TRY(launch(bwd_blk_d16_kernel<false, 0>, r0));
   return RGCN_OK;
 }
 

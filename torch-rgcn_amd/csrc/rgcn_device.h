@@ -141,4 +141,38 @@ __device__ __forceinline__ void fold_segments_multi(f32x4 (&acc)[NC], const int 
   for (int c = 0; c < NC; ++c) tail[c] = dpp_i<ROW_SHL + 1>(-2, dst[c]) != dst[c] && dst[c] >= 0;
 }
 
+
+constexpr int BW_SCR2 = 16 * 16;  // floats of transposition scratch per wave: [16 slots][16 features], the float4 column of features 4k..4k+3 of
+                                  // slot m is stored at column (k + (m >> 1)) & 3 (b128 writes of 8 consecutive slots and b32 reads of two
+                                  // consecutive slots are conflict-free without the 4-float row padding of the first form: 1 KiB, not 1.25)
+
+// LDS words other waves write: relaxed workgroup-scope atomics (ds_read_b32 / ds_write_b32).  NOT `volatile`: a volatile access through
+// a generic pointer compiles to flat_load / flat_store sc0 sc1 and a wait for vmcnt(0) -- every poll then drains the wave's global loads.
+__device__ __forceinline__ int lds_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// p[0..3] += v, atomically against the other waves of the workgroup (p: LDS, 16-byte aligned).  NOT ds_add_f32: measured on gfx950
+// (tools/micro/lds_atomic_rate.hip) one wave-level ds_add_f32 occupies the CU's LDS for ~190 cycles (3 per lane, serialised) against
+// 4.4 for ds_add_u32 / ds_write_b32 -- float atomics in LDS are 40x slower than integer ones.  So: optimistic read, add in registers,
+// two 64-bit compare-and-swaps (integer rate), each half retried on interference (rare: 16 waves on a 16 KiB tile).
+__device__ __forceinline__ void lds_cas_add4(float *p, const f32x4 &v) {
+  unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
+  const f32x4 o = *reinterpret_cast<const f32x4 *>(p);
+  asm volatile("" ::: "memory");
+  unsigned long long e0 = ((unsigned long long)__float_as_uint(o[1]) << 32) | __float_as_uint(o[0]);
+  unsigned long long e1 = ((unsigned long long)__float_as_uint(o[3]) << 32) | __float_as_uint(o[2]);
+  unsigned long long n0 = ((unsigned long long)__float_as_uint(o[1] + v[1]) << 32) | __float_as_uint(o[0] + v[0]);
+  unsigned long long n1 = ((unsigned long long)__float_as_uint(o[3] + v[3]) << 32) | __float_as_uint(o[2] + v[2]);
+  bool ok0 = __hip_atomic_compare_exchange_strong(q, &e0, n0, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  bool ok1 = __hip_atomic_compare_exchange_strong(q + 1, &e1, n1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (!ok0) {
+    n0 = ((unsigned long long)__float_as_uint(__uint_as_float((unsigned)(e0 >> 32)) + v[1]) << 32) | __float_as_uint(__uint_as_float((unsigned)e0) + v[0]);
+    ok0 = __hip_atomic_compare_exchange_strong(q, &e0, n0, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  while (!ok1) {
+    n1 = ((unsigned long long)__float_as_uint(__uint_as_float((unsigned)(e1 >> 32)) + v[3]) << 32) | __float_as_uint(__uint_as_float((unsigned)e1) + v[2]);
+    ok1 = __hip_atomic_compare_exchange_strong(q + 1, &e1, n1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+
 }  // namespace

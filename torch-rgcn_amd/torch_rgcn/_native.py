@@ -5,6 +5,7 @@ launch fails, the caller gets an exception.  The library is built in-tree by
 `__graft_entry__.build()` / `make -C torch-rgcn_amd/csrc`.
 """
 import ctypes
+import threading
 import os
 
 import numpy as np
@@ -34,6 +35,7 @@ def lib():
         L.rgcn_version.restype = ctypes.c_char_p
         L.rgcn_bwd_fused_scratch_floats.restype = ctypes.c_int64
         L.rgcn_bwd_lean_slot_bytes.restype = ctypes.c_int64
+        L.rgcn_bwd_blk_rec_bytes.restype = ctypes.c_int64
         L.rgcn_colsum_scratch_floats.restype = ctypes.c_int64
         L.rgcn_gemm_scratch_floats.restype = ctypes.c_int64
         L.rgcn_last_error.restype = ctypes.c_char_p
@@ -697,35 +699,55 @@ F_RELU, F_WPACKED = 1, 2
 F_DIAG4 = 16      # rgcn_bwd_blk_f32: block-diagonal weights, 4 x 4 blocks
 
 
-# (weak reference to the weight tensor, its version counter) -> (Wp, Wtp): both fragment orders of a [R,16,16] weight, packed
-# in ONE launch the first time either is asked for and reused until the tensor is written to (in-place optimiser updates
-# bump `_version`) or dies.  Keyed by object identity, never by address: a new tensor at a recycled address is a new entry.
-_PACKED_W16 = {}
+# Both fragment orders (Wp, Wtp) of a [R,16,16] weight are packed in ONE launch the first time either is asked for.  They are
+# remembered only inside a `w16_scope` -- one autograd call: the forward packs once and hands the pair to ITS backward through ctx
+# -- never in a process-wide cache: a parameter can change without its version counter moving (hipGraph replays run the
+# optimiser on the device, `W.data` writes), and a cache keyed on (identity, version) would then serve stale fragments
+# (an eager evaluation after replayed training steps scored with the weights of the first evaluation).
+_W16_TLS = threading.local()
+
+
+class w16_scope:
+    """`with w16_scope() as sc:` -- packed fragments made inside are reused inside (same tensor OBJECT only) and dropped at exit;
+    `sc.pair(W)` = what was packed for W (or None); `w16_scope(seed=(W, pair))` starts with a pair made earlier (the forward's)."""
+
+    def __init__(self, seed=None):
+        self.map = {}
+        if seed is not None and seed[1] is not None:
+            self.map[id(seed[0])] = (seed[0], seed[1])
+
+    def __enter__(self):
+        self.prev = getattr(_W16_TLS, "scope", None)
+        _W16_TLS.scope = self
+        return self
+
+    def __exit__(self, *exc):
+        _W16_TLS.scope = self.prev
+        self.map = {k: v for k, v in self.map.items()}     # (kept readable after exit: forward reads sc.pair(W))
+        return False
+
+    def pair(self, W):
+        hit = self.map.get(id(W))
+        return hit[1] if hit is not None and hit[0] is W else None
 
 
 def _packed_w16(W):
-    import weakref
-    key = id(W)
-    capturing = torch.cuda.is_current_stream_capturing()      # a captured step packs inside the graph: replays see the weights of THEIR step
-    hit = None if capturing else _PACKED_W16.get(key)
-    if hit is not None and hit[0]() is W and hit[1] == W._version:
-        return hit[2], hit[3]
-    if len(_PACKED_W16) >= 16:                      # dead or stale entries: drop them all (a model holds a handful of layers)
-        for k in [k for k, v in _PACKED_W16.items() if v[0]() is None or k == key]:
-            del _PACKED_W16[k]
-        if len(_PACKED_W16) >= 16:
-            _PACKED_W16.clear()
+    sc = getattr(_W16_TLS, "scope", None)
+    if sc is not None:
+        hit = sc.pair(W)
+        if hit is not None:
+            return hit
     Wp, Wtp = torch.empty_like(W), torch.empty_like(W)
     with _on(W.device):
         _check(lib().rgcn_pack_w16_pair_f32(_dp(W), _dp(Wp), _dp(Wtp), c_i32(W.shape[0]), _stream(W.device)), "pack_w16_pair")
-    if not capturing:
-        _PACKED_W16[key] = (weakref.ref(W), W._version, Wp, Wtp)
+    if sc is not None:
+        sc.map[id(W)] = (W, (Wp, Wtp))
     return Wp, Wtp
 
 
 def pack_w16(W):
-    """[R,16,16] weights -> MFMA fragment order (one float4 per lane), see rgcn_pack_w16_f32 (cached with the transposed
-    fragments, rgcn_pack_w16_pair_f32)"""
+    """[R,16,16] weights -> MFMA fragment order (one float4 per lane), see rgcn_pack_w16_f32 (packed together with the
+    transposed fragments, rgcn_pack_w16_pair_f32; remembered inside a w16_scope only)"""
     return _packed_w16(W)[0]
 
 
@@ -961,15 +983,16 @@ _BLK_MIN_NODES_SPARSE = 4096   # graphs with sparse (tile, relation) buckets: th
 
 def bwd_blk_rows(n_nodes, num_rels, deterministic=False, device=None, diag4=False, sparse=False):
     """tile height of the transposed plan for the block-tile backward kernel (rgcn_bwd_blk_f32), 0 when it does not apply:
-    the tallest tile <= 255 rows that gives every CU the same number of tiles (S1: 245 rows, 4082 tiles, 15.95 per CU).
-    diag4: the weights are block_diag() of 4 x 4 blocks (only the diagonal blocks of dW are kept: up to 447 relations)"""
-    if bwd_route() != "blk" or deterministic or n_nodes < (_BLK_MIN_NODES_SPARSE if sparse else _BLK_MIN_NODES) or \
-            not lib().rgcn_bwd_blk_supported(c_i32(255), c_i32(num_rels), c_i32(F_DIAG4 if diag4 else 0)):
+    the tallest tile the kernel's LDS holds next to the relations' dW (rgcn_bwd_blk_max_rows: 192 bytes per row) that gives every CU
+    the same number of tiles (S1, R = 101: up to 227 rows -> 218 rows, 4588 tiles, 17.9 per CU).
+    diag4: the weights are block_diag() of 4 x 4 blocks (only the diagonal blocks of dW are kept: AM's 267 relations leave 406 rows)"""
+    if bwd_route() != "blk" or deterministic or n_nodes < (_BLK_MIN_NODES_SPARSE if sparse else _BLK_MIN_NODES):
+        return 0
+    cap = int(lib().rgcn_bwd_blk_max_rows(c_i32(num_rels), c_i32(F_DIAG4 if diag4 else 0)))
+    cap = min(cap, int(os.environ.get("RGCN_BWD_BLK_CAP", "512")))
+    if cap < 64:
         return 0
     n_cu = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).multi_processor_count
-    # tiles of up to 512 rows (unpacked plan slots, 32 KiB more LDS) when they fit: fewer, fuller (tile, relation) buckets
-    cap = 512 if lib().rgcn_bwd_blk_supported(c_i32(512), c_i32(num_rels), c_i32(F_DIAG4 if diag4 else 0)) and \
-        os.environ.get("RGCN_BWD_BLK_CAP", "512") == "512" else 255
     per_cu = -(-n_nodes // (n_cu * cap))
     rows = -(-n_nodes // (n_cu * per_cu))
     return max(rows, min(cap, 128))      # small graphs: fewer, taller tiles (fuller buckets, fewer dW flushes) rather than one per CU
@@ -1029,6 +1052,23 @@ def _lean_plan(plan):
     return lean
 
 
+def _blk_rec(plan):
+    """chunk records of the block-tile backward kernel (rgcn_bwd_blk_prepare_f32: 176 bytes per chunk), made once per plan and
+    cached on it -- static (NC) graphs pay it once, per-call (LP) graphs one small launch per step"""
+    rec = getattr(plan, "_blk_rec", None)
+    if rec is None:
+        n_chunks = plan.chunk_rel.shape[0]
+        dev = plan.chunk_rel.device
+        rec = torch.empty(int(lib().rgcn_bwd_blk_rec_bytes(c_i64(n_chunks))) + 16, device=dev, dtype=torch.uint8)
+        packed = plan.pack is not None and plan.tile_rows <= 255
+        with _on(dev):
+            _check(lib().rgcn_bwd_blk_prepare_f32(_dp(plan.pack) if packed else None, _dp(plan.src), _dp(plan.dst), _dp(plan.val),
+                                                  c_i32(plan.tile_rows), _dp(plan.chunk_rel), c_i64(n_chunks), _dp(rec), _stream(dev)),
+                   "bwd_blk_prepare")
+        plan._blk_rec = rec
+    return rec
+
+
 def bwd_fused_relu_ok(plan, diag4=False):
     """RGCN_F_RELU of rgcn_bwd_fused_f32 (dX masked with X > 0 in the epilogue) exists in the window kernel only: its LDS
     (dX tile + X tile + scratch per wave, 8 waves at least) has to fit"""
@@ -1065,10 +1105,10 @@ def bwd_fused(G, X, W, plan, atomic=False, relu=False, want_db=False, diag4=Fals
     if blk:     # a plan of tall tiles (graph.bwd_plan asked bwd_blk_rows): one tile per workgroup
         if not atomic:
             raise NativeLibraryError("bwd_fused: the block-tile plan (tall tiles) has no bit-reproducible kernel")
-        slots, hdr = _lean_plan(plan)
+        rec = _blk_rec(plan)
         units, n_units, n_split = _blk_units(plan)
         with _on(dev), _timed("bwd_fused"):
-            _check(lib().rgcn_bwd_blk_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(slots), _dp(hdr), _dp(plan.run_ptr),
+            _check(lib().rgcn_bwd_blk_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(rec), _dp(plan.run_ptr),
                                           c_i64(plan.n_tiles), c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i32(W.shape[0]),
                                           c_i32((F_RELU if relu else 0) | (F_DIAG4 if diag4 else 0)), _dp(db), c_i64(plan.n_src),
                                           _dp(units), c_i64(n_units), c_i64(n_split), _stream(dev)), "bwd_blk")

@@ -179,21 +179,23 @@ class _RelationalMP(torch.autograd.Function):
         W = dense(W)
         b = None if bias is None else dense(bias)
         fused_relu = relu and (max(W.shape[1], W.shape[2]) <= 64 or _wide_gemm_path(graph, W.shape[1], W.shape[2]))   # kernel epilogues
-        if _sparse_buckets(graph, W) and blocks is not None and ctx.dims is None and tuple(blocks.shape[2:]) == (4, 4) and \
-                os.environ.get("RGCN_BLOCK_FWD", "1") != "0":
-            # W = block_diag(blocks), 4 x 4 blocks, sparse buckets (AM): the forward reads the blocks themselves on the CSR
-            # kernel (block table in LDS; one gather per message, no transformed-row buffer): 0.46 ms against 0.65 ms for the
-            # two passes below.  The backward stays on the dense W (dX rows + dW from one relation-major walk; autograd
-            # through block_diag() picks the blocks' gradient out of dW).
-            out = _native.block_spmm(X, blocks.detach().contiguous(), b, graph.csr("fwd"), relu=fused_relu)
-        elif _sparse_buckets(graph, W) and os.environ.get("RGCN_SPMM_CSR", "1") != "0" and \
-                _native.spmm_csr_d16_ok(graph.csr("fwd"), W.shape[0]):
-            # sparse buckets, up to 120 relations: ONE pass over the destination-major CSR, messages of mixed relations, W in LDS
-            out = _native.spmm_csr_d16(X, W, b, graph.csr("fwd"), relu=fused_relu)
-        elif _sparse_buckets(graph, W):
-            out = _native.spmm_two_pass(X, W, b, graph.scatter_plan("fwd"), graph.csr("fwd"), relu=fused_relu)
-        else:
-            out = _spmm_blocked(X, W, b, graph.fwd_plan, relu=fused_relu, graph=graph, kind="fwd")
+        with _native.w16_scope() as w16:        # [R,16,16] weights: both fragment orders packed once, handed to the backward below
+            if _sparse_buckets(graph, W) and blocks is not None and ctx.dims is None and tuple(blocks.shape[2:]) == (4, 4) and \
+                    os.environ.get("RGCN_BLOCK_FWD", "1") != "0":
+                # W = block_diag(blocks), 4 x 4 blocks, sparse buckets (AM): the forward reads the blocks themselves on the CSR
+                # kernel (block table in LDS; one gather per message, no transformed-row buffer): 0.46 ms against 0.65 ms for the
+                # two passes below.  The backward stays on the dense W (dX rows + dW from one relation-major walk; autograd
+                # through block_diag() picks the blocks' gradient out of dW).
+                out = _native.block_spmm(X, blocks.detach().contiguous(), b, graph.csr("fwd"), relu=fused_relu)
+            elif _sparse_buckets(graph, W) and os.environ.get("RGCN_SPMM_CSR", "1") != "0" and \
+                    _native.spmm_csr_d16_ok(graph.csr("fwd"), W.shape[0]):
+                # sparse buckets, up to 120 relations: ONE pass over the destination-major CSR, messages of mixed relations, W in LDS
+                out = _native.spmm_csr_d16(X, W, b, graph.csr("fwd"), relu=fused_relu)
+            elif _sparse_buckets(graph, W):
+                out = _native.spmm_two_pass(X, W, b, graph.scatter_plan("fwd"), graph.csr("fwd"), relu=fused_relu)
+            else:
+                out = _spmm_blocked(X, W, b, graph.fwd_plan, relu=fused_relu, graph=graph, kind="fwd")
+        ctx.w16 = w16.pair(W)
         if relu and not fused_relu:
             out = torch.relu_(out)
         ctx.graph = graph
@@ -210,6 +212,11 @@ class _RelationalMP(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         X, W = ctx.saved_tensors[:2]
+        with _native.w16_scope(seed=(W, ctx.w16)):
+            return _RelationalMP._backward(ctx, g, X, W)
+
+    @staticmethod
+    def _backward(ctx, g, X, W):
         graph = ctx.graph
         if ctx.dims is not None and ctx.dims[1] % 16:
             g = torch.nn.functional.pad(g, (0, -ctx.dims[1] % 16))
@@ -304,22 +311,29 @@ class _ShardedRelationalMP(torch.autograd.Function):
         X, W = dense(X), dense(W)
         rank = dist.get_rank(group)
         b = dense(bias) if (bias is not None and rank == 0) else None
-        if n_slabs > 0 and comm == "allreduce":
-            works = []
-            out = _native.spmm_slabs(X, W, b, graph.fwd_plan(W.shape[2]), n_slabs,
-                                     lambda o, r0, r1: works.append(dist.all_reduce(o[r0:r1], group=group, async_op=True)))
-            for w in works:
-                w.wait()
-        else:
-            out = _join_shards(_native.spmm(X, W, b, graph.fwd_plan(W.shape[2])), group, comm)
+        with _native.w16_scope() as w16:
+            if n_slabs > 0 and comm == "allreduce":
+                works = []
+                out = _native.spmm_slabs(X, W, b, graph.fwd_plan(W.shape[2]), n_slabs,
+                                         lambda o, r0, r1: works.append(dist.all_reduce(o[r0:r1], group=group, async_op=True)))
+                for w in works:
+                    w.wait()
+            else:
+                out = _join_shards(_native.spmm(X, W, b, graph.fwd_plan(W.shape[2])), group, comm)
+        ctx.w16 = w16.pair(W)
         ctx.graph, ctx.group, ctx.n_slabs, ctx.has_bias, ctx.comm = graph, group, n_slabs, bias is not None, comm
         ctx.save_for_backward(X, W)
         return out if ctx.dims is None else out[:, :ctx.dims[1]]
 
     @staticmethod
     def backward(ctx, g):
-        import torch.distributed as dist
         X, W = ctx.saved_tensors
+        with _native.w16_scope(seed=(W, ctx.w16)):
+            return _ShardedRelationalMP._backward(ctx, g, X, W)
+
+    @staticmethod
+    def _backward(ctx, g, X, W):
+        import torch.distributed as dist
         graph = ctx.graph
         if ctx.dims is not None and ctx.dims[1] % 16:
             g = torch.nn.functional.pad(g, (0, -ctx.dims[1] % 16))
