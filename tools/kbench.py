@@ -110,9 +110,19 @@ if "bwd" in a.what:
         dx, dw = _native.bwd_fused(G, X, W, bp, atomic=atomic)
         e1 = ((dx - ref_dx).abs().max() / ref_dx.abs().max()).item()
         e2 = ((dw - ref_dw).abs().max() / ref_dw.abs().max()).item()
+        dbg = getattr(_native.lib(), "rgcn_blk_debug_read", None) if atomic and os.environ.get("RGCN_HIP_LIB") else None
+        if dbg is not None:
+            import ctypes
+            buf = (ctypes.c_uint64 * 4)()
+            dbg(buf, 1)
         _native.profile_start()
         med, mn = timeit(lambda: _native.bwd_fused(G, X, W, bp, atomic=atomic), a.iters)
         _native.profile_stop()
+        if dbg is not None:
+            dbg(buf, 1)
+            w = max(buf[3], 1)
+            print(f"   per wave (100 MHz ticks -> us): barrier wait {buf[0] / w / 100:.1f} us, epilogue {buf[1] / w / 100:.1f} us, kernel {buf[2] / w / 100:.1f} us "
+                  f"({buf[3] // (a.iters + 3)} waves per launch)", flush=True)
         balg = M * (4 * d + 8) + 2 * N * 4 * d
         print(f"[{tag} K={os.environ.get('RGCN_BWD_KERNEL', 'blk')} NW={os.environ.get('RGCN_BWD_NW', '-')} BP={os.environ.get('RGCN_BWD_BPERM', '-')}] bwd_fused {'atomic' if atomic else 'partial'} tile={bp.tile_rows} relerr dX {e1:.2e} dW {e2:.2e} "
               f"med {med:.3f} ms min {mn:.3f} ms -> {balg / med / 1e6:.0f} GB/s algorithmic (backward bytes)", flush=True)

@@ -20,7 +20,7 @@ per = collections.defaultdict(list)
 for f in glob.glob(f"{out}/{tag}_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if "bwd_blk_d16" in n or (("bwd_win" in n or "bwd_lean_d16" in n or "bwd_fused_d16" in n) and "true" in n.split("<")[1][:30]):
+        if "bwd_blk" in n or (("bwd_win" in n or "bwd_lean_d16" in n or "bwd_fused_d16" in n) and "true" in n.split("<")[1][:30]):
             per[r["Counter_Name"]].append(float(r["Counter_Value"]))
 d = {k: sum(v) / len(v) for k, v in per.items()}
 json.dump(d, open(f"{out}/{tag}.json", "w"), indent=1, sort_keys=True)

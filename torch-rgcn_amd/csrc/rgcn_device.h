@@ -151,6 +151,14 @@ constexpr int BW_SCR2 = 16 * 16;  // floats of transposition scratch per wave: [
 __device__ __forceinline__ int lds_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt -- every wave would wait for its own outstanding
+// global loads (prefetches) and for the acknowledgement of its stores at each barrier.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // p[0..3] += v, atomically against the other waves of the workgroup (p: LDS, 16-byte aligned).  NOT ds_add_f32: measured on gfx950
 // (tools/micro/lds_atomic_rate.hip) one wave-level ds_add_f32 occupies the CU's LDS for ~190 cycles (3 per lane, serialised) against
 // 4.4 for ds_add_u32 / ds_write_b32 -- float atomics in LDS are 40x slower than integer ones.  So: optimistic read, add in registers,

@@ -11,7 +11,8 @@ import os
 import numpy as np
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librgcn_hip.so")
+# RGCN_HIP_LIB: tools/ only -- the ablation build (make -C csrc abl -> lib/librgcn_hip_abl.so), whose kernels can be told to skip work
+_LIB_PATH = os.environ.get("RGCN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librgcn_hip.so")
 _lib = None
 
 OK, EINVAL, ENOMEM, ERANGE, EHIP, EUNSUPPORTED = range(6)
