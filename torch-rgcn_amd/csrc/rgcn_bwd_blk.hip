@@ -112,6 +112,14 @@ __global__ __launch_bounds__(WG) void bwd_blk_prep_kernel(const int2 *__restrict
   }
 }
 
+// Register budget: 1024 threads per workgroup = 128 VGPRs per lane, and the loop below sits exactly on it.  ANY value that has to
+// be reloaded from scratch inside the loop is fatal here, not just slow: scratch reloads are VMEM operations, they return in
+// order behind the record prefetch of the next quad, so the wave stalls for a fabric round trip in the middle of its compute
+// phase (measured: 0.52 -> 0.60 .. 0.65 ms with 4 .. 6 reloads per quad).  Tried on that cliff in round 4 and NOT kept
+// (profiles/r04_blk_ablation.txt): software-pipelined pairs with the gathers of two pairs in flight across tile switches (no spills,
+// but 66 VALU + 54 SALU per chunk against 42 + 27: 0.548 against 0.527 ms); gathers of the next tile's first quad issued before
+// the tile-end barrier and a second copy of the loop body for it (70 .. 100 dwords of scratch); the same as one-dword "touch" loads
+// (20 dwords of scratch); the tile update before the dW products (the dX MFMA chains then have nothing to overlap with).
 // DIAG4: W is block-diagonal with 4 x 4 blocks (decomposition {type: block}, width 16): only the four diagonal blocks of dW_r are
 // wanted (64 floats per relation instead of 256: hundreds of relations fit, AM has 267)
 // TQ: float4 of X a thread carries from one tile to the next = ceil(tile_rows / 256)
@@ -438,337 +446,6 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
 }
 
 
-// ---- the same kernel, software-pipelined ("pipe").  What bounds the form above after the LDS fix is the memory system seen from a
-// wave: issue 4 gathers, wait ~a fabric round trip, compute ~2000 cycles with NOTHING in flight, repeat -- four waves per SIMD do
-// not cover that -- and a tile of ~83 quads dealt to 16 waves ends with most waves idle for half a quad (13 % of the tile).  Here
-//   * the work unit is a PAIR of chunks (166 per tile: the idle tail halves);
-//   * every wave runs a 4-deep pipeline over its stream of pairs: pair i computes while the gathers (and W fragments) of pairs
-//     i+1 and i+2 are in flight and the records of pair i+3 are being read; the loads only fill registers, so the stream runs
-//     ACROSS tile switches: the first NS = 4 pairs a wave takes from a tile are fixed (wave, wave + 16, ...), the rest are dealt
-//     from the LDS counter -- when the counter runs dry the wave's generator moves on to the next tile's fixed pairs, and the
-//     barrier pair of the tile switch is reached with the next tile's rows already on their way.
-// Entries of the stream are wave-uniform (scalar registers): epoch (tile sequence number of this workgroup), first chunk (-1: a
-// bubble -- nothing to compute, loads clamped to record 0), last chunk of its tile.
-constexpr int BLK_EP_END = 0x7FFFFFFF;
-
-template <bool RELU, bool DIAG4, int TQ BLK_ABL_PARAM>
-__global__ __launch_bounds__(64 * BLK_NW) void bwd_blkp_d16_kernel(
-    const float *__restrict__ G, const float *__restrict__ X, const float *__restrict__ Wtp, float *__restrict__ dX,
-    float *__restrict__ dWout, const char *__restrict__ rec, const int *__restrict__ run_ptr, int n_tiles, int tile_rows, int n_dst,
-    int R, float *__restrict__ dbias, int n_src, const int4 *__restrict__ units, int n_units) {
-  constexpr int U = 2, NW = BLK_NW, NT = 64 * BLK_NW, NS = 4;
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const unsigned xt_off = (unsigned)tile_rows * 128u;
-  const unsigned xs_off = (unsigned)tile_rows * 192u;
-  float4 *dxz = reinterpret_cast<float4 *>(lds);
-  const double2 *dxd2 = reinterpret_cast<const double2 *>(lds);
-  float4 *xt4 = reinterpret_cast<float4 *>(lds + xt_off);
-  float *xs = reinterpret_cast<float *>(lds + xs_off) + wave * BW_SCR2;
-  constexpr int DWR = DIAG4 ? 64 : 256;
-  float *dwl = reinterpret_cast<float *>(lds + xs_off) + NW * BW_SCR2;
-  int *ctl = reinterpret_cast<int *>(dwl + (size_t)R * DWR);
-  int *dirty = ctl + 4;
-
-  struct Tile { int un, row0, nrows, c0, c1, np, shared; };
-  auto tile_of = [&](int un) {
-    Tile T{un, 0, 0, 0, 0, 0, 0};
-    if (un < n_units) {
-      int4 u;
-      if (units) u = units[un];
-      else u = int4{un, run_ptr[(size_t)un * (R + 1)], run_ptr[(size_t)un * (R + 1) + R], 0};
-      const int t = __builtin_amdgcn_readfirstlane(u.x);
-      T.row0 = t * tile_rows;
-      T.nrows = min(tile_rows, n_dst - T.row0);
-      T.c0 = __builtin_amdgcn_readfirstlane(u.y);
-      T.c1 = __builtin_amdgcn_readfirstlane(u.z);
-      T.shared = __builtin_amdgcn_readfirstlane(u.w) & RGCN_U_SHARED;
-      T.np = (T.c1 - T.c0 + U - 1) / U;
-    }
-    return T;
-  };
-  Tile cur = tile_of(blockIdx.x), gen = cur, nxt = cur;
-  int cur_ep = 0, gen_ep = 0, gen_j = 0;
-
-  float4 gs = make_float4(0.f, 0.f, 0.f, 0.f);
-  const long long g_n4 = dbias ? (long long)n_src * 4 : 0, g_step = (long long)gridDim.x * NT;
-  long long g_i = (long long)blockIdx.x * NT + tid;
-  {
-#pragma unroll
-    for (int q = 0; q < TQ; ++q) {
-      const int idx = tid + q * NT;
-      if (idx < tile_rows * 4) {
-        float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < cur.nrows * 4) x0 = reinterpret_cast<const float4 *>(X + (size_t)cur.row0 * 16)[idx];
-        xt4[idx] = x0;
-      }
-    }
-    for (int i = tid; i < tile_rows * 8; i += NT) dxz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = tid; i < R * (DWR / 4); i += NT) reinterpret_cast<float4 *>(dwl)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = tid; i < R + 4; i += NT) ctl[i] = i == 0 ? NS * NW : 0;
-  }
-  __syncthreads();
-
-  const int m = lane & 15, k = lane >> 4;
-  const unsigned kofs = (unsigned)k << 4;
-  const unsigned dx_lane = (unsigned)m * 8u;
-  const unsigned xrd = xt_off + (unsigned)m * 4u;
-  float *xs_wr = xs + m * 16 + 4 * ((k + (m >> 2)) & 3);
-  const float *xs_rd = xs + (4 * k) * 16 + 4 * (((m >> 2) + k) & 3) + (m & 3);
-  const unsigned slot_lane = (unsigned)m * 8u;
-  const unsigned rows_lane = (unsigned)BLK_REC_ROWS + (unsigned)k * 8u;
-  const unsigned w_lane = (unsigned)lane * 16u;
-
-  f32x4 hold = f32x4{0.f, 0.f, 0.f, 0.f};
-  int cur_r = -1;
-  auto flush_hold = [&]() {
-    if (cur_r >= 0) {
-      if (DIAG4) {
-        if ((m >> 2) == k) lds_cas_add4(dwl + (size_t)cur_r * 64 + (4 * k + (m & 3)) * 4, hold);
-      } else {
-        lds_cas_add4(dwl + (size_t)cur_r * 256 + lane * 4, hold);
-      }
-      if (lane == 0) lds_st(dirty + cur_r, 1);
-    }
-  };
-
-  // the stream's entries: q0 computes, q1's gathers are in flight, q2's gathers are issued now, q3's records are requested now
-  struct Ent { int ep, c, last; };
-  auto gen_static = [&]() {
-    Ent e{gen_ep, -1, gen.c1 - 1};
-    const int p = wave + gen_j * NW;
-    ++gen_j;
-    if (gen.un >= n_units) e.ep = BLK_EP_END;
-    else if (p < gen.np) e.c = gen.c0 + U * p;
-    return e;
-  };
-  Ent q0{0, -1, 0}, q1{0, -1, 0}, q2{0, -1, 0}, q3 = gen_static();
-
-  // stage registers
-  uint2 i_sl[U], i_rw[U];                 // records of q2 (requested one iteration ago)
-  int i_hd[U];
-  float4 g1[U], w1[U], g0[U], w0[U];      // gathers + W fragments of q1 / q0
-  float v1[U], v0[U];
-  uint2 r1[U], r0[U];
-  int h1[U], h0[U];
-#pragma unroll
-  for (int j = 0; j < U; ++j) {
-    i_sl[j] = uint2{0u, 0u}; i_rw[j] = uint2{0u, 0u}; i_hd[j] = 0;
-    g1[j] = g0[j] = make_float4(0.f, 0.f, 0.f, 0.f); w1[j] = w0[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    v1[j] = v0[j] = 0.f; r1[j] = r0[j] = uint2{0u, 0u}; h1[j] = h0[j] = 0;
-  }
-
-  BLK_DBG(const long long dbg_t0 = BLK_T(); long long dbg_wait = 0; long long dbg_epi = 0; long long dbg_ta = 0; long long dbg_tb = 0;)
-  for (;;) {
-    // ---- tile switch: the head of the stream belongs to the next tile (or there is none)
-    if (q0.ep > cur_ep) {
-      float4 xn[TQ];
-#pragma unroll
-      for (int q = 0; q < TQ; ++q) xn[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      const bool more = q0.ep != BLK_EP_END;
-      if (more) {
-#pragma unroll
-        for (int q = 0; q < TQ; ++q)
-          if (tid + q * NT < nxt.nrows * 4) xn[q] = reinterpret_cast<const float4 *>(X + (size_t)nxt.row0 * 16)[tid + q * NT];
-      }
-      float4 gn = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g_i < g_n4) gn = reinterpret_cast<const float4 *>(G)[g_i];
-      g_i += g_step;
-      BLK_DBG(dbg_ta = BLK_T();)
-      __syncthreads();                                               // every wave has finished adding to the dX tile
-      BLK_DBG(dbg_tb = BLK_T(); dbg_wait += dbg_tb - dbg_ta;)
-      gs.x += gn.x; gs.y += gn.y; gs.z += gn.z; gs.w += gn.w;
-#pragma unroll
-      for (int q = 0; q < TQ; ++q) {
-        const int idx = tid + q * NT;
-        if (idx < cur.nrows * 4) {
-          const double2 d0 = dxd2[2 * idx], d1 = dxd2[2 * idx + 1];
-          float4 a = make_float4((float)d0.x, (float)d0.y, (float)d1.x, (float)d1.y);
-          if (RELU) {
-            const float4 x = xt4[idx];
-            a.x = x.x > 0.f ? a.x : 0.f; a.y = x.y > 0.f ? a.y : 0.f; a.z = x.z > 0.f ? a.z : 0.f; a.w = x.w > 0.f ? a.w : 0.f;
-          }
-          float4 *o = reinterpret_cast<float4 *>(dX + (size_t)cur.row0 * 16) + idx;
-          if (cur.shared) {
-            atomicAdd(&o->x, a.x); atomicAdd(&o->y, a.y); atomicAdd(&o->z, a.z); atomicAdd(&o->w, a.w);
-          } else {
-            *o = a;
-          }
-        }
-      }
-      if (!more) break;
-#pragma unroll
-      for (int q = 0; q < TQ; ++q) {
-        const int idx = tid + q * NT;
-        if (idx < tile_rows * 4) {
-          dxz[2 * idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-          dxz[2 * idx + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
-          xt4[idx] = xn[q];
-        }
-      }
-      if (tid == 0) ctl[0] = NS * NW;
-      __syncthreads();                                               // the next tile is installed
-      BLK_DBG(dbg_epi += BLK_T() - dbg_tb;)
-      cur = nxt;
-      ++cur_ep;
-    }
-    // ---- [a] the records of q3; the counter for the entry after it
-    const bool need_dyn = gen_ep == cur_ep && gen_j >= NS;
-    int q_dyn = 0;
-    if (need_dyn && lane == 0) q_dyn = __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    uint2 n_sl[U], n_rw[U];
-    int n_hd[U];
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
-      const int cc = q3.c < 0 ? 0 : min(q3.c + j, q3.last);
-      const char *r = rec + (size_t)cc * BLK_REC;
-      n_sl[j] = *reinterpret_cast<const uint2 *>(r + slot_lane);
-      n_rw[j] = *reinterpret_cast<const uint2 *>(r + rows_lane);
-      n_hd[j] = *reinterpret_cast<const int *>(r + BLK_REC_HDR);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- [b] the gathers of q2 (its records were requested one iteration ago)
-    float4 g2[U], w2[U];
-    float v2[U];
-    uint2 r2[U];
-    int h2[U];
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
-      const unsigned og = i_sl[j].x | kofs;
-      h2[j] = __builtin_amdgcn_readfirstlane(i_hd[j]);
-      g2[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(G) + og);
-      w2[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Wtp) + (size_t)h2[j] * 1024 + w_lane);
-      v2[j] = (q2.c >= 0 && q2.c + j <= q2.last) ? __builtin_bit_cast(float, i_sl[j].y) : 0.f;
-      r2[j] = i_rw[j];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- [c] compute q0
-    if (ABL & 16) {
-#pragma unroll
-      for (int j = 0; j < U; ++j) asm volatile("" :: "v"(g0[j].x), "v"(g0[j].y), "v"(g0[j].z), "v"(g0[j].w), "v"(w0[j].x), "v"(w0[j].w), "v"(r0[j].x), "v"(r0[j].y), "v"(v0[j]));
-    } else if (q0.c >= 0) {
-      f32x4 sc[U], acc[U];
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        sc[j] = f32x4{g0[j].x * v0[j], g0[j].y * v0[j], g0[j].z * v0[j], g0[j].w * v0[j]};
-        acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[j][0], w0[j].x, acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[j][1], w0[j].y, acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[j][2], w0[j].z, acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[j][3], w0[j].w, acc[j], 0, 0, 0);
-      unsigned ro[U][4];
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        ro[j][0] = r0[j].x & 0xFFFFu;
-        ro[j][1] = r0[j].x >> 16;
-        ro[j][2] = r0[j].y & 0xFFFFu;
-        ro[j][3] = r0[j].y >> 16;
-      }
-      // dW operands: scaled rows through the scratch, X rows of the slots
-      float bv[U][4], av[U][4];
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        asm volatile("" ::: "memory");
-        *reinterpret_cast<f32x4 *>(xs_wr) = sc[j];
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) bv[j][t4] = xs_rd[16 * t4];
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) av[j][t4] = *reinterpret_cast<const float *>(lds + (xrd + ro[j][t4]));
-        asm volatile("" ::: "memory");
-      }
-      // the tile update: one ds_add_f64 per slot quarter
-      if (ABL & 8) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) asm volatile("" :: "v"(acc[j][0]), "v"(acc[j][1]), "v"(acc[j][2]), "v"(acc[j][3]));
-      } else {
-#pragma unroll
-        for (int j = 0; j < U; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            __hip_atomic_fetch_add(static_cast<double *>(__builtin_assume_aligned(lds + (dx_lane + 2u * ro[j][e]), 8)), (double)acc[j][e],
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      f32x4 aw[U];
-#pragma unroll
-      for (int j = 0; j < U; ++j) aw[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4)
-#pragma unroll
-        for (int j = 0; j < U; ++j) aw[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][t4], bv[j][t4], aw[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        if (q0.c + j > q0.last) break;
-        const int rj = h0[j];
-        if (rj != cur_r) {
-          flush_hold();
-          cur_r = rj;
-          hold = aw[j];
-        } else {
-          hold += aw[j];
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- rotate the stages; the next entry of the stream
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
-      g0[j] = g1[j]; w0[j] = w1[j]; v0[j] = v1[j]; r0[j] = r1[j]; h0[j] = h1[j];
-      g1[j] = g2[j]; w1[j] = w2[j]; v1[j] = v2[j]; r1[j] = r2[j]; h1[j] = h2[j];
-      i_sl[j] = n_sl[j]; i_rw[j] = n_rw[j]; i_hd[j] = n_hd[j];
-    }
-    q0 = q1; q1 = q2; q2 = q3;
-    if (need_dyn) {
-      const int v = __builtin_amdgcn_readfirstlane(q_dyn);
-      if (v < gen.np) {
-        q3 = Ent{gen_ep, gen.c0 + U * v, gen.c1 - 1};
-      } else {                       // the tile is dealt out: on to the next tile's fixed pairs
-        gen = tile_of(gen.un + (int)gridDim.x);
-        nxt = gen;
-        ++gen_ep;
-        gen_j = 0;
-        q3 = gen_static();
-      }
-    } else if (gen_j < NS) {
-      q3 = gen_static();
-    } else {
-      q3 = Ent{gen_ep, -1, 0};       // the generator is a tile ahead and out of fixed pairs: a bubble until the switch
-    }
-  }
-  flush_hold();
-  BLK_DBG(if (lane == 0 && blockIdx.x < 256) { unsigned long long *d = rgcn_blk_dbg + 4 * (blockIdx.x * BLK_NW + wave); d[0] += (unsigned long long)dbg_wait;
-                                               d[1] += (unsigned long long)dbg_epi; d[2] += (unsigned long long)(BLK_T() - dbg_t0); d[3] += 1ull; })
-  if (dbias) {
-    for (; g_i < g_n4; g_i += g_step) {
-      const float4 gn = reinterpret_cast<const float4 *>(G)[g_i];
-      gs.x += gn.x; gs.y += gn.y; gs.z += gn.z; gs.w += gn.w;
-    }
-#pragma unroll
-    for (int sft = 4; sft < 64; sft <<= 1) {
-      gs.x += __shfl_xor(gs.x, sft); gs.y += __shfl_xor(gs.y, sft); gs.z += __shfl_xor(gs.z, sft); gs.w += __shfl_xor(gs.w, sft);
-    }
-    if (lane < 4) *reinterpret_cast<float4 *>(xs + 4 * lane) = gs;
-  }
-  __syncthreads();                                                   // every wave's last partial is in the dW table
-  if (dbias && tid < 16) {
-    float a = 0.f;
-    const float *all = reinterpret_cast<const float *>(lds + xs_off);
-    for (int i = 0; i < NW; ++i) a += all[i * BW_SCR2 + tid];
-    atomicAdd(dbias + tid, a);
-  }
-  for (int i = tid; i < R * DWR; i += NT) {
-    const int r = i / DWR, e = i & 3;
-    const int ln = DIAG4 ? 16 * ((i >> 4) & 3) + 4 * ((i >> 4) & 3) + ((i >> 2) & 3) : (i >> 2) & 63;
-    if (lds_ld(dirty + r)) atomicAdd(dWout + (size_t)r * 256 + (4 * (ln >> 4) + e) * 16 + (ln & 15), dwl[i]);
-  }
-}
-
 }  // namespace
 
 extern "C" int64_t rgcn_bwd_blk_rec_bytes(int64_t n_chunks) { return n_chunks * (int64_t)BLK_REC; }
@@ -844,43 +521,22 @@ extern "C" int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_
                        (int)n_tiles, tile_rows, (int)n_dst, R, dbias, (int)n_src, reinterpret_cast<const int4 *>(units), (int)n_units);
     return hipGetLastError();
   };
-  static const bool PIPE = getenv("RGCN_BWD_BLK_PIPE") && atoi(getenv("RGCN_BWD_BLK_PIPE")) == 1;
 #ifdef RGCN_ABLATIONS
   {
     static const int ABLV = getenv("RGCN_BWD_ABL") ? atoi(getenv("RGCN_BWD_ABL")) : 0;     // timing experiments (wrong results): this library only
-    static bool a0 = false, a1 = false, a2 = false, a3 = false, a4 = false, a5 = false, a6 = false, a7 = false, a8 = false, a9 = false;
+    static bool a0 = false, a1 = false, a2 = false, a3 = false, a4 = false, a5 = false, a6 = false, a7 = false;
     if (tq != 1 || diag4) { rgcn_set_error("bwd_blk (ablation library): only dense weights on tiles of up to 256 rows"); return RGCN_EUNSUPPORTED; }
-    if (PIPE) {
-      if (ABLV == 2) HIP_TRY(launch(bwd_blkp_d16_kernel<false, false, 1, 2>, a0));
-      else if (ABLV == 8) HIP_TRY(launch(bwd_blkp_d16_kernel<false, false, 1, 8>, a1));
-      else if (ABLV == 10) HIP_TRY(launch(bwd_blkp_d16_kernel<false, false, 1, 10>, a2));
-      else if (ABLV == 16) HIP_TRY(launch(bwd_blkp_d16_kernel<false, false, 1, 16>, a3));
-      else HIP_TRY(launch(bwd_blkp_d16_kernel<false, false, 1, 0>, a4));
-    } else {
-      if (ABLV == 2) HIP_TRY(launch(bwd_blk_d16_kernel<false, false, 1, 2>, a5));
-      else if (ABLV == 8) HIP_TRY(launch(bwd_blk_d16_kernel<false, false, 1, 8>, a6));
-      else if (ABLV == 10) HIP_TRY(launch(bwd_blk_d16_kernel<false, false, 1, 10>, a7));
-      else if (ABLV == 16) HIP_TRY(launch(bwd_blk_d16_kernel<false, false, 1, 16>, a8));
-      else if (ABLV == 4) { static bool b0 = false; HIP_TRY(launch(bwd_blk_d16_kernel<false, false, 1, 4>, b0)); }
-      else if (ABLV == 32) { static bool b1 = false; HIP_TRY(launch(bwd_blk_d16_kernel<false, false, 1, 32>, b1)); }
-      else if (ABLV == 36) { static bool b2 = false; HIP_TRY(launch(bwd_blk_d16_kernel<false, false, 1, 36>, b2)); }
-      else HIP_TRY(launch(bwd_blk_d16_kernel<false, false, 1, 0>, a9));
-    }
+    if (ABLV == 2) HIP_TRY(launch(bwd_blk_d16_kernel<false, false, 1, 2>, a0));
+    else if (ABLV == 8) HIP_TRY(launch(bwd_blk_d16_kernel<false, false, 1, 8>, a1));
+    else if (ABLV == 10) HIP_TRY(launch(bwd_blk_d16_kernel<false, false, 1, 10>, a2));
+    else if (ABLV == 16) HIP_TRY(launch(bwd_blk_d16_kernel<false, false, 1, 16>, a3));
+    else if (ABLV == 4) HIP_TRY(launch(bwd_blk_d16_kernel<false, false, 1, 4>, a4));
+    else if (ABLV == 32) HIP_TRY(launch(bwd_blk_d16_kernel<false, false, 1, 32>, a5));
+    else if (ABLV == 36) HIP_TRY(launch(bwd_blk_d16_kernel<false, false, 1, 36>, a6));
+    else HIP_TRY(launch(bwd_blk_d16_kernel<false, false, 1, 0>, a7));
     return RGCN_OK;
   }
 #else
-  if (PIPE) {
-    static bool p0 = false, p1 = false, p2 = false, p3 = false, p4 = false, p5 = false, p6 = false, p7 = false;
-    if (tq == 2 && diag4 && relu) HIP_TRY(launch(bwd_blkp_d16_kernel<true, true, 2>, p0));
-    else if (tq == 2 && diag4) HIP_TRY(launch(bwd_blkp_d16_kernel<false, true, 2>, p1));
-    else if (tq == 2 && relu) HIP_TRY(launch(bwd_blkp_d16_kernel<true, false, 2>, p2));
-    else if (tq == 2) HIP_TRY(launch(bwd_blkp_d16_kernel<false, false, 2>, p3));
-    else if (diag4 && relu) HIP_TRY(launch(bwd_blkp_d16_kernel<true, true, 1>, p4));
-    else if (diag4) HIP_TRY(launch(bwd_blkp_d16_kernel<false, true, 1>, p5));
-    else if (relu) HIP_TRY(launch(bwd_blkp_d16_kernel<true, false, 1>, p6));
-    else HIP_TRY(launch(bwd_blkp_d16_kernel<false, false, 1>, p7));
-    return RGCN_OK;
-  }
   static bool r0 = false, r1 = false, r2 = false, r3 = false, r4 = false, r5 = false, r6 = false, r7 = false;
   if (tq == 2 && diag4 && relu) HIP_TRY(launch(bwd_blk_d16_kernel<true, true, 2>, r0));
   else if (tq == 2 && diag4) HIP_TRY(launch(bwd_blk_d16_kernel<false, true, 2>, r1));
