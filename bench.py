@@ -134,6 +134,19 @@ class _MeanSquare(torch.autograd.Function):
         return out * (g * (2.0 / out.numel()))
 
 
+def make_step(l1, l2, X):
+    """THE timed step: layer 1 (horizontal flag) with its ReLU fused, layer 2 (vertical flag), loss = mean(out^2), backward to X and
+    to both layers' parameters (tests/test_gpu_parity.py::test_bench_step_composition_vs_cpu_port checks exactly this callable)"""
+    def step():
+        for p in (X, l1.weights, l1.bias, l2.weights, l2.bias):
+            p.grad = None
+        out = l2(l1.forward_activated(X, "relu"))
+        loss = _MeanSquare.apply(out)
+        loss.backward()
+        return loss
+    return step
+
+
 def build_layers(N, R0, E, d, seed, device, group, keep):
     from torch_rgcn import _native
     from torch_rgcn.dist import shard_layer
@@ -287,13 +300,7 @@ def main():
     graph_build_ms = 1e3 * (time.perf_counter() - t_b)
     my_messages = l1._graph.num_messages
 
-    def step():
-        for p in (X, l1.weights, l1.bias, l2.weights, l2.bias):
-            p.grad = None
-        out = l2(l1.forward_activated(X, "relu"))
-        loss = _MeanSquare.apply(out)
-        loss.backward()
-        return loss
+    step = make_step(l1, l2, X)
 
     def fence():
         torch.cuda.synchronize()

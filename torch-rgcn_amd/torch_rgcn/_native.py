@@ -690,9 +690,10 @@ def _req(t, name, dtype=torch.float32):
         raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
     if not t.is_contiguous():
         raise ValueError(f"{name} must be contiguous")
-    if t.data_ptr() % 16:
+    if t.data_ptr() % (16 if t.is_floating_point() else t.element_size()):
         # the kernels pick their 16-byte load / store forms from the row width alone; a contiguous view at an odd storage offset
-        # (a slice of a flattened tensor) would hand them a misaligned base -- functional.py's dense() copies such views
+        # (a slice of a flattened tensor) would hand them a misaligned base -- functional.py's dense() copies such views.
+        # Index tensors (int64 triples: 24-byte rows, read element by element) only need their natural alignment: triples[1:] is fine.
         raise ValueError(f"{name} must be 16-byte aligned (got a view at storage offset {t.storage_offset()}): pass x.clone()")
 
 
@@ -1176,12 +1177,25 @@ def featureless_csr_wgrad(G, csr, num_rels, n_src):
 
 def _csr_units(csr):
     """(units, n_units, n_split) of a CSR: one unit per row, hub rows cut into 512-entry pieces -- computed once per static
-    graph (host statistics); a CSR of a per-call LP graph has none: (None, n_rows, 0) = every row is one unit"""
+    graph (host statistics); a CSR of a per-call LP graph has none: (None, n_rows, 0) = every row is one unit.
+    RGCN_DETERMINISTIC=1: no pieces (they merge with fp32 atomics, in arrival order) -- a hub row is then one long unit"""
     if getattr(csr, "sync_free", False) or getattr(csr, "per_call", False):
         return None, csr.n_rows, 0              # (per-call graphs of the LP layer: the statistics would cost two read-backs a step)
+    if os.environ.get("RGCN_DETERMINISTIC", "0") == "1":
+        if getattr(csr, "units_whole", None) is None:
+            csr.units_whole = row_units(csr.rowptr, csr.n_rows, 1 << 30)
+        return csr.units_whole
     if getattr(csr, "units", None) is None:
         csr.units = row_units(csr.rowptr, csr.n_rows, 512)
     return csr.units
+
+
+def _empty_csr_out(csr, width, bias, relu, device):
+    """a CSR without a single entry (rows, no messages): out = bias on every row -- the kernels prefetch entry 0 unconditionally"""
+    out = torch.zeros((csr.n_rows, width), device=device, dtype=torch.float32)
+    if bias is not None:
+        out += bias
+    return out.relu_() if relu else out
 
 
 def block_supported(bi, bo):
@@ -1195,6 +1209,8 @@ def block_spmm(X, blocks, bias, csr, transposed=False, relu=False):
     _req(X, "features"); _req(blocks, "blocks"); _req(bias, "bias")
     Rb, nb, bi, bo = blocks.shape
     assert X.shape[1] == nb * (bo if transposed else bi)
+    if csr.src.numel() == 0:
+        return _empty_csr_out(csr, nb * (bi if transposed else bo), bias, relu, X.device)
     units, n_units, n_split = _csr_units(csr)
     fuse_relu = relu and n_split == 0
     out = torch.empty((csr.n_rows, nb * (bi if transposed else bo)), device=X.device, dtype=torch.float32)
@@ -1219,6 +1235,10 @@ def spmm_csr_d16(X, W, bias, csr, relu=False):
     """out[n_rows, 16] = bias + sum over the row's CSR entries of val * X[src] @ W[rel]   (W: [R, 16, 16]; rgcn_spmm_csr_d16_f32)"""
     _req(X, "features"); _req(W, "weights"); _req(bias, "bias")
     assert X.shape[1] == 16 and tuple(W.shape[1:]) == (16, 16)
+    num_rels = getattr(csr, "num_rels", None)
+    assert num_rels is None or W.shape[0] == num_rels, f"weights of {W.shape[0]} relations on a graph of {num_rels}: the kernel indexes its LDS table by the entries' relation"
+    if csr.src.numel() == 0:
+        return _empty_csr_out(csr, 16, bias, relu, X.device)
     units, n_units, n_split = _csr_units(csr)
     fuse_relu = relu and n_split == 0
     out = torch.empty((csr.n_rows, 16), device=X.device, dtype=torch.float32)

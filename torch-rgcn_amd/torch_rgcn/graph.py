@@ -148,6 +148,7 @@ class RelGraph:
             self._plans[key] = _native.build_csr_device(dst, src, p, val, alive, self.num_nodes, sync_free=self.sync_free,
                                                         want_slot=need_slot or not getattr(self, "per_call", False))
             self._plans[key].per_call = getattr(self, "per_call", False)
+            self._plans[key].num_rels = self.num_rels
         return self._plans[key]
 
     def fbasis_plan(self):
