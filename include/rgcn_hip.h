@@ -428,6 +428,16 @@ RGCN_API int rgcn_fbasis_bwd_f32(const float *bases, const float *comps, const f
                                  const int32_t *e_dst, const int32_t *e_rel, const float *e_val,
                                  const int32_t *units, int64_t n_units, int64_t n_split, int64_t n_nodes, int32_t R,
                                  int32_t B, int32_t d, int32_t basis_major, void *stream);
+/* The same layer with SMALL blocks (B <= 4: S2 of SURVEY 8d has B = 2, d = 16 -- a node's block is one 128-byte line), backward in ONE
+ * walk of the source-major CSR (rowptr / p_src = the messages' destination rows, whose G rows are gathered / p_rel / p_val as
+ * rgcn_basis_aggregate_f32 takes them): dbases[o, b, :] = sum_e val_e comps[r_e, b] G[s_e, :] (node-major [N, B, d], written once per
+ * node) AND dcomps[r, b] = sum_e val_e <table[o_e, b, :], G[s_e, :]> (summed in an LDS table of doubles per workgroup, one flush each;
+ * dcomps is zeroed here).  table: node-major [N, B, d].  d a power of two, 4 .. 64.  Replaces rgcn_basis_aggregate_f32 +
+ * rgcn_basis_dcomps_f32 (two gathers per message in the latter) on that route: the autograd duals of layers.py:241-242 + :286-288. */
+RGCN_API int rgcn_fbasis_small_supported(int32_t R, int32_t B, int32_t d);
+RGCN_API int rgcn_fbasis_small_bwd_f32(const float *G, const float *table, const float *comps, float *dbases, float *dcomps,
+                                       const int32_t *rowptr, const int32_t *p_src, const int32_t *p_rel, const float *p_val,
+                                       int64_t n_rows, int32_t R, int32_t B, int32_t d, void *stream);
 RGCN_API int rgcn_gather_rows_sum_f32(const float *Y, const int32_t *perm, const int32_t *units, int64_t n_units,
                                       int64_t n_split, const float *bias, float *out, int64_t n_rows, int32_t w,
                                       void *stream);

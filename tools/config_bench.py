@@ -366,6 +366,88 @@ def line_wn18(baseline_config):
             "roofline": roof}
 
 
+def line_s2(baseline_config):
+    """the S1 graph with a FEATURELESS first layer (faithful to NodeClassifier), basis B = 2 -- the weight-table gather
+    path; layer 2 is S1's (16 -> 16, vertical flag).  Roofline on a stated bytes model for the whole step and for the dominant kernel."""
+    N, R0, E, d, B = 1_000_000, 50, 10_000_000, 16, 2
+    T = _native.synthetic_triples_host(N, R0, E, 0)
+    tp = torch.from_numpy(_native.add_inverse_and_self_host(T, N, R0))
+    kw = dict(triples=tp, num_nodes=N, num_relations=2 * R0 + 1, out_features=d)
+    l1 = RelationalGraphConvolutionNC(in_features=None, vertical_stacking=False, decomposition={"type": "basis", "num_bases": B}, **kw).to(DEV)
+    l2 = RelationalGraphConvolutionNC(in_features=d, vertical_stacking=True, **kw).to(DEV)
+
+    def step():
+        for p in list(l1.parameters()) + list(l2.parameters()):
+            p.grad = None
+        _MeanSquare.apply(l2(l1.forward_activated(None, "relu"))).backward()
+    ms = timed(step, iters=10, warm=3)
+    name, kms, per_step, allk = _dominant(step)
+    counts = _launch_counts(step)
+    M = 2 * E + N
+    row = B * d * 4
+    # layer 1 forward: one B x d block of the bases table + 8 B of index per message, one output row per node; backward: the upstream
+    # row AND the table block per message (dcomps needs <bases, g>), the bases gradient written once; layer 2: SURVEY 8(d) S1 bytes
+    l1_fwd, l1_bwd = M * (row + 8) + N * d * 4, M * (row + 4 * d + 8) + N * row
+    l2_fwd, l2_bwd = M * (4 * d + 8) + N * 4 * d, M * (4 * d + 8) + 2 * N * 4 * d
+    step_alg = l1_fwd + l1_bwd + l2_fwd + l2_bwd
+    own = {"fbasis_fwd": l1_fwd, "basis_aggregate": l1_fwd, "fbasis_bwd": l1_bwd, "fbasis_small_bwd": l1_bwd, "spmm": l2_fwd, "bwd_fused": l2_bwd}.get(name)
+    roof = _roof(name, kms, own, "layer 1: messages x (B x d table block [+ upstream row in the backward] + 8 B) + rows written; layer 2: SURVEY 8(d)") if own else None
+    if roof:
+        roof["step_algorithmic_bytes"] = int(step_alg)
+        roof["step_frac"] = round(step_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    return {"baseline_config": baseline_config, "workload": "S2: S1 graph, featureless layer 1 with basis B=2 (no R x N x 16 table), ReLU, layer 2 16->16",
+            "N": N, "R0": R0, "E": E, "step": "2 layers, forward + backward", "ms_per_step": round(ms, 3), "edges_per_s": round(E / ms * 1e3),
+            "kernels_ms": allk, "launches_per_step": counts, "roofline": roof}
+
+
+def line_am_shipped(baseline_config):
+    """AM as the reference ships it (configs/rgcn/nc-AM.yaml: featureless layer 1 with basis 40, hidden 10, 11 classes, Adam): the
+    forward + backward and the optimiser step are timed SEPARATELY -- Adam over 667 M parameters is ~2.3 ms of pure streaming --
+    and the roofline is taken for forward + backward on a stated bytes model"""
+    N, R0, E, nhid, ncls, B, labelled = 1_666_764, 133, 5_988_321, 10, 11, 40, 802
+    T = _native.synthetic_triples_host(N, R0, E, 1)
+    model = NodeClassifier(triples=T, nnodes=N, nrel=R0, nhid=nhid, nclass=ncls, decomposition={"type": "basis", "num_bases": B}).to(DEV)
+    idx = torch.arange(labelled, device=DEV)
+    y = torch.randint(0, ncls, (labelled,), device=DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, fused=True)
+
+    def fwd_bwd():
+        opt.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy(model()[idx], y).backward()
+
+    def step():
+        fwd_bwd()
+        opt.step()
+    ms_step = timed(step, iters=5, warm=2)
+    ms_fb = timed(fwd_bwd, iters=5, warm=2)
+    fwd_bwd()
+    ms_adam = timed(opt.step, iters=5, warm=1)
+    name, kms, per_step, allk = _dominant(fwd_bwd)
+    M = 2 * E + N
+    n_par = sum(p.numel() for p in model.parameters())
+    # forward + backward of the step: the bases table (B x N x nhid floats) is READ once by the forward gather and its gradient WRITTEN
+    # once by the backward -- per message only the 8 B of index are inherent (a node's B x nhid block is shared by all its messages);
+    # layer 2 (10 -> 11, padded to 16): SURVEY 8(d).  Adam: 4 reads + 3 writes of 4 B per parameter.
+    table = B * N * nhid * 4
+    l2 = 2 * (M * (4 * 16 + 8) + N * 4 * 16) + N * 4 * 16
+    fb_alg = 2 * table + 2 * M * 8 + 2 * N * nhid * 4 + l2
+    adam_alg = 7 * 4 * n_par
+    fb = {"ms": round(ms_fb, 3), "algorithmic_bytes": int(fb_alg), "achieved": round(fb_alg / (ms_fb * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+          "frac": round(fb_alg / (ms_fb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bound": "hbm",
+          "bytes_model": "bases table read once + its gradient written once + 2 x 8 B of index per message + layer 2 per SURVEY 8(d)"}
+    adam = {"ms": round(ms_adam, 3), "algorithmic_bytes": int(adam_alg), "achieved": round(adam_alg / (ms_adam * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(adam_alg / (ms_adam * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bound": "hbm",
+            "bytes_model": "torch.optim.Adam(fused=True): param, grad, exp_avg, exp_avg_sq read; param, exp_avg, exp_avg_sq written"}
+    roof = dict(fb)
+    roof["kernel"] = f"forward + backward (dominant kernel: {name}, {round(kms, 4) if kms else None} ms per launch)"
+    roof["avg_launch_ms"] = fb["ms"]
+    roof["adam"] = adam
+    return {"baseline_config": baseline_config, "workload": "AM-shaped NodeClassifier as shipped (featureless L1, basis 40, hidden 10, 11 classes)",
+            "N": N, "R0": R0, "E": E, "params": n_par, "step": "NodeClassifier forward + cross-entropy + backward + Adam",
+            "ms_per_step": round(ms_step, 3), "ms_forward_backward": round(ms_fb, 3), "ms_adam": round(ms_adam, 3),
+            "edges_per_s": round(E / ms_step * 1e3), "kernels_ms": allk, "roofline": roof}
+
+
 def secondary_lines():
     """one dict per BASELINE.json config 1-4 (dataset-shaped synthetic graphs), each with the dominant kernel's
     roofline; bounded to a few seconds each"""
@@ -376,7 +458,13 @@ def secondary_lines():
                                             {"type": "basis", "num_bases": 30}, 340, "configs[1] MUTAG, basis decomposition"),
                lambda: line_featured("AM-shaped, block-diagonal (nb=4), 2 featured layers d=16 (layer-level, SURVEY 8d)", 1_666_764, 133,
                                      5_988_321, 16, {"type": "block", "num_blocks": 4}, 2, "configs[2] AM, block-diagonal"),
-               lambda: line_wn18("configs[3] WN18 link prediction, DistMult decoder")):
+               lambda: line_wn18("configs[3] WN18 link prediction, DistMult decoder"),
+               lambda: line_featured("S1(ii): S1 graph, basis decomposition B=10, 2 featured layers d=16", 1_000_000, 50, 10_000_000, 16,
+                                     {"type": "basis", "num_bases": 10}, 0, "SURVEY 8(d) S1 variant (ii)"),
+               lambda: line_featured("S1(iii): S1 graph, block-diagonal nb=4, 2 featured layers d=16", 1_000_000, 50, 10_000_000, 16,
+                                     {"type": "block", "num_blocks": 4}, 0, "SURVEY 8(d) S1 variant (iii)"),
+               lambda: line_s2("SURVEY 8(d) S2 (secondary)"),
+               lambda: line_am_shipped("configs[2] AM as the reference ships it (nc-AM.yaml: featureless, basis 40, hidden 10)")):
         try:
             out.append(fn())
         except Exception as exc:  # noqa: BLE001
@@ -388,7 +476,16 @@ def secondary_lines():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
+    ap.add_argument("--lines", default="", help="bench.py's secondary lines by name: s2,amshipped,s1ii,s1iii (JSON, one per line)")
     a = ap.parse_args()
+    if a.lines:
+        for nm in a.lines.split(","):
+            fn = {"s2": lambda: line_s2("S2"), "amshipped": lambda: line_am_shipped("AM shipped"),
+                  "s1ii": lambda: line_featured("S1(ii)", 1_000_000, 50, 10_000_000, 16, {"type": "basis", "num_bases": 10}, 0, "S1(ii)"),
+                  "s1iii": lambda: line_featured("S1(iii)", 1_000_000, 50, 10_000_000, 16, {"type": "block", "num_blocks": 4}, 0, "S1(iii)")}[nm]
+            print(json.dumps(fn()), flush=True)
+            torch.cuda.empty_cache()
+        sys.exit(0)
     todo = a.only.split(",") if a.only else ["aifb", "mutag", "am", "wn18", "s2", "s1"]
     if "s2" in todo:
         s2_featureless_basis()

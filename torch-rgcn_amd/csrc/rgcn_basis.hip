@@ -569,6 +569,112 @@ extern "C" int rgcn_basis_aggregate_f32(const float *X, const float *comps, floa
   return RGCN_OK;
 }
 
+// ------------------------------------------------------------------ featureless basis layer, SMALL blocks: the fused backward
+// S2 (S1's graph, featureless layer 1, B = 2, d = 16): a node's B x d block is ONE 128-byte line, and the source-major
+// kernels above (lane = basis) would run 2 lanes of 64.  Round 3 took the destination-major fallback: basis_aggregate on the
+// source-major CSR for dbases (gathers G[s]: 0.69 ms) and basis_dcomps on the relation-major plan for dcomps (gathers G[s] AND the
+// block again: 1.13 ms).  Here ONE walk of the source-major CSR does both: the wave holds the row's block in registers (read once),
+// gathers G[s] once per message, accumulates dbases[o] in registers (written once, no atomics) and adds t_e[b] = val <block[b], G[s]>
+// to an LDS table dcomps[R][B] kept in DOUBLES (ds_add_f64: the LDS float atomic that is native on gfx950); every workgroup
+// flushes its table once.  lpm = d / 4 lanes per message (16-byte loads), 64 / lpm messages of a row in flight per wave.
+namespace {
+template <int B>
+__global__ __launch_bounds__(TB) void fbasis_small_bwd_kernel(
+    const float *__restrict__ G, const float *__restrict__ table, const float *__restrict__ comps, float *__restrict__ dB,
+    float *__restrict__ dC, const int *__restrict__ rowptr, const int *__restrict__ p_src, const int *__restrict__ p_rel,
+    const float *__restrict__ p_val, long long n_rows, int R, int d, int lpm) {
+  extern __shared__ __attribute__((aligned(16))) double dcl[];          // [R][B]
+  for (int i = threadIdx.x; i < R * B; i += TB) dcl[i] = 0.0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / lpm, il = lane % lpm, ngrp = 64 / lpm;
+  const int f = 4 * il;
+  const bool on = f < d;
+  const long long wave0 = ((long long)blockIdx.x * TB + threadIdx.x) >> 6, nw = ((long long)gridDim.x * TB) >> 6;
+  constexpr int MB = 2;      // messages in flight per lane group
+  for (long long row = wave0; row < n_rows; row += nw) {
+    const int e0 = rowptr[row], e1 = rowptr[row + 1];
+    f32x4 blk[B], a[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      blk[b] = on ? *reinterpret_cast<const f32x4 *>(table + ((size_t)row * B + b) * d + f) : f32x4{0.f, 0.f, 0.f, 0.f};
+      a[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int eb = e0 + sub; eb < e1; eb += ngrp * MB) {
+      int rel[MB];
+      float v[MB];
+      f32x4 x[MB];
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        const int e = min(eb + m * ngrp, e1 - 1);
+        v[m] = (eb + m * ngrp < e1) ? p_val[e] : 0.f;
+        rel[m] = p_rel[e];
+        x[m] = on ? *reinterpret_cast<const f32x4 *>(G + (size_t)p_src[e] * d + f) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        const float *cp = comps + (size_t)rel[m] * B;
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          a[b] += x[m] * (cp[b] * v[m]);
+          float dot = blk[b][0] * x[m][0] + blk[b][1] * x[m][1] + blk[b][2] * x[m][2] + blk[b][3] * x[m][3];
+          for (int off = 1; off < lpm; off <<= 1) dot += __shfl_xor(dot, off, 64);
+          if (il == 0 && v[m] != 0.f)
+            __hip_atomic_fetch_add(dcl + rel[m] * B + b, (double)(v[m] * dot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a[b][c] = group_sum(a[b][c], lpm);
+    if (sub == 0 && on) {
+#pragma unroll
+      for (int b = 0; b < B; ++b) *reinterpret_cast<f32x4 *>(dB + ((size_t)row * B + b) * d + f) = a[b];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < R * B; i += TB) {
+    const float t = (float)dcl[i];
+    if (t != 0.f) atomicAdd(dC + i, t);
+  }
+}
+}  // namespace
+
+extern "C" int rgcn_fbasis_small_supported(int32_t R, int32_t B, int32_t d) {
+  return B >= 1 && B <= 4 && d >= 4 && d <= 64 && (d & 3) == 0 && (d & (d - 1)) == 0 && (size_t)R * B * sizeof(double) <= 60 * 1024;
+}
+
+extern "C" int rgcn_fbasis_small_bwd_f32(const float *G, const float *table, const float *comps, float *dbases, float *dcomps,
+                                         const int32_t *rowptr, const int32_t *p_src, const int32_t *p_rel, const float *p_val,
+                                         int64_t n_rows, int32_t R, int32_t B, int32_t d, void *stream) {
+  if (!G || !table || !comps || !dbases || !dcomps || !rowptr || n_rows < 0 || R <= 0) { rgcn_set_error("fbasis_small_bwd: bad argument"); return RGCN_EINVAL; }
+  if (!rgcn_fbasis_small_supported(R, B, d)) { rgcn_set_error("fbasis_small_bwd: B = %d (1..4), d = %d (power of two, 4..64), R = %d", B, d, R); return RGCN_EUNSUPPORTED; }
+  if (((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(dbases)) & 15) != 0) {
+    rgcn_set_error("fbasis_small_bwd: G / table / dbases must be 16-byte aligned");
+    return RGCN_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(zero_async(dcomps, (size_t)R * B * sizeof(float), st));
+  if (!n_rows) return RGCN_OK;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0, v = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+    n_cu = v > 0 ? v : 256;
+  }
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_rows * 64 + TB - 1) / TB, (int64_t)n_cu * 8));
+  const size_t lds = (size_t)R * B * sizeof(double);
+  const int lpm = d / 4;
+#define RGCN_FBS(BB) hipLaunchKernelGGL(fbasis_small_bwd_kernel<BB>, dim3(grid), dim3(TB), lds, st, G, table, comps, dbases, dcomps, rowptr, p_src, \
+                                        p_rel, p_val, (long long)n_rows, R, d, lpm)
+  if (B == 1) RGCN_FBS(1); else if (B == 2) RGCN_FBS(2); else if (B == 3) RGCN_FBS(3); else RGCN_FBS(4);
+#undef RGCN_FBS
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
 extern "C" int rgcn_basis_dcomps_f32(const float *X, const float *D, float *dcomps, const int32_t *p_src,
                                      const int32_t *p_dst, const float *p_val, const int32_t *chunk_rel,
                                      const int32_t *items, int64_t n_items, int32_t R, int32_t B, int32_t d,

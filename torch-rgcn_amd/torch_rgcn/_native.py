@@ -618,6 +618,24 @@ def basis_aggregate(X, comps, csr, B, d, n_b_in):
     return out
 
 
+def fbasis_small_ok(R, B, d):
+    return bool(lib().rgcn_fbasis_small_supported(c_i32(R), c_i32(B), c_i32(d)))
+
+
+def fbasis_small_bwd(G, table, comps, csr, B, d):
+    """featureless basis layer with small blocks (B <= 4), both gradients from ONE walk of the source-major CSR
+    (rgcn_fbasis_small_bwd_f32): table [N, B, d] node-major -> (dbases [N, B, d], dcomps [R, B])"""
+    _req(G, "grad_output"); _req(table, "bases"); _req(comps, "comps")
+    R = comps.shape[0]
+    dB = torch.empty((csr.n_rows, B, d), device=G.device, dtype=torch.float32)
+    dC = torch.empty((R, B), device=G.device, dtype=torch.float32)
+    with _on(G.device), _timed("fbasis_small_bwd"):
+        _check(lib().rgcn_fbasis_small_bwd_f32(_dp(G), _dp(table), _dp(comps), _dp(dB), _dp(dC), _dp(csr.rowptr), _dp(csr.src), _dp(csr.rel),
+                                               _dp(csr.val), c_i64(csr.n_rows), c_i32(R), c_i32(B), c_i32(d), _stream(G.device)),
+               "fbasis_small_bwd")
+    return dB, dC
+
+
 def basis_dcomps(X, D, plan, R, B, d, swap=False):
     """dcomps[r,b] = sum_e val <X[src_e], D[dst_e, b]>; plan: relation-major plan (graph.wgt_plan()).
     swap=True exchanges the roles of the two index arrays (featureless layers: X = grad rows by destination,

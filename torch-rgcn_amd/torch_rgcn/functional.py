@@ -122,10 +122,17 @@ class _ReluToken:
     through a weak reference, same version counter).  Anything else -- H had other consumers and autograd summed their
     gradients (a new tensor, or an in-place add that bumps the version), a hook replaced the tensor, the consumer took
     another route -- falls back to masking, which is idempotent on the pre-masked part: always exact."""
-    __slots__ = ("ref", "version")
+    __slots__ = ("ref", "version", "consumer_input")
 
     def __init__(self):
-        self.ref, self.version = None, -1
+        self.ref, self.version, self.consumer_input = None, -1, None
+
+    def observed(self):
+        """someone can SEE the gradient that arrives at H -- H.retain_grad() or a tensor hook on H: then it has to be dL/dH, not the
+        pre-masked dL/d(pre-activation), and the consumer leaves the masking to the producer.  (torch.autograd.grad(loss, H) cannot
+        be seen from here: it returns the pre-masked gradient, which differs from dL/dH exactly where H == 0.)"""
+        h = self.consumer_input() if self.consumer_input is not None else None
+        return h is None or h.retains_grad or bool(getattr(h, "_backward_hooks", None))
 
     def mark(self, dX):
         import weakref
@@ -233,7 +240,7 @@ class _RelationalMP(torch.autograd.Function):
         blk_sparse = sparse and os.environ.get("RGCN_BWD", "fused") != "split" and \
             _native.bwd_blk_rows(graph.num_nodes, graph.num_rels, deterministic(), graph.device, ctx.diag4, True) > 0
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and (not sparse or blk_sparse):
-            both = _fused_backward(X, W, g, graph, relu_in=ctx.in_token is not None and ctx.dims is None,
+            both = _fused_backward(X, W, g, graph, relu_in=ctx.in_token is not None and ctx.dims is None and not ctx.in_token.observed(),
                                    want_db=ctx.has_bias and ctx.needs_input_grad[2], diag4=ctx.diag4, sparse=sparse)
             if both is not None:
                 both, masked, db = both[:2], both[2], both[3]
@@ -620,6 +627,12 @@ class _FeaturelessBasisMP(torch.autograd.Function):
         table, comps = ctx.saved_tensors
         N, B, d = table.shape
         dB = dC = db = None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not deterministic() and _native.fbasis_small_ok(comps.shape[0], B, d):
+            # small blocks (S2: B = 2, d = 16): one walk of the source-major CSR for both gradients (one gather per message)
+            dB, dC = _native.fbasis_small_bwd(g, table, comps, ctx.graph.csr("bwd"), B, d)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = _native.colsum(g)
+            return dB.permute(1, 0, 2), dC, db, None
         if ctx.needs_input_grad[0]:
             dB = _native.basis_aggregate(g, comps, ctx.graph.csr("bwd"), B, d, 1).view(N, B, d).permute(1, 0, 2)
         if ctx.needs_input_grad[1]:
@@ -650,6 +663,9 @@ def relational_mp(features, weights, bias, graph, relu=False, blocks=None):
     [R, nb, bi, bo] parameter when weights = block_diag(blocks) (a hint: lets the forward skip the zero entries)"""
     # features = the output of a layer that applied ReLU in its kernel's epilogue: its backward node carries the token
     in_token = getattr(getattr(features, "grad_fn", None), "out_token", None)
+    if in_token is not None:
+        import weakref
+        in_token.consumer_input = weakref.ref(features)     # looked at again in the backward: see _ReluToken.observed
     return _RelationalMP.apply(features, weights, bias, graph, relu, blocks, in_token)
 
 

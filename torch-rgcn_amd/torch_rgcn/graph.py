@@ -84,8 +84,12 @@ class RelGraph:
             # graphs that live for one step (upper-bound sizes: at most 16 slots per message; one work unit per tile, no hub
             # splitting -- a sampled graph's hub is a few thousand messages).  Static (NC) graphs keep the exact path.
             nosync = self.sync_free or getattr(self, "per_call", False)
+            # RGCN_DETERMINISTIC=1: no hub pieces (a tile cut into several work units merges its pieces with fp32 atomics, in
+            # arrival order): a hub tile is one long unit for one wave -- slow on skewed graphs, bit-reproducible
+            whole = os.environ.get("RGCN_DETERMINISTIC", "0") == "1"
             self._plans[key] = _native.build_plan_device(dst, src, p, val, alive, N, N, R, tile_rows, self.num_messages,
-                                                         max_item_chunks, want_runs=True, want_pack=True, sync_free=nosync)
+                                                         max_item_chunks, want_runs=True, want_pack=True, sync_free=nosync,
+                                                         **({"max_unit_chunks": 1 << 30} if whole else {}))
         if key not in self._plans:
             N, R = self.num_nodes, self.num_rels
             if kind == "fwd":
