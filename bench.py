@@ -325,8 +325,9 @@ def main():
         # Untimed set-up: which form of the collective is fastest on THIS link (xGMI ring / direct, one rank, gloo)?
         # 3 steps per candidate, max over ranks, the same choice on every rank.
         cands = [("allreduce", "0"), ("rs_ag", "0"), ("a2a", "0"), ("allreduce", "2")] + ([("allreduce", "4")] if mode == "weak" else [])
-        if "RGCN_DIST_COMM" in os.environ or "RGCN_DIST_SLABS" in os.environ:
-            cands = [(os.environ.get("RGCN_DIST_COMM", "allreduce"), os.environ.get("RGCN_DIST_SLABS", "0"))]
+        from torch_rgcn import routes
+        if routes.is_set("dist_comm") or routes.is_set("dist_slabs"):
+            cands = [(routes.get("dist_comm", "allreduce"), routes.get("dist_slabs", "0"))]
         tried = {}
         for c, s in cands:
             set_transport(l1, c, int(s)), set_transport(l2, c, int(s))
@@ -365,10 +366,17 @@ def main():
     if group is not None:
         # what the collectives cost: (a) the step without them (RGCN_DIST_COMM=none: same kernels, wrong numbers),
         # (b) the four N x d collectives of one step on their own
-        set_transport(l1, "none"), set_transport(l2, "none")
-        compute_ms = timed_steps(3)
-        set_transport(l1, *chosen), set_transport(l2, *chosen)
-        from torch_rgcn.functional import _join_shards
+        # (a bench-local patch of the join -- there is no such transport in torch_rgcn.dist: nothing else can switch the sums off)
+        import torch_rgcn.functional as _fn
+        join = _fn._join_shards
+        _fn._join_shards = lambda partial, grp, mode="allreduce": partial
+        set_transport(l1, "allreduce", 0), set_transport(l2, "allreduce", 0)
+        try:
+            compute_ms = timed_steps(3)
+        finally:
+            _fn._join_shards = join
+            set_transport(l1, *chosen), set_transport(l2, *chosen)
+        _join_shards = join
         buf = torch.zeros(N, d, device=device)
         fence()
         t_c = time.perf_counter()
@@ -432,7 +440,7 @@ def main():
             if "bwd_fused" in launches:
                 bms = launches["bwd_fused"][0] + launches.get("dw_reduce", (0.0, 0))[0]
                 route = _native.bwd_route()
-                if route == "blk" and not _native.bwd_blk_rows(N, 2 * R0 + 1, os.environ.get("RGCN_DETERMINISTIC", "0") == "1"):
+                if route == "blk" and not _native.bwd_blk_rows(N, 2 * R0 + 1, routes.flag("deterministic")):
                     route = "lean"
                 kname, kkey = {"blk": ("bwd_blk_d16_kernel", "bwd_blk"), "lean": ("bwd_lean_d16_kernel", "bwd_lean")}.get(route, ("bwd_fused_d16_kernel", "bwd_fused"))
                 bwd = kernel_roofline(kname + " (dX + dW of one layer from one gather per message"

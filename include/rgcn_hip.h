@@ -44,6 +44,14 @@ extern "C" {
 
 RGCN_API const char *rgcn_version(void);
 RGCN_API const char *rgcn_last_error(void);
+/* Tuning options: the library never reads the environment -- whoever hosts it (torch_rgcn/routes.py) decides and says so here.
+ * Names: basis_vec4, block_lds, block_pipe, bwd_nw, bwd_d, bwd_waves, bwd_u, gemm_bm, spmm_u, wgrad_rg, wgrad_u,
+ * distmult_one_launch, rank_tile (all of them choose between kernels that compute the same result), and bwd_abl / rank_ablate:
+ * timing experiments with WRONG results that exist in the ablation build only (make -C torch-rgcn_amd/csrc abl) -- the shipped
+ * library refuses a non-zero value (RGCN_EUNSUPPORTED).  Process-wide; set them before launching from several threads.  No
+ * reference counterpart (the reference has no native layer). */
+RGCN_API int rgcn_set_option(const char *name, int32_t value);
+RGCN_API int rgcn_get_option(const char *name, int32_t *value);
 
 /* ------------------------------------------------------------------ graph preparation (host) */
 

@@ -32,3 +32,13 @@ def golden_dir():
 def load_golden(name):
     import numpy as np
     return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+@pytest.fixture(autouse=True)
+def _routes_restored():
+    """route choices made through routes.patch(monkeypatch, ...) are undone by monkeypatch; the integers that were pushed into the
+    loaded library (routes.NATIVE) are pushed again from the restored table after every test"""
+    yield
+    from torch_rgcn import routes
+    if routes._native_sink is not None:
+        routes.push_native()

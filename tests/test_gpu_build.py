@@ -3,6 +3,7 @@ integer work is bit-exact; plans are equal up to the (irrelevant) order inside o
 import numpy as np
 import pytest
 import torch
+from torch_rgcn import routes  # noqa: E402
 
 from oracle import oracle
 from torch_rgcn import _native as nat
@@ -110,7 +111,7 @@ def test_layers_give_same_result_with_host_and_device_build(monkeypatch):
     tp = oracle.add_inverse_and_self(graph(N, R0, E, 3), N, R0)
     outs = []
     for mode in ("device", "host"):
-        monkeypatch.setenv("RGCN_GRAPH_BUILD", mode)
+        routes.patch(monkeypatch, "graph_build", mode)
         torch.manual_seed(0)
         layer = RelationalGraphConvolutionNC(triples=torch.from_numpy(tp), num_nodes=N, num_relations=2 * R0 + 1,
                                              in_features=16, out_features=16).to(DEV)

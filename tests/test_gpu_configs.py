@@ -11,6 +11,7 @@ oracle (out, dX, every parameter gradient, 1e-4); full-size AM goes through size
 import numpy as np
 import pytest
 import torch
+from torch_rgcn import routes  # noqa: E402
 
 from oracle import oracle
 from test_gpu_parity import DEV, TOL, rel_err, run_layer_vs_oracle
@@ -33,12 +34,12 @@ def test_am_tenth_scale_block_diagonal_layer_vs_oracle(monkeypatch, route, verti
       tile     the (tile, relation) kernels of dense-bucket graphs
       block    forward and backward on the block kernels (RGCN_BLOCK_PATH=2; at width 16 not the default)"""
     from torch_rgcn import _native
-    monkeypatch.setenv("RGCN_BLOCK_PATH", "2" if route == "block" else "0")
-    monkeypatch.setenv("RGCN_BLOCK_FWD", "1" if route in ("hybrid", "hybrid_r2") else "0")
+    routes.patch(monkeypatch, "block_path", "2" if route == "block" else "0")
+    routes.patch(monkeypatch, "block_fwd", "1" if route in ("hybrid", "hybrid_r2") else "0")
     if route in ("hybrid_r2", "twopass"):
-        monkeypatch.setenv("RGCN_BWD_KERNEL", "lean")       # no block-tile kernel: the sparse graph's backward is the two-pass one
+        routes.patch(monkeypatch, "bwd_kernel", "lean")       # no block-tile kernel: the sparse graph's backward is the two-pass one
     if route in ("twopass", "tile"):
-        monkeypatch.setenv("RGCN_SPARSE_PATH", "1" if route == "twopass" else "0")
+        routes.patch(monkeypatch, "sparse_path", "1" if route == "twopass" else "0")
     _native.profile_start()
     run_layer_vs_oracle(N=166_676, R0=133, E=598_832, d_in=16, d_out=16, mode="block", num_blocks=4, vertical=vertical,
                         seed=301 + int(vertical))
@@ -94,14 +95,9 @@ def test_am_full_size_block_layer_properties():
     assert torch.isfinite(layer.blocks.grad).all()
     # the same forward with the block table read from L2 instead of LDS (68 KB: above the default 64 KB LDS limit) and on the
     # two-pass kernels
-    import os
     ref = out.detach()
-    for var, val in (("RGCN_BLOCK_FWD", "0"),):
-        os.environ[var] = val
-        try:
-            assert rel_err(layer(X).detach(), ref.cpu().numpy()) < 1e-5
-        finally:
-            del os.environ[var]
+    with routes.override(block_fwd="0"):
+        assert rel_err(layer(X).detach(), ref.cpu().numpy()) < 1e-5
 
 
 def test_am_full_size_featureless_basis40_properties():

@@ -4,6 +4,7 @@ aggregate-in-LDS + contract kernel against the CSR aggregation followed by a flo
 import numpy as np
 import pytest
 import torch
+from torch_rgcn import routes  # noqa: E402
 
 from oracle import oracle
 
@@ -23,7 +24,7 @@ def test_gemm_layouts_and_edges(monkeypatch, M, N, K, ta, tb, bm):
     """bm: rows of the C tile per workgroup (rgcn_gemm_f32 picks 64-row tiles per launch when they balance better over the
     CUs; RGCN_GEMM_BM forces either form)"""
     from torch_rgcn import _native
-    monkeypatch.setenv("RGCN_GEMM_BM", bm)
+    routes.patch(monkeypatch, "gemm_bm", bm)
     rng = np.random.default_rng(M * 31 + N * 7 + K)
     A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
     B = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)

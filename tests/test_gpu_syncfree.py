@@ -4,6 +4,7 @@ paths: basis at d = 200 (lp-WN18.yaml), dense hidden 16 (c-rgcn), block-diagonal
 import numpy as np
 import pytest
 import torch
+from torch_rgcn import routes  # noqa: E402
 
 from oracle import oracle
 
@@ -37,7 +38,7 @@ def _step_fn(layer, dm, emb, graph, batch, y, opt):
 
 @pytest.mark.parametrize("kind", ["basis", "dense16", "block"])
 def test_lp_training_step_issues_no_synchronisation(kind, monkeypatch):
-    monkeypatch.setenv("RGCN_DEFERRED_CHECKS", "1")
+    routes.patch(monkeypatch, "deferred_checks", "1")
     from torch_rgcn import _native
     N, R0, E, T = 6000, 9, 8000, 40_000
     layer, dm, emb, d = _setup(kind, N, R0)
@@ -72,7 +73,7 @@ def test_sync_free_plans_give_the_same_layer_as_exact_plans(monkeypatch):
     for d, decomp in ((16, None), (200, {"type": "basis", "num_bases": 2}), (40, {"type": "block", "num_blocks": 4})):
         res = {}
         for mode in ("0", "1"):
-            monkeypatch.setenv("RGCN_DEFERRED_CHECKS", mode)
+            routes.patch(monkeypatch, "deferred_checks", mode)
             torch.manual_seed(1)
             layer = RelationalGraphConvolutionLP(num_nodes=N, num_relations=2 * R0 + 1, in_features=d, out_features=d,
                                                  edge_dropout={"general": 0.5, "self_loop": 0.2, "self_loop_type": "other"},
@@ -87,7 +88,7 @@ def test_sync_free_plans_give_the_same_layer_as_exact_plans(monkeypatch):
 
 
 def test_deferred_range_check_still_raises(monkeypatch):
-    monkeypatch.setenv("RGCN_DEFERRED_CHECKS", "1")
+    routes.patch(monkeypatch, "deferred_checks", "1")
     from torch_rgcn import _native
     from torch_rgcn.layers import DistMult
     dm = DistMult(3, 8, 10, 3).to(DEV)
@@ -96,7 +97,7 @@ def test_deferred_range_check_still_raises(monkeypatch):
     with pytest.raises(IndexError):          # raised by the call itself if the GPU got there already, else by the explicit check
         dm(bad, nodes)
         _native.check_deferred_errors()
-    monkeypatch.setenv("RGCN_DEFERRED_CHECKS", "0")
+    routes.patch(monkeypatch, "deferred_checks", "0")
     with pytest.raises(IndexError):
         dm(bad, nodes)
     good = torch.tensor([[0, 2, 1]], device=DEV)
@@ -106,7 +107,7 @@ def test_deferred_range_check_still_raises(monkeypatch):
 def test_lp_step_captured_in_a_hipgraph_matches_eager(monkeypatch):
     """the whole training step (per-call graph build, encoder, decoder, loss, backward, Adam) replayed from a hipGraph:
     same loss trajectory as the eager step on the same inputs (eval-mode layer: no dropout randomness)"""
-    monkeypatch.setenv("RGCN_DEFERRED_CHECKS", "1")
+    routes.patch(monkeypatch, "deferred_checks", "1")
     N, R0, E, T = 6000, 9, 8000, 40_000
     graph = torch.from_numpy(oracle.synthetic_triples(N, R0, E, 3)).to(DEV)
     batch = torch.from_numpy(oracle.synthetic_triples(N, R0, T, 4)).to(DEV)

@@ -330,27 +330,22 @@ def line_wn18(baseline_config):
     # the same step without any host synchronisation (plans sized by upper bounds, deferred range checks), and replayed
     # from a hipGraph (nothing but the replay between the timing points)
     ms_nosync = ms_graph = None
-    prev = os.environ.get("RGCN_DEFERRED_CHECKS")
-    os.environ["RGCN_DEFERRED_CHECKS"] = "1"
+    from torch_rgcn import routes
     try:
-        ms_nosync = timed(step, iters=10, warm=3)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
+        with routes.override(deferred_checks="1"):
+            ms_nosync = timed(step, iters=10, warm=3)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            hg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(hg):
                 step()
-        torch.cuda.current_stream().wait_stream(side)
-        hg = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(hg):
-            step()
         ms_graph = timed(hg.replay, iters=10, warm=3)
     except Exception as exc:  # noqa: BLE001
         ms_graph = f"failed: {type(exc).__name__}: {exc}"[:200]
-    finally:
-        if prev is None:
-            os.environ.pop("RGCN_DEFERRED_CHECKS", None)
-        else:
-            os.environ["RGCN_DEFERRED_CHECKS"] = prev
     roof = _roof(name, kms, alg, "scored triples x (three d-wide rows + 24 B of indices [+ two gradient rows])")
     if name == "gemm":      # the dense (B d) x d contraction and its two backward products: bound by the matrix cores
         flops = 2.0 * N * 2 * d * d

@@ -23,6 +23,7 @@
 
 #include "rgcn_hip.h"
 #include "rgcn_zero.h"
+#include "rgcn_options.h"
 
 extern "C" void rgcn_set_error(const char *fmt, ...);
 
@@ -550,8 +551,8 @@ extern "C" int rgcn_basis_aggregate_f32(const float *X, const float *comps, floa
   (void)R;
   if (!X || !comps || !out || !rowptr || n_rows < 0 || B <= 0 || d <= 0 || (n_b_in != 1 && n_b_in != B)) { rgcn_set_error("basis_aggregate: bad argument"); return RGCN_EINVAL; }
   if (!n_rows) return RGCN_OK;
-  static const int vec_mode = getenv("RGCN_BASIS_VEC4") ? atoi(getenv("RGCN_BASIS_VEC4")) : 1;
-  if (vec_mode && (d & 3) == 0 && d >= 32 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+  const int vec_mode = rgcn_option_value(RGCN_OPT_BASIS_VEC4);
+  if (vec_mode && (d & 3) == 0 && d >= 16 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
     int lpm = 1;
     while (lpm < 64 && 4 * lpm < d) lpm *= 2;
     if (n_b_in == 1)

@@ -422,7 +422,7 @@ extern "C" int rgcn_block_spmm_f32(const float *X, const float *blocks, const fl
   const int4 *un = reinterpret_cast<const int4 *>(units);
   // table in LDS: worth it when the graph is large enough to amortise 512 table loads (and the table fits)
   const size_t table_bytes = (size_t)n_rel_blocks * nb * bi * bo * sizeof(float);
-  static const int lds_mode = getenv("RGCN_BLOCK_LDS") ? atoi(getenv("RGCN_BLOCK_LDS")) : 1;
+  const int lds_mode = rgcn_option_value(RGCN_OPT_BLOCK_LDS);
   const size_t lds_bytes = table_bytes + (size_t)n_rel_blocks * 4 * sizeof(float);          // + the per-relation pad
   if (bi == 4 && bo == 4 && lds_mode && lds_bytes <= LDS_TABLE_BYTES && n_units >= 64 * 1024) {
     const dim3 pgrid((unsigned)std::min<int64_t>(512, (n_units * lr + BIG_WG - 1) / BIG_WG));
@@ -438,7 +438,7 @@ extern "C" int rgcn_block_spmm_f32(const float *X, const float *blocks, const fl
       return hipGetLastError();
     };
     static bool raised_t = false, raised_n = false, raised_pt = false, raised_pn = false;
-    static const int pipe = getenv("RGCN_BLOCK_PIPE") ? atoi(getenv("RGCN_BLOCK_PIPE")) : 1;
+    const int pipe = rgcn_option_value(RGCN_OPT_BLOCK_PIPE);
     if (pipe && nb == 4 && un) {          // width 16: the software-pipelined form
       const dim3 pg((unsigned)std::min<int64_t>(512, (n_units + BIG_WG / 16 - 1) / (BIG_WG / 16)));
       auto launch_p = [&](auto kern, bool &raised) -> hipError_t {

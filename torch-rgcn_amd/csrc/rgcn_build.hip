@@ -19,6 +19,7 @@
 
 #include "rgcn_hip.h"
 #include "rgcn_zero.h"
+#include "rgcn_options.h"
 
 extern "C" void rgcn_set_error(const char *fmt, ...);
 

@@ -796,7 +796,8 @@ hipError_t launch_bwd_lean(const LeanLaunch &a) {
 }
 template <int NW, int NG, bool AT>
 hipError_t launch_bwd_lean_f(const LeanLaunch &a, bool relu) {
-  static const int ABL = getenv("RGCN_BWD_ABL") ? atoi(getenv("RGCN_BWD_ABL")) : 0;     // timing experiments (wrong results)
+#ifdef RGCN_ABLATIONS
+  const int ABL = rgcn_option_value(RGCN_OPT_BWD_ABL);     // timing experiments (wrong results): ablation build only
   if (NW == 16 && AT && ABL) {
     switch (ABL) {
       case 1: return launch_bwd_lean<16, 3, true, false, 1>(a);
@@ -808,6 +809,7 @@ hipError_t launch_bwd_lean_f(const LeanLaunch &a, bool relu) {
       default: break;
     }
   }
+#endif
   return relu ? launch_bwd_lean<NW, NG, AT, true>(a) : launch_bwd_lean<NW, NG, AT, false>(a);
 }
 
@@ -884,7 +886,7 @@ extern "C" int rgcn_bwd_lean_f32(const float *G, const float *X, const float *Wt
   }
   const bool atomic = (flags & RGCN_F_DW_ATOMIC) != 0, relu = (flags & RGCN_F_RELU) != 0;
   if (!atomic && !scratch) { rgcn_set_error("bwd_lean: the deterministic reduction needs a scratch buffer"); return RGCN_EINVAL; }
-  static const int WIN_NW = getenv("RGCN_BWD_NW") ? atoi(getenv("RGCN_BWD_NW")) : 16;
+  const int WIN_NW = rgcn_option_value(RGCN_OPT_BWD_NW);
   const bool nw16 = WIN_NW >= 16 && bwd_lean_lds<16, 3>(tile_rows) <= 160 * 1024;
   const bool nw8 = !nw16 && bwd_lean_lds<8, 1>(tile_rows) <= 160 * 1024;
   if (!nw16 && !nw8) { rgcn_set_error("bwd_lean: tile_rows = %d does not fit the LDS of a CU", tile_rows); return RGCN_EUNSUPPORTED; }
@@ -924,19 +926,19 @@ extern "C" int rgcn_bwd_fused_f32(const float *G, const float *X, const float *W
   // round 2's staging kernel: the fallback for wave-owned tiles the lean kernel's LDS does not hold (65..160 rows) and
   // RGCN_BWD_KERNEL=stage; rgcn_bwd_blk_f32 / rgcn_bwd_lean_f32 are the round-3 kernels
   if (relu) { rgcn_set_error("bwd_fused: RGCN_F_RELU is implemented by rgcn_bwd_blk_f32 / rgcn_bwd_lean_f32 only (tile_rows = %d)", tile_rows); return RGCN_EUNSUPPORTED; }
-  static const int DSEL = getenv("RGCN_BWD_D") ? atoi(getenv("RGCN_BWD_D")) : 4;
+  const int DSEL = rgcn_option_value(RGCN_OPT_BWD_D);
   const int Dv = DSEL >= 4 ? 4 : (DSEL >= 2 ? 2 : 1);
   // tiles per workgroup: 8 halve the number of dW partials -- measured at S1 (profiles/r02_bwd_fused_ablation.txt): atomic flush
   // 0.719 -> 0.740 ms (the barrier now waits for the slowest of 8 waves, which costs more than the saved atomics), plain-store
   // flush of the deterministic mode 0.798 -> 0.769 ms (half the partial bytes) -- so 8 only there
-  static const int NWSEL = getenv("RGCN_BWD_WAVES") ? atoi(getenv("RGCN_BWD_WAVES")) : 0;
+  const int NWSEL = rgcn_option_value(RGCN_OPT_BWD_WAVES);
   const int NWwant = NWSEL ? NWSEL : (atomic ? 4 : 8);
   const int NWv = (NWwant >= 8 && Dv == 4 && tile_rows <= 64) ? 8 : 4;
   const size_t lds = ((size_t)NWv * tile_rows * 16 + NWv * BW_SCR + NWv * Dv * 256) * sizeof(float);
   if (lds > (NWv == 8 ? 80 : 64) * 1024) { rgcn_set_error("bwd_fused: tile_rows = %d needs %zu bytes of LDS per workgroup", tile_rows, lds); return RGCN_EUNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
   const int n_blocks = (int)((n_tiles + NWv - 1) / NWv);
-  static const int USEL = getenv("RGCN_BWD_U") ? atoi(getenv("RGCN_BWD_U")) : 4;
+  const int USEL = rgcn_option_value(RGCN_OPT_BWD_U);
   const int2 *pk = reinterpret_cast<const int2 *>(p_pack);
   const BwdLaunch L{G, X, Wt_packed, dX, atomic ? dW : scratch, pk, chunk_rel, run_ptr, (int)n_tiles, n_blocks, tile_rows,
                     (int)n_dst, R, lds, st};

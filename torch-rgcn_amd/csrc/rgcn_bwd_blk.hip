@@ -523,7 +523,7 @@ extern "C" int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_
   };
 #ifdef RGCN_ABLATIONS
   {
-    static const int ABLV = getenv("RGCN_BWD_ABL") ? atoi(getenv("RGCN_BWD_ABL")) : 0;     // timing experiments (wrong results): this library only
+    const int ABLV = rgcn_option_value(RGCN_OPT_BWD_ABL);     // timing experiments (wrong results): this library only
     static bool a0 = false, a1 = false, a2 = false, a3 = false, a4 = false, a5 = false, a6 = false, a7 = false;
     if (tq != 1 || diag4) { rgcn_set_error("bwd_blk (ablation library): only dense weights on tiles of up to 256 rows"); return RGCN_EUNSUPPORTED; }
     if (ABLV == 2) HIP_TRY(launch(bwd_blk_d16_kernel<false, false, 1, 2>, a0));

@@ -13,6 +13,9 @@ extern "C" void rgcn_set_error(const char *fmt, ...);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#include "rgcn_options.h"
+
+
 #define HIP_TRY(expr)                                                                   \
   do {                                                                                  \
     hipError_t e_ = (expr);                                                             \

@@ -600,8 +600,7 @@ extern "C" int rgcn_gemm_f32(const float *A, const float *B, const float *bias, 
   float *out = S > 1 ? scratch : C;
   const long long ldo = S > 1 ? N : ldc, sstride = S > 1 ? (long long)M * N : 0;
   // 64-row tiles when they spread better over the 256 CUs: rounds of 128-row tile work on the busiest CU
-  const char *bm_s = getenv("RGCN_GEMM_BM");          // (read per call: the tests switch it)
-  const int bm_env = bm_s ? atoi(bm_s) : 0;
+  const int bm_env = rgcn_option_value(RGCN_OPT_GEMM_BM);
   const int64_t t128 = (int64_t)tiles_m * tiles_n * S, t64 = ((M + 63) / 64) * tiles_n * S;
   const bool half = bm_env ? bm_env == 64 : ((t64 + 255) / 256 < 2 * ((t128 + 255) / 256) && t128 > 256);
   if (half) tiles_m = (int)((M + 63) / 64);

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "rgcn_hip.h"
+#include "rgcn_options.h"
 
 namespace {
 thread_local char g_err[512] = "";
@@ -23,6 +24,55 @@ extern "C" void rgcn_set_error(const char *fmt, ...) {
 
 extern "C" const char *rgcn_last_error(void) { return g_err; }
 extern "C" const char *rgcn_version(void) { return "rgcn-hip 0.1 (gfx950)"; }
+
+// ---- tuning options: name, value (= default until rgcn_set_option).  No getenv anywhere in the library: torch_rgcn/routes.py (or any
+// other host) decides and says so through this table.
+namespace {
+struct OptEntry { const char *name; int32_t value; };
+OptEntry g_options[] = {
+    {"basis_vec4", 1},            // rgcn_basis_aggregate_f32: 16-byte loads when d % 4 == 0, d >= 16
+    {"block_lds", 1},             // rgcn_block_spmm_f32: block table in LDS
+    {"block_pipe", 1},            //   software-pipelined 4 x 4 kernel
+    {"bwd_nw", 16},               // rgcn_bwd_lean_f32: waves per workgroup (16 / 8)
+    {"bwd_d", 4},                 // rgcn_bwd_fused_f32 (staging kernel): relations per barrier interval
+    {"bwd_waves", 0},             //   tiles per workgroup (0: 4 atomic / 8 deterministic)
+    {"bwd_u", 4},                 //   chunks in flight
+    {"gemm_bm", 0},               // rgcn_gemm_f32: 0 auto, 64 / 128 rows per tile
+    {"spmm_u", 4},                // rgcn_spmm_f32 hidden-16 kernel: chunks per loop iteration
+    {"wgrad_rg", 1},              // rgcn_wgrad_tiled_f32 variants
+    {"wgrad_u", 2},
+    {"distmult_one_launch", 0},   // rgcn_distmult_bwd_all_f32: one launch for the three gradients
+    {"rank_tile", 1},             // rgcn_distmult_score_all_f32: 1 LDS-staged; 22 / 24 / 42 / 44 register tiles
+    {"bwd_abl", 0},               // ablation build only: timing experiments with WRONG results
+    {"rank_ablate", 0},
+};
+static_assert(sizeof(g_options) / sizeof(g_options[0]) == RGCN_OPT_COUNT, "option table out of step with enum RgcnOpt (rgcn_device.h)");
+}  // namespace
+
+extern "C" int32_t rgcn_option_value(int index) { return (index >= 0 && index < RGCN_OPT_COUNT) ? g_options[index].value : 0; }
+
+extern "C" int rgcn_set_option(const char *name, int32_t value) {
+  for (auto &o : g_options)
+    if (name && !strcmp(o.name, name)) {
+#ifndef RGCN_ABLATIONS
+      if ((!strcmp(name, "bwd_abl") || !strcmp(name, "rank_ablate")) && value) {
+        rgcn_set_error("set_option: %s exists in the ablation build only (make -C torch-rgcn_amd/csrc abl)", name);
+        return RGCN_EUNSUPPORTED;
+      }
+#endif
+      o.value = value;
+      return RGCN_OK;
+    }
+  rgcn_set_error("set_option: unknown option %s", name ? name : "(null)");
+  return RGCN_EINVAL;
+}
+
+extern "C" int rgcn_get_option(const char *name, int32_t *value) {
+  for (auto &o : g_options)
+    if (name && value && !strcmp(o.name, name)) { *value = o.value; return RGCN_OK; }
+  rgcn_set_error("get_option: unknown option %s", name ? name : "(null)");
+  return RGCN_EINVAL;
+}
 
 namespace {
 

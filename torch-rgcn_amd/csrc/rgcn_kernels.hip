@@ -1423,7 +1423,7 @@ extern "C" int rgcn_spmm_f32(const float *X, const float *W, const float *bias, 
   hipLaunchKernelGGL((spmm_d16_kernel<U, P>), grid, block, lds, st, X, W, bias, out, p_src, p_dst, p_val, pk,      \
                      chunk_rel, tile_ptr, nt, tile_rows, (int)n_dst, relu_out)
   if (d_in == 16 && d_out == 16) {
-    static const int U = getenv("RGCN_SPMM_U") ? atoi(getenv("RGCN_SPMM_U")) : 4;
+    const int U = rgcn_option_value(RGCN_OPT_SPMM_U);
     if (packed) {
       if (U >= 8) RGCN_LAUNCH_D16(8, true);
       else if (U >= 4) RGCN_LAUNCH_D16(4, true);
@@ -1565,8 +1565,8 @@ extern "C" int rgcn_wgrad_tiled_f32(const float *X, const float *G, float *dW, c
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(zero_async(dW, (size_t)R * 256 * sizeof(float), st));
   if (n_tiles == 0) return RGCN_OK;
-  static const int RGSEL = getenv("RGCN_WGRAD_RG") ? atoi(getenv("RGCN_WGRAD_RG")) : 1;
-  static const int USEL = getenv("RGCN_WGRAD_U") ? atoi(getenv("RGCN_WGRAD_U")) : 2;
+  const int RGSEL = rgcn_option_value(RGCN_OPT_WGRAD_RG);
+  const int USEL = rgcn_option_value(RGCN_OPT_WGRAD_U);
   const int RGv = RGSEL <= 1 ? 1 : RGSEL <= 2 ? 2 : RGSEL <= 4 ? 4 : RGSEL <= 8 ? 8 : 16;
   const int n_groups = (R + RGv - 1) / RGv;
   tiles_per_item = std::min(tiles_per_item, 8);   // the kernel keeps the run bounds of one item in registers
@@ -1797,7 +1797,7 @@ extern "C" int rgcn_distmult_bwd_all_f32(const int32_t *rowptr_s, const int32_t 
   if (!n_nodes) return RGCN_OK;
   const unsigned gx = (unsigned)std::min<int64_t>((n_nodes + 3) / 4, 512);
   const size_t lds = (size_t)4 * ((size_t)n_rel * d + n_rel) * sizeof(float);
-  static const int one_launch = getenv("RGCN_DISTMULT_ONE_LAUNCH") ? atoi(getenv("RGCN_DISTMULT_ONE_LAUNCH")) : 0;
+  const int one_launch = rgcn_option_value(RGCN_OPT_DISTMULT_ONE_LAUNCH);
   if (one_launch) {
     hipLaunchKernelGGL(distmult_bwd_all_kernel<3>, dim3(gx), dim3(WG), lds, st, rowptr_s, other_s, rel_s, g_s, rowptr_o, other_o, rel_o,
                        g_o, nodes, rel, dnodes, drel, dsbias, dpbias, dobias, (long long)n_nodes, n_rel, d);

@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 #include "rgcn_hip.h"
+#include "rgcn_options.h"
 
 extern "C" void rgcn_set_error(const char *fmt, ...);
 
@@ -77,7 +78,13 @@ __device__ __forceinline__ f32x4 mask_k4(f32x4 v, int k, int d) {
 template <bool VEC, int TA, int TB>
 __global__ __launch_bounds__(WG) void score_all_kernel(
     const float *__restrict__ qvec, const float *__restrict__ qb, const float *__restrict__ nodes,
-    const float *__restrict__ cbias, float *__restrict__ scores, int Q, long long N, int d, int head, int q_blocks, int ablate) {
+    const float *__restrict__ cbias, float *__restrict__ scores, int Q, long long N, int d, int head, int q_blocks, int ablate_arg) {
+#ifdef RGCN_ABLATIONS
+  const int ablate = ablate_arg;      // timing experiments (wrong results): ablation build only
+#else
+  constexpr int ablate = 0;
+  (void)ablate_arg;
+#endif
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = lane & 15, kq = lane >> 4;
   // query block fastest: workgroups that are resident together share one slab of the entity table (L2), and the whole
@@ -311,8 +318,12 @@ extern "C" int rgcn_distmult_score_all_f32(const int64_t *batch, int64_t Q, int3
   hipLaunchKernelGGL(rank_query_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(WG), 0, st,
                      reinterpret_cast<const long long *>(batch), (int)Q, head, nodes, rel, sbias, pbias, obias, qvec,
                      qbias, d);
-  static const int ablate = getenv("RGCN_RANK_ABLATE") ? atoi(getenv("RGCN_RANK_ABLATE")) : 0;   // measurement only
-  static const int tile_env = getenv("RGCN_RANK_TILE") ? atoi(getenv("RGCN_RANK_TILE")) : 1;   // 1 = LDS-staged (default); TA*10 + TB = register-only variant
+  #ifdef RGCN_ABLATIONS
+  const int ablate = rgcn_option_value(RGCN_OPT_RANK_ABLATE);   // measurement only (ablation build)
+#else
+  constexpr int ablate = 0;
+#endif
+  const int tile_env = rgcn_option_value(RGCN_OPT_RANK_TILE);   // 1 = LDS-staged (default); TA*10 + TB = register-only variant
   const int tile = (tile_env == 22 || tile_env == 24 || tile_env == 42 || tile_env == 44) ? tile_env : 1;
   if (tile == 1) {
     const int qbl = (int)((Q + 127) / 128);

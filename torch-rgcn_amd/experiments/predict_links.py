@@ -19,6 +19,7 @@ import torch.nn.functional as F
 import yaml
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from torch_rgcn import routes  # noqa: E402
 from torch_rgcn.models import CompressionRelationPredictor, LinkPredictor  # noqa: E402
 from utils.data import load_link_prediction_data  # noqa: E402
 from utils.misc import evaluate, generate_true_dict, negative_sampling, select_sampling  # noqa: E402
@@ -26,18 +27,12 @@ from utils.misc import evaluate, generate_true_dict, negative_sampling, select_s
 OPTIMISERS = {"adam": torch.optim.Adam, "adamw": torch.optim.AdamW, "adagrad": torch.optim.Adagrad, "sgd": torch.optim.SGD}
 
 
-def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None, synthetic=None, hipgraph=False):
-    """see _run; process-wide settings a run changes (RGCN_DEFERRED_CHECKS for --hipgraph) are restored on every way out"""
-    import contextlib
-    with contextlib.ExitStack() as cleanup:
-        return _run(cfg, data_dir, epochs, quiet, max_test, synthetic, hipgraph, cleanup)
-
-
-def _run(cfg, data_dir, epochs, quiet, max_test, synthetic, hipgraph, _cleanup):
+def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None, synthetic=None, hipgraph=None):
     """-> (loss per epoch, {"mrr", "hits@1", "hits@3", "hits@10"} of the final evaluation).
-    hipgraph=True: the training step (per-step graph build, encoder, decoder, loss, backward, optimiser) is captured once in
-    a hipGraph and replayed every epoch on freshly sampled inputs copied into static buffers; needs the sync-free plan
-    builder (RGCN_DEFERRED_CHECKS=1, set here)."""
+    The training step (per-step graph build, encoder, decoder, loss, backward, optimiser) is captured once in a hipGraph and replayed
+    every epoch on freshly sampled inputs copied into static buffers -- BY DEFAULT (hipgraph=None: unless route `capture` is "0";
+    falls back to the eager loop, with a warning, if the capture fails; True insists, False is the reference's loop literally).
+    The capture runs under the sync-free plan builder (route deferred_checks = 1, scoped to the warm-up and the capture)."""
     dataset, training, encoder = cfg["dataset"], cfg["training"], cfg["encoder"]
     decoder, evaluation = cfg.get("decoder", {}), cfg.get("evaluation", {})
     max_epochs = epochs or training.get("epochs", 5000)
@@ -88,22 +83,16 @@ def _run(cfg, data_dir, epochs, quiet, max_test, synthetic, hipgraph, _cleanup):
     if opt_cfg["algorithm"] not in OPTIMISERS:
         raise NotImplementedError(f"'{opt_cfg['algorithm']}' optimiser has not been implemented!")
     extra = {"fused": True} if opt_cfg["algorithm"] in ("adam", "adamw") else {}
-    deferred_before = os.environ.get("RGCN_DEFERRED_CHECKS")
+    insist = hipgraph is True
+    if hipgraph is None:
+        hipgraph = routes.get("capture", "1") != "0"
     if hipgraph:
         # a captured step cannot read the device-side range-check flags back: validate the triples the sampler draws from HERE,
         # once, on the host (the kernels additionally clamp and kill out-of-range triples, csrc/rgcn_build.hip)
         tr = np.asarray(train)
         assert tr.size == 0 or (tr[:, [0, 2]].min() >= 0 and tr[:, [0, 2]].max() < num_nodes and tr[:, 1].min() >= 0
                                 and tr[:, 1].max() < num_relations), "training triples: node or relation index out of range"
-        os.environ["RGCN_DEFERRED_CHECKS"] = "1"            # no device -> host reads inside the captured step
         extra = {"capturable": True} if opt_cfg["algorithm"] in ("adam", "adamw") else {}
-
-        def _restore_env():                                  # also when the run raises (registered below)
-            if deferred_before is None:
-                os.environ.pop("RGCN_DEFERRED_CHECKS", None)
-            else:
-                os.environ["RGCN_DEFERRED_CHECKS"] = deferred_before
-        _cleanup.callback(_restore_env)
     optimiser = OPTIMISERS[opt_cfg["algorithm"]](model.parameters(), lr=opt_cfg["learn_rate"],
                                                   weight_decay=opt_cfg["weight_decay"], **extra)
 
@@ -148,17 +137,26 @@ def _run(cfg, data_dir, epochs, quiet, max_test, synthetic, hipgraph, _cleanup):
         # hipMemsetAsync NODES with stale arguments; the library zero-fills with kernels now, tools/hipgraph_repro/.)
         static = [t.clone() for t in sample_inputs()]
         # the warm-up steps below are real optimiser steps: parameters and optimiser state are put back afterwards (in place -- the
-        # captured graph holds their addresses), so that a --hipgraph run starts epoch 1 from the same state as the eager run
+        # captured graph holds their addresses), so that a captured run starts epoch 1 from the same state as the eager run
         saved_params = [p.detach().clone() for p in model.parameters()]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                        # warm-up off the capture: allocator pools, lazy inits
-            for _ in range(3):
-                train_step(*static)
-        torch.cuda.current_stream().wait_stream(side)
-        captured = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(captured):
-            static_loss = train_step(*static)
+        try:
+            with routes.override(deferred_checks="1"):       # no device -> host reads inside the captured step
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):                    # warm-up off the capture: allocator pools, lazy inits
+                    for _ in range(3):
+                        train_step(*static)
+                torch.cuda.current_stream().wait_stream(side)
+                captured = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(captured):
+                    static_loss = train_step(*static)
+        except Exception as exc:  # noqa: BLE001  (the eager loop runs the same HIP kernels: a slower path, not another implementation)
+            if insist:
+                raise
+            import warnings
+            warnings.warn(f"hipGraph capture of the training step failed ({type(exc).__name__}: {exc}); running the eager loop")
+            torch.cuda.synchronize()
+            captured = None
         with torch.no_grad():
             for p, q in zip(model.parameters(), saved_params):
                 p.copy_(q)
@@ -215,7 +213,8 @@ if __name__ == "__main__":
                     "the dataset's entity / relation / triple counts (timing and plumbing only: MRR / Hits mean nothing)")
     ap.add_argument("--epochs", type=int, default=None)
     ap.add_argument("--max-test", type=int, default=None)
-    ap.add_argument("--hipgraph", action="store_true", help="capture the training step in a hipGraph and replay it every epoch")
+    ap.add_argument("--hipgraph", action="store_true", help="insist on the captured training step (the default tries it and falls back to eager)")
+    ap.add_argument("--eager", action="store_true", help="the reference's loop literally: no hipGraph capture")
     a = ap.parse_args()
     run(yaml.safe_load(open(a.config)), a.data, a.epochs, max_test=a.max_test, synthetic=True if a.synthetic else None,
-        hipgraph=a.hipgraph)
+        hipgraph=False if a.eager else (True if a.hipgraph else None))

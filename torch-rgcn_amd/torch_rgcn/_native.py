@@ -11,6 +11,8 @@ import os
 import numpy as np
 import torch
 
+from . import routes
+
 # RGCN_HIP_LIB: tools/ only -- the ablation build (make -C csrc abl -> lib/librgcn_hip_abl.so), whose kernels can be told to skip work
 _LIB_PATH = os.environ.get("RGCN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librgcn_hip.so")
 _lib = None
@@ -41,6 +43,18 @@ def lib():
         L.rgcn_gemm_scratch_floats.restype = ctypes.c_int64
         L.rgcn_last_error.restype = ctypes.c_char_p
         _lib = L
+        defaults = {}
+
+        def sink(name, value):      # routes -> the library's option table (None: back to the library's default)
+            if name not in defaults:
+                cur = ctypes.c_int32(0)
+                L.rgcn_get_option(name.encode(), ctypes.byref(cur))
+                defaults[name] = cur.value
+            v = defaults[name] if value is None else value
+            if L.rgcn_set_option(name.encode(), c_i32(v)) != OK:
+                raise NativeLibraryError(f"route {name} = {v}: {L.rgcn_last_error().decode()}")
+        routes._native_sink = sink
+        routes.push_native()
     return _lib
 
 
@@ -283,7 +297,7 @@ _PINNED_FREE = []        # recycled 1-int pinned host buffers (allocating pinned
 
 
 def _deferred_mode():
-    return os.environ.get("RGCN_DEFERRED_CHECKS", "0") == "1"
+    return routes.get("deferred_checks", "0") == "1"
 
 
 def dev_check_err(err_flag, what, exc=AssertionError):
@@ -796,7 +810,7 @@ def _spmm_prepare(X, W, bias, plan):
     assert X.shape == (plan.n_src, d_in), f"features {tuple(X.shape)} vs ({plan.n_src}, {d_in})"
     assert R == plan.num_rels
     flags = 0
-    if plan.pack is not None and not os.environ.get("RGCN_NO_PACK"):
+    if plan.pack is not None and not routes.get("no_pack"):
         if d_in == 16 and d_out == 16:
             W = pack_w16(W)
             flags |= F_WPACKED
@@ -881,7 +895,7 @@ def spmm_two_pass(X, W, bias, scatter_plan, csr, relu=False):
     p = scatter_plan
     n_msg = int(csr.rowptr[-1].item()) if csr.n_messages is None else csr.n_messages
     out = torch.empty((csr.n_rows, 16), device=X.device, dtype=torch.float32)
-    gather = os.environ.get("RGCN_TWOPASS", "gather") == "gather"
+    gather = routes.get("twopass", "gather") == "gather"
     if gather:
         _slot_perm(p, n_msg, X.device)
         Y = torch.empty((max(p.dst.shape[0], 1), 16), device=X.device, dtype=torch.float32)
@@ -994,7 +1008,7 @@ def pack_w16t(W):
 
 def bwd_route():
     """RGCN_BWD_KERNEL: blk (default: block-tile kernel where it applies, else lean) | lean | stage -- DESIGN.md 4.2"""
-    return os.environ.get("RGCN_BWD_KERNEL", "blk")
+    return routes.get("bwd_kernel", "blk")
 
 
 _BLK_MIN_NODES = 32768      # below: a tile per workgroup leaves most CUs idle; the wave-owned 64-row (or smaller) tiles stay
@@ -1009,7 +1023,7 @@ def bwd_blk_rows(n_nodes, num_rels, deterministic=False, device=None, diag4=Fals
     if bwd_route() != "blk" or deterministic or n_nodes < (_BLK_MIN_NODES_SPARSE if sparse else _BLK_MIN_NODES):
         return 0
     cap = int(lib().rgcn_bwd_blk_max_rows(c_i32(num_rels), c_i32(F_DIAG4 if diag4 else 0)))
-    cap = min(cap, int(os.environ.get("RGCN_BWD_BLK_CAP", "512")))
+    cap = min(cap, int(routes.get("bwd_blk_cap", "512")))
     if cap < 64:
         return 0
     n_cu = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).multi_processor_count
@@ -1199,7 +1213,7 @@ def _csr_units(csr):
     RGCN_DETERMINISTIC=1: no pieces (they merge with fp32 atomics, in arrival order) -- a hub row is then one long unit"""
     if getattr(csr, "sync_free", False) or getattr(csr, "per_call", False):
         return None, csr.n_rows, 0              # (per-call graphs of the LP layer: the statistics would cost two read-backs a step)
-    if os.environ.get("RGCN_DETERMINISTIC", "0") == "1":
+    if routes.get("deterministic", "0") == "1":
         if getattr(csr, "units_whole", None) is None:
             csr.units_whole = row_units(csr.rowptr, csr.n_rows, 1 << 30)
         return csr.units_whole

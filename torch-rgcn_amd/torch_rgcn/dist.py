@@ -14,6 +14,8 @@ The reference has no multi-GPU code at all.
 """
 import numpy as np
 import torch
+
+from . import routes
 import torch.distributed as dist
 
 
@@ -77,15 +79,15 @@ _SUMMED_PARAMS = ("bases",)
 _PER_RELATION_PARAMS = ("weights", "comps", "blocks")
 
 
-TRANSPORTS = ("allreduce", "rs_ag", "a2a", "none")
+TRANSPORTS = ("allreduce", "rs_ag", "a2a")
 
 
 def set_transport(layer, comm="allreduce", slabs=0):
     """How a sharded layer sums its partial N x d matrices over the group (functional._join_shards): "allreduce", "rs_ag"
     (reduce-scatter + all-gather), "a2a" (direct exchange: all-to-all of row blocks + local sum + all-gather); slabs > 0
     (with "allreduce"): the partial is produced slab by slab and every slab is reduced asynchronously while the next one's
-    kernels run.  "none" skips the collective -- TIMING ONLY (bench.py's compute-alone leg), the numbers are wrong.
-    State of the layer, not of the process."""
+    kernels run.  State of the layer, not of the process.  (There is no "no collective" transport: bench.py's compute-alone leg
+    patches functional._join_shards locally.)"""
     assert comm in TRANSPORTS, f"unknown transport {comm!r}"
     layer._shard_transport = (comm, int(slabs))
     return layer
@@ -112,10 +114,9 @@ def shard_layer(layer, group=None, keep="all", comm=None, slabs=None):
     layer._shard_group = group
     layer._shard_keep = keep
     layer._graph = None  # rebuild with the filter
-    # transport: argument, else the environment's default read ONCE here (RGCN_DIST_COMM / RGCN_DIST_SLABS), else all-reduce
-    import os
-    set_transport(layer, comm if comm is not None else os.environ.get("RGCN_DIST_COMM", "allreduce"),
-                  slabs if slabs is not None else int(os.environ.get("RGCN_DIST_SLABS", "0")))
+    # transport: argument, else the routes' default (dist_comm / dist_slabs), else all-reduce
+    set_transport(layer, comm if comm is not None else routes.get("dist_comm", "allreduce"),
+                  slabs if slabs is not None else int(routes.get("dist_slabs", "0")))
     # `bases` sums over ALL relations whichever way the relations were split: its gradient is all-reduced in both modes
     if not getattr(layer, "_shard_hooks", None):
         layer._shard_hooks = [getattr(layer, n).register_hook(_sum_over_group(group))

@@ -12,13 +12,15 @@ import os
 
 import torch
 
+from . import routes
+
 from . import _native
 
 
 def _wgrad_tiles(plan):
     """destination tiles per work item of the tile-major weight gradient: more tiles amortise the item's set-up and its
     256 atomics (8 measured best at S1), fewer keep small graphs parallel"""
-    env = os.environ.get("RGCN_WGRAD_TILES")
+    env = routes.get("wgrad_tiles")
     return int(env) if env else (8 if plan.n_tiles >= 4096 else 4)
 
 
@@ -27,7 +29,7 @@ def _sparse_buckets(graph, W):
     if W.shape[1] != 16 or W.shape[2] != 16 or getattr(graph, "_dev", None) is None or getattr(graph, "sync_free", False) or \
             getattr(graph, "per_call", False):
         return False            # (the two-pass path sizes its scratch by a message count read back from the device)
-    mode = os.environ.get("RGCN_SPARSE_PATH", "auto")
+    mode = routes.get("sparse_path", "auto")
     if mode != "auto":
         return mode == "1"
     fp = graph.fwd_plan(16)
@@ -45,7 +47,7 @@ def _pad_blocks(X, W, bias, graph=None):
     -> (X', W', bias', (d_in, d_out)) or the inputs unchanged and None."""
     d_in, d_out = W.shape[1], W.shape[2]
     pi, po = -d_in % 16, -d_out % 16
-    if max(d_in, d_out) > _BLOCKED_MAX or (pi == 0 and po == 0) or os.environ.get("RGCN_PAD16", "1") == "0" or \
+    if max(d_in, d_out) > _BLOCKED_MAX or (pi == 0 and po == 0) or routes.get("pad16", "1") == "0" or \
             (graph is not None and _wide_gemm_path(graph, d_in, d_out)):       # (the gather-GEMM takes ragged widths as they are)
         return X, W, bias, None
     pad = torch.nn.functional.pad
@@ -60,7 +62,7 @@ def _wide_gemm_path(graph, d_in, d_out):
     """undecomposed weights above width 64: relation-grouped gather-GEMM on the matrix cores + per-destination row sum
     (csrc/rgcn_gemm.hip); needs the device-side graph and host-known message counts (not the sync-free per-call build)"""
     return (max(d_in, d_out) > 64 and getattr(graph, "_dev", None) is not None and not getattr(graph, "sync_free", False)
-            and os.environ.get("RGCN_WIDE", "gemm") == "gemm")
+            and routes.get("wide", "gemm") == "gemm")
 
 
 def _spmm_blocked(X, W, bias, plan_of, relu=False, graph=None, kind="fwd"):
@@ -72,7 +74,7 @@ def _spmm_blocked(X, W, bias, plan_of, relu=False, graph=None, kind="fwd"):
     if graph is not None and _wide_gemm_path(graph, d_in, d_out):
         return _native.spmm_wide_two_pass(X, W, bias, graph.scatter_plan(kind, 8), graph.csr(kind), relu=relu)
     if max(d_in, d_out) <= 64 or d_in % 16 or d_out % 16 or max(d_in, d_out) > _BLOCKED_MAX or \
-            os.environ.get("RGCN_PAD16", "1") == "0":
+            routes.get("pad16", "1") == "0":
         return _native.spmm(X, W, bias, plan_of(d_out), relu=relu and max(d_in, d_out) <= 64)
     xs = [X[:, i:i + 64].contiguous() for i in range(0, d_in, 64)]
     cols = []
@@ -101,7 +103,7 @@ def deterministic():
     sum them in a fixed order (+0.1-0.15 ms per layer at S1) -- instead of the block-tile kernel, whose waves add to the shared
     dX tile, to dW and to the bias gradient in arrival order (fp32 sums differ in the last bits from run to run).  Outputs are
     reproducible either way."""
-    return os.environ.get("RGCN_DETERMINISTIC", "0") == "1"
+    return routes.get("deterministic", "0") == "1"
 
 
 def _dense_buckets(plan):
@@ -148,7 +150,7 @@ def _fused_backward(X, W, g, graph, relu_in=False, want_db=False, diag4=False, s
     RGCN_BWD=split asks for round 1's two-pass backward.  relu_in: X is the output of a ReLU and dX is wanted before it
     (masked with X > 0 in the kernel's epilogue); returns (dX, dW, masked, db) -- db: the bias gradient when want_db and the kernel
     sums G's columns on the side (block-tile kernel), else None."""
-    if W.shape[1] != 16 or W.shape[2] != 16 or os.environ.get("RGCN_BWD", "fused") == "split":
+    if W.shape[1] != 16 or W.shape[2] != 16 or routes.get("bwd", "fused") == "split":
         return None
     bp = graph.bwd_blk_plan(diag4, sparse)                  # tall tiles, one per workgroup -- or the wave-owned 64-row plan
     diag4 = diag4 and bp is not None and _native._bwd_blk_plan(bp, True)   # block-diagonal W (4 x 4 blocks): only on the block-tile kernel
@@ -171,7 +173,7 @@ def _weight_gradient(X, W, g, graph):
     # one wave would serialise it (hub nodes): then the relation-major kernel with bounded work items
     # and unless the (tile, relation) buckets are so sparse that a work item is a fraction of a chunk
     tiled_ok = W.shape[1] == 16 and W.shape[2] == 16 and fp.max_run_chunks <= 64 and _dense_buckets(fp)
-    if tiled_ok and os.environ.get("RGCN_WGRAD", "tiled") == "tiled":
+    if tiled_ok and routes.get("wgrad", "tiled") == "tiled":
         return _native.wgrad_tiled(X, g, fp, W.shape[0], _wgrad_tiles(fp))
     return _native.wgrad(X, g, graph.wgt_plan(), W.shape[0])
 
@@ -188,13 +190,13 @@ class _RelationalMP(torch.autograd.Function):
         fused_relu = relu and (max(W.shape[1], W.shape[2]) <= 64 or _wide_gemm_path(graph, W.shape[1], W.shape[2]))   # kernel epilogues
         with _native.w16_scope() as w16:        # [R,16,16] weights: both fragment orders packed once, handed to the backward below
             if _sparse_buckets(graph, W) and blocks is not None and ctx.dims is None and tuple(blocks.shape[2:]) == (4, 4) and \
-                    os.environ.get("RGCN_BLOCK_FWD", "1") != "0":
+                    routes.get("block_fwd", "1") != "0":
                 # W = block_diag(blocks), 4 x 4 blocks, sparse buckets (AM): the forward reads the blocks themselves on the CSR
                 # kernel (block table in LDS; one gather per message, no transformed-row buffer): 0.46 ms against 0.65 ms for the
                 # two passes below.  The backward stays on the dense W (dX rows + dW from one relation-major walk; autograd
                 # through block_diag() picks the blocks' gradient out of dW).
                 out = _native.block_spmm(X, blocks.detach().contiguous(), b, graph.csr("fwd"), relu=fused_relu)
-            elif _sparse_buckets(graph, W) and os.environ.get("RGCN_SPMM_CSR", "1") != "0" and \
+            elif _sparse_buckets(graph, W) and routes.get("spmm_csr", "1") != "0" and \
                     _native.spmm_csr_d16_ok(graph.csr("fwd"), W.shape[0]):
                 # sparse buckets, up to 120 relations: ONE pass over the destination-major CSR, messages of mixed relations, W in LDS
                 out = _native.spmm_csr_d16(X, W, b, graph.csr("fwd"), relu=fused_relu)
@@ -237,15 +239,15 @@ class _RelationalMP(torch.autograd.Function):
         # sparse (tile, relation) buckets normally leave the tile plan -- except on a graph the block-tile kernel takes: its tall tiles
         # (128 .. 512 rows) hold several messages per bucket where a 64-row tile holds one or two, and dW of all relations (block-diagonal
         # weights: its diagonal blocks) fits the workgroup's LDS.  One launch instead of the two-pass backward's three.
-        blk_sparse = sparse and os.environ.get("RGCN_BWD", "fused") != "split" and \
+        blk_sparse = sparse and routes.get("bwd", "fused") != "split" and \
             _native.bwd_blk_rows(graph.num_nodes, graph.num_rels, deterministic(), graph.device, ctx.diag4, True) > 0
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and (not sparse or blk_sparse):
             both = _fused_backward(X, W, g, graph, relu_in=ctx.in_token is not None and ctx.dims is None and not ctx.in_token.observed(),
                                    want_db=ctx.has_bias and ctx.needs_input_grad[2], diag4=ctx.diag4, sparse=sparse)
             if both is not None:
                 both, masked, db = both[:2], both[2], both[3]
-        if both is None and sparse and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and os.environ.get("RGCN_BWD", "fused") != "split" \
-                and os.environ.get("RGCN_TWOPASS", "gather") == "gather" and not deterministic():
+        if both is None and sparse and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and routes.get("bwd", "fused") != "split" \
+                and routes.get("twopass", "gather") == "gather" and not deterministic():
             # sparse buckets: relation-major walk, G[s] and X[o] gathered once each for dX's rows and dW together
             both = _native.bwd_two_pass_fused(g, X, W, graph.scatter_plan("bwd"), graph.csr("bwd"))
         if both is not None:
@@ -274,12 +276,9 @@ def _join_shards(partial, group, mode="allreduce"):
                            collectives: lets RCCL pick its direct algorithms per half; same bytes on every link)
       a2a                  direct exchange: all-to-all of the row blocks (every rank sends block j straight to rank j: on the
                            fully connected xGMI mesh all 7 links carry 1/8 of the matrix at once, a ring carries 7/8 of it
-                           through every link in turn), local sum of the world_size received blocks, all-gather
-      none                 no collective at all -- TIMING ONLY (bench.py's compute-alone leg); results are wrong"""
+                           through every link in turn), local sum of the world_size received blocks, all-gather"""
     import torch.distributed as dist
-    assert mode in ("allreduce", "rs_ag", "a2a", "none"), f"unknown transport {mode!r}"
-    if mode == "none":
-        return partial
+    assert mode in ("allreduce", "rs_ag", "a2a"), f"unknown transport {mode!r}"
     if mode == "a2a":
         world = dist.get_world_size(group)
         n, d = partial.shape
@@ -380,9 +379,9 @@ def _featureless_csr(graph, width):
     """the featureless layer's route: destination-major CSR kernels (one lane group per message) when the (tile, relation) buckets
     of the tile plan are mostly padding (AIFB: 91 relations on 8-row tiles, 23 slots per message) and the graph is static"""
     if getattr(graph, "_dev", None) is None or getattr(graph, "sync_free", False) or getattr(graph, "per_call", False) or \
-            os.environ.get("RGCN_FEATURELESS_CSR", "auto") == "0":
+            routes.get("featureless_csr", "auto") == "0":
         return False
-    if os.environ.get("RGCN_FEATURELESS_CSR", "auto") == "1":
+    if routes.get("featureless_csr", "auto") == "1":
         return True
     fp = graph.fwd_plan(width)
     return not _dense_buckets(fp) and graph.max_degree() <= 4096
@@ -462,7 +461,7 @@ def use_block_path(graph, blocks):
     width 16 the expanded 16 x 16 weights on the matrix-core kernels are faster (AM shape, 4 x 4 blocks: 1.96 ms per layer
     forward + backward against 2.43 -- every message re-reads its blocks from L2, 4x the bytes of its feature row), so
     RGCN_BLOCK_PATH=1 (default) takes the block kernels only above width 16; 2 = whenever supported; 0 = never."""
-    mode = os.environ.get("RGCN_BLOCK_PATH", "1")
+    mode = routes.get("block_path", "1")
     if mode == "0" or getattr(graph, "_dev", None) is None or not _native.block_supported(blocks.shape[2], blocks.shape[3]):
         return False
     wide = blocks.shape[1] * blocks.shape[2] > 16 or blocks.shape[1] * blocks.shape[3] > 16
@@ -505,7 +504,7 @@ def diag_mp(features, w, bias, graph):
 
 def use_diag_path(graph, d):
     """the diagonal kernels need the device-side graph build (CSR + relation-major plan)"""
-    return getattr(graph, "_dev", None) is not None and os.environ.get("RGCN_DIAG_PATH") != "0"
+    return getattr(graph, "_dev", None) is not None and routes.get("diag_path") != "0"
 
 
 def _split_k(K, M, N):
@@ -553,7 +552,7 @@ class _BasisMP(torch.autograd.Function):
         B, d_in, d_out = bases.shape
         b = None if bias is None else dense(bias)
         need_bwd = any(ctx.needs_input_grad[:4])
-        if _native.basis_fused_supported(B, d_in) and os.environ.get("RGCN_BASIS_FUSED", "0") == "1":
+        if _native.basis_fused_supported(B, d_in) and routes.get("basis_fused", "0") == "1":
             out, ag = _native.basis_fused_fwd(X, comps, bases, b, graph.csr("fwd"), keep_ag=need_bwd and ctx.needs_input_grad[1])
         else:
             ag = _native.basis_aggregate(X, comps, graph.csr("fwd"), B, d_in, 1)          # [N, B*d_in]
@@ -588,12 +587,12 @@ class _FeaturelessBasisMP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, bases, comps, bias, graph):
         B, N, d = bases.shape
-        ctx.src_major = _native.fbasis_supported(B, d) and os.environ.get("RGCN_FBASIS", "src") == "src"
+        ctx.src_major = _native.fbasis_supported(B, d) and routes.get("fbasis", "src") == "src"
         # Layout of the table the source-major kernels walk.  Node-major [N, B, d] (a transposed copy per step, and a transposed
         # gradient back): a node's B rows are ONE contiguous run -- what a table far beyond the caches needs (AM as shipped: 2.7 GB,
         # rows of 40 bytes: reading them in place, 40 half-used lines per node, cost 33.5 ms per step against 24).  Basis-major
         # [B, N, d] = the parameter itself, no copies: wins while the table stays cache-resident (MUTAG: 45 MB, step 0.56 -> 0.51 ms).
-        ctx.in_place = ctx.src_major and B * N * d * 4 <= int(os.environ.get("RGCN_FBASIS_INPLACE_MB", "256")) << 20
+        ctx.in_place = ctx.src_major and B * N * d * 4 <= int(routes.get("fbasis_inplace_mb", "256")) << 20
         if ctx.src_major and ctx.in_place:
             comps, bases = dense(comps), dense(bases)
             ctx.graph, ctx.has_bias = graph, bias is not None
@@ -652,7 +651,7 @@ def basis_mp(features, bases, comps, bias, graph):
 
 def use_basis_path(num_bases, d_in, d_out, graph):
     """aggregate-then-contract pays when the per-message d_in x d_out product is large and B is small"""
-    if os.environ.get("RGCN_BASIS_PATH") == "0" or getattr(graph, "_dev", None) is None:
+    if routes.get("basis_path") == "0" or getattr(graph, "_dev", None) is None:
         return False
     return d_in * d_out >= 64 * 64 and num_bases <= 8
 
@@ -692,7 +691,7 @@ class _DistMultScore(torch.autograd.Function):
         tr, nodes, relations = ctx.saved_tensors
         gs = gs.reshape(-1)
         gs = dense(gs)
-        mode = os.environ.get("RGCN_DISTMULT_BWD", "csr")
+        mode = routes.get("distmult_bwd", "csr")
         scatter = mode == "atomic" or tr.shape[0] == 0
         if not scatter and mode != "split" and _native.distmult_bwd_all_supported(relations.shape[0], nodes.shape[1]):
             # small relation tables (WN18: 18 x 200): every gradient from the two CSR walks, no predicate sort

@@ -16,6 +16,8 @@ import os
 import numpy as np
 import torch
 
+from . import routes
+
 from . import _native
 
 _LDS_WAVE_FLOATS = 2048  # 8 KiB of LDS per wave-owned destination tile (4 waves per workgroup)
@@ -27,7 +29,7 @@ def pick_tile_rows(width, n_rows=None):
     (more waves in flight) win; the LDS row stride is the width rounded up to 4 floats.
     Small graphs get smaller tiles still: a tile is one wave, and a few dozen waves cannot fill 256 CUs."""
     ld = (max(1, width) + 3) & ~3
-    env = os.environ.get("RGCN_TILE_ROWS")
+    env = routes.get("tile_rows")
     if env:
         return max(1, min(int(env), 4096 // ld))
     rows = max(1, min(128, _LDS_WAVE_FLOATS // ld))        # widths up to 4096 floats fit the 64 KiB workgroup budget
@@ -86,7 +88,7 @@ class RelGraph:
             nosync = self.sync_free or getattr(self, "per_call", False)
             # RGCN_DETERMINISTIC=1: no hub pieces (a tile cut into several work units merges its pieces with fp32 atomics, in
             # arrival order): a hub tile is one long unit for one wave -- slow on skewed graphs, bit-reproducible
-            whole = os.environ.get("RGCN_DETERMINISTIC", "0") == "1"
+            whole = routes.get("deterministic", "0") == "1"
             self._plans[key] = _native.build_plan_device(dst, src, p, val, alive, N, N, R, tile_rows, self.num_messages,
                                                          max_item_chunks, want_runs=True, want_pack=True, sync_free=nosync,
                                                          **({"max_unit_chunks": 1 << 30} if whole else {}))
@@ -109,28 +111,28 @@ class RelGraph:
     def bwd_plan(self, d_in):
         """transposed plan with wave-owned tiles (spmm on the transposed graph, the wave-owned fused backward kernels)"""
         rows = pick_tile_rows(d_in, self.num_nodes)
-        if d_in == 16 and "RGCN_TILE_ROWS" not in os.environ:
+        if d_in == 16 and not routes.is_set("tile_rows"):
             # hidden 16: the fused backward kernels (dX + dW in one walk) keep a dX tile, an X tile, a transposition scratch and
             # the dW hand-over slots in LDS: 64-row tiles (measured in round 2: 0.71 ms at 64 rows, 0.80 at 128)
-            rows = int(os.environ["RGCN_BWD_TILE_ROWS"]) if "RGCN_BWD_TILE_ROWS" in os.environ else min(rows, 64)
+            rows = int(routes.get("bwd_tile_rows")) if routes.is_set("bwd_tile_rows") else min(rows, 64)
         return self._plan("bwd", rows)
 
     def bwd_blk_plan(self, diag4=False, sparse=False):
         """transposed plan of TALL tiles (one per workgroup, up to 255 / 512 rows) for the block-tile backward kernel, or None
         when that kernel does not apply (small graph, too many relations, RGCN_DETERMINISTIC=1, RGCN_BWD_KERNEL != blk).
         Only rgcn_bwd_blk_f32 can walk it -- every other kernel gets bwd_plan()."""
-        if "RGCN_TILE_ROWS" in os.environ:
+        if routes.is_set("tile_rows"):
             return None
-        if "RGCN_BWD_TILE_ROWS" in os.environ and _native.bwd_route() == "blk":
-            rows = int(os.environ["RGCN_BWD_TILE_ROWS"])         # experiments (tools/r3_blk.sh)
+        if routes.is_set("bwd_tile_rows") and _native.bwd_route() == "blk":
+            rows = int(routes.get("bwd_tile_rows"))         # experiments (tools/r3_blk.sh)
             return self._plan("bwd", rows) if rows > 64 else None
-        rows = _native.bwd_blk_rows(self.num_nodes, self.num_rels, os.environ.get("RGCN_DETERMINISTIC", "0") == "1", self.device, diag4,
+        rows = _native.bwd_blk_rows(self.num_nodes, self.num_rels, routes.get("deterministic", "0") == "1", self.device, diag4,
                                     sparse)
         return self._plan("bwd", rows) if rows else None
 
     def wgt_plan(self):
         """relation-major (single tile): long runs per relation for the weight gradient"""
-        return self._plan("fwd", max(self.num_nodes, 1), int(os.environ.get("RGCN_WGRAD_ITEM_CHUNKS", "64")))
+        return self._plan("fwd", max(self.num_nodes, 1), int(routes.get("wgrad_item_chunks", "64")))
 
     def csr(self, kind, need_slot=False):
         """destination-major ("fwd": rows = subjects) or source-major ("bwd") CSR for the basis kernels.  need_slot: with the
@@ -205,7 +207,7 @@ class RelGraph:
 
 
 def _device_build_enabled():
-    return os.environ.get("RGCN_GRAPH_BUILD", "device") == "device"
+    return routes.get("graph_build", "device") == "device"
 
 
 def node_order(s, o, num_nodes, how):
@@ -256,7 +258,7 @@ def graph_from_nc_triples(triples_plus, num_nodes, num_rels, vertical, device, r
     (node_order); graph.perm[old] = new, graph.inv[new] = old on the device -- the layer reads its features through inv and
     returns its output through perm, so callers never see the relabelling.  The normalisation is computed on the original
     ids first (it only counts equal (relation, node) keys: invariant under a relabelling)."""
-    relabel = relabel if relabel is not None else (os.environ.get("RGCN_RELABEL") or None)
+    relabel = relabel if relabel is not None else (routes.get("relabel") or None)
     if _device_build_enabled() and num_nodes * num_rels < _MAX_CELLS:
         t = torch.as_tensor(triples_plus, dtype=torch.long).reshape(-1, 3).to(device)
         M = t.shape[0]

@@ -18,6 +18,8 @@ import math
 import os
 
 import torch
+
+from . import routes
 from torch import nn
 from torch.nn import Module, Parameter
 
@@ -231,7 +233,7 @@ class RelationalGraphConvolutionNC(_RGCBase):
             features = features.index_select(0, graph.inv)
 
         fl_basis = (self.in_features is None and self.weight_decomp == 'basis' and not self.vertical_stacking and
-                    getattr(graph, "_dev", None) is not None and os.environ.get("RGCN_BASIS_PATH") != "0")
+                    getattr(graph, "_dev", None) is not None and routes.get("basis_path") != "0")
         # block-diagonal weights: the blocks are applied as they are (csrc/rgcn_block.hip); blocks above 8 x 8, or a host-built
         # graph, are expanded to dense R x d x d weights and multiplied per message by the relation-grouped gather-GEMM of
         # csrc/rgcn_gemm.hip (hand-written MFMA).  Round 1-2 had a third route for small graphs -- einsum('nbi,rbio->rnbo') on
