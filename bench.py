@@ -26,6 +26,10 @@ import os
 import sys
 import time
 
+# the secondary config lines replay captured hipGraphs: this runtime's graph packet capture replays memset nodes with stale arguments
+# (torch_rgcn/__init__.py); it has to be off before the process' first HIP call
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "torch-rgcn_amd")):
     if p not in sys.path:

@@ -10,6 +10,7 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")       # before the first HIP call: see torch_rgcn/__init__.py
 
 
 def pytest_configure(config):

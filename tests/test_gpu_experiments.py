@@ -25,18 +25,47 @@ def test_classify_nodes_aifb_shaped_learns():
 
 
 def test_classify_nodes_hipgraph_replay_matches_eager():
-    """the captured training step is the same computation: identical loss trajectory (same seed, deterministic plan)"""
+    """the captured training step is the same computation, from the same state (the warm-up steps of the capture are undone): the
+    loss trajectory of the DEFAULT path (capture unless it fails), of hipgraph=True and of the eager loop agree epoch by epoch"""
     sys.path.insert(0, os.path.join(PKG, "experiments"))
     import classify_nodes
     import torch
     hist = {}
-    for mode in (False, True):
+    for mode in (False, True, None):
         torch.manual_seed(0)
         hist[mode] = classify_nodes.run(cfg("nc-MUTAG.yaml"), epochs=8, quiet=True, hipgraph=mode, synthetic=True)
-    # the capture warms up with 3 extra optimiser steps: epoch k of the replay is eager epoch k + 3... compare shapes and trend
     assert len(hist[True]) == 8 and hist[True][-1][0] < hist[True][0][0]
-    # (fp32 atomics in the featureless weight gradient make the two trajectories drift apart in the last digits)
-    assert abs(hist[True][0][0] - hist[False][3][0]) < 5e-2 * abs(hist[False][3][0])
+    # (fp32 atomics in the weight gradients make the trajectories drift apart in the last digits, amplified by Adam over the epochs)
+    for mode in (True, None):
+        for k in range(8):
+            assert abs(hist[mode][k][0] - hist[False][k][0]) < 2e-2 * abs(hist[False][k][0]), (mode, k, hist[mode][k][0], hist[False][k][0])
+        assert abs(hist[mode][0][0] - hist[False][0][0]) < 1e-4 * abs(hist[False][0][0]), "epoch 1 starts from the same state"
+
+
+def test_experiments_default_to_the_captured_step(monkeypatch):
+    """the default run of both experiments replays a captured hipGraph (route capture=0 / --eager: the reference's loop)"""
+    sys.path.insert(0, os.path.join(PKG, "experiments"))
+    import classify_nodes
+    import predict_links
+    import torch
+    replays = []
+    orig = torch.cuda.CUDAGraph.replay
+    monkeypatch.setattr(torch.cuda.CUDAGraph, "replay", lambda self: (replays.append(1), orig(self))[1])
+    classify_nodes.run(cfg("nc-AIFB.yaml"), epochs=3, quiet=True, synthetic=True)
+    assert len(replays) == 6, "3 training replays + 3 evaluation replays"
+    del replays[:]
+    c = cfg("lp-WN18.yaml")
+    c["dataset"]["name"] = "fb-toy"
+    c["encoder"].update(node_embedding=32, hidden1_size=32)
+    c["training"].update(graph_batch_size=500)
+    c["evaluation"].update(check_every=1000, batch_size=32, verbose=False)
+    predict_links.run(c, epochs=4, quiet=True, max_test=10, synthetic=True)
+    assert len(replays) == 4
+    del replays[:]
+    from torch_rgcn import routes
+    with routes.override(capture="0"):
+        classify_nodes.run(cfg("nc-AIFB.yaml"), epochs=2, quiet=True, synthetic=True)
+    assert not replays
 
 
 def test_classify_nodes_mutag_shaped_basis():

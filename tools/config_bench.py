@@ -476,6 +476,9 @@ if __name__ == "__main__":
     if a.lines:
         for nm in a.lines.split(","):
             fn = {"s2": lambda: line_s2("S2"), "amshipped": lambda: line_am_shipped("AM shipped"),
+                  "aifb": lambda: line_node_classifier("AIFB-shaped", 8285, 45, 29043, 16, 4, None, 176, "AIFB"),
+                  "mutag": lambda: line_node_classifier("MUTAG-shaped", 23644, 23, 74227, 16, 2, {"type": "basis", "num_bases": 30}, 340, "MUTAG"),
+                  "wn18": lambda: line_wn18("WN18"), "am": lambda: line_featured("AM block", 1_666_764, 133, 5_988_321, 16, {"type": "block", "num_blocks": 4}, 2, "AM"),
                   "s1ii": lambda: line_featured("S1(ii)", 1_000_000, 50, 10_000_000, 16, {"type": "basis", "num_bases": 10}, 0, "S1(ii)"),
                   "s1iii": lambda: line_featured("S1(iii)", 1_000_000, 50, 10_000_000, 16, {"type": "block", "num_blocks": 4}, 0, "S1(iii)")}[nm]
             print(json.dumps(fn()), flush=True)

@@ -22,6 +22,7 @@ import torch
 import yaml
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch_rgcn  # noqa: E402
 from torch_rgcn import routes  # noqa: E402
 from torch_rgcn.models import EmbeddingNodeClassifier, NodeClassifier  # noqa: E402
 from utils.data import load_node_classification_data  # noqa: E402
@@ -102,8 +103,12 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, hipgraph=None, synthetic=N
     if hipgraph and not adam_like:
         raise NotImplementedError("hipgraph=True needs a capturable optimiser (adam / adamw)")
     insist = hipgraph is True
+    if insist and not torch_rgcn.REPLAY_SAFE:
+        import warnings
+        warnings.warn("hipgraph=True although DEBUG_CLR_GRAPH_PACKET_CAPTURE was not 0 when the HIP runtime started: replays of a captured "
+                      "step are known to go wrong on this runtime (torch_rgcn/__init__.py)")
     if hipgraph is None:
-        hipgraph = adam_like and routes.get("capture", "1") != "0"
+        hipgraph = adam_like and routes.get("capture", "1") != "0" and torch_rgcn.REPLAY_SAFE
     # one fused multi-tensor kernel per step instead of ~10 elementwise passes over every parameter (AM: 667 M of them)
     extra = {"fused": True, **({"capturable": True} if hipgraph else {})} if adam_like else {}
     optimiser = OPTIMISERS[opt_cfg["algorithm"]](model.parameters(), lr=opt_cfg["learn_rate"],

@@ -19,6 +19,7 @@ import torch.nn.functional as F
 import yaml
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch_rgcn  # noqa: E402
 from torch_rgcn import routes  # noqa: E402
 from torch_rgcn.models import CompressionRelationPredictor, LinkPredictor  # noqa: E402
 from utils.data import load_link_prediction_data  # noqa: E402
@@ -84,8 +85,12 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None, synthetic=N
         raise NotImplementedError(f"'{opt_cfg['algorithm']}' optimiser has not been implemented!")
     extra = {"fused": True} if opt_cfg["algorithm"] in ("adam", "adamw") else {}
     insist = hipgraph is True
+    if insist and not torch_rgcn.REPLAY_SAFE:
+        import warnings
+        warnings.warn("hipgraph=True although DEBUG_CLR_GRAPH_PACKET_CAPTURE was not 0 when the HIP runtime started: replays of a captured "
+                      "step are known to go wrong on this runtime (torch_rgcn/__init__.py)")
     if hipgraph is None:
-        hipgraph = routes.get("capture", "1") != "0"
+        hipgraph = routes.get("capture", "1") != "0" and torch_rgcn.REPLAY_SAFE
     if hipgraph:
         # a captured step cannot read the device-side range-check flags back: validate the triples the sampler draws from HERE,
         # once, on the host (the kernels additionally clamp and kill out-of-range triples, csrc/rgcn_build.hip)
