@@ -47,7 +47,7 @@ import torch.distributed as dist  # noqa: E402
 
 METRIC = "edges/s/GPU (fwd+bwd) 2-layer RGCN, 1M nodes/10M edges/50 rels, h=16"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def fwd_bytes(M, N, d_in, d_out):
@@ -61,7 +61,7 @@ def bwd_bytes(M, N, d_in, d_out, x_needs_grad=True):
 
 
 def _profile_json(name):
-    for rnd in (PROFILE_ROUND, "r02", "r01"):
+    for rnd in (PROFILE_ROUND, "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")) as f:
                 return json.load(f), f"profiles/{rnd}_{name}.json"
@@ -76,9 +76,15 @@ def pmc_traffic(kernel_substr, doubled=True):
     if data is None:
         return None, None
     for name, c in data.items():
-        if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        if name != "_meta" and kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             return int(((2.0 if doubled else 1.0) * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024), src
     return None, None
+
+
+def static_profile_identity():
+    """csrc_sha the committed counter files were taken on (their _meta block; None for files older than round 4)"""
+    data, src = _profile_json("pmc_kernels")
+    return ((data or {}).get("_meta") or {}).get("csrc_sha"), src
 
 
 def pmc_detail(kernel_key):
@@ -99,6 +105,11 @@ def pmc_detail(kernel_key):
         return None
 
 
+def _loaded_csrc_sha():
+    from torch_rgcn import _native
+    return _native.csrc_sha()
+
+
 def kernel_roofline(kernel, avg_ms, alg_bytes, bytes_model, step_ms, launches_per_step, pmc_substrs, pmc_key):
     """roofline block of one kernel (group): achieved = SURVEY 8(d) ALGORITHMIC bytes / the average launch time measured
     live with HIP events inside the timed region; traffic / pmc are STATIC (the committed rocprofv3 --pmc summaries of
@@ -116,6 +127,8 @@ def kernel_roofline(kernel, avg_ms, alg_bytes, bytes_model, step_ms, launches_pe
             "algorithmic_bytes_per_launch": alg_bytes, "bytes_model": bytes_model,
             "traffic": traffic, "traffic_if_64B_requests": traffic64,
             "traffic_rate_GBs": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None,
+            "traffic_static_csrc_sha": static_profile_identity()[0] if traffic else None,
+            "traffic_static_csrc_match": (static_profile_identity()[0] == _loaded_csrc_sha()) if traffic else None,
             "traffic_static": (f"{tsrc}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on the same S1 launch, NOT measured in "
                                "this run; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B, "
                                "MI355X_MICROARCH.md HBM section)") if traffic else None,
@@ -463,21 +476,38 @@ def main():
             path_ms = n_spmm * spmm_ms + (2 * bwd["avg_launch_ms"] if "bwd_fused" in launches else (2 * launches["wgrad"][0] if "wgrad" in launches else 0.0))
             roof["step_minus_path_kernels_ms"] = round(ms - path_ms, 4)
             roof["other_kernels_ms"] = {k: round(v[0], 4) for k, v in launches.items() if k != spmm_key}
-        elif spmm_key:   # strong scaling: a rank's launch covers its share of the messages only
+        elif spmm_key:   # strong scaling: a rank's launches cover ITS share of the messages only (rank 0's shard here)
             spmm_ms = launches[spmm_key][0]
             m_local = my_messages
-            ach = fwd_bytes(m_local, N, d, d) / (spmm_ms * 1e-3) / 1e9
-            roof = {"kernel": "spmm_d16_kernel on rank 0's relation shard", "bound": "hbm", "achieved": round(ach, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                    "avg_launch_ms": round(spmm_ms, 4), "algorithmic_bytes_per_launch": fwd_bytes(m_local, N, d, d),
-                    "other_kernels_ms": {k: round(v[0], 4) for k, v in launches.items() if k != spmm_key}}
+
+            def local(kernel, t_ms, alg_b, model, per_step):
+                ach = alg_b / (t_ms * 1e-3) / 1e9
+                return {"kernel": kernel + " on rank 0's relation shard", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(t_ms, 4),
+                        "launches_per_step": per_step, "algorithmic_bytes_per_launch": int(alg_b), "bytes_model": model,
+                        "share_of_step": round(per_step * t_ms / ms, 4)}
+            n_spmm = 2 if "bwd_fused" in launches else 4
+            fwd = local("spmm_d16_kernel", spmm_ms, fwd_bytes(m_local, N, d, d), "SURVEY 8(d) forward on the local messages: M_local(4 d_in + 8) + N 4 d_out", n_spmm)
+            bwd = None
+            if "bwd_fused" in launches:
+                bwd = local("fused backward (dX + dW from one gather per local message)", launches["bwd_fused"][0], bwd_bytes(m_local, N, d, d),
+                            "SURVEY 8(d) backward on the local messages: M_local(4 d_out + 8) + 2 N 4 d_in", 2)
+            elif "wgrad" in launches:
+                bwd = local("spmm_d16_kernel (dX) + wgrad (dW)", spmm_ms + launches["wgrad"][0], bwd_bytes(m_local, N, d, d),
+                            "SURVEY 8(d) backward on the local messages: M_local(4 d_out + 8) + 2 N 4 d_in", 2)
+            roof = dict(bwd if (bwd is not None and bwd["share_of_step"] >= fwd["share_of_step"]) else fwd)
+            roof["forward"] = fwd
+            if bwd is not None:
+                roof["backward"] = bwd
+            roof["local_messages"] = int(m_local)
+            roof["other_kernels_ms"] = {k: round(v[0], 4) for k, v in launches.items() if k != spmm_key}
         res = {"metric": METRIC, "value": value, "unit": "edges/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
                "scaling": "weak" if mode == "weak" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "per_gpu_edges_per_s": value / world,
                "step_ms_median": round(float(np.median(per_step)), 4), "step_ms_min": round(float(np.min(per_step)), 4),
                "step_ms_p95": round(float(np.percentile(per_step, 95)), 4), "sustained": sustained,
-               "graph_build_ms": round(graph_build_ms, 2),
+               "graph_build_ms": round(graph_build_ms, 2), "csrc_sha": _native.csrc_sha(),
                "config": {"workload": (f"S1: N={N} nodes, E={E} base triples" + ("/GPU" if mode == "weak" else "") +
                                        f", R0={R0} relations" + ("/GPU" if mode == "weak" else "") +
                                        f" (layer R={2 * R0 + 1}), M={M} messages/layer, hidden={d}, 2 NC layers "

@@ -44,6 +44,9 @@ extern "C" {
 
 RGCN_API const char *rgcn_version(void);
 RGCN_API const char *rgcn_last_error(void);
+/* first 16 hex digits of the SHA-256 over the library's sources (csrc/*.hip, *.cpp, *.h + this header) at build time: profiles/ carry
+ * it, bench.py reports whether the committed counter files were taken on THIS binary (no reference counterpart) */
+RGCN_API const char *rgcn_csrc_sha(void);
 /* Tuning options: the library never reads the environment -- whoever hosts it (torch_rgcn/routes.py) decides and says so here.
  * Names: basis_vec4, block_lds, block_pipe, bwd_nw, bwd_d, bwd_waves, bwd_u, gemm_bm, spmm_u, wgrad_rg, wgrad_u,
  * distmult_one_launch, rank_tile (all of them choose between kernels that compute the same result), and bwd_abl / rank_ablate:

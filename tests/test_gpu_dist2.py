@@ -244,6 +244,14 @@ def test_bench_contract_with_two_ranks_on_one_gpu():
     assert sum(comm["messages_per_rank"]) == 2 * 1_000_000 + 200_000 and min(comm["messages_per_rank"]) > 0
     assert comm["collectives_per_step"] == 4 and comm["compute_alone_ms_per_step"] > 0 and comm["collectives_alone_ms_per_step"] > 0
     assert comm["collective"] in comm["candidates_ms_per_step"] and res["graph_build_ms"] > 0
+    # the strong-scaling line carries the LOCAL kernels' rooflines (forward and backward on rank 0's shard) and the
+    # exposed communication time
+    roof = res["roofline"]
+    assert roof["local_messages"] == comm["messages_per_rank"][0]
+    assert roof["forward"]["kernel"].startswith("spmm_d16_kernel") and 0 < roof["forward"]["frac"] < 1
+    assert "backward" in roof and 0 < roof["backward"]["frac"] < 1 and roof["backward"]["launches_per_step"] == 2
+    assert roof["backward"]["algorithmic_bytes_per_launch"] == roof["local_messages"] * (4 * 16 + 8) + 2 * 200_000 * 64
+    assert "exposed_ms_per_step" in comm and comm["exposed_ms_per_step"] == pytest.approx(res["ms_per_step"] - comm["compute_alone_ms_per_step"], abs=1e-3)
 
 
 def test_bench_weak_mode_still_available():

@@ -23,11 +23,16 @@ for f in glob.glob(out + "/k*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         per[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 keys = {"spmm": "spmm_d16_kernel", "bwd_fused": "bwd_fused_d16_kernel<4, true", "bwd_fused_deterministic": "bwd_fused_d16_kernel<4, false",
-        "bwd_blk": "bwd_blk_d16_kernel<false, 0, false, 1>", "bwd_lean": "bwd_lean_d16_kernel<16, 3, true, false", "bwd_lean_deterministic": "bwd_lean_d16_kernel<16, 3, false, false",
+        "bwd_blk": "bwd_blk_d16_kernel<false, false, 1>", "bwd_lean": "bwd_lean_d16_kernel<16, 3, true, false", "bwd_lean_deterministic": "bwd_lean_d16_kernel<16, 3, false, false",
         "wgrad_tiled": "wgrad_tiled_d16_kernel"}
-detail = {"_how": "tools/pmc_passes.sh: separate rocprofv3 --pmc passes over tools/kbench.py --what spmm,bwd,wtiled (S1 launches); means per launch. "
+import os, subprocess
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "torch-rgcn_amd"))
+from torch_rgcn import _native
+head = open(".git_head_for_profiles").read().strip() if os.path.exists(".git_head_for_profiles") else "unknown"
+meta = {"csrc_sha": _native.csrc_sha(), "git_head": head, "command": "tools/pmc_passes.sh (rocprofv3 --pmc, separate passes, tools/kbench.py --what spmm,bwd at S1)"}
+detail = {"_meta": meta, "_how": "tools/pmc_passes.sh: separate rocprofv3 --pmc passes over tools/kbench.py --what spmm,bwd,wtiled (S1 launches); means per launch. "
                   "GRBM_GUI_ACTIVE is summed over the 8 XCDs: MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)"}
-kernels = {}
+kernels = {"_meta": meta}
 for name, c in per.items():
     means = {k: sum(v) / len(v) for k, v in c.items()}
     for key, sub in keys.items():

@@ -24,6 +24,10 @@ extern "C" void rgcn_set_error(const char *fmt, ...) {
 
 extern "C" const char *rgcn_last_error(void) { return g_err; }
 extern "C" const char *rgcn_version(void) { return "rgcn-hip 0.1 (gfx950)"; }
+#ifndef RGCN_CSRC_SHA
+#define RGCN_CSRC_SHA "unknown"
+#endif
+extern "C" const char *rgcn_csrc_sha(void) { return RGCN_CSRC_SHA; }
 
 // ---- tuning options: name, value (= default until rgcn_set_option).  No getenv anywhere in the library: torch_rgcn/routes.py (or any
 // other host) decides and says so through this table.

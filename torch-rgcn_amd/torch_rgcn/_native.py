@@ -36,6 +36,7 @@ def lib():
                 "(hipcc --offload-arch=gfx950). torch_rgcn has no CPU/eager fallback.")
         L = ctypes.CDLL(_LIB_PATH)
         L.rgcn_version.restype = ctypes.c_char_p
+        L.rgcn_csrc_sha.restype = ctypes.c_char_p
         L.rgcn_bwd_fused_scratch_floats.restype = ctypes.c_int64
         L.rgcn_bwd_lean_slot_bytes.restype = ctypes.c_int64
         L.rgcn_bwd_blk_rec_bytes.restype = ctypes.c_int64
@@ -60,6 +61,11 @@ def lib():
 
 def version():
     return lib().rgcn_version().decode()
+
+
+def csrc_sha():
+    """identity of the kernel sources the loaded library was built from (rgcn_csrc_sha)"""
+    return lib().rgcn_csrc_sha().decode()
 
 
 def _check(rc, what):
