@@ -44,7 +44,7 @@ extern "C" {
 
 RGCN_API const char *rgcn_version(void);
 RGCN_API const char *rgcn_last_error(void);
-/* first 16 hex digits of the SHA-256 over the library's sources (csrc/*.hip, *.cpp, *.h + this header) at build time: profiles/ carry
+/* first 16 hex digits of the SHA-256 over the library sources (every .hip / .cpp / .h under csrc plus this header) at build time: profiles/ carry
  * it, bench.py reports whether the committed counter files were taken on THIS binary (no reference counterpart) */
 RGCN_API const char *rgcn_csrc_sha(void);
 /* Tuning options: the library never reads the environment -- whoever hosts it (torch_rgcn/routes.py) decides and says so here.
@@ -452,6 +452,13 @@ RGCN_API int rgcn_fbasis_small_bwd_f32(const float *G, const float *table, const
 RGCN_API int rgcn_gather_rows_sum_f32(const float *Y, const int32_t *perm, const int32_t *units, int64_t n_units,
                                       int64_t n_split, const float *bias, float *out, int64_t n_rows, int32_t w,
                                       void *stream);
+
+/* Classifier head of the node-classification experiments, one launch: loss = mean cross-entropy of the logits' LABELLED rows and
+ * dlogits [N, C] = d loss / d logits (zero rows for unlabelled nodes).  Replaces `criterion(model()[train_idx, :], train_lbl)` with
+ * nn.CrossEntropyLoss() and its autograd graph (reference experiments/classify_nodes.py:107-110, :129): row_label [N] = class of the
+ * node or -1, lab_rows [n_lab] = the labelled nodes (each once).  C <= 64. */
+RGCN_API int rgcn_ce_head_f32(const float *logits, const int32_t *row_label, const int32_t *lab_rows, float *loss, float *dlogits,
+                              int64_t N, int32_t C, int32_t n_lab, void *stream);
 
 /* ------------------------------------------------------------------ dense contractions on the matrix cores
  * Basis decomposition (layers.py:241-242, :468-469: W_r = sum_b comps[r,b] bases[b]) at large width: the layer is

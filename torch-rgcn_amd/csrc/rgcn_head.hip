@@ -1,0 +1,76 @@
+// Classifier head of the node-classification experiments: mean cross-entropy over the LABELLED rows of the logits and its gradient,
+// one launch.
+//
+// Reference: experiments/classify_nodes.py:107-110 -- `criterion(model()[train_idx, :], train_lbl)` with nn.CrossEntropyLoss() --
+// which ATen runs as a gather, log-softmax, nll-loss, and in the backward nll-loss backward, log-softmax backward and an
+// index_put with accumulation (a radix sort, an arange, three index-arithmetic kernels, a zero fill): ~13 launches around 200 rows
+// of 4 numbers -- and memset nodes inside a captured step, which this ROCm runtime replays wrongly (torch_rgcn/__init__.py).
+//   blocks 0 .. nb-1 : one thread per node: dlogits[n, :] = (softmax(logits[n, :]) - onehot(label_n)) / n_lab for labelled nodes, 0 else
+//   block  nb        : loss = -1 / n_lab * sum over the labelled rows of log softmax(logits[row])[label]   (double accumulation,
+//                      fixed order: bit-reproducible)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "rgcn_hip.h"
+
+extern "C" void rgcn_set_error(const char *fmt, ...);
+
+namespace {
+constexpr int HB = 256;
+constexpr int MAXC = 64;
+
+__global__ __launch_bounds__(HB) void ce_head_kernel(const float *__restrict__ logits, const int *__restrict__ row_label,
+                                                      const int *__restrict__ lab_rows, float *__restrict__ loss,
+                                                      float *__restrict__ dlogits, long long N, int C, int n_lab, int nb) {
+  if ((int)blockIdx.x < nb) {
+    const long long n = (long long)blockIdx.x * HB + threadIdx.x;
+    if (n >= N) return;
+    const int lbl = row_label[n];
+    float *g = dlogits + n * C;
+    if (lbl < 0) {
+      for (int c = 0; c < C; ++c) g[c] = 0.f;
+      return;
+    }
+    const float *x = logits + n * C;
+    float m = x[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(x[c] - m);
+    const float inv = 1.f / (s * (float)n_lab), il = 1.f / (float)n_lab;
+    for (int c = 0; c < C; ++c) g[c] = expf(x[c] - m) * inv - (c == lbl ? il : 0.f);
+    return;
+  }
+  __shared__ double part[HB];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n_lab; i += HB) {
+    const long long n = lab_rows[i];
+    const int lbl = row_label[n];
+    const float *x = logits + n * C;
+    float m = x[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(x[c] - m);
+    acc += (double)(m + logf(s) - x[lbl]);
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = HB / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = (float)(part[0] / (double)n_lab);
+}
+}  // namespace
+
+extern "C" int rgcn_ce_head_f32(const float *logits, const int32_t *row_label, const int32_t *lab_rows, float *loss, float *dlogits,
+                                int64_t N, int32_t C, int32_t n_lab, void *stream) {
+  if (!logits || !row_label || !lab_rows || !loss || !dlogits || N <= 0 || C <= 0 || n_lab <= 0) { rgcn_set_error("ce_head: bad argument"); return RGCN_EINVAL; }
+  if (C > MAXC) { rgcn_set_error("ce_head: %d classes (at most %d)", C, MAXC); return RGCN_EUNSUPPORTED; }
+  const int nb = (int)((N + HB - 1) / HB);
+  hipLaunchKernelGGL(ce_head_kernel, dim3((unsigned)(nb + 1)), dim3(HB), 0, (hipStream_t)stream, logits, row_label, lab_rows, loss, dlogits,
+                     (long long)N, C, n_lab, nb);
+  if (hipGetLastError() != hipSuccess) { rgcn_set_error("ce_head: launch failed"); return RGCN_EHIP; }
+  return RGCN_OK;
+}

@@ -24,6 +24,7 @@ import yaml
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch_rgcn  # noqa: E402
 from torch_rgcn import routes  # noqa: E402
+from torch_rgcn.functional import MaskedCrossEntropy  # noqa: E402
 from torch_rgcn.models import EmbeddingNodeClassifier, NodeClassifier  # noqa: E402
 from utils.data import load_node_classification_data  # noqa: E402
 
@@ -113,12 +114,13 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, hipgraph=None, synthetic=N
     extra = {"fused": True, **({"capturable": True} if hipgraph else {})} if adam_like else {}
     optimiser = OPTIMISERS[opt_cfg["algorithm"]](model.parameters(), lr=opt_cfg["learn_rate"],
                                                   weight_decay=opt_cfg["weight_decay"], **extra)
-    criterion = torch.nn.CrossEntropyLoss()
+    # criterion(model()[train_idx, :], train_lbl) with nn.CrossEntropyLoss() (classify_nodes.py:107-110) as one launch for loss + gradient
+    criterion = MaskedCrossEntropy(train_idx, train_lbl, len(n2i))
     if l2_emb > 0.0 and rgcn.get("model") != "e-rgcn":
         raise ValueError(f"Cannot apply L2-regularisation on node embeddings for {rgcn.get('model')} model")
 
     def objective():
-        loss = criterion(model()[train_idx, :], train_lbl)
+        loss = criterion(model())
         if l2_first > 0.0:
             loss = loss + l2_first * _first_layer_l2(model, decomposition)
         if l2_emb > 0.0:

@@ -1352,6 +1352,18 @@ def colsum(G):
     return db
 
 
+def ce_head(logits, row_label, lab_rows):
+    """(loss [1], dlogits [N, C]) of the mean cross-entropy over the labelled rows (rgcn_ce_head_f32)"""
+    _req(logits, "logits"); _req(row_label, "row_label", torch.int32); _req(lab_rows, "lab_rows", torch.int32)
+    N, C = logits.shape
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    dl = torch.empty_like(logits)
+    with _on(logits.device), _timed("ce_head"):
+        _check(lib().rgcn_ce_head_f32(_dp(logits), _dp(row_label), _dp(lab_rows), _dp(loss), _dp(dl), c_i64(N), c_i32(C),
+                                      c_i32(lab_rows.shape[0]), _stream(logits.device)), "ce_head")
+    return loss, dl
+
+
 def distmult_fwd(triples, nodes, rel, sbias, pbias, obias):
     _req(nodes, "nodes"); _req(rel, "relations"); _req(triples, "triples", torch.int64)
     for b, n in ((sbias, "sbias"), (pbias, "pbias"), (obias, "obias")):

@@ -707,3 +707,36 @@ class _DistMultScore(torch.autograd.Function):
 
 def distmult_score(triples, nodes, relations, sbias=None, pbias=None, obias=None):
     return _DistMultScore.apply(triples, nodes, relations, sbias, pbias, obias)
+
+
+class _MaskedCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, row_label, lab_rows):
+        loss, dl = _native.ce_head(dense(logits), row_label, lab_rows)
+        ctx.save_for_backward(dl)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dl, = ctx.saved_tensors
+        return dl * g, None, None
+
+
+class MaskedCrossEntropy(torch.nn.Module):
+    """`criterion(logits[idx, :], labels)` with nn.CrossEntropyLoss() (reference experiments/classify_nodes.py:107-110) for a FIXED
+    set of labelled nodes, as one kernel for the loss and its gradient instead of ATen's ~13 launches (gather, log-softmax, nll,
+    their backwards and an index_put through a sort): `MaskedCrossEntropy(idx, labels, num_nodes)(logits)`; idx must not repeat."""
+
+    def __init__(self, idx, labels, num_nodes):
+        super().__init__()
+        idx, labels = idx.reshape(-1).long(), labels.reshape(-1).long()
+        assert idx.numel() == labels.numel() and idx.numel() > 0 and torch.unique(idx).numel() == idx.numel(), "labelled nodes: one label each"
+        row_label = torch.full((num_nodes,), -1, dtype=torch.int32, device=idx.device)
+        row_label[idx] = labels.to(torch.int32)
+        self.register_buffer("row_label", row_label, persistent=False)
+        self.register_buffer("lab_rows", idx.to(torch.int32).contiguous(), persistent=False)
+
+    def forward(self, logits):
+        assert logits.dim() == 2 and logits.shape[0] == self.row_label.shape[0]
+        assert int(logits.shape[1]) <= 64, "at most 64 classes"
+        return _MaskedCE.apply(logits, self.row_label, self.lab_rows)
