@@ -61,7 +61,7 @@ def timeit(fn, iters):
 ref = None
 for how in a.orders.split(","):
     t0 = time.time()
-    g = graph_from_nc_triples(tp, N, R, False, dev, relabel=None if how == "none" else how)
+    g = graph_from_nc_triples(tp, N, R, False, dev, relabel=how)
     t_order = time.time() - t0
     Xp, Gp = (X, G) if g.perm is None else (X.index_select(0, g.inv), G.index_select(0, g.inv))
     fp = g.fwd_plan(d)

@@ -252,13 +252,32 @@ def node_order(s, o, num_nodes, how):
     return perm
 
 
+_AUTO_MIN_NODES = 500_000        # below: the feature matrix (64 B rows) sits in L2 / the first MB of the Infinity Cache anyway
+_AUTO_HUB_SHARE = 0.30           # the busiest 1 % of the nodes touch at least this share of the messages' endpoints
+
+
+def _auto_order(s, o, num_nodes):
+    """relabel="auto" (the default): "degree" for LARGE SKEWED static graphs, "none" otherwise.  Measured (profiles/r03_locality.json,
+    r04_locality_auto.json): on a uniform graph (S1) no order helps -- every row is as cold as every other --, on an AM-sized graph
+    with Zipf(0.9) endpoints the degree order makes the hubs' rows neighbours (a handful of lines carries most gathers and stays in
+    L2): -13 % kernel time; rcm / bfs cost seconds of host time per graph and gain less.  The test is one device-side sort of the
+    node degrees, once per graph."""
+    if num_nodes < _AUTO_MIN_NODES or s.numel() == 0:
+        return "none"
+    deg = torch.bincount(s.long(), minlength=num_nodes) + torch.bincount(o.long(), minlength=num_nodes)
+    top = max(1, num_nodes // 100)
+    share = deg.topk(top).values.sum().item() / max(1, int(deg.sum().item()))
+    return "degree" if share >= _AUTO_HUB_SHARE else "none"
+
+
 def graph_from_nc_triples(triples_plus, num_nodes, num_rels, vertical, device, relabel=None):
     """NC layer: n = int((M - N) / 2), i = N  (torch_rgcn/layers.py:235-236, :269-271).
-    relabel ("degree" / "rcm" / "bfs", default: RGCN_RELABEL or none): the plans are built on locality-relabelled node ids
+    relabel ("degree" / "rcm" / "bfs" / "none" / "auto"; default: route `relabel`, else "auto" = degree order for large skewed
+    graphs, _auto_order): the plans are built on locality-relabelled node ids
     (node_order); graph.perm[old] = new, graph.inv[new] = old on the device -- the layer reads its features through inv and
     returns its output through perm, so callers never see the relabelling.  The normalisation is computed on the original
     ids first (it only counts equal (relation, node) keys: invariant under a relabelling)."""
-    relabel = relabel if relabel is not None else (routes.get("relabel") or None)
+    relabel = relabel if relabel is not None else (routes.get("relabel") or "auto")
     if _device_build_enabled() and num_nodes * num_rels < _MAX_CELLS:
         t = torch.as_tensor(triples_plus, dtype=torch.long).reshape(-1, 3).to(device)
         M = t.shape[0]
@@ -269,6 +288,8 @@ def graph_from_nc_triples(triples_plus, num_nodes, num_rels, vertical, device, r
         _native.dev_check_err(err, "stack_matrices")
         val = _native.dev_edge_norm(s, p, o, None, num_nodes, num_rels, vertical, max(n_swap, 0))
         perm = None
+        if relabel == "auto":
+            relabel = _auto_order(s, o, num_nodes)
         if relabel and relabel != "none":
             perm = torch.from_numpy(node_order(s.cpu().numpy(), o.cpu().numpy(), num_nodes, relabel)).to(device)
             p32 = perm.to(torch.int32)

@@ -194,7 +194,10 @@ class RelationalGraphConvolutionNC(_RGCBase):
         t = self.triples
         key = (id(t), t._version if torch.is_tensor(t) else None, str(device), self.vertical_stacking)
         if self._graph is None or self._graph_key != key:
-            self._graph = graph_from_nc_triples(t, self.num_nodes, self.num_relations, self.vertical_stacking, device)
+            # featureless layers index their R x N x d weight table by node id: no locality relabelling for them (the automatic
+            # choice skips them; an explicit route `relabel` raises in forward, as before)
+            relabel = "none" if (self.in_features is None and not routes.is_set("relabel")) else None
+            self._graph = graph_from_nc_triples(t, self.num_nodes, self.num_relations, self.vertical_stacking, device, relabel=relabel)
             if getattr(self, "_shard_group", None) is not None and self._shard_keep == "lpt":
                 from .dist import filter_graph_for_rank
                 filter_graph_for_rank(self._graph, self._shard_group)
