@@ -226,7 +226,7 @@ def line_node_classifier(tag, N, R0, E, nhid, ncls, decomp, labelled, baseline_c
     return {"baseline_config": baseline_config, "workload": tag, "N": N, "R0": R0, "E": E, "params": sum(p.numel() for p in model.parameters()),
             "step": "NodeClassifier forward + cross-entropy + backward + Adam", "ms_per_step": round(ms, 3),
             "ms_per_step_hipgraph_replay": ms_graph,
-            "edges_per_s": round(E / ms * 1e3), "kernels_ms": allk,
+            "edges_per_s": round(E / ms * 1e3), "kernels_ms": allk, "library_launches_per_step": round(sum(_launch_counts(step).values()), 1),
             "roofline": _roof(name, kms, alg, "messages x (weight-table row + 8 B index) + node rows written")}
 
 
@@ -355,6 +355,12 @@ def line_wn18(baseline_config):
         roof = {"kernel": "gemm_kernel (ag @ flat(bases); d_ag = g @ flat^T; dbases = ag^T @ g)", "bound": "mfma", "avg_launch_ms": round(kms, 4),
                 "algorithmic_flops_per_launch": flops, "achieved": round(flops / (kms * 1e-3) / 1e12, 1), "peak": 157.3, "unit": "TFLOP/s",
                 "frac": round(flops / (kms * 1e-3) / 1e12 / 157.3, 4)}
+    # the largest single kernel of the step after the GEMMs: all DistMult gradients from one pass (rgcn_distmult_bwd_all_f32)
+    if roof is not None and "distmult_bwd_all" in allk:
+        dm_alg = Tn * (3 * d * 4 + 28) + (N + R0) * d * 4       # the three embedding rows + indices + upstream scalar per scored triple; every
+        roof["distmult_bwd_all"] = _roof("distmult_bwd_all_kernel", allk["distmult_bwd_all"], dm_alg,       # entity / relation gradient row written once
+                                         "scored triples x (three d-wide rows + 28 B) + (entities + relations) x one gradient row")
+        roof["distmult_fwd"] = _roof("distmult_fwd_kernel", allk.get("distmult_fwd"), Tn * (3 * d * 4 + 28), "scored triples x (three d-wide rows + 28 B)")
     return {"baseline_config": baseline_config, "workload": "WN18-shaped: LP layer d=200 basis 2 (graph of 15,000 triples built per step) + "
             "DistMult on 330,000 triples", "N": N, "R0": R0, "graph_triples": E, "scored_triples": Tn,
             "step": "encoder + decoder forward + BCE + backward (per-step graph build included)", "ms_per_step": round(ms, 3),
