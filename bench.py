@@ -185,9 +185,10 @@ def cpu_baseline(full_scale):
     """The reference's op sequence (oracle/torch_cpu_port.py) on the host cores: S1 at 1/10 scale (3 timed steps) and,
     when the host has the memory for the dense R x N x d intermediates (~15 GB), S1 itself (1 warm-up + 2 timed)."""
     from oracle import oracle, torch_cpu_port
-    # ATen's sparse kernels stop scaling (and then regress) long before 256 host threads: 13.1 s/step at
-    # 256 threads vs the figures below; the baseline gets the best thread count we measured, not the worst.
-    threads = int(os.environ.get("RGCN_CPU_THREADS", min(os.cpu_count() or 1, 32)))
+    # ATen's sparse kernels stop scaling -- and then regress -- long before a many-core host is used up (thread sweep at 1/10 of S1 on
+    # the GPU box's host: profiles/r04_cpu_threads.json, tools/cpu_threads_probe.py): the baseline gets the best thread count measured
+    # there (4 .. 16 threads: 2.42 s per step; 32: 2.70; 128: 4.19; all 256: 12.7), not all cores; `cores_available` rides along.
+    threads = int(os.environ.get("RGCN_CPU_THREADS", min(os.cpu_count() or 1, 16)))
     torch.set_num_threads(threads)
 
     def leg(N, R0, E, d, steps):
@@ -205,7 +206,8 @@ def cpu_baseline(full_scale):
         return E / min(times[1:]), min(times[1:])
 
     small_v, small_t = leg(100_000, 50, 1_000_000, 16, 3)
-    res = {"value": small_v, "unit": "edges/s", "cores": threads, "kind": "port",
+    res = {"value": small_v, "unit": "edges/s", "cores": threads, "cores_available": os.cpu_count(), "kind": "port",
+           "threads_note": "min(cores, 16): ATen's sparse kernels are flat from 4 to 16 threads and regress past that (profiles/r04_cpu_threads.json)",
            "sample": f"S1 at 1/10 scale (N=100000, E=1000000, R0=50, d=16), 1 warm-up + 3 timed steps, best; {small_t:.2f} s/step",
            "port_vs_reference": "profiles/r02_port_vs_reference.json (tools/port_vs_reference.py, build container)"}
     if full_scale:
