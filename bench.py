@@ -299,7 +299,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     mode = "single" if group is None else ("weak" if args.weak else "strong")
 
-    from torch_rgcn import _native
+    from torch_rgcn import _native, routes
     from torch_rgcn.dist import set_transport
     N, R0, E, d = args.nodes, args.rels, args.edges, args.hidden
     l1, l2, M = build_layers(N, R0, E, d, seed=rank if mode == "weak" else 0, device=device, group=group,
@@ -344,7 +344,6 @@ def main():
         # Untimed set-up: which form of the collective is fastest on THIS link (xGMI ring / direct, one rank, gloo)?
         # 3 steps per candidate, max over ranks, the same choice on every rank.
         cands = [("allreduce", "0"), ("rs_ag", "0"), ("a2a", "0"), ("allreduce", "2")] + ([("allreduce", "4")] if mode == "weak" else [])
-        from torch_rgcn import routes
         if routes.is_set("dist_comm") or routes.is_set("dist_slabs"):
             cands = [(routes.get("dist_comm", "allreduce"), routes.get("dist_slabs", "0"))]
         tried = {}

@@ -389,13 +389,14 @@ def line_s2(baseline_config):
     counts = _launch_counts(step)
     M = 2 * E + N
     row = B * d * 4
-    # layer 1 forward: one B x d block of the bases table + 8 B of index per message, one output row per node; backward: the upstream
-    # row AND the table block per message (dcomps needs <bases, g>), the bases gradient written once; layer 2: SURVEY 8(d) S1 bytes
-    l1_fwd, l1_bwd = M * (row + 8) + N * d * 4, M * (row + 4 * d + 8) + N * row
+    # layer 1 forward: one B x d block of the bases table + 8 B of index per message (the block belongs to the message's SOURCE node: a
+    # destination-major walk reads it per message), one output row per node; backward: one upstream row + 8 B per message, every node's
+    # block read once and its gradient written once (the source-major walk); layer 2: SURVEY 8(d) S1 bytes
+    l1_fwd, l1_bwd = M * (row + 8) + N * d * 4, M * (4 * d + 8) + 2 * N * row
     l2_fwd, l2_bwd = M * (4 * d + 8) + N * 4 * d, M * (4 * d + 8) + 2 * N * 4 * d
     step_alg = l1_fwd + l1_bwd + l2_fwd + l2_bwd
     own = {"fbasis_fwd": l1_fwd, "basis_aggregate": l1_fwd, "fbasis_bwd": l1_bwd, "fbasis_small_bwd": l1_bwd, "spmm": l2_fwd, "bwd_fused": l2_bwd}.get(name)
-    roof = _roof(name, kms, own, "layer 1: messages x (B x d table block [+ upstream row in the backward] + 8 B) + rows written; layer 2: SURVEY 8(d)") if own else None
+    roof = _roof(name, kms, own, "layer 1 forward: messages x (B x d table block + 8 B) + node rows; backward: messages x (upstream row + 8 B) + 2 x table; layer 2: SURVEY 8(d)") if own else None
     if roof:
         roof["step_algorithmic_bytes"] = int(step_alg)
         roof["step_frac"] = round(step_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
