@@ -460,6 +460,13 @@ RGCN_API int rgcn_gather_rows_sum_f32(const float *Y, const int32_t *perm, const
 RGCN_API int rgcn_ce_head_f32(const float *logits, const int32_t *row_label, const int32_t *lab_rows, float *loss, float *dlogits,
                               int64_t N, int32_t C, int32_t n_lab, void *stream);
 
+/* Zero-padding / cropping of the two trailing dimensions of a [A][B][C] tensor into [A][Bd][Cd], with an optional 1-D tensor (n1 -> n1d
+ * elements) in the same launch: how widths that are no multiple of 16 (classifier outputs: layers.py weights [R, 16, 4], bias [4]) reach
+ * the MFMA block kernels and how their gradients come back -- one launch where torch.nn.functional.pad and the gradient slices cost
+ * two each (a fill and a copy).  No reference counterpart (plumbing). */
+RGCN_API int rgcn_resize3_f32(const float *src, float *dst, int64_t A, int32_t B, int32_t C, int32_t Bd, int32_t Cd, const float *src1,
+                              float *dst1, int32_t n1, int32_t n1d, void *stream);
+
 /* ------------------------------------------------------------------ dense contractions on the matrix cores
  * Basis decomposition (layers.py:241-242, :468-469: W_r = sum_b comps[r,b] bases[b]) at large width: the layer is
  * out = ag @ flat(bases) + bias with ag[s, b, :] = sum_e comps[r_e, b] val_e X[o_e, :].

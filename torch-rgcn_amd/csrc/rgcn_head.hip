@@ -62,7 +62,38 @@ __global__ __launch_bounds__(HB) void ce_head_kernel(const float *__restrict__ l
   }
   if (threadIdx.x == 0) loss[0] = (float)(part[0] / (double)n_lab);
 }
+// dst[a][b][c] = (b < B && c < C) ? src[a][b][c] : 0 over dst [A][Bd][Cd]: zero-padding (Bd >= B, Cd >= C) or cropping (Bd <= B, Cd <= C)
+// of the two trailing dimensions; a second, 1-D tensor (the bias) rides in the same launch
+__global__ __launch_bounds__(HB) void resize3_kernel(const float *__restrict__ src, float *__restrict__ dst, long long A, int B, int C,
+                                                      int Bd, int Cd, const float *__restrict__ src1, float *__restrict__ dst1, int n1,
+                                                      int n1d) {
+  const long long total = A * Bd * Cd;
+  for (long long i = (long long)blockIdx.x * HB + threadIdx.x; i < total + n1d; i += (long long)gridDim.x * HB) {
+    if (i < total) {
+      const int c = (int)(i % Cd), b = (int)((i / Cd) % Bd);
+      const long long a = i / ((long long)Cd * Bd);
+      dst[i] = (b < B && c < C) ? src[(a * B + b) * C + c] : 0.f;
+    } else {
+      const int j = (int)(i - total);
+      dst1[j] = j < n1 ? src1[j] : 0.f;
+    }
+  }
+}
 }  // namespace
+
+extern "C" int rgcn_resize3_f32(const float *src, float *dst, int64_t A, int32_t B, int32_t C, int32_t Bd, int32_t Cd, const float *src1,
+                                float *dst1, int32_t n1, int32_t n1d, void *stream) {
+  if (!src || !dst || A <= 0 || B <= 0 || C <= 0 || Bd <= 0 || Cd <= 0 || ((src1 == nullptr) != (dst1 == nullptr)) || (src1 && (n1 <= 0 || n1d <= 0))) {
+    rgcn_set_error("resize3: bad argument");
+    return RGCN_EINVAL;
+  }
+  const long long total = (long long)A * Bd * Cd + (src1 ? n1d : 0);
+  const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((total + HB - 1) / HB, 4096));
+  hipLaunchKernelGGL(resize3_kernel, dim3(grid), dim3(HB), 0, (hipStream_t)stream, src, dst, (long long)A, B, C, Bd, Cd, src1, dst1, src1 ? n1 : 0,
+                     src1 ? n1d : 0);
+  if (hipGetLastError() != hipSuccess) { rgcn_set_error("resize3: launch failed"); return RGCN_EHIP; }
+  return RGCN_OK;
+}
 
 extern "C" int rgcn_ce_head_f32(const float *logits, const int32_t *row_label, const int32_t *lab_rows, float *loss, float *dlogits,
                                 int64_t N, int32_t C, int32_t n_lab, void *stream) {

@@ -1352,6 +1352,22 @@ def colsum(G):
     return db
 
 
+def resize3(src, shape, src1=None, n1d=None):
+    """zero-pad / crop the two trailing dimensions of `src` ([A, B, C] or [B, C]) to `shape`, and optionally a 1-D tensor to n1d
+    elements, in ONE launch (rgcn_resize3_f32) -> dst or (dst, dst1)"""
+    _req(src, "tensor"); _req(src1, "vector")
+    s3 = src if src.dim() == 3 else src.unsqueeze(0)
+    A, B, C = s3.shape
+    Bd, Cd = shape[-2], shape[-1]
+    dst = torch.empty((A, Bd, Cd) if src.dim() == 3 else (Bd, Cd), device=src.device, dtype=torch.float32)
+    dst1 = None if src1 is None else torch.empty(n1d, device=src.device, dtype=torch.float32)
+    with _on(src.device):
+        _check(lib().rgcn_resize3_f32(_dp(s3), _dp(dst), c_i64(A), c_i32(B), c_i32(C), c_i32(Bd), c_i32(Cd), _dp(src1), _dp(dst1),
+                                      c_i32(0 if src1 is None else src1.numel()), c_i32(0 if src1 is None else n1d), _stream(src.device)),
+               "resize3")
+    return dst if src1 is None else (dst, dst1)
+
+
 def ce_head(logits, row_label, lab_rows):
     """(loss [1], dlogits [N, C]) of the mean cross-entropy over the labelled rows (rgcn_ce_head_f32)"""
     _req(logits, "logits"); _req(row_label, "row_label", torch.int32); _req(lab_rows, "lab_rows", torch.int32)

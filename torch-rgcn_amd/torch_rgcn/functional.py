@@ -50,9 +50,13 @@ def _pad_blocks(X, W, bias, graph=None):
     if max(d_in, d_out) > _BLOCKED_MAX or (pi == 0 and po == 0) or routes.get("pad16", "1") == "0" or \
             (graph is not None and _wide_gemm_path(graph, d_in, d_out)):       # (the gather-GEMM takes ragged widths as they are)
         return X, W, bias, None
-    pad = torch.nn.functional.pad
-    return (X if pi == 0 else pad(X, (0, pi)), pad(W, (0, po, 0, pi)), None if bias is None else pad(bias, (0, po)),
-            (d_in, d_out))
+    # one launch for W and the bias together (torch.nn.functional.pad: a fill and a copy each)
+    Xp = X if pi == 0 else _native.resize3(dense(X), (X.shape[0], d_in + pi))
+    if bias is None:
+        Wp, bp = _native.resize3(dense(W), (d_in + pi, d_out + po)), None
+    else:
+        Wp, bp = _native.resize3(dense(W), (d_in + pi, d_out + po), dense(bias), d_out + po)
+    return Xp, Wp, bp, (d_in, d_out)
 
 
 _BLOCKED_MAX = 512     # widest layer that is cut into 64-wide blocks of the MFMA block kernel
@@ -93,8 +97,16 @@ def _unpad_blocks(dims, dX, dW, db):
     if dims is None:
         return dX, dW, db
     d_in, d_out = dims
-    return (None if dX is None else dX[:, :d_in], None if dW is None else dW[:, :d_in, :d_out],
-            None if db is None else db[:d_out])
+    if dX is not None and dX.shape[1] != d_in:
+        dX = _native.resize3(dense(dX), (dX.shape[0], d_in))
+    if dW is not None and (dW.shape[1] != d_in or dW.shape[2] != d_out):      # contiguous gradients in one launch (a sliced view costs
+        if db is not None:                                                     # AccumulateGrad a strided copy per tensor)
+            dW, db = _native.resize3(dense(dW), (d_in, d_out), dense(db), d_out)
+        else:
+            dW = _native.resize3(dense(dW), (d_in, d_out))
+    elif db is not None and db.shape[0] != d_out:
+        db = db[:d_out]
+    return dX, dW, db
 
 
 def deterministic():
@@ -216,7 +228,9 @@ class _RelationalMP(torch.autograd.Function):
             ctx.save_for_backward(X, W, out)
         else:
             ctx.save_for_backward(X, W)
-        return out if ctx.dims is None else out[:, :ctx.dims[1]]
+        if ctx.dims is None or out.shape[1] == ctx.dims[1]:
+            return out
+        return _native.resize3(out, (out.shape[0], ctx.dims[1]))       # contiguous (the consumer would copy a sliced view anyway)
 
     @staticmethod
     def backward(ctx, g):
@@ -228,8 +242,8 @@ class _RelationalMP(torch.autograd.Function):
     def _backward(ctx, g, X, W):
         graph = ctx.graph
         if ctx.dims is not None and ctx.dims[1] % 16:
-            g = torch.nn.functional.pad(g, (0, -ctx.dims[1] % 16))
-        g = dense(g)   # after the pad: a zero-width pad keeps the strides of a non-contiguous upstream gradient
+            g = _native.resize3(dense(g), (g.shape[0], ctx.dims[1] + (-ctx.dims[1] % 16)))
+        g = dense(g)
         if ctx.relu and not ctx.out_token.premasked(g):     # out = relu(pre): the gradient passes where the stored output is positive
             g = torch.ops.aten.threshold_backward(g, ctx.saved_tensors[2], 0.0)
         dX = dW = db = None
@@ -342,8 +356,8 @@ class _ShardedRelationalMP(torch.autograd.Function):
         import torch.distributed as dist
         graph = ctx.graph
         if ctx.dims is not None and ctx.dims[1] % 16:
-            g = torch.nn.functional.pad(g, (0, -ctx.dims[1] % 16))
-        g = dense(g)   # after the pad: a zero-width pad keeps the strides of a non-contiguous upstream gradient
+            g = _native.resize3(dense(g), (g.shape[0], ctx.dims[1] + (-ctx.dims[1] % 16)))
+        g = dense(g)
         dX = dW = db = None
         works = []
         slabbed = ctx.n_slabs > 0 and ctx.comm == "allreduce"
