@@ -449,6 +449,13 @@ RGCN_API int rgcn_fbasis_small_supported(int32_t R, int32_t B, int32_t d);
 RGCN_API int rgcn_fbasis_small_bwd_f32(const float *G, const float *table, const float *comps, float *dbases, float *dcomps,
                                        const int32_t *rowptr, const int32_t *p_src, const int32_t *p_rel, const float *p_val,
                                        int64_t n_rows, int32_t R, int32_t B, int32_t d, void *stream);
+/* rgcn_fbasis_bwd_f32 with dcomps finished on the chip (round 4): no T scratch, no relation-major pass 2 -- t_e[b] is added to a per-workgroup
+ * LDS table of doubles (R x B x 8 bytes <= 120 KiB: rgcn_fbasis_bwd_dc_supported) and every workgroup flushes once into dcomps (zeroed here). */
+RGCN_API int rgcn_fbasis_bwd_dc_supported(int32_t R, int32_t B, int32_t d);
+RGCN_API int rgcn_fbasis_bwd_dc_f32(const float *bases, const float *comps, const float *G, float *dbases, float *dcomps,
+                                    const int32_t *e_dst, const int32_t *e_rel, const float *e_val, const int32_t *units,
+                                    int64_t n_units, int64_t n_split, int64_t n_nodes, int32_t R, int32_t B, int32_t d,
+                                    int32_t basis_major, void *stream);
 RGCN_API int rgcn_gather_rows_sum_f32(const float *Y, const int32_t *perm, const int32_t *units, int64_t n_units,
                                       int64_t n_split, const float *bias, float *out, int64_t n_rows, int32_t w,
                                       void *stream);

@@ -108,6 +108,100 @@ __global__ __launch_bounds__(FWD_WG) void fbasis_fwd_kernel(
   }
 }
 
+// ---------------------------------------------------------------- backward with dcomps summed on the chip (round 4)
+// The same walk as fbasis_bwd_kernel below, persistent 1024-thread workgroups striding over the units; t_e[b] = val <block[b], G[s_e]> is
+// not written to a [M][B] scratch (AM as shipped: 2.2 GB out and 2.2 GB back in through a relation-major permutation) but added to an LDS
+// table dcomps[R][B] of DOUBLES (ds_add_f64: lane = basis -> the B lanes of a message add to B consecutive doubles) that every workgroup
+// flushes once.
+constexpr int DC_WG = 1024;
+template <int DP>
+__global__ __launch_bounds__(DC_WG) void fbasis_bwd_dc_kernel(
+    const float *__restrict__ bases, const float *__restrict__ comps, const float *__restrict__ G,
+    float *__restrict__ dbases, float *__restrict__ dC, const int *__restrict__ e_dst, const int *__restrict__ e_rel,
+    const float *__restrict__ e_val, const int4 *__restrict__ units, int n_units, int R, int B, int d, long long sn,
+    long long sb) {
+  extern __shared__ __attribute__((aligned(16))) double dcl[];          // [R][B]
+  for (int i = threadIdx.x; i < R * B; i += DC_WG) dcl[i] = 0.0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool has_b = lane < B;
+  const bool vec = DP % 4 == 0 && d == DP;
+  for (int u = blockIdx.x * (DC_WG / 64) + wave; u < n_units; u += gridDim.x * (DC_WG / 64)) {
+    const int4 unit = units[u];
+    const long long o = unit.x;
+    float blk[DP], dblk[DP];
+#pragma unroll
+    for (int i = 0; i < DP; ++i) {
+      blk[i] = 0.f;
+      dblk[i] = 0.f;
+    }
+    if (has_b) {
+      const float *bp = bases + (size_t)o * sn + (size_t)lane * sb;
+      if (vec) {
+#pragma unroll
+        for (int i = 0; i < DP / 4; ++i) {
+          const f32x4 t4 = reinterpret_cast<const f32x4 *>(bp)[i];
+          blk[4 * i] = t4[0]; blk[4 * i + 1] = t4[1]; blk[4 * i + 2] = t4[2]; blk[4 * i + 3] = t4[3];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < DP; ++i)
+          if (i < d) blk[i] = bp[i];
+      }
+    }
+    constexpr int MB = 4;
+    for (int e0 = unit.y; e0 < unit.z; e0 += 64) {
+      const int n = min(64, unit.z - e0);
+      const int my_s = lane < n ? e_dst[e0 + lane] : 0, my_r = lane < n ? e_rel[e0 + lane] : 0;
+      const float my_v = lane < n ? e_val[e0 + lane] : 0.f;
+      for (int j0 = 0; j0 < n; j0 += MB) {
+        float grow[MB], cv[MB], vv[MB];
+        int rr[MB];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+          const int j = min(j0 + m, n - 1);
+          const int s = __builtin_amdgcn_readlane(my_s, j);
+          rr[m] = __builtin_amdgcn_readlane(my_r, j);
+          vv[m] = (j0 + m < n) ? lane_bcast(my_v, j) : 0.f;
+          grow[m] = (lane < d) ? G[(size_t)s * d + lane] : 0.f;
+          cv[m] = (has_b) ? comps[(size_t)rr[m] * B + lane] * vv[m] : 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+          float t = 0.f;
+#pragma unroll
+          for (int i = 0; i < DP; ++i) {
+            const float gi = lane_bcast(grow[m], i);
+            dblk[i] += cv[m] * gi;
+            t += blk[i] * gi;
+          }
+          if (has_b && j0 + m < n)
+            __hip_atomic_fetch_add(dcl + rr[m] * B + lane, (double)(vv[m] * t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+    if (dbases && has_b) {
+      float *dp_ = dbases + (size_t)o * sn + (size_t)lane * sb;
+      if (vec && !(unit.w & U_SHARED)) {
+#pragma unroll
+        for (int i = 0; i < DP / 4; ++i)
+          reinterpret_cast<f32x4 *>(dp_)[i] = f32x4{dblk[4 * i], dblk[4 * i + 1], dblk[4 * i + 2], dblk[4 * i + 3]};
+      } else {
+#pragma unroll
+        for (int i = 0; i < DP; ++i)
+          if (i < d) {
+            if (unit.w & U_SHARED) atomicAdd(dp_ + i, dblk[i]); else dp_[i] = dblk[i];
+          }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < R * B; i += DC_WG) {
+    const float t = (float)dcl[i];
+    if (t != 0.f) atomicAdd(dC + i, t);
+  }
+}
+
 // ---------------------------------------------------------------- backward, pass 1
 // lane = basis b (B <= 64); registers over the d <= DP features: block[b][:] and the block's gradient.
 template <int DP>
@@ -287,6 +381,48 @@ extern "C" int rgcn_fbasis_bwd_f32(const float *bases, const float *comps, const
                      (int)n_units, (long long)n_nodes, B, d, sn, sb)
   if (d <= 4) RGCN_FB_BWD(4); else if (d <= 8) RGCN_FB_BWD(8); else if (d <= 12) RGCN_FB_BWD(12); else RGCN_FB_BWD(16);
 #undef RGCN_FB_BWD
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_fbasis_bwd_dc_supported(int32_t R, int32_t B, int32_t d) {
+  return R > 0 && B > 0 && B <= 64 && d > 0 && d <= 16 && (size_t)R * B * sizeof(double) <= 120 * 1024;
+}
+
+extern "C" int rgcn_fbasis_bwd_dc_f32(const float *bases, const float *comps, const float *G, float *dbases, float *dcomps,
+                                      const int32_t *e_dst, const int32_t *e_rel, const float *e_val, const int32_t *units,
+                                      int64_t n_units, int64_t n_split, int64_t n_nodes, int32_t R, int32_t B, int32_t d,
+                                      int32_t basis_major, void *stream) {
+  const long long sn = basis_major ? d : (long long)B * d, sb = basis_major ? (long long)n_nodes * d : d;
+  if (n_units < 0 || n_nodes <= 0 || !dcomps || (n_units && (!bases || !comps || !G || !units))) { rgcn_set_error("fbasis_bwd_dc: bad argument"); return RGCN_EINVAL; }
+  if (!rgcn_fbasis_bwd_dc_supported(R, B, d)) { rgcn_set_error("fbasis_bwd_dc: needs B <= 64, d_out <= 16 and R x B doubles within 120 KiB of LDS"); return RGCN_EUNSUPPORTED; }
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(zero_async(dcomps, (size_t)R * B * sizeof(float), st));
+  if (dbases && n_split) HIP_TRY(zero_async(dbases, (size_t)B * n_nodes * d * sizeof(float), st));
+  if (n_units == 0) return RGCN_OK;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0, v = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+    n_cu = v > 0 ? v : 256;
+  }
+  const size_t lds = (size_t)R * B * sizeof(double);
+  const int per_cu = lds <= 72 * 1024 ? 2 : 1;
+  const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((n_units + DC_WG / 64 - 1) / (DC_WG / 64), (int64_t)n_cu * per_cu)));
+  const int4 *un = reinterpret_cast<const int4 *>(units);
+#define RGCN_FB_DC(DPC)                                                                                                            \
+  {                                                                                                                                \
+    static bool raised = false;                                                                                                    \
+    if (lds > 64 * 1024 && !raised) {                                                                                              \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fbasis_bwd_dc_kernel<DPC>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024)); \
+      raised = true;                                                                                                               \
+    }                                                                                                                              \
+    hipLaunchKernelGGL(fbasis_bwd_dc_kernel<DPC>, grid, dim3(DC_WG), lds, st, bases, comps, G, dbases, dcomps, e_dst, e_rel, e_val, un, \
+                       (int)n_units, R, B, d, sn, sb);                                                                             \
+  }
+  if (d <= 4) RGCN_FB_DC(4) else if (d <= 8) RGCN_FB_DC(8) else if (d <= 12) RGCN_FB_DC(12) else RGCN_FB_DC(16)
+#undef RGCN_FB_DC
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

@@ -614,9 +614,17 @@ def fbasis_bwd(table, comps, g, plan, need_bases=True, need_comps=True, basis_ma
     R = comps.shape[0]
     dev = bases.device
     dB = torch.empty_like(bases) if need_bases else None
-    T = torch.empty(max(plan.n_messages, 1), B, device=dev, dtype=torch.float32) if need_comps else None
     dC = torch.empty(R, B, device=dev, dtype=torch.float32) if need_comps else None
     units, n_units, n_split = plan.units_src
+    if need_comps and routes.get("fbasis_dc", "1") != "0" and not routes.flag("deterministic") and \
+            lib().rgcn_fbasis_bwd_dc_supported(c_i32(R), c_i32(B), c_i32(d)):
+        # dcomps summed in an LDS table of doubles inside the walk: no [M, B] scratch, no second pass
+        with _on(dev), _timed("fbasis_bwd"):
+            _check(lib().rgcn_fbasis_bwd_dc_f32(_dp(bases), _dp(comps), _dp(g), _dp(dB), _dp(dC), _dp(plan.e_dst), _dp(plan.e_rel),
+                                                _dp(plan.e_val), _dp(units), c_i64(n_units), c_i64(n_split), c_i64(N), c_i32(R),
+                                                c_i32(B), c_i32(d), c_i32(1 if basis_major else 0), _stream(dev)), "fbasis_bwd_dc")
+        return dB, dC
+    T = torch.empty(max(plan.n_messages, 1), B, device=dev, dtype=torch.float32) if need_comps else None
     with _on(dev), _timed("fbasis_bwd"):
         _check(lib().rgcn_fbasis_bwd_f32(_dp(bases), _dp(comps), _dp(g), _dp(dB), _dp(T), _dp(plan.e_dst), _dp(plan.e_rel),
                                          _dp(plan.e_val), _dp(units), c_i64(n_units), c_i64(n_split), c_i64(N), c_i32(R),
