@@ -236,9 +236,8 @@ class _MeanSquare(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, out):
-        flat = out.reshape(-1)
         ctx.save_for_backward(out)
-        return torch.dot(flat, flat) / flat.numel()
+        return torch.linalg.vector_norm(out.reshape(-1)).square() / out.numel()      # (an ATen reduction; torch.dot is a rocBLAS call)
 
     @staticmethod
     def backward(ctx, g):
