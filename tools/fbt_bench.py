@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""AM-as-shipped first layer (featureless, basis 40, hidden 10) alone: per-kernel times of the tile kernels (rgcn_fbasis_tile.hip).
+With the ablation library (RGCN_HIP_LIB=.../librgcn_hip_abl.so) RGCN_BWD_ABL = 1 no message loop, 2 no tile loads, 4 no row gathers,
+8 no LDS adds (wrong results, timing only)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "torch-rgcn_amd"))
+from torch_rgcn import _native, routes  # noqa: E402
+from torch_rgcn.layers import RelationalGraphConvolutionNC  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=1_666_764)
+ap.add_argument("--r0", type=int, default=133)
+ap.add_argument("--e", type=int, default=5_988_321)
+ap.add_argument("--bases", type=int, default=40)
+ap.add_argument("--d", type=int, default=10)
+ap.add_argument("--iters", type=int, default=5)
+a = ap.parse_args()
+dev = torch.device("cuda")
+T = torch.from_numpy(np.asarray(_native.synthetic_triples_host(a.n, a.r0, a.e, 1)))
+from torch_rgcn.utils import add_inverse_and_self  # noqa: E402
+tp = add_inverse_and_self(T, a.n, a.r0)
+layer = RelationalGraphConvolutionNC(triples=tp, num_nodes=a.n, num_relations=2 * a.r0 + 1, in_features=None, out_features=a.d,
+                                     decomposition={"type": "basis", "num_bases": a.bases}).to(dev)
+g = torch.randn(a.n, a.d, device=dev)
+layer.zero_grad(set_to_none=True)
+layer().backward(g)                 # builds the plan
+plan = layer._graph.fbasis_plan()
+bases, comps, bias = layer.bases.detach(), layer.comps.detach(), layer.bias.detach()
+
+
+def timed(fn):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return round(e0.elapsed_time(e1) / a.iters, 4)
+
+
+res = {"fwd+gather": timed(lambda: _native.fbasis_tile_fwd(bases, comps, bias, plan)),
+       "dbases": timed(lambda: _native.fbasis_tile_bwd(bases, comps, g, plan, True, False)),
+       "dcomps": timed(lambda: _native.fbasis_tile_bwd(bases, comps, g, plan, False, True))}
+_native.profile_start()
+_native.fbasis_tile_fwd(bases, comps, bias, plan)
+prof = _native.profile_stop()
+res.update({k: round(float(np.mean(v)), 4) for k, v in prof.items()})
+print("abl", routes.get("bwd_abl", "0"), "messages", plan.n_messages, res)

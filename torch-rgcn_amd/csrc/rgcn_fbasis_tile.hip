@@ -1,0 +1,685 @@
+// Featureless layer with basis decomposition on a table far beyond the caches, IN the parameter's own [B, N, d] layout
+// (layers.py:241-242 + :286-288; nc-AM.yaml: B = 40, N = 1.67 M, d = 10 -- a 2.67 GB table).  Round 4.
+//
+//   out[s,:] = sum_{e=(s,r,o)} val_e * sum_b comps[r,b] * bases[b,o,:]
+//
+// rgcn_basis.hip walks the messages source-major with ONE WAVE PER SOURCE NODE: unit -> block -> messages are three dependent round trips
+// per node and nothing overlaps them (1.8 ms forward, 3.9 ms backward on AM as shipped, both latency-bound), and it wants the table
+// node-major -- a transposed 2.67 GB copy per step and a transposed gradient back (3.2 ms of elementwise kernels).  Here:
+//
+//   * a TILE is 16 consecutive source nodes.  In [B, N, d] their blocks are B runs of 16 d floats = 64 d bytes each, aligned to whole
+//     128-byte lines when d is even: the 1024 threads of a workgroup stage a tile with 16-byte loads into LDS (forward, dcomps) or write
+//     its gradient out of LDS the same way (dbases) -- the table and its gradient stream through HBM once, in place, fully coalesced;
+//   * workgroups are persistent (one per CU) and software-pipelined over their tiles: row pointers three tiles ahead, message indices
+//     two, gathered gradient rows one, the tile itself two (one in registers in flight, one in LDS).  Everything issued in one
+//     iteration is consumed at the TOP of the next (after a full tile of compute), so the conservative s_waitcnt the compiler places
+//     there never waits for a load that was just issued; the barriers are LDS-only (lds_barrier: no vmcnt drain);
+//   * a tile's messages (8 per node on AM) are dealt evenly over the 16 waves as contiguous ranges, so hub nodes spread over the
+//     workgroup; the node of a message comes from a ballot over the tile's 17 row pointers.  A wave keeps the block (or block gradient) of
+//     its current node in registers and exchanges it with LDS when the node changes;
+//   * block gradients and dcomps are summed in LDS DOUBLES with ds_add_f64 -- the one native LDS float atomic on gfx950 (ds_add_f32
+//     is serialised, 3 cycles per lane: profiles/r04_lds_cas_patterns.txt) -- lane = basis b, so the lanes of a quarter wave hit
+//     distinct banks.  The backward is two kernels because of LDS: dbases needs the tile gradient in doubles (2 x 51 KB) next to the
+//     coefficient table (43 KB), dcomps the R x B doubles (85 KB) next to two staged tiles (2 x 26 KB).
+//
+// Not bit-reproducible (arrival order of the LDS adds); the deterministic route stays in rgcn_basis.hip.
+#include "rgcn_device.h"
+
+namespace {
+
+constexpr int TW = 1024, TWV = TW / 64;     // threads / waves of a workgroup
+constexpr int TN = 16;                      // nodes of a tile
+constexpr int PER = 32;                     // messages of one wave per chunk (a chunk = 16 x PER messages of a tile)
+constexpr int LDS_MAX = 160 * 1024;
+
+__device__ __forceinline__ float bcast(float v, int src_lane) {   // src_lane wave-uniform
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+}
+__device__ __forceinline__ int rlane(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
+#define FBT_ARRIVED(x) asm volatile("" : "+v"(x))          // the value must be in its register HERE (pins the s_waitcnt)
+#ifdef RGCN_ABLATIONS       // timing experiments with WRONG results (tools/fbt_bench.py, ablation build only): 1 no message loop, 2 no tile loads, 4 no row gathers, 8 no LDS adds
+#define FBT_ABL(bit) (abl & (bit))
+#else
+#define FBT_ABL(bit) false
+#endif
+
+// x + y after exchanging halves (W = 32: lanes 32..63 of x with lanes 0..31 of y) or rows (W = 16: the odd 16-lane rows of x with the even
+// rows of y): with x, y = the partial sums of two messages, the lower (even) part of the result belongs to x's message and the upper (odd)
+// part to y's -- one level of a transpose-reduce in two VALU instructions (v_permlane32_swap / v_permlane16_swap, gfx950; no LDS).
+template <int W>
+__device__ __forceinline__ float swap_add(float x, float y) {
+  // inline asm, not __builtin_amdgcn_permlane{32,16}_swap: hipcc 7.2 folds the builtin's two results into ONE register when they are added
+  // (v_permlane32_swap v71, v73; v_add_f32 v58, v71, v71 -- tools/micro/permlane_swap.hip shows the instruction itself is fine).  The
+  // s_nop cover the VALU -> permlane and permlane -> VALU hazards the compiler would otherwise pad.
+  if (W == 32) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+  else asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+  return x + y;
+}
+
+// the part of a tile's messages one wave walks first; rp: lane l <= 16 holds rowptr[tile's first node + l]
+struct Share { int mb, me, per, a, n; };
+template <int PERW = PER>
+__device__ __forceinline__ Share share_of(int rp, int wave, bool valid) {
+  Share s;
+  s.mb = rlane(rp, 0);
+  s.me = rlane(rp, TN);
+  s.per = min(PERW, (s.me - s.mb + TWV - 1) / TWV);
+  s.a = s.mb + wave * s.per;
+  s.n = valid ? max(0, min(s.per, s.me - s.a)) : 0;
+  return s;
+}
+// tile-local node of message position p
+__device__ __forceinline__ int node_of(int rp, int lane, int p) {
+  return __popcll(__ballot(lane >= 1 && lane <= TN && rp <= p));
+}
+
+// staging geometry of one thread: its 16-byte pieces of a tile (piece = 4 consecutive floats of one basis' run)
+template <int KLD>
+struct Geo { long long goff[KLD]; int loff[KLD], pos[KLD]; bool act[KLD]; };
+template <int KLD>
+__device__ __forceinline__ void geo_init(Geo<KLD> &g, int tid, int B, int d, long long N, int ts) {
+  const int q4 = 4 * d;                                     // pieces per basis
+#pragma unroll
+  for (int k = 0; k < KLD; ++k) {
+    const int idx = tid + k * TW;
+    g.act[k] = idx < B * q4;                                 // (an inactive piece aliases piece 0: its loads stay unconditional)
+    const int b = g.act[k] ? idx / q4 : 0, q = g.act[k] ? idx - b * q4 : 0;
+    g.goff[k] = (long long)b * N * d + 4 * q;
+    g.loff[k] = b * ts + 4 * q;
+    g.pos[k] = 4 * q;
+  }
+}
+template <int KLD, bool VEC>
+__device__ __forceinline__ void stage_load(f32x4 (&st)[KLD], const Geo<KLD> &g, const float *__restrict__ bases, long long base) {
+#pragma unroll
+  for (int k = 0; k < KLD; ++k) {                            // no branches: a conditional load costs a phi, and the phi's temporary a wait
+    const float *p = bases + g.goff[k] + base;
+    if (VEC) st[k] = *reinterpret_cast<const f32x4 *>(p);
+    else st[k] = f32x4{p[0], p[1], p[2], p[3]};
+  }
+}
+template <int KLD, bool V4>
+__device__ __forceinline__ void stage_store(float *buf, const f32x4 (&st)[KLD], const Geo<KLD> &g) {
+#pragma unroll
+  for (int k = 0; k < KLD; ++k)
+    if (g.act[k]) {
+      if (V4) *reinterpret_cast<f32x4 *>(buf + g.loff[k]) = st[k];
+      else { buf[g.loff[k]] = st[k][0]; buf[g.loff[k] + 1] = st[k][1]; buf[g.loff[k] + 2] = st[k][2]; buf[g.loff[k] + 3] = st[k][3]; }
+    }
+}
+
+// ================================================================== forward
+// lane = (bg, i): feature i = lane % DP, basis group bg = lane / DP; the lane keeps block[bg * NREG + k][i], k < NREG, of the wave's current
+// node; coefficient table in LDS as [R][BP = NREG * (64 / DP)], zero padded.  Y rows are DP floats wide (zero padded: rgcn_gather_rows_sum4_f32
+// reads them 16 bytes per lane), written by the wave one iteration later from a wave-private LDS strip (coalesced, and issued before the
+// iteration's loads so no wait ever includes them).
+template <int DP, int NREG, int KLD, bool VEC>
+__global__ __launch_bounds__(TW) void fbt_fwd_kernel(
+    const float *__restrict__ bases, const float *__restrict__ comps, float *__restrict__ Y, const int *__restrict__ rowptr,
+    const int *__restrict__ e_rel, const float *__restrict__ e_val, int n_tiles, int N, int R, int B, int d, int ts, int last, int abl) {
+  constexpr int NGRP = 64 / DP, BP = NREG * NGRP;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform: message counts stay in SGPRs)
+  const int i = lane % DP, bg = lane / DP;
+  float *ctab = lds;
+  float *tb = lds + ((R * BP + 3) & ~3);
+  float *yb = tb + 2 * B * ts + wave * (PER * DP);
+  for (int j = tid; j < R * BP; j += TW) {
+    const int r = j / BP, b = j % BP;
+    ctab[j] = b < B ? comps[(size_t)r * B + b] : 0.f;
+  }
+  Geo<KLD> g;
+  geo_init(g, tid, B, d, N, ts);
+  const int G = gridDim.x;
+  int t = blockIdx.x;
+  auto rp_of = [&](int tt) {
+    tt = min(tt, n_tiles - 1);
+    return rowptr[min((long long)tt * TN + min(lane, TN), (long long)N)];
+  };
+  auto base_of = [&](int tt) { return (long long)min(min(tt, n_tiles - 1) * TN, N - TN) * d; };     // the last tile is staged from node N - 16
+
+  f32x4 st[KLD];
+  int rp = rp_of(t), rp1 = rp_of(t + G);
+  stage_load<KLD, VEC>(st, g, bases, base_of(t));
+  Share s = share_of(rp, wave, true);
+  int er = e_rel[min(s.a + lane, last)];
+  float ev = e_val[min(s.a + lane, last)];
+  stage_store<KLD, true>(tb, st, g);
+  stage_load<KLD, VEC>(st, g, bases, base_of(t + G));
+  int pa = 0, pn = 0;                                      // the wave's results waiting in yb: rows pa .. pa + pn
+  auto flush = [&]() {
+    f32x4 *dst = reinterpret_cast<f32x4 *>(Y + (size_t)pa * DP);
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(yb);
+    for (int x = lane; x < pn * (DP / 4); x += 64) dst[x] = src[x];
+    pn = 0;
+  };
+  lds_barrier();
+  for (int k = 0;; ++k) {
+    const bool has1 = t + G < n_tiles, has2 = t + 2 * G < n_tiles;
+    const float *cb = tb + (k & 1) * (B * ts);
+    // everything issued one iteration ago has had a tile of compute to arrive
+    if (has1) stage_store<KLD, true>(tb + ((k + 1) & 1) * (B * ts), st, g);
+    flush();
+    __builtin_amdgcn_sched_barrier(0);
+    if (!FBT_ABL(2)) stage_load<KLD, VEC>(st, g, bases, base_of(t + 2 * G));           // (past the end: the last tile again, never stored)
+    const int rp2 = rp_of(t + 2 * G);
+    const Share s1 = share_of(rp1, wave, has1);
+    const int er1 = e_rel[min(s1.a + lane, last)];
+    const float ev1 = e_val[min(s1.a + lane, last)];
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- tile t
+    const int shift = t * TN - min(t * TN, N - TN);
+    int c_a = s.a, c_n = s.n, c_er = er;
+    float c_ev = ev, blk[NREG];
+    for (int c0 = s.mb;;) {
+      // node by node: the wave's messages of one source node are a run; the node's block comes out of LDS once per run
+      for (int p = c_a, end = FBT_ABL(1) ? c_a : c_a + c_n; p < end;) {
+        const int nt = node_of(rp, lane, p);
+        const int run_end = min(end, rlane(rp, nt + 1));
+        const int nl = nt + shift;
+#pragma unroll
+        for (int q = 0; q < NREG; ++q)                       // (lanes without an element re-read a neighbour's: their coefficient is 0 / their column unused)
+          blk[q] = cb[min(bg * NREG + q, B - 1) * ts + nl * d + min(i, d - 1)];
+        while (p < run_end) {
+          const int j0 = p - c_a, nv = min(DP == 16 ? 4 : 1, run_end - p);
+          if (DP == 16) {
+            // four messages at once (independent chains), then a transpose-reduce over the four basis groups: group g ends up with message g's sum
+            float a4[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {                   // (messages past the run: entries the wave holds anyway, results dropped)
+              const int r = rlane(c_er, j0 + m);
+              const f32x4 *c4 = reinterpret_cast<const f32x4 *>(ctab + r * BP + bg * NREG);
+              float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+              for (int q4 = 0; q4 < NREG / 4; ++q4) {
+                const f32x4 c = c4[q4];
+                e0 += c[0] * blk[4 * q4] + c[1] * blk[4 * q4 + 1];
+                e1 += c[2] * blk[4 * q4 + 2] + c[3] * blk[4 * q4 + 3];
+              }
+              a4[m] = (e0 + e1) * bcast(c_ev, j0 + m);
+            }
+            const float u = swap_add<32>(a4[0], a4[2]), w = swap_add<32>(a4[1], a4[3]);
+            const float y = swap_add<16>(u, w);
+            if (bg < nv) yb[(j0 + bg) * DP + i] = i < d ? y : 0.f;
+          } else {
+            const int r = rlane(c_er, j0);
+            const f32x4 *c4 = reinterpret_cast<const f32x4 *>(ctab + r * BP + bg * NREG);
+            float acc = 0.f;
+#pragma unroll
+            for (int q4 = 0; q4 < NREG / 4; ++q4) {
+              const f32x4 c = c4[q4];
+              acc += c[0] * blk[4 * q4] + c[1] * blk[4 * q4 + 1] + c[2] * blk[4 * q4 + 2] + c[3] * blk[4 * q4 + 3];
+            }
+#pragma unroll
+            for (int off = DP; off < 64; off <<= 1) acc += __shfl_xor(acc, off, 64);
+            if (bg == 0) yb[j0 * DP + i] = i < d ? bcast(c_ev, j0) * acc : 0.f;
+          }
+          p += nv;
+        }
+      }
+      pa = c_a;
+      pn = c_n;
+      c0 += TWV * s.per;
+      if (c0 >= s.me) break;
+      flush();                                              // tiles with more than 16 x PER messages: further chunks, loaded on demand
+      c_a = c0 + wave * s.per;
+      c_n = max(0, min(s.per, min(c0 + TWV * s.per, s.me) - c_a));
+      c_er = e_rel[min(c_a + lane, last)];
+      c_ev = e_val[min(c_a + lane, last)];
+      FBT_ARRIVED(c_er); FBT_ARRIVED(c_ev);                 // (the wait belongs HERE, on the rare path: left to the compiler it lands inside the message loop)
+    }
+    lds_barrier();
+    if (!has1) break;
+    t += G;
+    rp = rp1; rp1 = rp2; s = s1; er = er1; ev = ev1;
+  }
+  flush();
+}
+
+// out[row, 0..w) = (bias) + sum_j Y[perm[j], :] over the units of a row; Y rows are 4 LPR floats (16-byte pieces, one per lane), LPR lanes
+// per unit, two row reads in flight per lane (the layout of segment_gather_sum_units_d16_kernel for any width <= 16).
+template <int LPR>
+__global__ __launch_bounds__(256) void gather_rows_sum4_kernel(const float *__restrict__ Y, const int *__restrict__ perm,
+                                                               const int4 *__restrict__ units, const float *__restrict__ bias,
+                                                               float *__restrict__ out, long long n_units, int w) {
+  const int q = threadIdx.x % LPR;
+  for (long long u = ((long long)blockIdx.x * 256 + threadIdx.x) / LPR; u < n_units; u += ((long long)gridDim.x * 256) / LPR) {
+    const int4 unit = units[u];
+    const bool shared = unit.w & RGCN_U_SHARED;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    if (bias && (!shared || (unit.w & RGCN_U_FIRST))) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (4 * q + c < w) a[c] = bias[4 * q + c];
+    }
+    int e = unit.y;
+    const int e1 = unit.z;
+    for (; e + 1 < e1; e += 2) {
+      const int p0 = perm[e], p1 = perm[e + 1];
+      a += *reinterpret_cast<const f32x4 *>(Y + (size_t)p0 * (4 * LPR) + 4 * q);
+      b += *reinterpret_cast<const f32x4 *>(Y + (size_t)p1 * (4 * LPR) + 4 * q);
+    }
+    if (e < e1) a += *reinterpret_cast<const f32x4 *>(Y + (size_t)perm[e] * (4 * LPR) + 4 * q);
+    a += b;
+    float *o = out + (size_t)unit.x * w + 4 * q;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (4 * q + c < w) {
+        if (shared) atomicAdd(o + c, a[c]); else o[c] = a[c];
+      }
+  }
+}
+
+// ================================================================== backward
+// Both kernels: lane = basis b for the sums.  The upstream gradient rows of the wave's messages are gathered one tile ahead into registers
+// (packed: register q of lane (m, c) = G[dst of message 4 q + m][c]) and, once arrived, laid down in a wave-private LDS strip
+// [PERB messages][GS = 4 ceil(d / 4) floats]: the message loops then read a row with broadcast 16-byte reads (dcomps) or as the MFMA's B
+// operand (dbases) -- no readlane per feature, no register indexed by the message.
+constexpr int PERB = 16, GQ = PERB / 4;     // messages of one wave per chunk in the backward kernels
+
+struct Idx { int es, er; float ev; };
+// (lanes past the wave's n messages re-read entry `last` = M - 1: every load of the pipeline is unconditional -- see stage_load)
+__device__ __forceinline__ Idx idx_load(const int *__restrict__ e_dst, const int *__restrict__ e_rel, const float *__restrict__ e_val,
+                                        int a, int last, int lane) {
+  Idx x;
+  const int e = min(a + lane, last);
+  x.es = e_dst[e];
+  x.er = e_rel[e];
+  x.ev = e_val[e];
+  return x;
+}
+// lanes (m, c >= d) re-read column d - 1 and messages past n the wave's last one: finite duplicates that no sum ever uses
+__device__ __forceinline__ void gather_rows(float (&gp)[GQ], const float *__restrict__ G, int es, int n, int d, int lane) {
+  const int m = lane >> 4, c = min(lane & 15, d - 1);
+#pragma unroll
+  for (int q = 0; q < GQ; ++q)
+    if (4 * q < n) {                                       // wave-uniform
+      const int s = __shfl(es, min(4 * q + m, n - 1), 64);
+      gp[q] = G[(size_t)s * d + c];
+    }
+}
+template <int GS>
+__device__ __forceinline__ void strip_store(float *gs, const float (&gp)[GQ], int n, int lane) {
+  const int m = lane >> 4, c = lane & 15;
+#pragma unroll
+  for (int q = 0; q < GQ; ++q)
+    if (4 * q < n && c < GS) gs[(4 * q + m) * GS + c] = gp[q];          // (rows n .. 4 ceil(n / 4) hold duplicates of row n - 1)
+}
+
+// ---- dcomps[r,b] += val_e <bases[b,o_e,:], G[s_e,:]>: tiles staged like the forward's; dcomps summed per workgroup in an LDS table of doubles
+template <int DPB, int KLD, bool VEC>
+__global__ __launch_bounds__(TW) void fbt_dcomps_kernel(
+    const float *__restrict__ bases, const float *__restrict__ G, float *__restrict__ dC, const int *__restrict__ rowptr,
+    const int *__restrict__ e_dst, const int *__restrict__ e_rel, const float *__restrict__ e_val, int n_tiles, int N, int R, int B,
+    int d, int ts, int last, int abl) {
+  constexpr int GS = DPB;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double *dcl = reinterpret_cast<double *>(lds);            // [R][B]
+  const int strips0 = (2 * R * B + 3) & ~3;                 // (16-byte aligned: the rows are read 16 bytes at a time)
+  float *gs = lds + strips0 + wave * (PERB * GS);           // the wave's strip of gradient rows
+  float *tb = lds + strips0 + TWV * PERB * GS;              // 2 x [B][ts], ts odd: lane b reads tb[b * ts + ...] without bank conflicts
+  for (int j = tid; j < R * B; j += TW) dcl[j] = 0.0;
+  Geo<KLD> g;
+  geo_init(g, tid, B, d, N, ts);
+  const int Gd = gridDim.x;
+  int t = blockIdx.x;
+  auto rp_of = [&](int tt) {
+    tt = min(tt, n_tiles - 1);
+    return rowptr[min((long long)tt * TN + min(lane, TN), (long long)N)];
+  };
+  auto base_of = [&](int tt) { return (long long)min(min(tt, n_tiles - 1) * TN, N - TN) * d; };
+  const int bl = min(lane, B - 1);
+  const bool has_b = lane < B;
+
+  f32x4 st[KLD];
+  int rp = rp_of(t), rp1 = rp_of(t + Gd), rp2 = rp_of(t + 2 * Gd);
+  stage_load<KLD, VEC>(st, g, bases, base_of(t));
+  Share s = share_of<PERB>(rp, wave, true);
+  Idx x = idx_load(e_dst, e_rel, e_val, s.a, last, lane);
+  Share s1 = share_of<PERB>(rp1, wave, t + Gd < n_tiles);
+  Idx x1 = idx_load(e_dst, e_rel, e_val, s1.a, last, lane);
+  float gp1[GQ] = {};
+  gather_rows(gp1, G, x.es, s.n, d, lane);
+  strip_store<GS>(gs, gp1, s.n, lane);
+  stage_store<KLD, false>(tb, st, g);
+  stage_load<KLD, VEC>(st, g, bases, base_of(t + Gd));
+  lds_barrier();
+  for (int k = 0;; ++k) {
+    const bool has1 = t + Gd < n_tiles, has2 = t + 2 * Gd < n_tiles;
+    const float *cb = tb + (k & 1) * (B * ts);
+    if (has1) stage_store<KLD, false>(tb + ((k + 1) & 1) * (B * ts), st, g);
+    __builtin_amdgcn_sched_barrier(0);
+    // issue: the tile two ahead, row pointers three, indices two, gradient rows one -- all arrive before the rotation at the bottom
+    if (!FBT_ABL(2)) stage_load<KLD, VEC>(st, g, bases, base_of(t + 2 * Gd));
+    const int rp3 = rp_of(t + 3 * Gd);
+    const Share s2 = share_of<PERB>(rp2, wave, has2);
+    const Idx x2 = idx_load(e_dst, e_rel, e_val, s2.a, last, lane);
+    if (!FBT_ABL(4)) gather_rows(gp1, G, x1.es, s1.n, d, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- tile t
+    const int shift = t * TN - min(t * TN, N - TN);
+    int c_a = s.a, c_n = s.n;
+    Idx c_x = x;
+    for (int c0 = s.mb;;) {
+      for (int p = c_a, end = FBT_ABL(1) ? c_a : c_a + c_n; p < end;) {
+        const int nt = node_of(rp, lane, p);
+        const int run_end = min(end, rlane(rp, nt + 1));
+        const int nl = nt + shift;
+        float blk[DPB];
+#pragma unroll
+        for (int i = 0; i < DPB; ++i) {
+          const float v = cb[bl * ts + nl * d + min(i, d - 1)];
+          blk[i] = i < d ? v : 0.f;
+        }
+        auto one = [&](int j) {
+          const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gs + j * GS);      // the same address in every lane: a broadcast read
+          float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+          for (int i4 = 0; i4 < DPB / 4; ++i4) {
+            const f32x4 gv = g4[i4];
+            e0 += blk[4 * i4] * gv[0] + blk[4 * i4 + 1] * gv[1];
+            e1 += blk[4 * i4 + 2] * gv[2] + blk[4 * i4 + 3] * gv[3];
+          }
+          const int r = rlane(c_x.er, j);
+          const float v = bcast(c_x.ev, j);
+          if (has_b && !FBT_ABL(8)) __hip_atomic_fetch_add(dcl + r * B + lane, (double)(v * (e0 + e1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        for (; p + 4 <= run_end; p += 4) {                  // four independent chains
+          one(p - c_a); one(p - c_a + 1); one(p - c_a + 2); one(p - c_a + 3);
+        }
+        for (; p < run_end; ++p) one(p - c_a);
+      }
+      c0 += TWV * s.per;
+      if (c0 >= s.me) break;
+      c_a = c0 + wave * s.per;                              // tiles with more than 16 x PERB messages: further chunks, loaded on demand
+      c_n = max(0, min(s.per, min(c0 + TWV * s.per, s.me) - c_a));
+      c_x = idx_load(e_dst, e_rel, e_val, c_a, last, lane);
+      float gq[GQ] = {};
+      gather_rows(gq, G, c_x.es, c_n, d, lane);
+      FBT_ARRIVED(c_x.er); FBT_ARRIVED(c_x.ev);
+      strip_store<GS>(gs, gq, c_n, lane);
+    }
+    lds_barrier();
+    if (!has1) break;
+    t += Gd;
+    rp = rp1; rp1 = rp2; rp2 = rp3; s = s1; s1 = s2; x = x1; x1 = x2;
+    strip_store<GS>(gs, gp1, s.n, lane);                    // (wave-private: written after the wave's own reads of the tile before)
+  }
+  for (int j = tid; j < R * B; j += TW) {
+    const float v = (float)dcl[j];
+    if (v != 0.f) atomicAdd(dC + j, v);
+  }
+}
+
+// ---- dbases[b,o,:] = sum_e val_e comps[r_e,b] G[s_e,:]: per run of a node's messages D[b][i] += sum_m A[b][m] B[m][i] on the matrix cores
+// (v_mfma_f32_16x16x4_f32, four messages per step: A = val_m comps[r_m, 16 t + row] out of the LDS coefficient table, B = the strip's rows);
+// the tile's gradient is summed in LDS doubles (two tiles: one being written out while the next is summed) and written once, in place
+template <int DPB, int KLD, bool VEC>
+__global__ __launch_bounds__(TW) void fbt_dbases_kernel(
+    const float *__restrict__ comps, const float *__restrict__ G, float *__restrict__ dbases, const int *__restrict__ rowptr,
+    const int *__restrict__ e_dst, const int *__restrict__ e_rel, const float *__restrict__ e_val, int n_tiles, int N, int R, int B,
+    int d, int ts, int last, int abl) {
+  constexpr int GS = DPB, NT = 4;                           // NT 16-row tiles of bases (B <= 64)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double *dt = reinterpret_cast<double *>(lds);             // 2 x [B][ts] doubles, ts odd
+  float *gs = lds + 4 * B * ts + wave * (PERB * GS);
+  float *ctab = lds + 4 * B * ts + TWV * PERB * GS;         // [R][B]
+  for (int j = tid; j < R * B; j += TW) ctab[j] = comps[j];
+  for (int j = tid; j < 2 * B * ts; j += TW) dt[j] = 0.0;
+  Geo<KLD> g;
+  geo_init(g, tid, B, d, N, ts);
+  const int Gd = gridDim.x;
+  int t = blockIdx.x;
+  auto rp_of = [&](int tt) {
+    tt = min(tt, n_tiles - 1);
+    return rowptr[min((long long)tt * TN + min(lane, TN), (long long)N)];
+  };
+  const int nbt = (B + 15) >> 4;                            // 16-row tiles in use
+  const int lm = lane >> 4, lc = lane & 15;
+
+  int rp = rp_of(t), rp1 = rp_of(t + Gd), rp2 = rp_of(t + 2 * Gd);
+  Share s = share_of<PERB>(rp, wave, true);
+  Idx x = idx_load(e_dst, e_rel, e_val, s.a, last, lane);
+  Share s1 = share_of<PERB>(rp1, wave, t + Gd < n_tiles);
+  Idx x1 = idx_load(e_dst, e_rel, e_val, s1.a, last, lane);
+  float gp1[GQ] = {};
+  gather_rows(gp1, G, x.es, s.n, d, lane);
+  strip_store<GS>(gs, gp1, s.n, lane);
+  int t_out = -1;                                           // the tile whose gradient waits in dt[(k - 1) & 1]
+  auto write_out = [&](double *src) {
+    const int n0 = t_out * TN, n0s = min(n0, N - TN);
+    const long long base = (long long)n0s * d;
+    const int lo = (n0 - n0s) * d;                          // the last tile: positions below `lo` belong to the tile before
+#pragma unroll
+    for (int k2 = 0; k2 < KLD; ++k2)
+      if (g.act[k2]) {
+        double *p = src + g.loff[k2];
+        const f32x4 v = {(float)p[0], (float)p[1], (float)p[2], (float)p[3]};
+        p[0] = 0.0; p[1] = 0.0; p[2] = 0.0; p[3] = 0.0;
+        float *o = dbases + g.goff[k2] + base;
+        const int pos = g.pos[k2];
+        if (VEC && pos >= lo) *reinterpret_cast<f32x4 *>(o) = v;
+        else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (pos + c >= lo) o[c] = v[c];
+        }
+      }
+  };
+  lds_barrier();
+  for (int k = 0;; ++k) {
+    const bool has1 = t + Gd < n_tiles, has2 = t + 2 * Gd < n_tiles;
+    double *dtc = dt + (k & 1) * (B * ts);
+    if (t_out >= 0) write_out(dt + ((k + 1) & 1) * (B * ts));
+    __builtin_amdgcn_sched_barrier(0);
+    const int rp3 = rp_of(t + 3 * Gd);
+    const Share s2 = share_of<PERB>(rp2, wave, has2);
+    const Idx x2 = idx_load(e_dst, e_rel, e_val, s2.a, last, lane);
+    if (!FBT_ABL(4)) gather_rows(gp1, G, x1.es, s1.n, d, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- tile t (never the overlapped part of the last tile: local node = tile-relative + shift)
+    const int shift = t * TN - min(t * TN, N - TN);
+    int c_a = s.a, c_n = s.n;
+    Idx c_x = x;
+    for (int c0 = s.mb;;) {
+      for (int p = c_a, end = FBT_ABL(1) ? c_a : c_a + c_n; p < end;) {
+        const int nt = node_of(rp, lane, p);
+        const int run_end = min(end, rlane(rp, nt + 1));
+        const int nl = nt + shift;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int tb = 0; tb < NT; ++tb) acc[tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int p4 = p; p4 < run_end; p4 += 4) {
+          const int j0 = p4 - c_a, jm = min(j0 + lm, c_n - 1);                    // this lane group's message (past the run: weight 0)
+          const int r = __shfl(c_x.er, jm, 64);
+          const float v = (p4 + lm < run_end) ? __shfl(c_x.ev, jm, 64) : 0.f;
+          const float bv = gs[jm * GS + min(lc, GS - 1)];                        // B operand: lane (m, c) = G row of message m, column c
+#pragma unroll
+          for (int tb = 0; tb < NT; ++tb)
+            if (tb < nbt) {                                                      // uniform
+              const float av = ctab[r * B + min(16 * tb + lc, B - 1)] * v;       // A operand: lane (m, row) = val_m comps[r_m][16 tb + row]
+              acc[tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[tb], 0, 0, 0);
+            }
+        }
+        p = run_end;
+        // D: lane (q, column i) holds rows 4 q .. 4 q + 3 of every 16-row tile: the lanes of a quarter wave add to consecutive doubles
+        if (lc < d && !FBT_ABL(8)) {
+#pragma unroll
+          for (int tb = 0; tb < NT; ++tb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int b = 16 * tb + 4 * lm + e;
+              if (tb < nbt && b < B)
+                __hip_atomic_fetch_add(dtc + b * ts + nl * d + lc, (double)acc[tb][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+      }
+      c0 += TWV * s.per;
+      if (c0 >= s.me) break;
+      c_a = c0 + wave * s.per;
+      c_n = max(0, min(s.per, min(c0 + TWV * s.per, s.me) - c_a));
+      c_x = idx_load(e_dst, e_rel, e_val, c_a, last, lane);
+      float gq[GQ] = {};
+      gather_rows(gq, G, c_x.es, c_n, d, lane);
+      FBT_ARRIVED(c_x.er); FBT_ARRIVED(c_x.ev);
+      strip_store<GS>(gs, gq, c_n, lane);
+    }
+    t_out = t;
+    lds_barrier();
+    if (!has1) {
+      write_out(dtc);
+      break;
+    }
+    t += Gd;
+    rp = rp1; rp1 = rp2; rp2 = rp3; s = s1; s1 = s2; x = x1; x1 = x2;
+    strip_store<GS>(gs, gp1, s.n, lane);
+  }
+}
+
+inline int pow2_at_least(int v, int lo) {
+  int p = lo;
+  while (p < v) p <<= 1;
+  return p;
+}
+struct TileShape { int dp, nreg, bp, kld, ts_f, ts_b, dpb; size_t lds_fwd, lds_dc, lds_db; };
+inline bool tile_shape(int R, int B, int d, long long N, TileShape &s) {
+  if (R <= 0 || B < 1 || B > 64 || d < 1 || d > 16 || N < TN) return false;
+  s.dp = pow2_at_least(d, 4);
+  const int ngrp = 64 / s.dp;
+  s.nreg = 4 * ((B + 4 * ngrp - 1) / (4 * ngrp));
+  if (s.nreg > 16) return false;
+  s.bp = s.nreg * ngrp;
+  const int pieces = B * 4 * d;
+  if (pieces > 4 * TW) return false;
+  s.kld = pieces <= 2 * TW ? 2 : 4;
+  s.ts_f = TN * d + 4;                                      // forward: 16-byte pieces stay aligned, basis groups land on different banks
+  s.ts_b = TN * d + 1;                                      // backward: lane = basis reads / adds at stride ts -> odd
+  s.dpb = 4 * ((d + 3) / 4);
+  s.lds_fwd = ((size_t)((R * s.bp + 3) & ~3) + 2 * (size_t)B * s.ts_f + (size_t)TWV * PER * s.dp) * 4;
+  const size_t strips = (size_t)TWV * PERB * s.dpb * 4;    // the waves' strips of gradient rows
+  s.lds_dc = (size_t)R * B * 8 + 16 + strips + 2 * (size_t)B * s.ts_b * 4;
+  s.lds_db = 2 * (size_t)B * s.ts_b * 8 + strips + (size_t)R * B * 4;
+  return true;
+}
+int n_cus() {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cu = v;
+    else n_cu = 256;
+  }
+  return n_cu;
+}
+template <typename K>
+hipError_t raise_lds(K kernel, size_t bytes) {
+  return bytes > 64 * 1024 ? hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX) : hipSuccess;
+}
+
+}  // namespace
+
+extern "C" int rgcn_fbasis_tile_supported(int32_t R, int32_t B, int32_t d, int64_t n_nodes) {
+  TileShape s;
+  if (!tile_shape(R, B, d, n_nodes, s)) return 0;
+  return (s.lds_fwd <= (size_t)LDS_MAX ? 1 : 0) | ((s.lds_dc <= (size_t)LDS_MAX && s.lds_db <= (size_t)LDS_MAX) ? 2 : 0);
+}
+
+extern "C" int rgcn_fbasis_tile_ystride(int32_t d) { return d >= 1 && d <= 16 ? pow2_at_least(d, 4) : 0; }
+
+extern "C" int rgcn_fbasis_tile_fwd_f32(const float *bases, const float *comps, float *Y, const int32_t *rowptr, const int32_t *e_rel,
+                                        const float *e_val, int64_t n_messages, int64_t n_nodes, int32_t R, int32_t B, int32_t d, void *stream) {
+  TileShape s;
+  if (n_messages == 0) return RGCN_OK;
+  if (!bases || !comps || !Y || !rowptr || !e_rel || !e_val || n_messages < 0 || n_messages > INT32_MAX) { rgcn_set_error("fbasis_tile_fwd: bad argument"); return RGCN_EINVAL; }
+  const int last = (int)(n_messages - 1);
+  const int abl = rgcn_option_value(RGCN_OPT_BWD_ABL);      // 0 in the shipped library (rgcn_set_option refuses it)
+  if (!tile_shape(R, B, d, n_nodes, s) || s.lds_fwd > (size_t)LDS_MAX) { rgcn_set_error("fbasis_tile_fwd: shape outside the tile kernel (rgcn_fbasis_tile_supported)"); return RGCN_EUNSUPPORTED; }
+  const int n_tiles = (int)((n_nodes + TN - 1) / TN);
+  const bool vec = ((n_nodes * d) % 4 == 0) && (reinterpret_cast<uintptr_t>(bases) % 16 == 0);
+  const dim3 grid((unsigned)std::min<int64_t>(n_tiles, n_cus()));
+  hipStream_t st = (hipStream_t)stream;
+#define FBT_FWD3(DP_, NR_, KL_)                                                                                                   \
+  {                                                                                                                               \
+    if (vec) {                                                                                                                    \
+      HIP_TRY(raise_lds(fbt_fwd_kernel<DP_, NR_, KL_, true>, s.lds_fwd));                                                         \
+      hipLaunchKernelGGL((fbt_fwd_kernel<DP_, NR_, KL_, true>), grid, dim3(TW), s.lds_fwd, st, bases, comps, Y, rowptr, e_rel, e_val, n_tiles, \
+                         (int)n_nodes, R, B, d, s.ts_f, last, abl);                                                                          \
+    } else {                                                                                                                      \
+      HIP_TRY(raise_lds(fbt_fwd_kernel<DP_, NR_, KL_, false>, s.lds_fwd));                                                        \
+      hipLaunchKernelGGL((fbt_fwd_kernel<DP_, NR_, KL_, false>), grid, dim3(TW), s.lds_fwd, st, bases, comps, Y, rowptr, e_rel, e_val, n_tiles, \
+                         (int)n_nodes, R, B, d, s.ts_f, last, abl);                                                                          \
+    }                                                                                                                             \
+  }
+#define FBT_FWD2(DP_, NR_) { if (s.kld == 2) FBT_FWD3(DP_, NR_, 2) else FBT_FWD3(DP_, NR_, 4) }
+#define FBT_FWD1(DP_) { if (s.nreg <= 4) FBT_FWD2(DP_, 4) else if (s.nreg <= 8) FBT_FWD2(DP_, 8) else if (s.nreg <= 12) FBT_FWD2(DP_, 12) else FBT_FWD2(DP_, 16) }
+  if (s.dp == 4) FBT_FWD1(4) else if (s.dp == 8) FBT_FWD1(8) else FBT_FWD1(16)
+#undef FBT_FWD1
+#undef FBT_FWD2
+#undef FBT_FWD3
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_gather_rows_sum4_f32(const float *Y, int32_t ys, const int32_t *perm, const int32_t *units, int64_t n_units,
+                                         int64_t n_split, const float *bias, float *out, int64_t n_rows, int32_t w, void *stream) {
+  if (n_units < 0 || n_rows < 0 || w <= 0 || w > ys || (ys != 4 && ys != 8 && ys != 16) || (n_units && (!Y || !perm || !units || !out))) {
+    rgcn_set_error("gather_rows_sum4: bad argument");
+    return RGCN_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (n_split) HIP_TRY(zero_async(out, (size_t)n_rows * w * sizeof(float), st));
+  if (n_units == 0) return RGCN_OK;
+  const int lpr = ys / 4;
+  const dim3 grid((unsigned)std::min<int64_t>((n_units * lpr + 255) / 256, (int64_t)n_cus() * 32));
+  const int4 *un = reinterpret_cast<const int4 *>(units);
+  if (lpr == 1) hipLaunchKernelGGL(gather_rows_sum4_kernel<1>, grid, dim3(256), 0, st, Y, perm, un, bias, out, (long long)n_units, w);
+  else if (lpr == 2) hipLaunchKernelGGL(gather_rows_sum4_kernel<2>, grid, dim3(256), 0, st, Y, perm, un, bias, out, (long long)n_units, w);
+  else hipLaunchKernelGGL(gather_rows_sum4_kernel<4>, grid, dim3(256), 0, st, Y, perm, un, bias, out, (long long)n_units, w);
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+extern "C" int rgcn_fbasis_tile_bwd_f32(const float *bases, const float *comps, const float *G, float *dbases, float *dcomps,
+                                        const int32_t *rowptr, const int32_t *e_dst, const int32_t *e_rel, const float *e_val,
+                                        int64_t n_messages, int64_t n_nodes, int32_t R, int32_t B, int32_t d, void *stream) {
+  TileShape s;
+  if (!bases || !comps || !G || !rowptr || !e_dst || !e_rel || !e_val || (!dbases && !dcomps) || n_messages < 0 || n_messages > INT32_MAX) { rgcn_set_error("fbasis_tile_bwd: bad argument"); return RGCN_EINVAL; }
+  if (n_messages == 0) {                                    // no messages: both gradients are zero
+    if (dbases) HIP_TRY(zero_async(dbases, (size_t)B * n_nodes * d * sizeof(float), (hipStream_t)stream));
+    if (dcomps) HIP_TRY(zero_async(dcomps, (size_t)R * B * sizeof(float), (hipStream_t)stream));
+    return RGCN_OK;
+  }
+  const int last = (int)(n_messages - 1);
+  const int abl = rgcn_option_value(RGCN_OPT_BWD_ABL);      // 0 in the shipped library (rgcn_set_option refuses it)
+  if (!tile_shape(R, B, d, n_nodes, s) || s.lds_dc > (size_t)LDS_MAX || s.lds_db > (size_t)LDS_MAX) { rgcn_set_error("fbasis_tile_bwd: shape outside the tile kernels (rgcn_fbasis_tile_supported)"); return RGCN_EUNSUPPORTED; }
+  const int n_tiles = (int)((n_nodes + TN - 1) / TN);
+  const bool vec = ((n_nodes * d) % 4 == 0) && (reinterpret_cast<uintptr_t>(bases) % 16 == 0) && (!dbases || reinterpret_cast<uintptr_t>(dbases) % 16 == 0);
+  const dim3 grid((unsigned)std::min<int64_t>(n_tiles, n_cus()));
+  hipStream_t st = (hipStream_t)stream;
+#define FBT_BWD3(KERNEL, LDSB, DPB_, KL_, ...)                                                                            \
+  {                                                                                                                       \
+    if (vec) {                                                                                                            \
+      HIP_TRY(raise_lds(KERNEL<DPB_, KL_, true>, LDSB));                                                                  \
+      hipLaunchKernelGGL((KERNEL<DPB_, KL_, true>), grid, dim3(TW), LDSB, st, __VA_ARGS__);                               \
+    } else {                                                                                                              \
+      HIP_TRY(raise_lds(KERNEL<DPB_, KL_, false>, LDSB));                                                                 \
+      hipLaunchKernelGGL((KERNEL<DPB_, KL_, false>), grid, dim3(TW), LDSB, st, __VA_ARGS__);                              \
+    }                                                                                                                     \
+  }
+#define FBT_BWD2(KERNEL, LDSB, DPB_, ...) { if (s.kld == 2) FBT_BWD3(KERNEL, LDSB, DPB_, 2, __VA_ARGS__) else FBT_BWD3(KERNEL, LDSB, DPB_, 4, __VA_ARGS__) }
+#define FBT_BWD1(KERNEL, LDSB, ...)                                                                                        \
+  { if (s.dpb == 4) FBT_BWD2(KERNEL, LDSB, 4, __VA_ARGS__) else if (s.dpb == 8) FBT_BWD2(KERNEL, LDSB, 8, __VA_ARGS__)       \
+    else if (s.dpb == 12) FBT_BWD2(KERNEL, LDSB, 12, __VA_ARGS__) else FBT_BWD2(KERNEL, LDSB, 16, __VA_ARGS__) }
+  if (dbases)
+    FBT_BWD1(fbt_dbases_kernel, s.lds_db, comps, G, dbases, rowptr, e_dst, e_rel, e_val, n_tiles, (int)n_nodes, R, B, d, s.ts_b, last, abl)
+  if (dcomps) {
+    HIP_TRY(zero_async(dcomps, (size_t)R * B * sizeof(float), st));
+    FBT_BWD1(fbt_dcomps_kernel, s.lds_dc, bases, G, dcomps, rowptr, e_dst, e_rel, e_val, n_tiles, (int)n_nodes, R, B, d, s.ts_b, last, abl)
+  }
+#undef FBT_BWD1
+#undef FBT_BWD2
+#undef FBT_BWD3
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}

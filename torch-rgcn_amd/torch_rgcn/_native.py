@@ -550,7 +550,7 @@ def row_units(rowptr, n_rows, max_len):
 class FBasisPlan:
     """source-major view of a graph for the featureless basis layer (see csrc/rgcn_basis.hip)"""
     __slots__ = ("e_dst", "e_rel", "e_val", "n_messages", "units_src", "perm_dst", "units_dst", "perm_rel", "units_rel",
-                 "n_nodes", "num_rels")
+                 "n_nodes", "num_rels", "rowptr_src")
 
 
 def build_fbasis_plan(csr_src, csr_dst, n_nodes, num_rels, max_len=1024):
@@ -560,6 +560,7 @@ def build_fbasis_plan(csr_src, csr_dst, n_nodes, num_rels, max_len=1024):
     M = int(csr_src.rowptr[n_nodes].item())
     p.n_messages, p.n_nodes, p.num_rels = M, n_nodes, num_rels
     p.e_dst, p.e_rel, p.e_val = csr_src.src, csr_src.rel, csr_src.val
+    p.rowptr_src = csr_src.rowptr
     p.units_src = row_units(csr_src.rowptr, n_nodes, max_len)
     live = csr_src.msg_slot >= 0
     perm = torch.zeros(max(M, 1), dtype=torch.int32, device=csr_src.rowptr.device)
@@ -633,6 +634,50 @@ def fbasis_bwd(table, comps, g, plan, need_bases=True, need_comps=True, basis_ma
             units, n_units, n_split = plan.units_rel
             _check(lib().rgcn_gather_rows_sum_f32(_dp(T), _dp(plan.perm_rel), _dp(units), c_i64(n_units), c_i64(n_split),
                                                   None, _dp(dC), c_i64(R), c_i32(B), _stream(dev)), "gather_rows_sum")
+    return dB, dC
+
+
+def fbasis_tile_ok(R, B, d, n_nodes):
+    """-> (forward, backward) availability of the tile kernels (rgcn_fbasis_tile.hip: the table walked IN the parameter's [B, N, d]
+    layout, 16 source nodes per tile); route fbasis_tile=0 turns them off, the deterministic mode keeps the wave-per-node kernels"""
+    if routes.get("fbasis_tile", "1") == "0" or routes.flag("deterministic"):
+        return False, False
+    m = lib().rgcn_fbasis_tile_supported(c_i32(R), c_i32(B), c_i32(d), c_i64(n_nodes))
+    return bool(m & 1), bool(m & 2)
+
+
+def fbasis_tile_fwd(bases, comps, bias, plan):
+    """bases [B, N, d] (the parameter itself) -> out [N, d]"""
+    _req(bases, "bases"); _req(comps, "comps"); _req(bias, "bias")
+    B, N, d = bases.shape
+    dev = bases.device
+    ys = int(lib().rgcn_fbasis_tile_ystride(c_i32(d)))
+    Y = torch.empty(max(plan.n_messages, 1), ys, device=dev, dtype=torch.float32)
+    out = torch.empty(N, d, device=dev, dtype=torch.float32)
+    with _on(dev), _timed("fbasis_tile_fwd"):
+        _check(lib().rgcn_fbasis_tile_fwd_f32(_dp(bases), _dp(comps), _dp(Y), _dp(plan.rowptr_src), _dp(plan.e_rel), _dp(plan.e_val),
+                                              c_i64(plan.n_messages), c_i64(N), c_i32(comps.shape[0]), c_i32(B), c_i32(d), _stream(dev)), "fbasis_tile_fwd")
+    units, n_units, n_split = plan.units_dst
+    with _on(dev), _timed("gather_rows_sum4"):
+        _check(lib().rgcn_gather_rows_sum4_f32(_dp(Y), c_i32(ys), _dp(plan.perm_dst), _dp(units), c_i64(n_units), c_i64(n_split),
+                                               _dp(bias), _dp(out), c_i64(N), c_i32(d), _stream(dev)), "gather_rows_sum4")
+    return out
+
+
+def fbasis_tile_bwd(bases, comps, g, plan, need_bases=True, need_comps=True):
+    """-> (dbases [B, N, d] in the parameter's layout, dcomps [R, B])"""
+    _req(bases, "bases"); _req(comps, "comps"); _req(g, "grad")
+    B, N, d = bases.shape
+    R = comps.shape[0]
+    dev = bases.device
+    dB = torch.empty_like(bases) if need_bases else None
+    dC = torch.empty(R, B, device=dev, dtype=torch.float32) if need_comps else None
+    if dB is None and dC is None:
+        return None, None
+    with _on(dev), _timed("fbasis_tile_bwd"):
+        _check(lib().rgcn_fbasis_tile_bwd_f32(_dp(bases), _dp(comps), _dp(g), _dp(dB), _dp(dC), _dp(plan.rowptr_src), _dp(plan.e_dst),
+                                              _dp(plan.e_rel), _dp(plan.e_val), c_i64(plan.n_messages), c_i64(N), c_i32(R), c_i32(B), c_i32(d), _stream(dev)),
+               "fbasis_tile_bwd")
     return dB, dC
 
 

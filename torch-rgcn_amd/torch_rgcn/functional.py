@@ -607,6 +607,16 @@ class _FeaturelessBasisMP(torch.autograd.Function):
         # rows of 40 bytes: reading them in place, 40 half-used lines per node, cost 33.5 ms per step against 24).  Basis-major
         # [B, N, d] = the parameter itself, no copies: wins while the table stays cache-resident (MUTAG: 45 MB, step 0.56 -> 0.51 ms).
         ctx.in_place = ctx.src_major and B * N * d * 4 <= int(routes.get("fbasis_inplace_mb", "256")) << 20
+        # Round 4: tables beyond the caches are walked in place too, by the tile kernels (rgcn_fbasis_tile.hip: 16 source nodes per tile,
+        # staged through LDS with aligned 16-byte accesses, software-pipelined) -- no transposed copy, no transposed gradient.
+        tile_f, tile_b = _native.fbasis_tile_ok(comps.shape[0], B, d, N) if (ctx.src_major and not ctx.in_place) else (False, False)
+        ctx.tile_bwd = tile_f and tile_b
+        if tile_f and tile_b:
+            comps, bases = dense(comps), dense(bases)
+            ctx.graph, ctx.has_bias = graph, bias is not None
+            ctx.in_place = True
+            ctx.save_for_backward(bases, comps)
+            return _native.fbasis_tile_fwd(bases, comps, bias, graph.fbasis_plan())
         if ctx.src_major and ctx.in_place:
             comps, bases = dense(comps), dense(bases)
             ctx.graph, ctx.has_bias = graph, bias is not None
@@ -631,8 +641,11 @@ class _FeaturelessBasisMP(torch.autograd.Function):
         g = dense(g)
         if ctx.src_major:
             table, comps = ctx.saved_tensors
-            dB, dC = _native.fbasis_bwd(table, comps, g, ctx.graph.fbasis_plan(), ctx.needs_input_grad[0],
-                                        ctx.needs_input_grad[1], basis_major=ctx.in_place)
+            if getattr(ctx, "tile_bwd", False):
+                dB, dC = _native.fbasis_tile_bwd(table, comps, g, ctx.graph.fbasis_plan(), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+            else:
+                dB, dC = _native.fbasis_bwd(table, comps, g, ctx.graph.fbasis_plan(), ctx.needs_input_grad[0],
+                                            ctx.needs_input_grad[1], basis_major=ctx.in_place)
             if dB is not None and not ctx.in_place:
                 dB = dB.permute(1, 0, 2)      # a view: autograd accumulates it into the [B, N, d] parameter gradient
             db = _native.colsum(g) if ctx.has_bias and ctx.needs_input_grad[2] else None
