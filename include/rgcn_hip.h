@@ -407,11 +407,12 @@ RGCN_API int rgcn_featureless_wgrad_f32(const float *G, float *dtable, const int
                                         int32_t d_out, void *stream);
 /* The featureless layer on a destination-major CSR (graphs whose (tile, relation) buckets are sparse: the tile plan of an AIFB-sized
  * graph with 91 relations is 23 padded slots per message).  Same results as rgcn_featureless_fwd_f32 / rgcn_featureless_wgrad_f32
- * (reference layers.py:293-301 with the one-hot input folded into the weight table).  units: [n_units][4] = {row, e0, e1, flags}
+ * (reference layers.py:293-301 with the one-hot input folded into the weight table; relu != 0: the models' F.relu(self.rgc1()) --
+ * models.py:194 -- in the epilogue, rows not cut into shared pieces only -- the same flag on the rgcn_gather_rows_sum*_f32).  units: [n_units][4] = {row, e0, e1, flags}
  * (hub rows cut into pieces, RGCN_U_SHARED); the weight-gradient form walks the n_entries CSR entries, rowptr gives an entry's row. */
 RGCN_API int rgcn_featureless_csr_fwd_f32(const float *table, const float *bias, float *out, const int32_t *units, int64_t n_units,
                                           int64_t n_split, const int32_t *e_src, const int32_t *e_rel, const float *e_val,
-                                          int64_t n_rows, int64_t n_src, int32_t R, int32_t d, void *stream);
+                                          int64_t n_rows, int64_t n_src, int32_t R, int32_t d, int32_t relu, void *stream);
 RGCN_API int rgcn_featureless_csr_wgrad_f32(const float *G, float *dtable, const int32_t *rowptr, const int32_t *e_src,
                                             const int32_t *e_rel, const float *e_val, int64_t n_entries, int64_t n_rows, int64_t n_src,
                                             int32_t R, int32_t d, void *stream);
@@ -458,7 +459,7 @@ RGCN_API int rgcn_fbasis_bwd_dc_f32(const float *bases, const float *comps, cons
                                     int32_t basis_major, void *stream);
 RGCN_API int rgcn_gather_rows_sum_f32(const float *Y, const int32_t *perm, const int32_t *units, int64_t n_units,
                                       int64_t n_split, const float *bias, float *out, int64_t n_rows, int32_t w,
-                                      void *stream);
+                                      int32_t relu, void *stream);
 
 /* The same layer on a table far beyond the caches, IN the parameter's own [B, N, d] layout and software-pipelined (round 4,
  * rgcn_fbasis_tile.hip; reference layers.py:241-242 + :286-288 with nc-AM.yaml's B = 40, d = 10: a 2.67 GB table): persistent
@@ -477,7 +478,8 @@ RGCN_API int rgcn_fbasis_tile_fwd_f32(const float *bases, const float *comps, fl
                                       const float *e_val, int64_t n_messages, int64_t n_nodes, int32_t R, int32_t B, int32_t d,
                                       void *stream);
 RGCN_API int rgcn_gather_rows_sum4_f32(const float *Y, int32_t ys, const int32_t *perm, const int32_t *units, int64_t n_units,
-                                       int64_t n_split, const float *bias, float *out, int64_t n_rows, int32_t w, void *stream);
+                                       int64_t n_split, const float *bias, float *out, int64_t n_rows, int32_t w, int32_t relu,
+                                       void *stream);
 RGCN_API int rgcn_fbasis_tile_bwd_f32(const float *bases, const float *comps, const float *G, float *dbases, float *dcomps,
                                       const int32_t *rowptr, const int32_t *e_dst, const int32_t *e_rel, const float *e_val,
                                       int64_t n_messages, int64_t n_nodes, int32_t R, int32_t B, int32_t d, void *stream);
@@ -485,9 +487,10 @@ RGCN_API int rgcn_fbasis_tile_bwd_f32(const float *bases, const float *comps, co
 /* Classifier head of the node-classification experiments, one launch: loss = mean cross-entropy of the logits' LABELLED rows and
  * dlogits [N, C] = d loss / d logits (zero rows for unlabelled nodes).  Replaces `criterion(model()[train_idx, :], train_lbl)` with
  * nn.CrossEntropyLoss() and its autograd graph (reference experiments/classify_nodes.py:107-110, :129): row_label [N] = class of the
- * node or -1, lab_rows [n_lab] = the labelled nodes (each once).  C <= 64. */
+ * node or -1, lab_rows [n_lab] = the labelled nodes (each once).  C <= 64.  Rows of logits and dlogits are ld >= C floats apart (a layer's
+ * zero-padded output read in place; columns C .. ld of dlogits are written 0). */
 RGCN_API int rgcn_ce_head_f32(const float *logits, const int32_t *row_label, const int32_t *lab_rows, float *loss, float *dlogits,
-                              int64_t N, int32_t C, int32_t n_lab, void *stream);
+                              int64_t N, int32_t C, int32_t ld, int32_t n_lab, void *stream);
 
 /* Zero-padding / cropping of the two trailing dimensions of a [A][B][C] tensor into [A][Bd][Cd], with an optional 1-D tensor (n1 -> n1d
  * elements) in the same launch: how widths that are no multiple of 16 (classifier outputs: layers.py weights [R, 16, 4], bias [4]) reach

@@ -50,6 +50,15 @@ def timed(fn):
 res = {"fwd+gather": timed(lambda: _native.fbasis_tile_fwd(bases, comps, bias, plan)),
        "dbases": timed(lambda: _native.fbasis_tile_bwd(bases, comps, g, plan, True, False)),
        "dcomps": timed(lambda: _native.fbasis_tile_bwd(bases, comps, g, plan, False, True))}
+L = _native.lib()
+if hasattr(L, "rgcn_fbt_debug_read"):
+    import ctypes
+    buf = (ctypes.c_ulonglong * 6)()
+    L.rgcn_fbt_debug_read(buf, 1)
+    _native.fbasis_tile_fwd(bases, comps, bias, plan)
+    L.rgcn_fbt_debug_read(buf, 1)
+    w = max(buf[5], 1)
+    res["fwd_us_per_wave"] = {k: round(buf[i] / w / 100.0, 1) for i, k in enumerate(("arrive+store+flush", "issue", "messages", "barrier", "rotate"))}
 _native.profile_start()
 _native.fbasis_tile_fwd(bases, comps, bias, plan)
 prof = _native.profile_stop()

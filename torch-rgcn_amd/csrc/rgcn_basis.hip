@@ -285,7 +285,7 @@ __global__ __launch_bounds__(WG) void fbasis_bwd_kernel(
 // lane = (g, i): column i = lane % wp, message group g = lane / wp.
 __global__ __launch_bounds__(WG) void gather_rows_sum_kernel(
     const float *__restrict__ Y, const int *__restrict__ perm, const int4 *__restrict__ units, int n_units,
-    const float *__restrict__ bias, float *__restrict__ out, int w, int wp) {
+    const float *__restrict__ bias, float *__restrict__ out, int w, int wp, int relu_out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int u = blockIdx.x * WAVES + wave;
   if (u >= n_units) return;
@@ -315,7 +315,8 @@ __global__ __launch_bounds__(WG) void gather_rows_sum_kernel(
       if ((unit.w & U_FIRST) && bias) a += bias[i];
       atomicAdd(p, a);
     } else {
-      *p = bias ? a + bias[i] : a;
+      a = bias ? a + bias[i] : a;
+      *p = relu_out ? fmaxf(a, 0.f) : a;
     }
   }
 }
@@ -429,17 +430,18 @@ extern "C" int rgcn_fbasis_bwd_dc_f32(const float *bases, const float *comps, co
 
 extern "C" int rgcn_gather_rows_sum_f32(const float *Y, const int32_t *perm, const int32_t *units, int64_t n_units,
                                         int64_t n_split, const float *bias, float *out, int64_t n_rows, int32_t w,
-                                        void *stream) {
+                                        int32_t relu, void *stream) {
   if (n_units < 0 || n_rows < 0 || w <= 0 || (n_units && (!Y || !units || !out))) {
     rgcn_set_error("gather_rows_sum: bad argument");
     return RGCN_EINVAL;
   }
+  if (relu && n_split) { rgcn_set_error("gather_rows_sum: relu in the epilogue needs rows that are not cut into shared pieces"); return RGCN_EUNSUPPORTED; }
   if (w > 64) { rgcn_set_error("gather_rows_sum: width > 64 unsupported"); return RGCN_EUNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
   if (n_split) HIP_TRY(zero_async(out, (size_t)n_rows * w * sizeof(float), st));
   if (n_units == 0) return RGCN_OK;
   hipLaunchKernelGGL(gather_rows_sum_kernel, dim3((unsigned)((n_units + WAVES - 1) / WAVES)), dim3(WG), 0, st, Y, perm,
-                     reinterpret_cast<const int4 *>(units), (int)n_units, bias, out, w, pow2_at_least(w, 4));
+                     reinterpret_cast<const int4 *>(units), (int)n_units, bias, out, w, pow2_at_least(w, 4), relu ? 1 : 0);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

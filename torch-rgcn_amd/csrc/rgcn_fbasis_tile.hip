@@ -24,6 +24,7 @@
 //
 // Not bit-reproducible (arrival order of the LDS adds); the deterministic route stays in rgcn_basis.hip.
 #include "rgcn_device.h"
+#include <string.h>
 
 namespace {
 
@@ -39,8 +40,14 @@ __device__ __forceinline__ int rlane(int v, int src_lane) { return __builtin_amd
 #define FBT_ARRIVED(x) asm volatile("" : "+v"(x))          // the value must be in its register HERE (pins the s_waitcnt)
 #ifdef RGCN_ABLATIONS       // timing experiments with WRONG results (tools/fbt_bench.py, ablation build only): 1 no message loop, 2 no tile loads, 4 no row gathers, 8 no LDS adds
 #define FBT_ABL(bit) (abl & (bit))
+// the instrumented kernels also add up, per wave, the 100 MHz ticks of every phase of the pipeline (rgcn_fbt_debug_read)
+#define FBT_T() ((long long)__builtin_amdgcn_s_memtime())
+#define FBT_DBG(...) __VA_ARGS__
+__device__ unsigned long long rgcn_fbt_dbg[8 * 256 * 16];
 #else
 #define FBT_ABL(bit) false
+#define FBT_T() 0ll
+#define FBT_DBG(...)
 #endif
 
 // x + y after exchanging halves (W = 32: lanes 32..63 of x with lanes 0..31 of y) or rows (W = 16: the odd 16-lane rows of x with the even
@@ -146,6 +153,7 @@ __global__ __launch_bounds__(TW) void fbt_fwd_kernel(
   float ev = e_val[min(s.a + lane, last)];
   stage_store<KLD, true>(tb, st, g);
   stage_load<KLD, VEC>(st, g, bases, base_of(t + G));
+  FBT_DBG(long long dbg[5] = {0, 0, 0, 0, 0};)
   int pa = 0, pn = 0;                                      // the wave's results waiting in yb: rows pa .. pa + pn
   auto flush = [&]() {
     f32x4 *dst = reinterpret_cast<f32x4 *>(Y + (size_t)pa * DP);
@@ -155,18 +163,21 @@ __global__ __launch_bounds__(TW) void fbt_fwd_kernel(
   };
   lds_barrier();
   for (int k = 0;; ++k) {
-    const bool has1 = t + G < n_tiles, has2 = t + 2 * G < n_tiles;
+    const bool has1 = t + G < n_tiles;
     const float *cb = tb + (k & 1) * (B * ts);
+    FBT_DBG(const long long T0 = FBT_T();)
     // everything issued one iteration ago has had a tile of compute to arrive
     if (has1) stage_store<KLD, true>(tb + ((k + 1) & 1) * (B * ts), st, g);
     flush();
     __builtin_amdgcn_sched_barrier(0);
+    FBT_DBG(const long long T1 = FBT_T();)
     if (!FBT_ABL(2)) stage_load<KLD, VEC>(st, g, bases, base_of(t + 2 * G));           // (past the end: the last tile again, never stored)
     const int rp2 = rp_of(t + 2 * G);
     const Share s1 = share_of(rp1, wave, has1);
     const int er1 = e_rel[min(s1.a + lane, last)];
     const float ev1 = e_val[min(s1.a + lane, last)];
     __builtin_amdgcn_sched_barrier(0);
+    FBT_DBG(const long long T2 = FBT_T();)
     // ---- tile t
     const int shift = t * TN - min(t * TN, N - TN);
     int c_a = s.a, c_n = s.n, c_er = er;
@@ -228,12 +239,17 @@ __global__ __launch_bounds__(TW) void fbt_fwd_kernel(
       c_ev = e_val[min(c_a + lane, last)];
       FBT_ARRIVED(c_er); FBT_ARRIVED(c_ev);                 // (the wait belongs HERE, on the rare path: left to the compiler it lands inside the message loop)
     }
+    FBT_DBG(const long long T3 = FBT_T();)
     lds_barrier();
+    FBT_DBG(const long long T4 = FBT_T(); dbg[0] += T1 - T0; dbg[1] += T2 - T1; dbg[2] += T3 - T2; dbg[3] += T4 - T3;)
     if (!has1) break;
     t += G;
     rp = rp1; rp1 = rp2; s = s1; er = er1; ev = ev1;
+    FBT_ARRIVED(er); FBT_ARRIVED(ev); FBT_ARRIVED(rp1);
+    FBT_DBG(dbg[4] += FBT_T() - T4;)
   }
   flush();
+  FBT_DBG(if (lane == 0) { unsigned long long *o = rgcn_fbt_dbg + 8 * ((blockIdx.x & 255) * 16 + wave); for (int q = 0; q < 5; ++q) o[q] += dbg[q]; o[5] += 1; })
 }
 
 // out[row, 0..w) = (bias) + sum_j Y[perm[j], :] over the units of a row; Y rows are 4 LPR floats (16-byte pieces, one per lane), LPR lanes
@@ -241,7 +257,7 @@ __global__ __launch_bounds__(TW) void fbt_fwd_kernel(
 template <int LPR>
 __global__ __launch_bounds__(256) void gather_rows_sum4_kernel(const float *__restrict__ Y, const int *__restrict__ perm,
                                                                const int4 *__restrict__ units, const float *__restrict__ bias,
-                                                               float *__restrict__ out, long long n_units, int w) {
+                                                               float *__restrict__ out, long long n_units, int w, int relu_out) {
   const int q = threadIdx.x % LPR;
   for (long long u = ((long long)blockIdx.x * 256 + threadIdx.x) / LPR; u < n_units; u += ((long long)gridDim.x * 256) / LPR) {
     const int4 unit = units[u];
@@ -265,7 +281,7 @@ __global__ __launch_bounds__(256) void gather_rows_sum4_kernel(const float *__re
 #pragma unroll
     for (int c = 0; c < 4; ++c)
       if (4 * q + c < w) {
-        if (shared) atomicAdd(o + c, a[c]); else o[c] = a[c];
+        if (shared) atomicAdd(o + c, a[c]); else o[c] = relu_out ? fmaxf(a[c], 0.f) : a[c];
       }
   }
 }
@@ -579,6 +595,21 @@ hipError_t raise_lds(K kernel, size_t bytes) {
 
 }  // namespace
 
+#ifdef RGCN_ABLATIONS
+/* ablation library only: 100 MHz ticks summed over the waves of all forward tile launches since the last reset:
+ * {arrival + tile store + Y flush, issue of the next loads, message loops, barrier, rotation, waves} */
+extern "C" __attribute__((visibility("default"))) int rgcn_fbt_debug_read(unsigned long long *out6, int reset) {
+  static unsigned long long h[8 * 256 * 16];
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(rgcn_fbt_dbg), sizeof(h)));
+  for (int i = 0; i < 6; ++i) out6[i] = 0;
+  for (int w = 0; w < 256 * 16; ++w)
+    for (int i = 0; i < 6; ++i) out6[i] += h[8 * w + i];
+  if (reset) { memset(h, 0, sizeof(h)); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rgcn_fbt_dbg), h, sizeof(h))); }
+  return RGCN_OK;
+}
+#endif
+
 extern "C" int rgcn_fbasis_tile_supported(int32_t R, int32_t B, int32_t d, int64_t n_nodes) {
   TileShape s;
   if (!tile_shape(R, B, d, n_nodes, s)) return 0;
@@ -622,20 +653,22 @@ extern "C" int rgcn_fbasis_tile_fwd_f32(const float *bases, const float *comps, 
 }
 
 extern "C" int rgcn_gather_rows_sum4_f32(const float *Y, int32_t ys, const int32_t *perm, const int32_t *units, int64_t n_units,
-                                         int64_t n_split, const float *bias, float *out, int64_t n_rows, int32_t w, void *stream) {
+                                         int64_t n_split, const float *bias, float *out, int64_t n_rows, int32_t w, int32_t relu,
+                                         void *stream) {
   if (n_units < 0 || n_rows < 0 || w <= 0 || w > ys || (ys != 4 && ys != 8 && ys != 16) || (n_units && (!Y || !perm || !units || !out))) {
     rgcn_set_error("gather_rows_sum4: bad argument");
     return RGCN_EINVAL;
   }
+  if (relu && n_split) { rgcn_set_error("gather_rows_sum4: relu in the epilogue needs rows that are not cut into shared pieces"); return RGCN_EUNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
   if (n_split) HIP_TRY(zero_async(out, (size_t)n_rows * w * sizeof(float), st));
   if (n_units == 0) return RGCN_OK;
   const int lpr = ys / 4;
   const dim3 grid((unsigned)std::min<int64_t>((n_units * lpr + 255) / 256, (int64_t)n_cus() * 32));
   const int4 *un = reinterpret_cast<const int4 *>(units);
-  if (lpr == 1) hipLaunchKernelGGL(gather_rows_sum4_kernel<1>, grid, dim3(256), 0, st, Y, perm, un, bias, out, (long long)n_units, w);
-  else if (lpr == 2) hipLaunchKernelGGL(gather_rows_sum4_kernel<2>, grid, dim3(256), 0, st, Y, perm, un, bias, out, (long long)n_units, w);
-  else hipLaunchKernelGGL(gather_rows_sum4_kernel<4>, grid, dim3(256), 0, st, Y, perm, un, bias, out, (long long)n_units, w);
+  if (lpr == 1) hipLaunchKernelGGL(gather_rows_sum4_kernel<1>, grid, dim3(256), 0, st, Y, perm, un, bias, out, (long long)n_units, w, relu ? 1 : 0);
+  else if (lpr == 2) hipLaunchKernelGGL(gather_rows_sum4_kernel<2>, grid, dim3(256), 0, st, Y, perm, un, bias, out, (long long)n_units, w, relu ? 1 : 0);
+  else hipLaunchKernelGGL(gather_rows_sum4_kernel<4>, grid, dim3(256), 0, st, Y, perm, un, bias, out, (long long)n_units, w, relu ? 1 : 0);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

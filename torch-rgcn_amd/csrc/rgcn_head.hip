@@ -23,17 +23,18 @@ constexpr int MAXC = 64;
 
 __global__ __launch_bounds__(HB) void ce_head_kernel(const float *__restrict__ logits, const int *__restrict__ row_label,
                                                       const int *__restrict__ lab_rows, float *__restrict__ loss,
-                                                      float *__restrict__ dlogits, long long N, int C, int n_lab, int nb) {
+                                                      float *__restrict__ dlogits, long long N, int C, int ld, int n_lab, int nb) {
   if ((int)blockIdx.x < nb) {
     const long long n = (long long)blockIdx.x * HB + threadIdx.x;
     if (n >= N) return;
     const int lbl = row_label[n];
-    float *g = dlogits + n * C;
+    float *g = dlogits + n * ld;
+    for (int c = C; c < ld; ++c) g[c] = 0.f;                 // rows of ld >= C floats (a layer's padded output): the padding's gradient is 0
     if (lbl < 0) {
       for (int c = 0; c < C; ++c) g[c] = 0.f;
       return;
     }
-    const float *x = logits + n * C;
+    const float *x = logits + n * ld;
     float m = x[0];
     for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
     float s = 0.f;
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(HB) void ce_head_kernel(const float *__restrict__ l
   for (int i = threadIdx.x; i < n_lab; i += HB) {
     const long long n = lab_rows[i];
     const int lbl = row_label[n];
-    const float *x = logits + n * C;
+    const float *x = logits + n * ld;
     float m = x[0];
     for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
     float s = 0.f;
@@ -96,12 +97,12 @@ extern "C" int rgcn_resize3_f32(const float *src, float *dst, int64_t A, int32_t
 }
 
 extern "C" int rgcn_ce_head_f32(const float *logits, const int32_t *row_label, const int32_t *lab_rows, float *loss, float *dlogits,
-                                int64_t N, int32_t C, int32_t n_lab, void *stream) {
-  if (!logits || !row_label || !lab_rows || !loss || !dlogits || N <= 0 || C <= 0 || n_lab <= 0) { rgcn_set_error("ce_head: bad argument"); return RGCN_EINVAL; }
+                                int64_t N, int32_t C, int32_t ld, int32_t n_lab, void *stream) {
+  if (!logits || !row_label || !lab_rows || !loss || !dlogits || N <= 0 || C <= 0 || ld < C || n_lab <= 0) { rgcn_set_error("ce_head: bad argument"); return RGCN_EINVAL; }
   if (C > MAXC) { rgcn_set_error("ce_head: %d classes (at most %d)", C, MAXC); return RGCN_EUNSUPPORTED; }
   const int nb = (int)((N + HB - 1) / HB);
   hipLaunchKernelGGL(ce_head_kernel, dim3((unsigned)(nb + 1)), dim3(HB), 0, (hipStream_t)stream, logits, row_label, lab_rows, loss, dlogits,
-                     (long long)N, C, n_lab, nb);
+                     (long long)N, C, ld, n_lab, nb);
   if (hipGetLastError() != hipSuccess) { rgcn_set_error("ce_head: launch failed"); return RGCN_EHIP; }
   return RGCN_OK;
 }

@@ -854,7 +854,7 @@ template <bool TABLE>
 __global__ __launch_bounds__(WG) void diag_csr_kernel(
     const float *__restrict__ X, const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ out,
     const int4 *__restrict__ units, long long n_units, const int *__restrict__ e_src, const int *__restrict__ e_rel,
-    const float *__restrict__ e_val, int d, int lpm, int lr, long long n_src) {
+    const float *__restrict__ e_val, int d, int lpm, int lr, long long n_src, int relu_out) {
   const long long u = ((long long)blockIdx.x * WG + threadIdx.x) / lr;
   const int sub = threadIdx.x % lr, g = sub / lpm, j = sub % lpm, gpr = lr / lpm;
   const bool on = u < n_units;
@@ -901,6 +901,10 @@ __global__ __launch_bounds__(WG) void diag_csr_kernel(
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (add_bias && f + q < d) a[q] += bias[f + q];
+      if (relu_out && !shared) {                  // (the launcher refuses relu_out with hub rows cut into shared pieces)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = fmaxf(a[q], 0.f);
+      }
       if (vec && !shared) {
         *reinterpret_cast<f32x4 *>(o) = a;
       } else {
@@ -1633,19 +1637,20 @@ extern "C" int rgcn_diag_spmm_f32(const float *X, const float *w, const float *b
   const int upw = WG / lr;                      // units per workgroup
   const unsigned gx = (unsigned)((n_units + upw - 1) / upw);
   hipLaunchKernelGGL(diag_csr_kernel<false>, dim3(gx), dim3(WG), 0, (hipStream_t)stream, X, w, bias, out,
-                     reinterpret_cast<const int4 *>(rowptr_units), (long long)n_units, e_src, e_rel, e_val, d, lpm, lr, 0LL);
+                     reinterpret_cast<const int4 *>(rowptr_units), (long long)n_units, e_src, e_rel, e_val, d, lpm, lr, 0LL, 0);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
 
 extern "C" int rgcn_featureless_csr_fwd_f32(const float *table, const float *bias, float *out, const int32_t *units, int64_t n_units,
                                             int64_t n_split, const int32_t *e_src, const int32_t *e_rel, const float *e_val,
-                                            int64_t n_rows, int64_t n_src, int32_t R, int32_t d, void *stream) {
+                                            int64_t n_rows, int64_t n_src, int32_t R, int32_t d, int32_t relu, void *stream) {
   if (!table || !out || d <= 0 || n_rows < 0 || n_src <= 0 || R <= 0 || n_units < 0 || n_split < 0 ||
       (n_units && (!units || !e_src || !e_rel || !e_val))) {
     rgcn_set_error("featureless_csr_fwd: bad argument");
     return RGCN_EINVAL;
   }
+  if (relu && n_split) { rgcn_set_error("featureless_csr_fwd: relu in the epilogue needs rows that are not cut into shared pieces"); return RGCN_EUNSUPPORTED; }
   if (n_rows == 0 || n_units == 0) return RGCN_OK;
   if (n_split) HIP_TRY(zero_async(out, (size_t)n_rows * d * sizeof(float), (hipStream_t)stream));
   int lpm = 1;                                  // lanes per message: float4 each, a power of two
@@ -1654,7 +1659,7 @@ extern "C" int rgcn_featureless_csr_fwd_f32(const float *table, const float *bia
   const int upw = WG / lr;
   const unsigned gx = (unsigned)((n_units + upw - 1) / upw);
   hipLaunchKernelGGL(diag_csr_kernel<true>, dim3(gx), dim3(WG), 0, (hipStream_t)stream, table, nullptr, bias, out,
-                     reinterpret_cast<const int4 *>(units), (long long)n_units, e_src, e_rel, e_val, d, lpm, lr, (long long)n_src);
+                     reinterpret_cast<const int4 *>(units), (long long)n_units, e_src, e_rel, e_val, d, lpm, lr, (long long)n_src, relu ? 1 : 0);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

@@ -588,8 +588,9 @@ def fbasis_supported(B, d):
     return d <= 16 and B <= 64 and 4 * ((B + 4 * ngrp - 1) // (4 * ngrp)) <= 16
 
 
-def fbasis_fwd(table, comps, bias, plan, basis_major=False):
-    """table: the bases, node-major [N, B, d] or -- basis_major -- in the parameter's own [B, N, d] layout (no transposed copy)"""
+def fbasis_fwd(table, comps, bias, plan, basis_major=False, relu=False):
+    """table: the bases, node-major [N, B, d] or -- basis_major -- in the parameter's own [B, N, d] layout (no transposed copy);
+    relu: applied in the row sum's epilogue (-> (out, True)) unless hub rows are cut into shared pieces (-> (out, False))"""
     bases = table
     _req(bases, "bases"); _req(comps, "comps"); _req(bias, "bias")
     N, B, d = (bases.shape[1], bases.shape[0], bases.shape[2]) if basis_major else bases.shape
@@ -602,9 +603,10 @@ def fbasis_fwd(table, comps, bias, plan, basis_major=False):
                                          c_i64(n_units), c_i64(N), c_i32(comps.shape[0]), c_i32(B), c_i32(d),
                                          c_i32(1 if basis_major else 0), _stream(dev)), "fbasis_fwd")
         units, n_units, n_split = plan.units_dst
+        fused = bool(relu) and n_split == 0
         _check(lib().rgcn_gather_rows_sum_f32(_dp(Y), _dp(plan.perm_dst), _dp(units), c_i64(n_units), c_i64(n_split),
-                                              _dp(bias), _dp(out), c_i64(N), c_i32(d), _stream(dev)), "gather_rows_sum")
-    return out
+                                              _dp(bias), _dp(out), c_i64(N), c_i32(d), c_i32(1 if fused else 0), _stream(dev)), "gather_rows_sum")
+    return (out, fused) if relu else out
 
 
 def fbasis_bwd(table, comps, g, plan, need_bases=True, need_comps=True, basis_major=False):
@@ -633,7 +635,7 @@ def fbasis_bwd(table, comps, g, plan, need_bases=True, need_comps=True, basis_ma
         if need_comps:
             units, n_units, n_split = plan.units_rel
             _check(lib().rgcn_gather_rows_sum_f32(_dp(T), _dp(plan.perm_rel), _dp(units), c_i64(n_units), c_i64(n_split),
-                                                  None, _dp(dC), c_i64(R), c_i32(B), _stream(dev)), "gather_rows_sum")
+                                                  None, _dp(dC), c_i64(R), c_i32(B), c_i32(0), _stream(dev)), "gather_rows_sum")
     return dB, dC
 
 
@@ -646,8 +648,8 @@ def fbasis_tile_ok(R, B, d, n_nodes):
     return bool(m & 1), bool(m & 2)
 
 
-def fbasis_tile_fwd(bases, comps, bias, plan):
-    """bases [B, N, d] (the parameter itself) -> out [N, d]"""
+def fbasis_tile_fwd(bases, comps, bias, plan, relu=False):
+    """bases [B, N, d] (the parameter itself) -> out [N, d]; relu: as fbasis_fwd"""
     _req(bases, "bases"); _req(comps, "comps"); _req(bias, "bias")
     B, N, d = bases.shape
     dev = bases.device
@@ -658,10 +660,11 @@ def fbasis_tile_fwd(bases, comps, bias, plan):
         _check(lib().rgcn_fbasis_tile_fwd_f32(_dp(bases), _dp(comps), _dp(Y), _dp(plan.rowptr_src), _dp(plan.e_rel), _dp(plan.e_val),
                                               c_i64(plan.n_messages), c_i64(N), c_i32(comps.shape[0]), c_i32(B), c_i32(d), _stream(dev)), "fbasis_tile_fwd")
     units, n_units, n_split = plan.units_dst
+    fused = bool(relu) and n_split == 0
     with _on(dev), _timed("gather_rows_sum4"):
         _check(lib().rgcn_gather_rows_sum4_f32(_dp(Y), c_i32(ys), _dp(plan.perm_dst), _dp(units), c_i64(n_units), c_i64(n_split),
-                                               _dp(bias), _dp(out), c_i64(N), c_i32(d), _stream(dev)), "gather_rows_sum4")
-    return out
+                                               _dp(bias), _dp(out), c_i64(N), c_i32(d), c_i32(1 if fused else 0), _stream(dev)), "gather_rows_sum4")
+    return (out, fused) if relu else out
 
 
 def fbasis_tile_bwd(bases, comps, g, plan, need_bases=True, need_comps=True):
@@ -1237,7 +1240,7 @@ def featureless_fwd(table, bias, plan):
     return out
 
 
-def featureless_csr_fwd(table, bias, csr):
+def featureless_csr_fwd(table, bias, csr, relu=False):
     """out[n_rows, d] = bias + sum over the row's CSR entries of val * table[rel, src, :] (rgcn_featureless_csr_fwd_f32): the
     featureless layer on graphs whose (tile, relation) buckets are sparse -- one lane group per MESSAGE, not per padded plan slot"""
     _req(table, "weights"); _req(bias, "bias")
@@ -1245,11 +1248,12 @@ def featureless_csr_fwd(table, bias, csr):
     units, n_units, n_split = _csr_units(csr)
     assert units is not None, "the CSR featureless kernels serve static graphs"
     out = torch.empty((csr.n_rows, d), device=table.device, dtype=torch.float32)
+    fused = bool(relu) and n_split == 0          # relu in the epilogue unless hub rows are cut into shared pieces
     with _on(table.device), _timed("featureless_csr_fwd"):
         _check(lib().rgcn_featureless_csr_fwd_f32(_dp(table), _dp(bias), _dp(out), _dp(units), c_i64(n_units), c_i64(n_split),
                                                   _dp(csr.src), _dp(csr.rel), _dp(csr.val), c_i64(csr.n_rows), c_i64(n_src),
-                                                  c_i32(R), c_i32(d), _stream(table.device)), "featureless_csr_fwd")
-    return out
+                                                  c_i32(R), c_i32(d), c_i32(1 if fused else 0), _stream(table.device)), "featureless_csr_fwd")
+    return (out, fused) if relu else out
 
 
 def featureless_csr_wgrad(G, csr, num_rels, n_src):
@@ -1422,15 +1426,18 @@ def resize3(src, shape, src1=None, n1d=None):
 
 
 def ce_head(logits, row_label, lab_rows):
-    """(loss [1], dlogits [N, C]) of the mean cross-entropy over the labelled rows (rgcn_ce_head_f32)"""
-    _req(logits, "logits"); _req(row_label, "row_label", torch.int32); _req(lab_rows, "lab_rows", torch.int32)
+    """(loss [1], dlogits [N, C], the zero-padded [N, ld] buffer dlogits is the first columns of -- or None) of the mean cross-entropy
+    over the labelled rows (rgcn_ce_head_f32).  logits: rows of C floats at a stride of ld >= C floats (a layer's padded output)."""
+    _req(row_label, "row_label", torch.int32); _req(lab_rows, "lab_rows", torch.int32)
+    assert logits.dtype == torch.float32 and logits.is_cuda and logits.dim() == 2 and logits.stride(1) == 1 and logits.data_ptr() % 16 == 0
     N, C = logits.shape
+    ld = logits.stride(0) if N > 1 else C
     loss = torch.empty(1, device=logits.device, dtype=torch.float32)
-    dl = torch.empty_like(logits)
+    full = torch.empty((N, ld), device=logits.device, dtype=torch.float32)
     with _on(logits.device), _timed("ce_head"):
-        _check(lib().rgcn_ce_head_f32(_dp(logits), _dp(row_label), _dp(lab_rows), _dp(loss), _dp(dl), c_i64(N), c_i32(C),
+        _check(lib().rgcn_ce_head_f32(_dp(logits), _dp(row_label), _dp(lab_rows), _dp(loss), _dp(full), c_i64(N), c_i32(C), c_i32(ld),
                                       c_i32(lab_rows.shape[0]), _stream(logits.device)), "ce_head")
-    return loss, dl
+    return (loss, full, None) if ld == C else (loss, full[:, :C], full)
 
 
 def distmult_fwd(triples, nodes, rel, sbias, pbias, obias):

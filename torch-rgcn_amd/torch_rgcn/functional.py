@@ -230,7 +230,9 @@ class _RelationalMP(torch.autograd.Function):
             ctx.save_for_backward(X, W)
         if ctx.dims is None or out.shape[1] == ctx.dims[1]:
             return out
-        return _native.resize3(out, (out.shape[0], ctx.dims[1]))       # contiguous (the consumer would copy a sliced view anyway)
+        if routes.get("pad16_view", "1") != "0":
+            return out[:, :ctx.dims[1]]       # the first columns of the padded rows, no copy (MaskedCrossEntropy reads them in place)
+        return _native.resize3(out, (out.shape[0], ctx.dims[1]))
 
     @staticmethod
     def backward(ctx, g):
@@ -242,7 +244,11 @@ class _RelationalMP(torch.autograd.Function):
     def _backward(ctx, g, X, W):
         graph = ctx.graph
         if ctx.dims is not None and ctx.dims[1] % 16:
-            g = _native.resize3(dense(g), (g.shape[0], ctx.dims[1] + (-ctx.dims[1] % 16)))
+            wide = ctx.dims[1] + (-ctx.dims[1] % 16)
+            if getattr(g, "_rgcn_zero_padded", False) and _rows16(g) and g.stride(0) == wide:
+                g = torch.as_strided(g, (g.shape[0], wide), (wide, 1))       # MaskedCrossEntropy wrote the zero-padded rows already
+            else:
+                g = _native.resize3(dense(g), (g.shape[0], wide))
         g = dense(g)
         if ctx.relu and not ctx.out_token.premasked(g):     # out = relu(pre): the gradient passes where the stored output is positive
             g = torch.ops.aten.threshold_backward(g, ctx.saved_tensors[2], 0.0)
@@ -356,7 +362,11 @@ class _ShardedRelationalMP(torch.autograd.Function):
         import torch.distributed as dist
         graph = ctx.graph
         if ctx.dims is not None and ctx.dims[1] % 16:
-            g = _native.resize3(dense(g), (g.shape[0], ctx.dims[1] + (-ctx.dims[1] % 16)))
+            wide = ctx.dims[1] + (-ctx.dims[1] % 16)
+            if getattr(g, "_rgcn_zero_padded", False) and _rows16(g) and g.stride(0) == wide:
+                g = torch.as_strided(g, (g.shape[0], wide), (wide, 1))       # MaskedCrossEntropy wrote the zero-padded rows already
+            else:
+                g = _native.resize3(dense(g), (g.shape[0], wide))
         g = dense(g)
         dX = dW = db = None
         works = []
@@ -401,16 +411,36 @@ def _featureless_csr(graph, width):
     return not _dense_buckets(fp) and graph.max_degree() <= 4096
 
 
+def _relu_epilogue(ctx, res, relu):
+    """res: what a native forward returned for relu=True -- (out, applied in the kernel's epilogue) -- or the plain output; finishes the
+    activation where the kernel could not, and keeps what the backward needs (see _ReluToken)"""
+    ctx.relu = bool(relu)
+    ctx.out_token = _ReluToken() if relu else None
+    if not relu:
+        return res
+    out, applied = res if isinstance(res, tuple) else (res, False)
+    return out if applied else torch.relu_(out)
+
+
+def _relu_backward(ctx, g, out):
+    """the gradient before the fused ReLU: masked here unless the consumer's backward kernel already did it (_ReluToken)"""
+    if ctx.relu and not ctx.out_token.premasked(g):
+        g = torch.ops.aten.threshold_backward(g, out, 0.0)
+    return g
+
+
 class _FeaturelessMP(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, table, bias, graph):
+    def forward(ctx, table, bias, graph, relu=False):
         table = dense(table)
         b = None if bias is None else dense(bias)
         ctx.csr = _featureless_csr(graph, table.shape[2])
         if ctx.csr:
-            out = _native.featureless_csr_fwd(table, b, graph.csr("fwd"))
+            out = _relu_epilogue(ctx, _native.featureless_csr_fwd(table, b, graph.csr("fwd"), relu=relu), relu)
         else:
-            out = _native.featureless_fwd(table, b, graph.fwd_plan(table.shape[2]))
+            out = _relu_epilogue(ctx, _native.featureless_fwd(table, b, graph.fwd_plan(table.shape[2])), relu)
+        if relu:
+            ctx.save_for_backward(out)
         ctx.graph = graph
         ctx.has_bias = bias is not None
         ctx.num_rels = table.shape[0]
@@ -421,6 +451,8 @@ class _FeaturelessMP(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g = dense(g)
+        if ctx.relu:
+            g = _relu_backward(ctx, g, ctx.saved_tensors[0])
         dT = db = None
         if ctx.needs_input_grad[0]:
             if ctx.csr:
@@ -429,7 +461,7 @@ class _FeaturelessMP(torch.autograd.Function):
                 dT = _native.featureless_wgrad(g, ctx.graph.fwd_plan(ctx.width), ctx.num_rels)
         if ctx.has_bias and ctx.needs_input_grad[1]:
             db = _native.colsum(g)
-        return dT, db, None
+        return dT, db, None, None
 
 
 class _BlockMP(torch.autograd.Function):
@@ -599,7 +631,15 @@ class _FeaturelessBasisMP(torch.autograd.Function):
     materialises (layers.py:242 + :288; 17.8 GB for AM):  out[s] = sum_e val_e sum_b comps[r_e,b] bases[b,o_e,:]."""
 
     @staticmethod
-    def forward(ctx, bases, comps, bias, graph):
+    def forward(ctx, bases, comps, bias, graph, relu=False):
+        out = _FeaturelessBasisMP._forward(ctx, bases, comps, bias, graph, relu)
+        to_save = ctx.to_save
+        del ctx.to_save
+        ctx.save_for_backward(*to_save, *((out,) if relu else ()))
+        return out
+
+    @staticmethod
+    def _forward(ctx, bases, comps, bias, graph, relu):
         B, N, d = bases.shape
         ctx.src_major = _native.fbasis_supported(B, d) and routes.get("fbasis", "src") == "src"
         # Layout of the table the source-major kernels walk.  Node-major [N, B, d] (a transposed copy per step, and a transposed
@@ -615,32 +655,34 @@ class _FeaturelessBasisMP(torch.autograd.Function):
             comps, bases = dense(comps), dense(bases)
             ctx.graph, ctx.has_bias = graph, bias is not None
             ctx.in_place = True
-            ctx.save_for_backward(bases, comps)
-            return _native.fbasis_tile_fwd(bases, comps, bias, graph.fbasis_plan())
+            ctx.to_save = (bases, comps)
+            return _relu_epilogue(ctx, _native.fbasis_tile_fwd(bases, comps, bias, graph.fbasis_plan(), relu=relu), relu)
         if ctx.src_major and ctx.in_place:
             comps, bases = dense(comps), dense(bases)
             ctx.graph, ctx.has_bias = graph, bias is not None
-            ctx.save_for_backward(bases, comps)
-            return _native.fbasis_fwd(bases, comps, bias, graph.fbasis_plan(), basis_major=True)
+            ctx.to_save = (bases, comps)
+            return _relu_epilogue(ctx, _native.fbasis_fwd(bases, comps, bias, graph.fbasis_plan(), basis_major=True, relu=relu), relu)
         table = bases.permute(1, 0, 2).contiguous()                   # [N, B, d]: one contiguous block per source node
         if ctx.src_major:   # every node's B x d block is read once
             comps = dense(comps)
             ctx.graph, ctx.has_bias = graph, bias is not None
-            ctx.save_for_backward(table, comps)
-            return _native.fbasis_fwd(table, comps, bias, graph.fbasis_plan())
+            ctx.to_save = (table, comps)
+            return _relu_epilogue(ctx, _native.fbasis_fwd(table, comps, bias, graph.fbasis_plan(), relu=relu), relu)
         comps = dense(comps)
         out = _native.basis_aggregate(table.view(N, B * d), comps, graph.csr("fwd"), B, d, B)
         if bias is not None:
             out += bias
         ctx.graph, ctx.has_bias = graph, bias is not None
-        ctx.save_for_backward(table, comps)
-        return out
+        ctx.to_save = (table, comps)
+        return _relu_epilogue(ctx, out, relu)
 
     @staticmethod
     def backward(ctx, g):
         g = dense(g)
+        if ctx.relu:
+            g = _relu_backward(ctx, g, ctx.saved_tensors[2])
         if ctx.src_major:
-            table, comps = ctx.saved_tensors
+            table, comps = ctx.saved_tensors[:2]
             if getattr(ctx, "tile_bwd", False):
                 dB, dC = _native.fbasis_tile_bwd(table, comps, g, ctx.graph.fbasis_plan(), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
             else:
@@ -649,8 +691,8 @@ class _FeaturelessBasisMP(torch.autograd.Function):
             if dB is not None and not ctx.in_place:
                 dB = dB.permute(1, 0, 2)      # a view: autograd accumulates it into the [B, N, d] parameter gradient
             db = _native.colsum(g) if ctx.has_bias and ctx.needs_input_grad[2] else None
-            return dB, dC, db, None
-        table, comps = ctx.saved_tensors
+            return dB, dC, db, None, None
+        table, comps = ctx.saved_tensors[:2]
         N, B, d = table.shape
         dB = dC = db = None
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not deterministic() and _native.fbasis_small_ok(comps.shape[0], B, d):
@@ -658,18 +700,18 @@ class _FeaturelessBasisMP(torch.autograd.Function):
             dB, dC = _native.fbasis_small_bwd(g, table, comps, ctx.graph.csr("bwd"), B, d)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = _native.colsum(g)
-            return dB.permute(1, 0, 2), dC, db, None
+            return dB.permute(1, 0, 2), dC, db, None, None
         if ctx.needs_input_grad[0]:
             dB = _native.basis_aggregate(g, comps, ctx.graph.csr("bwd"), B, d, 1).view(N, B, d).permute(1, 0, 2)
         if ctx.needs_input_grad[1]:
             dC = _native.basis_dcomps(g, table.view(N, B * d), ctx.graph.wgt_plan(), comps.shape[0], B, d, swap=True)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _native.colsum(g)
-        return dB, dC, db, None
+        return dB, dC, db, None, None
 
 
-def featureless_basis_mp(bases, comps, bias, graph):
-    return _FeaturelessBasisMP.apply(bases, comps, bias, graph)
+def featureless_basis_mp(bases, comps, bias, graph, relu=False):
+    return _FeaturelessBasisMP.apply(bases, comps, bias, graph, relu)
 
 
 def basis_mp(features, bases, comps, bias, graph):
@@ -695,9 +737,9 @@ def relational_mp(features, weights, bias, graph, relu=False, blocks=None):
     return _RelationalMP.apply(features, weights, bias, graph, relu, blocks, in_token)
 
 
-def featureless_mp(table, bias, graph):
-    """table [R, N, d_out] -> [N, d_out]"""
-    return _FeaturelessMP.apply(table, bias, graph)
+def featureless_mp(table, bias, graph, relu=False):
+    """table [R, N, d_out] -> [N, d_out]; relu: the activation the models apply right after the layer, in the kernel's epilogue"""
+    return _FeaturelessMP.apply(table, bias, graph, relu)
 
 
 class _DistMultScore(torch.autograd.Function):
@@ -736,17 +778,49 @@ def distmult_score(triples, nodes, relations, sbias=None, pbias=None, obias=None
     return _DistMultScore.apply(triples, nodes, relations, sbias, pbias, obias)
 
 
+_UNIT = {}
+
+
+def unit_gradient(device):
+    """the constant 1.0 to start a backward pass with -- `loss.backward(gradient=unit_gradient(loss.device))` -- instead of the ones_like()
+    autograd fills per call; MaskedCrossEntropy's backward recognises it and skips the multiplication by it (two launches per step of a
+    launch-bound graph).  Never written to."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    if device not in _UNIT:
+        _UNIT[device] = torch.ones((), device=device)
+    return _UNIT[device]
+
+
+def _is_unit(g):
+    u = _UNIT.get(g.device)
+    return u is not None and g.dim() == 0 and g.data_ptr() == u.data_ptr() and u._version == 0
+
+
+def _rows16(t):
+    """t = the first columns of a contiguous [N, 16 k] buffer (what a layer of fewer than 16 k outputs returns, see _RelationalMP.forward)?"""
+    return t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 16 == 0 and t.stride(0) > t.shape[1] and t.storage_offset() == 0 and \
+        t.data_ptr() % 16 == 0
+
+
 class _MaskedCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, row_label, lab_rows):
-        loss, dl = _native.ce_head(dense(logits), row_label, lab_rows)
+        logits = logits if _rows16(logits) else dense(logits)      # the padded rows are read in place
+        loss, dl, dl_full = _native.ce_head(logits, row_label, lab_rows)
         ctx.save_for_backward(dl)
+        ctx.dl_full = dl_full is not None
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         dl, = ctx.saved_tensors
-        return dl * g, None, None
+        if not _is_unit(g):
+            return dl * g, None, None
+        if ctx.dl_full:      # dl = the first columns of a zero-padded [N, 16] buffer: the layer's backward takes the buffer as it is
+            dl._rgcn_zero_padded = True
+        return dl, None, None
 
 
 class MaskedCrossEntropy(torch.nn.Module):

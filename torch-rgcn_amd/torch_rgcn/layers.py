@@ -265,10 +265,14 @@ class RelationalGraphConvolutionNC(_RGCBase):
             if self.vertical_stacking:
                 raise RuntimeError("featureless message passing needs horizontal stacking "
                                    f"(mat1 and mat2 shapes cannot be multiplied: {R * N}x{N} and {R * N}x{out_dim})")
+            # the models' F.relu(self.rgc1()) (reference models.py:194) in the kernel's epilogue; the consumer layer's backward masks
+            fuse_act = activation == "relu" and getattr(self, "_shard_group", None) is None
             if fl_basis:
-                local = lambda _x, b: F_.featureless_basis_mp(self.bases, self.comps, b, graph)
+                local = lambda _x, b: F_.featureless_basis_mp(self.bases, self.comps, b, graph, relu=fuse_act)
             else:
-                local = lambda _x, b: F_.featureless_mp(weights, b, graph)
+                local = lambda _x, b: F_.featureless_mp(weights, b, graph, relu=fuse_act)
+            if fuse_act:
+                activation = None
         else:
             _require_gpu(features, "features")
             assert features.size() == (N, in_dim), f"features {tuple(features.size())} vs ({N}, {in_dim})"

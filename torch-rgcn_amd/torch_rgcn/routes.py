@@ -22,7 +22,7 @@ NAMES = (
     "deterministic", "relabel", "tile_rows", "bwd_tile_rows", "bwd", "bwd_kernel", "bwd_blk_cap", "twopass", "wide", "pad16",
     "featureless_csr", "dist_comm", "dist_slabs", "deferred_checks", "block_path", "block_fwd", "basis_path", "basis_fused",
     "wgrad_tiles", "wgrad_item_chunks", "wgrad", "spmm_csr", "sparse_path", "no_pack", "graph_build", "fbasis_inplace_mb", "fbasis",
-    "distmult_bwd", "diag_path", "capture", "fbasis_dc", "fbasis_tile",
+    "distmult_bwd", "diag_path", "capture", "fbasis_dc", "fbasis_tile", "pad16_view",
 )
 NATIVE = ("basis_vec4", "block_lds", "block_pipe", "bwd_nw", "bwd_d", "bwd_waves", "bwd_u", "gemm_bm", "spmm_u", "wgrad_rg", "wgrad_u",
           "distmult_one_launch", "rank_tile", "bwd_abl", "rank_ablate")
