@@ -11,11 +11,13 @@ out, w = sys.argv[1:3]
 f = glob.glob(out + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-# one step = the period of the sequence: find the last occurrence of the fused Adam kernel and the one before
-idx = [i for i, n in enumerate(names) if "multi_tensor_apply" in n or "fused_adam" in n.lower()]
-a, b = idx[-2] + 1, idx[-1] + 1
-print(w, "launches per step:", b - a)
+# one step ends with the optimiser's kernels (a _foreach step counter + the fused Adam): boundaries = an Adam kernel followed by another kernel
+idx = [i for i, n in enumerate(names) if "multi_tensor_apply" in n]
+ends = [i for i in idx if i + 1 >= len(names) or "multi_tensor_apply" not in names[i + 1]]
+a, b = ends[-2] + 1, ends[-1] + 1
+us = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+print(w, "launches per step:", b - a, " kernel time %.1f us" % sum(us(r) for r in rows[a:b]))
 for r in rows[a:b]:
-    print("  %7.1f us  %s" % ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r["Kernel_Name"][:110]))
+    print("  %7.1f us  %s" % (us(r), r["Kernel_Name"][:110]))
 PY
 done

@@ -262,7 +262,7 @@ class _RelationalMP(torch.autograd.Function):
         blk_sparse = sparse and routes.get("bwd", "fused") != "split" and \
             _native.bwd_blk_rows(graph.num_nodes, graph.num_rels, deterministic(), graph.device, ctx.diag4, True) > 0
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and (not sparse or blk_sparse):
-            both = _fused_backward(X, W, g, graph, relu_in=ctx.in_token is not None and ctx.dims is None and not ctx.in_token.observed(),
+            both = _fused_backward(X, W, g, graph, relu_in=ctx.in_token is not None and (ctx.dims is None or ctx.dims[0] % 16 == 0) and not ctx.in_token.observed(),
                                    want_db=ctx.has_bias and ctx.needs_input_grad[2], diag4=ctx.diag4, sparse=sparse)
             if both is not None:
                 both, masked, db = both[:2], both[2], both[3]
