@@ -28,6 +28,7 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int TW = 1024, TWV = TW / 64;     // threads / waves of a workgroup
 constexpr int TN = 16;                      // nodes of a tile
 constexpr int PER = 32;                     // messages of one wave per chunk (a chunk = 16 x PER messages of a tile)
@@ -200,14 +201,14 @@ __global__ __launch_bounds__(TW) void fbt_fwd_kernel(
             for (int m = 0; m < 4; ++m) {                   // (messages past the run: entries the wave holds anyway, results dropped)
               const int r = rlane(c_er, j0 + m);
               const f32x4 *c4 = reinterpret_cast<const f32x4 *>(ctab + r * BP + bg * NREG);
-              float e0 = 0.f, e1 = 0.f;
+              f32x2 e = {0.f, 0.f};                          // two floats per lane and instruction (v_pk_fma_f32)
 #pragma unroll
               for (int q4 = 0; q4 < NREG / 4; ++q4) {
                 const f32x4 c = c4[q4];
-                e0 += c[0] * blk[4 * q4] + c[1] * blk[4 * q4 + 1];
-                e1 += c[2] * blk[4 * q4 + 2] + c[3] * blk[4 * q4 + 3];
+                e += f32x2{c[0], c[1]} * f32x2{blk[4 * q4], blk[4 * q4 + 1]};
+                e += f32x2{c[2], c[3]} * f32x2{blk[4 * q4 + 2], blk[4 * q4 + 3]};
               }
-              a4[m] = (e0 + e1) * bcast(c_ev, j0 + m);
+              a4[m] = (e[0] + e[1]) * bcast(c_ev, j0 + m);
             }
             const float u = swap_add<32>(a4[0], a4[2]), w = swap_add<32>(a4[1], a4[3]);
             const float y = swap_add<16>(u, w);
@@ -390,16 +391,16 @@ __global__ __launch_bounds__(TW) void fbt_dcomps_kernel(
         }
         auto one = [&](int j) {
           const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gs + j * GS);      // the same address in every lane: a broadcast read
-          float e0 = 0.f, e1 = 0.f;
+          f32x2 e = {0.f, 0.f};
 #pragma unroll
           for (int i4 = 0; i4 < DPB / 4; ++i4) {
             const f32x4 gv = g4[i4];
-            e0 += blk[4 * i4] * gv[0] + blk[4 * i4 + 1] * gv[1];
-            e1 += blk[4 * i4 + 2] * gv[2] + blk[4 * i4 + 3] * gv[3];
+            e += f32x2{blk[4 * i4], blk[4 * i4 + 1]} * f32x2{gv[0], gv[1]};
+            e += f32x2{blk[4 * i4 + 2], blk[4 * i4 + 3]} * f32x2{gv[2], gv[3]};
           }
           const int r = rlane(c_x.er, j);
           const float v = bcast(c_x.ev, j);
-          if (has_b && !FBT_ABL(8)) __hip_atomic_fetch_add(dcl + r * B + lane, (double)(v * (e0 + e1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (has_b && !FBT_ABL(8)) __hip_atomic_fetch_add(dcl + r * B + lane, (double)(v * (e[0] + e[1])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
         for (; p + 4 <= run_end; p += 4) {                  // four independent chains
           one(p - c_a); one(p - c_a + 1); one(p - c_a + 2); one(p - c_a + 3);
