@@ -171,6 +171,25 @@ def _launch_counts(step, iters=2):
     return {k: len(v) / iters for k, v in prof.items()}
 
 
+def _count_launches(step):
+    """GPU kernel launches of ONE step, counted by torch.profiler (roctracer: every kernel of the process, this library's included)"""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        import warnings
+        step()
+        torch.cuda.synchronize()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                step()
+                torch.cuda.synchronize()
+        evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+        copies = sum(1 for e in evs if e.name.startswith(("Memcpy", "Memset")))
+        return {"kernels": len(evs) - copies, "memcpy_memset": copies}
+    except Exception as exc:  # noqa: BLE001
+        return {"failed": f"{type(exc).__name__}: {exc}"[:120]}
+
+
 def _roof(name, ms, alg_bytes, note):
     if not name or not ms:
         return None
@@ -229,7 +248,7 @@ def line_node_classifier(tag, N, R0, E, nhid, ncls, decomp, labelled, baseline_c
             # the experiments replay the captured step by default (experiments/classify_nodes.py); the eager loop's time is the host's
             "ms_per_step": ms_graph if isinstance(ms_graph, float) else round(ms, 3), "ms_per_step_eager": round(ms, 3),
             "ms_per_step_hipgraph_replay": ms_graph,
-            "edges_per_s": round(E / (ms_graph if isinstance(ms_graph, float) else ms) * 1e3), "kernels_ms": allk, "library_launches_per_step": round(sum(_launch_counts(step).values()), 1),
+            "edges_per_s": round(E / (ms_graph if isinstance(ms_graph, float) else ms) * 1e3), "launches_per_step": _count_launches(step), "kernels_ms": allk, "library_launches_per_step": round(sum(_launch_counts(step).values()), 1),
             "roofline": _roof(name, kms, alg, "messages x (weight-table row + 8 B index) + node rows written")}
 
 
@@ -368,7 +387,7 @@ def line_wn18(baseline_config):
             "step": "encoder + decoder forward + BCE + backward (per-step graph build included)", "ms_per_step": round(ms, 3),
             "ms_per_step_sync_free": None if ms_nosync is None else round(ms_nosync, 3),
             "ms_per_step_hipgraph_replay": round(ms_graph, 3) if isinstance(ms_graph, float) else ms_graph,
-            "scored_triples_per_s": round(Tn / ms * 1e3), "kernels_ms": allk,
+            "scored_triples_per_s": round(Tn / ms * 1e3), "kernels_ms": allk, "launches_per_step": _count_launches(step),
             "roofline": roof}
 
 
