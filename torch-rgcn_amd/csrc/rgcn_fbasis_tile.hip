@@ -197,18 +197,28 @@ __global__ __launch_bounds__(TW) void fbt_fwd_kernel(
           if (DP == 16) {
             // four messages at once (independent chains), then a transpose-reduce over the four basis groups: group g ends up with message g's sum
             float a4[4];
+            constexpr int QB = (NREG <= 12 && KLD == 2) ? 4 : 2;     // messages whose coefficient reads fly together (registers)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {                   // (messages past the run: entries the wave holds anyway, results dropped)
-              const int r = rlane(c_er, j0 + m);
-              const f32x4 *c4 = reinterpret_cast<const f32x4 *>(ctab + r * BP + bg * NREG);
-              f32x2 e = {0.f, 0.f};                          // two floats per lane and instruction (v_pk_fma_f32)
+            for (int h = 0; h < 4; h += QB) {
+              f32x4 cq[QB][NREG / 4];
 #pragma unroll
-              for (int q4 = 0; q4 < NREG / 4; ++q4) {
-                const f32x4 c = c4[q4];
-                e += f32x2{c[0], c[1]} * f32x2{blk[4 * q4], blk[4 * q4 + 1]};
-                e += f32x2{c[2], c[3]} * f32x2{blk[4 * q4 + 2], blk[4 * q4 + 3]};
+              for (int m = 0; m < QB; ++m) {                // (messages past the run: entries the wave holds anyway, results dropped)
+                const f32x4 *c4 = reinterpret_cast<const f32x4 *>(ctab + rlane(c_er, j0 + h + m) * BP + bg * NREG);
+#pragma unroll
+                for (int q4 = 0; q4 < NREG / 4; ++q4) cq[m][q4] = c4[q4];
               }
-              a4[m] = (e[0] + e[1]) * bcast(c_ev, j0 + m);
+              __builtin_amdgcn_sched_barrier(0);            // all of these reads in flight before the first FMA: one LDS round trip, not QB
+#pragma unroll
+              for (int m = 0; m < QB; ++m) {
+                f32x2 e = {0.f, 0.f};                        // two floats per lane and instruction (v_pk_fma_f32)
+#pragma unroll
+                for (int q4 = 0; q4 < NREG / 4; ++q4) {
+                  const f32x4 c = cq[m][q4];
+                  e += f32x2{c[0], c[1]} * f32x2{blk[4 * q4], blk[4 * q4 + 1]};
+                  e += f32x2{c[2], c[3]} * f32x2{blk[4 * q4 + 2], blk[4 * q4 + 3]};
+                }
+                a4[h + m] = (e[0] + e[1]) * bcast(c_ev, j0 + h + m);
+              }
             }
             const float u = swap_add<32>(a4[0], a4[2]), w = swap_add<32>(a4[1], a4[3]);
             const float y = swap_add<16>(u, w);
@@ -402,8 +412,30 @@ __global__ __launch_bounds__(TW) void fbt_dcomps_kernel(
           const float v = bcast(c_x.ev, j);
           if (has_b && !FBT_ABL(8)) __hip_atomic_fetch_add(dcl + r * B + lane, (double)(v * (e[0] + e[1])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
-        for (; p + 4 <= run_end; p += 4) {                  // four independent chains
-          one(p - c_a); one(p - c_a + 1); one(p - c_a + 2); one(p - c_a + 3);
+        for (; p + 4 <= run_end; p += 4) {                  // four messages: all row reads in flight before the first FMA
+          constexpr int QB = (DPB <= 12 && KLD == 2) ? 4 : 2;
+#pragma unroll
+          for (int h = 0; h < 4; h += QB) {
+            const int j0 = p - c_a + h;
+            f32x4 gq[QB][DPB / 4];
+#pragma unroll
+            for (int m = 0; m < QB; ++m)
+#pragma unroll
+              for (int i4 = 0; i4 < DPB / 4; ++i4) gq[m][i4] = reinterpret_cast<const f32x4 *>(gs + (j0 + m) * GS)[i4];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < QB; ++m) {
+              f32x2 e = {0.f, 0.f};
+#pragma unroll
+              for (int i4 = 0; i4 < DPB / 4; ++i4) {
+                e += f32x2{blk[4 * i4], blk[4 * i4 + 1]} * f32x2{gq[m][i4][0], gq[m][i4][1]};
+                e += f32x2{blk[4 * i4 + 2], blk[4 * i4 + 3]} * f32x2{gq[m][i4][2], gq[m][i4][3]};
+              }
+              const int r = rlane(c_x.er, j0 + m);
+              const float v = bcast(c_x.ev, j0 + m);
+              if (has_b && !FBT_ABL(8)) __hip_atomic_fetch_add(dcl + r * B + lane, (double)(v * (e[0] + e[1])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
         }
         for (; p < run_end; ++p) one(p - c_a);
       }
