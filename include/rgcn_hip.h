@@ -466,7 +466,10 @@ RGCN_API int rgcn_gather_rows_sum_f32(const float *Y, const int32_t *perm, const
  * 1024-thread workgroups walk TILES of 16 consecutive source nodes, whose blocks are staged into LDS (or whose gradient is written
  * out of LDS) with aligned 16-byte accesses -- no node-major copy of the table, no transposed gradient.  rowptr [N + 1] = the
  * source-major CSR's row pointers; e_dst / e_rel / e_val [M = n_messages] its entries.
- *   rgcn_fbasis_tile_supported -> bit 0: forward, bit 1: backward (LDS budget: forward R x 64 floats + 2 tiles; backward R x B doubles + 2 tiles
+ * mode 0: a tile's messages are dealt evenly over the workgroup's 16 waves (any degree distribution); mode 1: wave w takes node w of the tile and
+ * runs its messages through the matrix cores sixteen at a time (a node costs about the same for 1 or 16 messages: the waves stay in step) --
+ * for graphs without hub sources (the caller decides from the largest source degree; torch_rgcn/_native.py: <= 4096).
+ *   rgcn_fbasis_tile_supported -> bit 0: forward, bit 1: backward, bits 2 / 3: the same in mode 1 (LDS budget: forward R x 64 floats + 2 tiles; backward R x B doubles + 2 tiles
  *                                 and 2 tiles of doubles + R x B floats; B <= 64, d <= 16, N >= 16)
  *   rgcn_fbasis_tile_fwd_f32:     Y[e, 0..ys) = val_e * comps[r_e,:] . bases[:,o,:], zero padded to ys = rgcn_fbasis_tile_ystride(d) = pow2(d) >= 4 columns
  *   rgcn_gather_rows_sum4_f32:    out[row, 0..w) = (bias) + sum over the row's units of Y[perm[j], 0..w); Y rows ys = 4 / 8 / 16 floats
@@ -476,13 +479,13 @@ RGCN_API int rgcn_fbasis_tile_supported(int32_t R, int32_t B, int32_t d, int64_t
 RGCN_API int rgcn_fbasis_tile_ystride(int32_t d);
 RGCN_API int rgcn_fbasis_tile_fwd_f32(const float *bases, const float *comps, float *Y, const int32_t *rowptr, const int32_t *e_rel,
                                       const float *e_val, int64_t n_messages, int64_t n_nodes, int32_t R, int32_t B, int32_t d,
-                                      void *stream);
+                                      int32_t mode, void *stream);
 RGCN_API int rgcn_gather_rows_sum4_f32(const float *Y, int32_t ys, const int32_t *perm, const int32_t *units, int64_t n_units,
                                        int64_t n_split, const float *bias, float *out, int64_t n_rows, int32_t w, int32_t relu,
                                        void *stream);
 RGCN_API int rgcn_fbasis_tile_bwd_f32(const float *bases, const float *comps, const float *G, float *dbases, float *dcomps,
                                       const int32_t *rowptr, const int32_t *e_dst, const int32_t *e_rel, const float *e_val,
-                                      int64_t n_messages, int64_t n_nodes, int32_t R, int32_t B, int32_t d, void *stream);
+                                      int64_t n_messages, int64_t n_nodes, int32_t R, int32_t B, int32_t d, int32_t mode, void *stream);
 
 /* Classifier head of the node-classification experiments, one launch: loss = mean cross-entropy of the logits' LABELLED rows and
  * dlogits [N, C] = d loss / d logits (zero rows for unlabelled nodes).  Replaces `criterion(model()[train_idx, :], train_lbl)` with

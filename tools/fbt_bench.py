@@ -47,20 +47,22 @@ def timed(fn):
     return round(e0.elapsed_time(e1) / a.iters, 4)
 
 
-res = {"fwd+gather": timed(lambda: _native.fbasis_tile_fwd(bases, comps, bias, plan)),
-       "dbases": timed(lambda: _native.fbasis_tile_bwd(bases, comps, g, plan, True, False)),
-       "dcomps": timed(lambda: _native.fbasis_tile_bwd(bases, comps, g, plan, False, True))}
+mode = int(os.environ.get("FBT_MODE", "1"))
+res = {"mode": mode, "max_degree": plan.max_src_degree,
+       "fwd+gather": timed(lambda: _native.fbasis_tile_fwd(bases, comps, bias, plan, mode=mode)),
+       "dbases": timed(lambda: _native.fbasis_tile_bwd(bases, comps, g, plan, True, False, mode=mode)),
+       "dcomps": timed(lambda: _native.fbasis_tile_bwd(bases, comps, g, plan, False, True, mode=mode))}
 L = _native.lib()
 if hasattr(L, "rgcn_fbt_debug_read"):
     import ctypes
     buf = (ctypes.c_ulonglong * 6)()
     L.rgcn_fbt_debug_read(buf, 1)
-    _native.fbasis_tile_fwd(bases, comps, bias, plan)
+    _native.fbasis_tile_fwd(bases, comps, bias, plan, mode=0)
     L.rgcn_fbt_debug_read(buf, 1)
     w = max(buf[5], 1)
     res["fwd_us_per_wave"] = {k: round(buf[i] / w / 100.0, 1) for i, k in enumerate(("arrive+store+flush", "issue", "messages", "barrier", "rotate"))}
 _native.profile_start()
-_native.fbasis_tile_fwd(bases, comps, bias, plan)
+_native.fbasis_tile_fwd(bases, comps, bias, plan, mode=mode)
 prof = _native.profile_stop()
 res.update({k: round(float(np.mean(v)), 4) for k, v in prof.items()})
 print("abl", routes.get("bwd_abl", "0"), "messages", plan.n_messages, res)

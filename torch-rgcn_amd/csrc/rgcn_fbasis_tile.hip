@@ -543,7 +543,8 @@ __global__ __launch_bounds__(TW) void fbt_dbases_kernel(
         for (int p4 = p; p4 < run_end; p4 += 4) {
           const int j0 = p4 - c_a, jm = min(j0 + lm, c_n - 1);                    // this lane group's message (past the run: weight 0)
           const int r = __shfl(c_x.er, jm, 64);
-          const float v = (p4 + lm < run_end) ? __shfl(c_x.ev, jm, 64) : 0.f;
+          const float vs = __shfl(c_x.ev, jm, 64);                                // (unconditional: a shuffle inside `cond ? ... : 0` runs under the
+          const float v = (p4 + lm < run_end) ? vs : 0.f;                        //  condition's EXEC mask, and a masked-off SOURCE lane delivers 0)
           const float bv = gs[jm * GS + min(lc, GS - 1)];                        // B operand: lane (m, c) = G row of message m, column c
 #pragma unroll
           for (int tb = 0; tb < NT; ++tb)
@@ -587,12 +588,365 @@ __global__ __launch_bounds__(TW) void fbt_dbases_kernel(
   }
 }
 
+// ================================================================== one wave per node, on the matrix cores (round 4, second form)
+// The kernels above deal a tile's MESSAGES evenly over the waves: balanced on any degree distribution, but the per-message instruction
+// streams (VALU dot products, a transpose-reduce per four messages, one LDS atomic flush per node run) and the partial quads at node
+// boundaries bound them, and the waves reach the tile barrier unevenly.  When no node is a hub (rgcn_fbasis_tile_*: mode 1, chosen by
+// the caller from the largest source degree) wave w of the workgroup takes NODE w of the tile and runs its messages through
+// v_mfma_f32_16x16x4_f32, sixteen at a time -- the cost of a node is nearly the same for 1 or 16 messages, so the waves stay in step:
+//   forward  D[m][i] = sum_b (val_m comps[r_m, b]) bases[b, o, i]      A = scaled coefficient rows out of the LDS table, B = the node's block
+//   dcomps   D[m][b] = sum_i G[s_m, i] bases[b, o, i]                   A = the gathered rows (LDS strip), B = the block transposed;
+//                                                                       val_m D[m][b] is added to the R x B doubles (16 consecutive b per quarter wave)
+//   dbases   D[b][i] = sum_m (val_m comps[r_m, b]) G[s_m, i]            four messages per step; the wave OWNS its node's gradient: plain
+//                                                                       stores into an fp32 tile in LDS, no atomics
+// Lane = (k, c) = (lane >> 4, lane & 15) throughout: A operand lane 16 k + row, B operand lane 16 k + column, D lane 16 q + column holds
+// rows 4 q .. 4 q + 3.  The pipeline (tile two ahead, row pointers three, indices two, gradient rows one) is the one above.
+struct NodeRange { int a, n; };
+__device__ __forceinline__ NodeRange node_range(int rp, int wave, bool valid) {
+  NodeRange r;
+  r.a = rlane(rp, wave);
+  r.n = valid ? rlane(rp, wave + 1) - r.a : 0;
+  return r;
+}
+// rows of up to 16 messages starting at entry `off` of the wave's 64 prefetched indices -> packed registers (see gather_rows)
+__device__ __forceinline__ void gather_rows_at(float (&gp)[GQ], const float *__restrict__ G, int es, int off, int n, int d, int lane) {
+  const int m = lane >> 4, c = min(lane & 15, d - 1);
+#pragma unroll
+  for (int q = 0; q < GQ; ++q)
+    if (4 * q < n) {
+      const int s = __shfl(es, off + min(4 * q + m, n - 1), 64);
+      gp[q] = G[(size_t)s * d + c];
+    }
+}
+
+template <int NKSM, int KLD, bool VEC>
+__global__ __launch_bounds__(TW) void fbn_fwd_kernel(
+    const float *__restrict__ bases, const float *__restrict__ comps, float *__restrict__ Y, const int *__restrict__ rowptr,
+    const int *__restrict__ e_rel, const float *__restrict__ e_val, int n_tiles, int N, int R, int B, int d, int ts, int last, int ys,
+    int abl) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k = lane >> 4, c = lane & 15;
+  const int nks = (B + 3) >> 2, BP = 4 * nks;
+  float *ctab = lds;                                        // [R][BP], zero padded
+  float *tb = lds + ((R * BP + 3) & ~3);
+  float *yb = tb + 2 * B * ts + wave * (16 * 16);
+  for (int j = tid; j < R * BP; j += TW) {
+    const int r = j / BP, b = j % BP;
+    ctab[j] = b < B ? comps[(size_t)r * B + b] : 0.f;
+  }
+  Geo<KLD> g;
+  geo_init(g, tid, B, d, N, ts);
+  const int G = gridDim.x;
+  int t = blockIdx.x;
+  auto rp_of = [&](int tt) {
+    tt = min(tt, n_tiles - 1);
+    return rowptr[min((long long)tt * TN + min(lane, TN), (long long)N)];
+  };
+  auto base_of = [&](int tt) { return (long long)min(min(tt, n_tiles - 1) * TN, N - TN) * d; };
+
+  f32x4 st[KLD];
+  int rp = rp_of(t), rp1 = rp_of(t + G);
+  stage_load<KLD, VEC>(st, g, bases, base_of(t));
+  NodeRange s = node_range(rp, wave, true);
+  int er = e_rel[min(s.a + lane, last)];
+  float ev = e_val[min(s.a + lane, last)];
+  stage_store<KLD, true>(tb, st, g);
+  stage_load<KLD, VEC>(st, g, bases, base_of(t + G));
+  int pa = 0, pn = 0;                                      // rows pa .. pa + pn of Y wait in the wave's strip
+  auto flush = [&]() {
+    if (lane < pn * (ys >> 2)) reinterpret_cast<f32x4 *>(Y + (size_t)pa * ys)[lane] = reinterpret_cast<const f32x4 *>(yb)[lane];
+    pn = 0;
+  };
+  lds_barrier();
+  for (int it = 0;; ++it) {
+    const bool has1 = t + G < n_tiles;
+    const float *cb = tb + (it & 1) * (B * ts);
+    if (has1) stage_store<KLD, true>(tb + ((it + 1) & 1) * (B * ts), st, g);
+    flush();
+    __builtin_amdgcn_sched_barrier(0);
+    if (!FBT_ABL(2)) stage_load<KLD, VEC>(st, g, bases, base_of(t + 2 * G));
+    const int rp2 = rp_of(t + 2 * G);
+    const NodeRange s1 = node_range(rp1, wave, has1);
+    const int er1 = e_rel[min(s1.a + lane, last)];
+    const float ev1 = e_val[min(s1.a + lane, last)];
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- node `wave` of tile t
+    const int nl = wave + t * TN - min(t * TN, N - TN);
+    if (s.n > 0 && !FBT_ABL(1)) {
+      float bb[NKSM];
+#pragma unroll
+      for (int ks = 0; ks < NKSM; ++ks)
+        if (ks < nks) bb[ks] = cb[min(4 * ks + k, B - 1) * ts + nl * d + min(c, d - 1)];      // (rows past B meet zero coefficients)
+      int c_er = er;
+      float c_ev = ev;
+      for (int g0 = 0; g0 < s.n; g0 += 16) {
+        if (g0) {
+          flush();
+          if ((g0 & 63) == 0) {                             // more than 64 messages: the next 64 indices, on demand
+            c_er = e_rel[min(s.a + g0 + lane, last)];
+            c_ev = e_val[min(s.a + g0 + lane, last)];
+            FBT_ARRIVED(c_er); FBT_ARRIVED(c_ev);
+          }
+        }
+        const int src = (g0 & 63) + c;
+        const int r = __shfl(c_er, src, 64);
+        const float vs = __shfl(c_ev, src, 64);            // (never inside the conditional: a masked-off source lane delivers 0)
+        const float v = (g0 + c < s.n) ? vs : 0.f;
+        const float *crow = ctab + r * BP + k;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKSM; ++ks)
+          if (ks < nks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(crow[4 * ks] * v, bb[ks], acc, 0, 0, 0);
+        if (c < ys) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) yb[(4 * k + e) * ys + c] = c < d ? acc[e] : 0.f;
+        }
+        pa = s.a + g0;
+        pn = min(16, s.n - g0);
+      }
+    }
+    lds_barrier();
+    if (!has1) break;
+    t += G;
+    rp = rp1; rp1 = rp2; s = s1; er = er1; ev = ev1;
+    FBT_ARRIVED(er); FBT_ARRIVED(ev); FBT_ARRIVED(rp1);
+  }
+  flush();
+}
+
+template <int NKD, int KLD, bool VEC>
+__global__ __launch_bounds__(TW) void fbn_dcomps_kernel(
+    const float *__restrict__ bases, const float *__restrict__ G, float *__restrict__ dC, const int *__restrict__ rowptr,
+    const int *__restrict__ e_dst, const int *__restrict__ e_rel, const float *__restrict__ e_val, int n_tiles, int N, int R, int B,
+    int d, int ts, int last, int abl) {
+  constexpr int GS = 4 * NKD, NBTM = 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k = lane >> 4, c = lane & 15;
+  const int nbt = (B + 15) >> 4;
+  double *dcl = reinterpret_cast<double *>(lds);            // [R][B]
+  const int strips0 = (2 * R * B + 3) & ~3;
+  float *gs = lds + strips0 + wave * (PERB * GS);
+  float *tb = lds + strips0 + TWV * PERB * GS;              // 2 x [B][ts]
+  for (int j = tid; j < R * B; j += TW) dcl[j] = 0.0;
+  Geo<KLD> g;
+  geo_init(g, tid, B, d, N, ts);
+  const int Gd = gridDim.x;
+  int t = blockIdx.x;
+  auto rp_of = [&](int tt) {
+    tt = min(tt, n_tiles - 1);
+    return rowptr[min((long long)tt * TN + min(lane, TN), (long long)N)];
+  };
+  auto base_of = [&](int tt) { return (long long)min(min(tt, n_tiles - 1) * TN, N - TN) * d; };
+
+  f32x4 st[KLD];
+  int rp = rp_of(t), rp1 = rp_of(t + Gd), rp2 = rp_of(t + 2 * Gd);
+  stage_load<KLD, VEC>(st, g, bases, base_of(t));
+  NodeRange s = node_range(rp, wave, true);
+  Idx x = idx_load(e_dst, e_rel, e_val, s.a, last, lane);
+  NodeRange s1 = node_range(rp1, wave, t + Gd < n_tiles);
+  Idx x1 = idx_load(e_dst, e_rel, e_val, s1.a, last, lane);
+  float gp1[GQ] = {};
+  gather_rows_at(gp1, G, x.es, 0, min(16, s.n), d, lane);
+  strip_store<GS>(gs, gp1, min(16, s.n), lane);
+  stage_store<KLD, false>(tb, st, g);
+  stage_load<KLD, VEC>(st, g, bases, base_of(t + Gd));
+  lds_barrier();
+  for (int it = 0;; ++it) {
+    const bool has1 = t + Gd < n_tiles, has2 = t + 2 * Gd < n_tiles;
+    const float *cb = tb + (it & 1) * (B * ts);
+    if (has1) stage_store<KLD, false>(tb + ((it + 1) & 1) * (B * ts), st, g);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!FBT_ABL(2)) stage_load<KLD, VEC>(st, g, bases, base_of(t + 2 * Gd));
+    const int rp3 = rp_of(t + 3 * Gd);
+    const NodeRange s2 = node_range(rp2, wave, has2);
+    const Idx x2 = idx_load(e_dst, e_rel, e_val, s2.a, last, lane);
+    if (!FBT_ABL(4)) gather_rows_at(gp1, G, x1.es, 0, min(16, s1.n), d, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- node `wave` of tile t
+    const int nl = wave + t * TN - min(t * TN, N - TN);
+    if (s.n > 0 && !FBT_ABL(1)) {
+      float bt[NBTM][NKD];                                  // the block transposed: B operand lane (k, c) = bases[16 tb + c][4 ks + k]
+#pragma unroll
+      for (int tb2 = 0; tb2 < NBTM; ++tb2)
+#pragma unroll
+        for (int ks = 0; ks < NKD; ++ks) {
+          bt[tb2][ks] = 0.f;
+          if (tb2 < nbt) {
+            const float v = cb[min(16 * tb2 + c, B - 1) * ts + nl * d + min(4 * ks + k, d - 1)];
+            bt[tb2][ks] = (16 * tb2 + c < B && 4 * ks + k < d) ? v : 0.f;
+          }
+        }
+      Idx c_x = x;
+      for (int g0 = 0; g0 < s.n; g0 += 16) {
+        const int n16 = min(16, s.n - g0);
+        if (g0) {                                           // more than 16 messages: indices per 64, rows per 16, on demand
+          if ((g0 & 63) == 0) {
+            c_x = idx_load(e_dst, e_rel, e_val, s.a + g0, last, lane);
+            FBT_ARRIVED(c_x.es); FBT_ARRIVED(c_x.er); FBT_ARRIVED(c_x.ev);
+          }
+          float gq[GQ] = {};
+          gather_rows_at(gq, G, c_x.es, g0 & 63, n16, d, lane);
+          strip_store<GS>(gs, gq, n16, lane);
+        }
+        float av[NKD];
+#pragma unroll
+        for (int ks = 0; ks < NKD; ++ks) av[ks] = gs[min(c, n16 - 1) * GS + 4 * ks + k];       // A operand lane (k, m) = G row of message m, feature 4 ks + k
+        int rq[4];
+        float vq[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                       // D's rows of this lane: messages 4 k + e
+          const int src = (g0 & 63) + min(4 * k + e, n16 - 1);
+          rq[e] = __shfl(c_x.er, src, 64);
+          const float vs = __shfl(c_x.ev, src, 64);
+          vq[e] = (4 * k + e < n16) ? vs : 0.f;
+        }
+#pragma unroll
+        for (int tb2 = 0; tb2 < NBTM; ++tb2)
+          if (tb2 < nbt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKD; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bt[tb2][ks], acc, 0, 0, 0);
+            if (16 * tb2 + c < B && !FBT_ABL(8)) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (4 * k + e < n16)
+                  __hip_atomic_fetch_add(dcl + rq[e] * B + 16 * tb2 + c, (double)(vq[e] * acc[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+      }
+    }
+    lds_barrier();
+    if (!has1) break;
+    t += Gd;
+    rp = rp1; rp1 = rp2; rp2 = rp3; s = s1; s1 = s2; x = x1; x1 = x2;
+    strip_store<GS>(gs, gp1, min(16, s.n), lane);
+  }
+  for (int j = tid; j < R * B; j += TW) {
+    const float v = (float)dcl[j];
+    if (v != 0.f) atomicAdd(dC + j, v);
+  }
+}
+
+template <int NKD, int KLD, bool VEC>
+__global__ __launch_bounds__(TW) void fbn_dbases_kernel(
+    const float *__restrict__ comps, const float *__restrict__ G, float *__restrict__ dbases, const int *__restrict__ rowptr,
+    const int *__restrict__ e_dst, const int *__restrict__ e_rel, const float *__restrict__ e_val, int n_tiles, int N, int R, int B,
+    int d, int ts, int last, int abl) {
+  constexpr int GS = 4 * NKD, NBTM = 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k = lane >> 4, c = lane & 15;
+  const int nbt = (B + 15) >> 4;
+  float *dt = lds;                                          // 2 x [B][ts] floats: every entry is stored by the wave that owns its node
+  float *gs = lds + 2 * B * ts + wave * (PERB * GS);
+  float *ctab = lds + 2 * B * ts + TWV * PERB * GS;         // [R][B]
+  for (int j = tid; j < R * B; j += TW) ctab[j] = comps[j];
+  Geo<KLD> g;
+  geo_init(g, tid, B, d, N, ts);
+  const int Gd = gridDim.x;
+  int t = blockIdx.x;
+  auto rp_of = [&](int tt) {
+    tt = min(tt, n_tiles - 1);
+    return rowptr[min((long long)tt * TN + min(lane, TN), (long long)N)];
+  };
+
+  int rp = rp_of(t), rp1 = rp_of(t + Gd), rp2 = rp_of(t + 2 * Gd);
+  NodeRange s = node_range(rp, wave, true);
+  Idx x = idx_load(e_dst, e_rel, e_val, s.a, last, lane);
+  NodeRange s1 = node_range(rp1, wave, t + Gd < n_tiles);
+  Idx x1 = idx_load(e_dst, e_rel, e_val, s1.a, last, lane);
+  float gp1[GQ] = {};
+  gather_rows_at(gp1, G, x.es, 0, min(16, s.n), d, lane);
+  strip_store<GS>(gs, gp1, min(16, s.n), lane);
+  int t_out = -1;
+  auto write_out = [&](const float *src) {
+    const int n0 = t_out * TN, n0s = min(n0, N - TN);
+    const long long base = (long long)n0s * d;
+    const int lo = (n0 - n0s) * d;                          // the last tile: positions below `lo` belong to the tile before
+#pragma unroll
+    for (int k2 = 0; k2 < KLD; ++k2)
+      if (g.act[k2]) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + g.loff[k2]);
+        float *o = dbases + g.goff[k2] + base;
+        const int pos = g.pos[k2];
+        if (VEC && pos >= lo) *reinterpret_cast<f32x4 *>(o) = v;      // (non-temporal stores measured the same)
+        else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (pos + q >= lo) o[q] = v[q];
+        }
+      }
+  };
+  lds_barrier();
+  for (int it = 0;; ++it) {
+    const bool has1 = t + Gd < n_tiles, has2 = t + 2 * Gd < n_tiles;
+    float *dtc = dt + (it & 1) * (B * ts);
+    if (t_out >= 0) write_out(dt + ((it + 1) & 1) * (B * ts));
+    __builtin_amdgcn_sched_barrier(0);
+    const int rp3 = rp_of(t + 3 * Gd);
+    const NodeRange s2 = node_range(rp2, wave, has2);
+    const Idx x2 = idx_load(e_dst, e_rel, e_val, s2.a, last, lane);
+    if (!FBT_ABL(4)) gather_rows_at(gp1, G, x1.es, 0, min(16, s1.n), d, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- node `wave` of tile t: the wave owns the node's B x d gradient (zero for a node without messages)
+    const int node = t * TN + wave, nl = node - min(t * TN, N - TN);
+    if (node < N) {
+      f32x4 acc[NBTM];
+#pragma unroll
+      for (int tb2 = 0; tb2 < NBTM; ++tb2) acc[tb2] = f32x4{0.f, 0.f, 0.f, 0.f};
+      Idx c_x = x;
+      for (int g0 = 0; g0 < s.n && !FBT_ABL(1); g0 += 16) {
+        const int n16 = min(16, s.n - g0);
+        if (g0) {
+          if ((g0 & 63) == 0) {
+            c_x = idx_load(e_dst, e_rel, e_val, s.a + g0, last, lane);
+            FBT_ARRIVED(c_x.es); FBT_ARRIVED(c_x.er); FBT_ARRIVED(c_x.ev);
+          }
+          float gq[GQ] = {};
+          gather_rows_at(gq, G, c_x.es, g0 & 63, n16, d, lane);
+          strip_store<GS>(gs, gq, n16, lane);
+        }
+        for (int j0 = 0; j0 < n16; j0 += 4) {               // four messages per step: k = the message
+          const int jm = min(j0 + k, n16 - 1), src = (g0 & 63) + jm;
+          const int r = __shfl(c_x.er, src, 64);
+          const float vs = __shfl(c_x.ev, src, 64);
+          const float v = (j0 + k < n16) ? vs : 0.f;
+          const float bv = gs[jm * GS + min(c, GS - 1)];
+#pragma unroll
+          for (int tb2 = 0; tb2 < NBTM; ++tb2)
+            if (tb2 < nbt) acc[tb2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ctab[r * B + min(16 * tb2 + c, B - 1)] * v, bv, acc[tb2], 0, 0, 0);
+        }
+      }
+      if (c < d) {                                          // D: lane (q, column i): rows 4 q .. 4 q + 3 of every 16-row tile of bases
+#pragma unroll
+        for (int tb2 = 0; tb2 < NBTM; ++tb2)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int b = 16 * tb2 + 4 * k + e;
+            if (tb2 < nbt && b < B) dtc[b * ts + nl * d + c] = acc[tb2][e];
+          }
+      }
+    }
+    t_out = t;
+    lds_barrier();
+    if (!has1) {
+      write_out(dtc);
+      break;
+    }
+    t += Gd;
+    rp = rp1; rp1 = rp2; rp2 = rp3; s = s1; s1 = s2; x = x1; x1 = x2;
+    strip_store<GS>(gs, gp1, min(16, s.n), lane);
+  }
+}
+
 inline int pow2_at_least(int v, int lo) {
   int p = lo;
   while (p < v) p <<= 1;
   return p;
 }
-struct TileShape { int dp, nreg, bp, kld, ts_f, ts_b, dpb; size_t lds_fwd, lds_dc, lds_db; };
+struct TileShape { int dp, nreg, bp, kld, ts_f, ts_b, dpb, nks; size_t lds_fwd, lds_dc, lds_db, lds_fwd_n, lds_db_n; };
 inline bool tile_shape(int R, int B, int d, long long N, TileShape &s) {
   if (R <= 0 || B < 1 || B > 64 || d < 1 || d > 16 || N < TN) return false;
   s.dp = pow2_at_least(d, 4);
@@ -610,6 +964,9 @@ inline bool tile_shape(int R, int B, int d, long long N, TileShape &s) {
   const size_t strips = (size_t)TWV * PERB * s.dpb * 4;    // the waves' strips of gradient rows
   s.lds_dc = (size_t)R * B * 8 + 16 + strips + 2 * (size_t)B * s.ts_b * 4;
   s.lds_db = 2 * (size_t)B * s.ts_b * 8 + strips + (size_t)R * B * 4;
+  s.nks = (B + 3) / 4;                                      // one wave per node (mode 1): K steps of the forward's MFMAs
+  s.lds_fwd_n = ((size_t)((R * 4 * s.nks + 3) & ~3) + 2 * (size_t)B * s.ts_f + (size_t)TWV * 16 * 16) * 4;
+  s.lds_db_n = 2 * (size_t)B * s.ts_f * 4 + strips + (size_t)R * B * 4;
   return true;
 }
 int n_cus() {
@@ -646,23 +1003,42 @@ extern "C" __attribute__((visibility("default"))) int rgcn_fbt_debug_read(unsign
 extern "C" int rgcn_fbasis_tile_supported(int32_t R, int32_t B, int32_t d, int64_t n_nodes) {
   TileShape s;
   if (!tile_shape(R, B, d, n_nodes, s)) return 0;
-  return (s.lds_fwd <= (size_t)LDS_MAX ? 1 : 0) | ((s.lds_dc <= (size_t)LDS_MAX && s.lds_db <= (size_t)LDS_MAX) ? 2 : 0);
+  return (s.lds_fwd <= (size_t)LDS_MAX ? 1 : 0) | ((s.lds_dc <= (size_t)LDS_MAX && s.lds_db <= (size_t)LDS_MAX) ? 2 : 0) |
+         (s.lds_fwd_n <= (size_t)LDS_MAX ? 4 : 0) | ((s.lds_dc <= (size_t)LDS_MAX && s.lds_db_n <= (size_t)LDS_MAX) ? 8 : 0);
 }
 
 extern "C" int rgcn_fbasis_tile_ystride(int32_t d) { return d >= 1 && d <= 16 ? pow2_at_least(d, 4) : 0; }
 
 extern "C" int rgcn_fbasis_tile_fwd_f32(const float *bases, const float *comps, float *Y, const int32_t *rowptr, const int32_t *e_rel,
-                                        const float *e_val, int64_t n_messages, int64_t n_nodes, int32_t R, int32_t B, int32_t d, void *stream) {
+                                        const float *e_val, int64_t n_messages, int64_t n_nodes, int32_t R, int32_t B, int32_t d, int32_t mode,
+                                        void *stream) {
   TileShape s;
   if (n_messages == 0) return RGCN_OK;
   if (!bases || !comps || !Y || !rowptr || !e_rel || !e_val || n_messages < 0 || n_messages > INT32_MAX) { rgcn_set_error("fbasis_tile_fwd: bad argument"); return RGCN_EINVAL; }
   const int last = (int)(n_messages - 1);
   const int abl = rgcn_option_value(RGCN_OPT_BWD_ABL);      // 0 in the shipped library (rgcn_set_option refuses it)
-  if (!tile_shape(R, B, d, n_nodes, s) || s.lds_fwd > (size_t)LDS_MAX) { rgcn_set_error("fbasis_tile_fwd: shape outside the tile kernel (rgcn_fbasis_tile_supported)"); return RGCN_EUNSUPPORTED; }
+  if (!tile_shape(R, B, d, n_nodes, s) || (mode ? s.lds_fwd_n : s.lds_fwd) > (size_t)LDS_MAX || (mode != 0 && mode != 1)) { rgcn_set_error("fbasis_tile_fwd: shape outside the tile kernel (rgcn_fbasis_tile_supported)"); return RGCN_EUNSUPPORTED; }
   const int n_tiles = (int)((n_nodes + TN - 1) / TN);
   const bool vec = ((n_nodes * d) % 4 == 0) && (reinterpret_cast<uintptr_t>(bases) % 16 == 0);
   const dim3 grid((unsigned)std::min<int64_t>(n_tiles, n_cus()));
   hipStream_t st = (hipStream_t)stream;
+  if (mode == 1) {                                          // one wave per node, MFMA
+    const int ys = pow2_at_least(d, 4);
+#define FBN_FWD3(NK_, KL_, VE_)                                                                                                 \
+  {                                                                                                                             \
+    HIP_TRY(raise_lds(fbn_fwd_kernel<NK_, KL_, VE_>, s.lds_fwd_n));                                                             \
+    hipLaunchKernelGGL((fbn_fwd_kernel<NK_, KL_, VE_>), grid, dim3(TW), s.lds_fwd_n, st, bases, comps, Y, rowptr, e_rel, e_val, n_tiles, \
+                       (int)n_nodes, R, B, d, s.ts_f, last, ys, abl);                                                            \
+  }
+#define FBN_FWD2(NK_, KL_) { if (vec) FBN_FWD3(NK_, KL_, true) else FBN_FWD3(NK_, KL_, false) }
+#define FBN_FWD1(NK_) { if (s.kld == 2) FBN_FWD2(NK_, 2) else FBN_FWD2(NK_, 4) }
+    if (s.nks <= 4) FBN_FWD1(4) else if (s.nks <= 8) FBN_FWD1(8) else if (s.nks <= 12) FBN_FWD1(12) else FBN_FWD1(16)
+#undef FBN_FWD1
+#undef FBN_FWD2
+#undef FBN_FWD3
+    HIP_TRY(hipGetLastError());
+    return RGCN_OK;
+  }
 #define FBT_FWD3(DP_, NR_, KL_)                                                                                                   \
   {                                                                                                                               \
     if (vec) {                                                                                                                    \
@@ -708,7 +1084,7 @@ extern "C" int rgcn_gather_rows_sum4_f32(const float *Y, int32_t ys, const int32
 
 extern "C" int rgcn_fbasis_tile_bwd_f32(const float *bases, const float *comps, const float *G, float *dbases, float *dcomps,
                                         const int32_t *rowptr, const int32_t *e_dst, const int32_t *e_rel, const float *e_val,
-                                        int64_t n_messages, int64_t n_nodes, int32_t R, int32_t B, int32_t d, void *stream) {
+                                        int64_t n_messages, int64_t n_nodes, int32_t R, int32_t B, int32_t d, int32_t mode, void *stream) {
   TileShape s;
   if (!bases || !comps || !G || !rowptr || !e_dst || !e_rel || !e_val || (!dbases && !dcomps) || n_messages < 0 || n_messages > INT32_MAX) { rgcn_set_error("fbasis_tile_bwd: bad argument"); return RGCN_EINVAL; }
   if (n_messages == 0) {                                    // no messages: both gradients are zero
@@ -718,7 +1094,7 @@ extern "C" int rgcn_fbasis_tile_bwd_f32(const float *bases, const float *comps, 
   }
   const int last = (int)(n_messages - 1);
   const int abl = rgcn_option_value(RGCN_OPT_BWD_ABL);      // 0 in the shipped library (rgcn_set_option refuses it)
-  if (!tile_shape(R, B, d, n_nodes, s) || s.lds_dc > (size_t)LDS_MAX || s.lds_db > (size_t)LDS_MAX) { rgcn_set_error("fbasis_tile_bwd: shape outside the tile kernels (rgcn_fbasis_tile_supported)"); return RGCN_EUNSUPPORTED; }
+  if (!tile_shape(R, B, d, n_nodes, s) || s.lds_dc > (size_t)LDS_MAX || (mode ? s.lds_db_n : s.lds_db) > (size_t)LDS_MAX || (mode != 0 && mode != 1)) { rgcn_set_error("fbasis_tile_bwd: shape outside the tile kernels (rgcn_fbasis_tile_supported)"); return RGCN_EUNSUPPORTED; }
   const int n_tiles = (int)((n_nodes + TN - 1) / TN);
   const bool vec = ((n_nodes * d) % 4 == 0) && (reinterpret_cast<uintptr_t>(bases) % 16 == 0) && (!dbases || reinterpret_cast<uintptr_t>(dbases) % 16 == 0);
   const dim3 grid((unsigned)std::min<int64_t>(n_tiles, n_cus()));
@@ -737,11 +1113,26 @@ extern "C" int rgcn_fbasis_tile_bwd_f32(const float *bases, const float *comps, 
 #define FBT_BWD1(KERNEL, LDSB, ...)                                                                                        \
   { if (s.dpb == 4) FBT_BWD2(KERNEL, LDSB, 4, __VA_ARGS__) else if (s.dpb == 8) FBT_BWD2(KERNEL, LDSB, 8, __VA_ARGS__)       \
     else if (s.dpb == 12) FBT_BWD2(KERNEL, LDSB, 12, __VA_ARGS__) else FBT_BWD2(KERNEL, LDSB, 16, __VA_ARGS__) }
+  if (mode == 1) {                                          // one wave per node, MFMA: template on the K steps over the features (d / 4)
+#define FBN_BWD2(KERNEL, LDSB, NK_, ...) { if (s.kld == 2) FBT_BWD3(KERNEL, LDSB, NK_, 2, __VA_ARGS__) else FBT_BWD3(KERNEL, LDSB, NK_, 4, __VA_ARGS__) }
+#define FBN_BWD1(KERNEL, LDSB, ...)                                                                                         \
+  { if (s.dpb == 4) FBN_BWD2(KERNEL, LDSB, 1, __VA_ARGS__) else if (s.dpb == 8) FBN_BWD2(KERNEL, LDSB, 2, __VA_ARGS__)        \
+    else if (s.dpb == 12) FBN_BWD2(KERNEL, LDSB, 3, __VA_ARGS__) else FBN_BWD2(KERNEL, LDSB, 4, __VA_ARGS__) }
+    if (dbases)
+      FBN_BWD1(fbn_dbases_kernel, s.lds_db_n, comps, G, dbases, rowptr, e_dst, e_rel, e_val, n_tiles, (int)n_nodes, R, B, d, s.ts_f, last, abl)
+    if (dcomps) {
+      HIP_TRY(zero_async(dcomps, (size_t)R * B * sizeof(float), st));
+      FBN_BWD1(fbn_dcomps_kernel, s.lds_dc, bases, G, dcomps, rowptr, e_dst, e_rel, e_val, n_tiles, (int)n_nodes, R, B, d, s.ts_b, last, abl)
+    }
+#undef FBN_BWD1
+#undef FBN_BWD2
+  } else {
   if (dbases)
     FBT_BWD1(fbt_dbases_kernel, s.lds_db, comps, G, dbases, rowptr, e_dst, e_rel, e_val, n_tiles, (int)n_nodes, R, B, d, s.ts_b, last, abl)
   if (dcomps) {
     HIP_TRY(zero_async(dcomps, (size_t)R * B * sizeof(float), st));
     FBT_BWD1(fbt_dcomps_kernel, s.lds_dc, bases, G, dcomps, rowptr, e_dst, e_rel, e_val, n_tiles, (int)n_nodes, R, B, d, s.ts_b, last, abl)
+  }
   }
 #undef FBT_BWD1
 #undef FBT_BWD2

@@ -550,7 +550,7 @@ def row_units(rowptr, n_rows, max_len):
 class FBasisPlan:
     """source-major view of a graph for the featureless basis layer (see csrc/rgcn_basis.hip)"""
     __slots__ = ("e_dst", "e_rel", "e_val", "n_messages", "units_src", "perm_dst", "units_dst", "perm_rel", "units_rel",
-                 "n_nodes", "num_rels", "rowptr_src")
+                 "n_nodes", "num_rels", "rowptr_src", "max_src_degree")
 
 
 def build_fbasis_plan(csr_src, csr_dst, n_nodes, num_rels, max_len=1024):
@@ -561,6 +561,8 @@ def build_fbasis_plan(csr_src, csr_dst, n_nodes, num_rels, max_len=1024):
     p.n_messages, p.n_nodes, p.num_rels = M, n_nodes, num_rels
     p.e_dst, p.e_rel, p.e_val = csr_src.src, csr_src.rel, csr_src.val
     p.rowptr_src = csr_src.rowptr
+    rp = csr_src.rowptr[: n_nodes + 1]
+    p.max_src_degree = int((rp[1:] - rp[:-1]).max().item()) if n_nodes > 0 else 0       # static graph: read once (the tile kernels' mode)
     p.units_src = row_units(csr_src.rowptr, n_nodes, max_len)
     live = csr_src.msg_slot >= 0
     perm = torch.zeros(max(M, 1), dtype=torch.int32, device=csr_src.rowptr.device)
@@ -639,17 +641,30 @@ def fbasis_bwd(table, comps, g, plan, need_bases=True, need_comps=True, basis_ma
     return dB, dC
 
 
-def fbasis_tile_ok(R, B, d, n_nodes):
-    """-> (forward, backward) availability of the tile kernels (rgcn_fbasis_tile.hip: the table walked IN the parameter's [B, N, d]
-    layout, 16 source nodes per tile); route fbasis_tile=0 turns them off, the deterministic mode keeps the wave-per-node kernels"""
-    if routes.get("fbasis_tile", "1") == "0" or routes.flag("deterministic"):
-        return False, False
+TILE_NODE_MODE_MAX_DEGREE = 4096
+
+
+def fbasis_tile_ok(R, B, d, n_nodes, max_degree=None):
+    """-> (available, mode) of the tile kernels (rgcn_fbasis_tile.hip: the table walked IN the parameter's [B, N, d] layout, 16 source
+    nodes per tile).  mode 1 = one wave per node on the matrix cores -- for graphs without hub sources (largest source degree <=
+    TILE_NODE_MODE_MAX_DEGREE: a hub is ONE wave's work there); mode 0 = a tile's messages dealt evenly over the 16 waves.
+    Route fbasis_tile: 0 off, ranges / nodes force a mode; the deterministic mode keeps the wave-per-node kernels of rgcn_basis.hip."""
+    route = routes.get("fbasis_tile", "1")
+    if route == "0" or routes.flag("deterministic"):
+        return False, 0
     m = lib().rgcn_fbasis_tile_supported(c_i32(R), c_i32(B), c_i32(d), c_i64(n_nodes))
-    return bool(m & 1), bool(m & 2)
+    ranges, nodes = (m & 3) == 3, (m & 12) == 12
+    if route == "nodes":
+        return nodes, 1
+    if route == "ranges":
+        return ranges, 0
+    if nodes and max_degree is not None and max_degree <= TILE_NODE_MODE_MAX_DEGREE:
+        return True, 1
+    return ranges, 0
 
 
-def fbasis_tile_fwd(bases, comps, bias, plan, relu=False):
-    """bases [B, N, d] (the parameter itself) -> out [N, d]; relu: as fbasis_fwd"""
+def fbasis_tile_fwd(bases, comps, bias, plan, relu=False, mode=0):
+    """bases [B, N, d] (the parameter itself) -> out [N, d]; relu: as fbasis_fwd; mode: fbasis_tile_ok"""
     _req(bases, "bases"); _req(comps, "comps"); _req(bias, "bias")
     B, N, d = bases.shape
     dev = bases.device
@@ -658,7 +673,8 @@ def fbasis_tile_fwd(bases, comps, bias, plan, relu=False):
     out = torch.empty(N, d, device=dev, dtype=torch.float32)
     with _on(dev), _timed("fbasis_tile_fwd"):
         _check(lib().rgcn_fbasis_tile_fwd_f32(_dp(bases), _dp(comps), _dp(Y), _dp(plan.rowptr_src), _dp(plan.e_rel), _dp(plan.e_val),
-                                              c_i64(plan.n_messages), c_i64(N), c_i32(comps.shape[0]), c_i32(B), c_i32(d), _stream(dev)), "fbasis_tile_fwd")
+                                              c_i64(plan.n_messages), c_i64(N), c_i32(comps.shape[0]), c_i32(B), c_i32(d), c_i32(mode), _stream(dev)),
+               "fbasis_tile_fwd")
     units, n_units, n_split = plan.units_dst
     fused = bool(relu) and n_split == 0
     with _on(dev), _timed("gather_rows_sum4"):
@@ -667,7 +683,7 @@ def fbasis_tile_fwd(bases, comps, bias, plan, relu=False):
     return (out, fused) if relu else out
 
 
-def fbasis_tile_bwd(bases, comps, g, plan, need_bases=True, need_comps=True):
+def fbasis_tile_bwd(bases, comps, g, plan, need_bases=True, need_comps=True, mode=0):
     """-> (dbases [B, N, d] in the parameter's layout, dcomps [R, B])"""
     _req(bases, "bases"); _req(comps, "comps"); _req(g, "grad")
     B, N, d = bases.shape
@@ -679,8 +695,8 @@ def fbasis_tile_bwd(bases, comps, g, plan, need_bases=True, need_comps=True):
         return None, None
     with _on(dev), _timed("fbasis_tile_bwd"):
         _check(lib().rgcn_fbasis_tile_bwd_f32(_dp(bases), _dp(comps), _dp(g), _dp(dB), _dp(dC), _dp(plan.rowptr_src), _dp(plan.e_dst),
-                                              _dp(plan.e_rel), _dp(plan.e_val), c_i64(plan.n_messages), c_i64(N), c_i32(R), c_i32(B), c_i32(d), _stream(dev)),
-               "fbasis_tile_bwd")
+                                              _dp(plan.e_rel), _dp(plan.e_val), c_i64(plan.n_messages), c_i64(N), c_i32(R), c_i32(B), c_i32(d), c_i32(mode),
+                                              _stream(dev)), "fbasis_tile_bwd")
     return dB, dC
 
 

@@ -649,14 +649,15 @@ class _FeaturelessBasisMP(torch.autograd.Function):
         ctx.in_place = ctx.src_major and B * N * d * 4 <= int(routes.get("fbasis_inplace_mb", "256")) << 20
         # Round 4: tables beyond the caches are walked in place too, by the tile kernels (rgcn_fbasis_tile.hip: 16 source nodes per tile,
         # staged through LDS with aligned 16-byte accesses, software-pipelined) -- no transposed copy, no transposed gradient.
-        tile_f, tile_b = _native.fbasis_tile_ok(comps.shape[0], B, d, N) if (ctx.src_major and not ctx.in_place) else (False, False)
-        ctx.tile_bwd = tile_f and tile_b
-        if tile_f and tile_b:
+        tiled, ctx.tile_mode = _native.fbasis_tile_ok(comps.shape[0], B, d, N, graph.fbasis_plan().max_src_degree) \
+            if (ctx.src_major and not ctx.in_place) else (False, 0)
+        ctx.tile_bwd = tiled
+        if tiled:
             comps, bases = dense(comps), dense(bases)
             ctx.graph, ctx.has_bias = graph, bias is not None
             ctx.in_place = True
             ctx.to_save = (bases, comps)
-            return _relu_epilogue(ctx, _native.fbasis_tile_fwd(bases, comps, bias, graph.fbasis_plan(), relu=relu), relu)
+            return _relu_epilogue(ctx, _native.fbasis_tile_fwd(bases, comps, bias, graph.fbasis_plan(), relu=relu, mode=ctx.tile_mode), relu)
         if ctx.src_major and ctx.in_place:
             comps, bases = dense(comps), dense(bases)
             ctx.graph, ctx.has_bias = graph, bias is not None
@@ -684,7 +685,7 @@ class _FeaturelessBasisMP(torch.autograd.Function):
         if ctx.src_major:
             table, comps = ctx.saved_tensors[:2]
             if getattr(ctx, "tile_bwd", False):
-                dB, dC = _native.fbasis_tile_bwd(table, comps, g, ctx.graph.fbasis_plan(), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+                dB, dC = _native.fbasis_tile_bwd(table, comps, g, ctx.graph.fbasis_plan(), ctx.needs_input_grad[0], ctx.needs_input_grad[1], mode=ctx.tile_mode)
             else:
                 dB, dC = _native.fbasis_bwd(table, comps, g, ctx.graph.fbasis_plan(), ctx.needs_input_grad[0],
                                             ctx.needs_input_grad[1], basis_major=ctx.in_place)
