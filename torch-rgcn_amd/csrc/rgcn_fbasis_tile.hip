@@ -39,6 +39,7 @@ __device__ __forceinline__ float bcast(float v, int src_lane) {   // src_lane wa
 }
 __device__ __forceinline__ int rlane(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
 #define FBT_ARRIVED(x) asm volatile("" : "+v"(x))          // the value must be in its register HERE (pins the s_waitcnt)
+#define FBT_KEEP(x) asm volatile("" ::"v"(x))               // the registers of x are not reused before HERE
 #ifdef RGCN_ABLATIONS       // timing experiments with WRONG results (tools/fbt_bench.py, ablation build only): 1 no message loop, 2 no tile loads, 4 no row gathers, 8 no LDS adds
 #define FBT_ABL(bit) (abl & (bit))
 // the instrumented kernels also add up, per wave, the 100 MHz ticks of every phase of the pipeline (rgcn_fbt_debug_read)
@@ -85,8 +86,8 @@ __device__ __forceinline__ int node_of(int rp, int lane, int p) {
 template <int KLD>
 struct Geo { long long goff[KLD]; int loff[KLD], pos[KLD]; bool act[KLD]; };
 template <int KLD>
-__device__ __forceinline__ void geo_init(Geo<KLD> &g, int tid, int B, int d, long long N, int ts) {
-  const int q4 = 4 * d;                                     // pieces per basis
+__device__ __forceinline__ void geo_init(Geo<KLD> &g, int tid, int B, int d, long long N, int ts, int tn = TN) {
+  const int q4 = tn * d / 4;                                // pieces per basis (tn nodes per tile)
 #pragma unroll
   for (int k = 0; k < KLD; ++k) {
     const int idx = tid + k * TW;
@@ -619,6 +620,17 @@ __device__ __forceinline__ void gather_rows_at(float (&gp)[GQ], const float *__r
     }
 }
 
+// the first rows of the wave's run, ALWAYS four loads (a run shorter than 16 re-reads its last row, an empty one entry 0 of the indices):
+// a fixed number of loads per iteration lets the compiler count them (s_waitcnt vmcnt(n)) instead of draining everything
+__device__ __forceinline__ void gather_rows_all(float (&gp)[GQ], const float *__restrict__ G, int es, int n, int d, int lane) {
+  const int m = lane >> 4, c = min(lane & 15, d - 1);
+#pragma unroll
+  for (int q = 0; q < GQ; ++q) {
+    const int s = __shfl(es, min(4 * q + m, max(n - 1, 0)), 64);
+    gp[q] = G[(size_t)s * d + c];
+  }
+}
+
 template <int NKSM, int KLD, bool VEC>
 __global__ __launch_bounds__(TW) void fbn_fwd_kernel(
     const float *__restrict__ bases, const float *__restrict__ comps, float *__restrict__ Y, const int *__restrict__ rowptr,
@@ -654,16 +666,24 @@ __global__ __launch_bounds__(TW) void fbn_fwd_kernel(
   stage_store<KLD, true>(tb, st, g);
   stage_load<KLD, VEC>(st, g, bases, base_of(t + G));
   int pa = 0, pn = 0;                                      // rows pa .. pa + pn of Y wait in the wave's strip
+  // -> the stored registers: the caller keeps them alive (FBT_KEEP) across the message loops.  hipcc guards a store's DATA registers with
+  // s_waitcnt vmcnt(0) before their next write; reused right away -- by the address arithmetic of the loads that follow -- every
+  // iteration waited for its Y store to COMPLETE before it issued a single load
   auto flush = [&]() {
-    if (lane < pn * (ys >> 2)) reinterpret_cast<f32x4 *>(Y + (size_t)pa * ys)[lane] = reinterpret_cast<const f32x4 *>(yb)[lane];
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (lane < pn * (ys >> 2)) {
+      v = reinterpret_cast<const f32x4 *>(yb)[lane];
+      reinterpret_cast<f32x4 *>(Y + (size_t)pa * ys)[lane] = v;
+    }
     pn = 0;
+    return v;
   };
   lds_barrier();
   for (int it = 0;; ++it) {
     const bool has1 = t + G < n_tiles;
     const float *cb = tb + (it & 1) * (B * ts);
     if (has1) stage_store<KLD, true>(tb + ((it + 1) & 1) * (B * ts), st, g);
-    flush();
+    f32x4 kept = flush();
     __builtin_amdgcn_sched_barrier(0);
     if (!FBT_ABL(2)) stage_load<KLD, VEC>(st, g, bases, base_of(t + 2 * G));
     const int rp2 = rp_of(t + 2 * G);
@@ -706,6 +726,7 @@ __global__ __launch_bounds__(TW) void fbn_fwd_kernel(
         pn = min(16, s.n - g0);
       }
     }
+    FBT_KEEP(kept);
     lds_barrier();
     if (!has1) break;
     t += G;
@@ -829,12 +850,14 @@ __global__ __launch_bounds__(TW) void fbn_dcomps_kernel(
   }
 }
 
-template <int NKD, int KLD, bool VEC>
+// NPW nodes per wave (tiles of 16 NPW nodes): with 32-node tiles the per-tile costs (write-out, issue, barrier, the wait for the loads) are paid
+// half as often and a tile's message loops are as long as the memory latency they have to cover
+template <int NKD, int KLD, bool VEC, int NPW>
 __global__ __launch_bounds__(TW) void fbn_dbases_kernel(
     const float *__restrict__ comps, const float *__restrict__ G, float *__restrict__ dbases, const int *__restrict__ rowptr,
     const int *__restrict__ e_dst, const int *__restrict__ e_rel, const float *__restrict__ e_val, int n_tiles, int N, int R, int B,
     int d, int ts, int last, int abl) {
-  constexpr int GS = 4 * NKD, NBTM = 4;
+  constexpr int GS = 4 * NKD, NBTM = 4, TNV = TN * NPW;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k = lane >> 4, c = lane & 15;
@@ -844,76 +867,89 @@ __global__ __launch_bounds__(TW) void fbn_dbases_kernel(
   float *ctab = lds + 2 * B * ts + TWV * PERB * GS;         // [R][B]
   for (int j = tid; j < R * B; j += TW) ctab[j] = comps[j];
   Geo<KLD> g;
-  geo_init(g, tid, B, d, N, ts);
+  geo_init(g, tid, B, d, N, ts, TNV);
   const int Gd = gridDim.x;
   int t = blockIdx.x;
-  auto rp_of = [&](int tt) {
-    tt = min(tt, n_tiles - 1);
-    return rowptr[min((long long)tt * TN + min(lane, TN), (long long)N)];
+  // tile tt = nodes first_of(tt) .. + TNV; the LAST tile is nodes N - TNV .. N whatever N: where it overlaps the tile before, both workgroups
+  // compute and store the same gradients (identical values) -- no partial tile, no guarded stores, every tile's write-out is the same
+  // KLD 16-byte stores per thread
+  auto first_of = [&](int tt) { return min(min(tt, n_tiles - 1) * TNV, N - TNV); };
+  auto rp_of = [&](int tt) { return rowptr[first_of(tt) + min(lane, TNV)]; };      // lane l <= TNV: rowptr[tile's first node + l]
+  auto range_of = [&](int rpv, bool valid) {                // the wave's NPW nodes send one contiguous run of messages
+    NodeRange r;
+    r.a = rlane(rpv, wave * NPW);
+    r.n = valid ? rlane(rpv, wave * NPW + NPW) - r.a : 0;
+    return r;
   };
 
   int rp = rp_of(t), rp1 = rp_of(t + Gd), rp2 = rp_of(t + 2 * Gd);
-  NodeRange s = node_range(rp, wave, true);
+  NodeRange s = range_of(rp, true);
   Idx x = idx_load(e_dst, e_rel, e_val, s.a, last, lane);
-  NodeRange s1 = node_range(rp1, wave, t + Gd < n_tiles);
+  NodeRange s1 = range_of(rp1, t + Gd < n_tiles);
   Idx x1 = idx_load(e_dst, e_rel, e_val, s1.a, last, lane);
   float gp1[GQ] = {};
   gather_rows_at(gp1, G, x.es, 0, min(16, s.n), d, lane);
   strip_store<GS>(gs, gp1, min(16, s.n), lane);
-  int t_out = -1;
-  auto write_out = [&](const float *src) {
-    const int n0 = t_out * TN, n0s = min(n0, N - TN);
-    const long long base = (long long)n0s * d;
-    const int lo = (n0 - n0s) * d;                          // the last tile: positions below `lo` belong to the tile before
+  // the tile whose gradient waits in the other buffer.  Before the first tile: the workgroup's own first tile -- whatever the LDS holds goes out
+  // and is overwritten one iteration later by the same threads: every iteration then issues the same number of stores, which lets the
+  // compiler wait for the iteration's LOADS with an exact count and leave the stores in flight
+  int t_out = t;
+  f32x4 kept[KLD];                                          // the stored pieces, kept alive over the message loops (see fbn_fwd_kernel's flush)
+  auto write_out = [&](const float *src, int part) {        // part < NPW: that share of the thread's pieces; part < 0: all of them
+    const long long base = (long long)first_of(t_out) * d;
 #pragma unroll
     for (int k2 = 0; k2 < KLD; ++k2)
-      if (g.act[k2]) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + g.loff[k2]);
+      if (!FBT_ABL(32) && (part < 0 || k2 * NPW / KLD == part)) {      // (a thread without a k2-th piece stores piece 0 again: same bytes, no predicate)
+        kept[k2] = *reinterpret_cast<const f32x4 *>(src + g.loff[k2]);
         float *o = dbases + g.goff[k2] + base;
-        const int pos = g.pos[k2];
-        if (VEC && pos >= lo) *reinterpret_cast<f32x4 *>(o) = v;      // (non-temporal stores measured the same)
-        else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (pos + q >= lo) o[q] = v[q];
-        }
+        if (VEC) *reinterpret_cast<f32x4 *>(o) = kept[k2];  // (non-temporal stores measured the same)
+        else { o[0] = kept[k2][0]; o[1] = kept[k2][1]; o[2] = kept[k2][2]; o[3] = kept[k2][3]; }
       }
   };
   lds_barrier();
   for (int it = 0;; ++it) {
     const bool has1 = t + Gd < n_tiles, has2 = t + 2 * Gd < n_tiles;
     float *dtc = dt + (it & 1) * (B * ts);
-    if (t_out >= 0) write_out(dt + ((it + 1) & 1) * (B * ts));
-    __builtin_amdgcn_sched_barrier(0);
     const int rp3 = rp_of(t + 3 * Gd);
-    const NodeRange s2 = node_range(rp2, wave, has2);
+    const NodeRange s2 = range_of(rp2, has2);
     const Idx x2 = idx_load(e_dst, e_rel, e_val, s2.a, last, lane);
-    if (!FBT_ABL(4)) gather_rows_at(gp1, G, x1.es, 0, min(16, s1.n), d, lane);
+    if (!FBT_ABL(4)) gather_rows_all(gp1, G, x1.es, min(16, s1.n), d, lane);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- node `wave` of tile t: the wave owns the node's B x d gradient (zero for a node without messages)
-    const int node = t * TN + wave, nl = node - min(t * TN, N - TN);
-    if (node < N) {
+    // the stores of the tile before go out AFTER this iteration's loads (the wait for those loads at the bottom -- vmcnt counts in order -- then
+    // leaves the stores a whole iteration to drain) and in NPW shares, one ahead of each node's message loops: 51 KB per tile and CU take
+    // ~3 us to leave the CU, and a store blocks at issue once the write queue is full
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- nodes wave * NPW .. of tile t: the wave owns their B x d gradients (zero for a node without messages)
+    Idx c_x = x;
+    int cb0 = 0, sb0 = 0;                                   // windows over the wave's messages: 64 indices from cb0, 16 strip rows from sb0
+    for (int i2 = 0; i2 < NPW; ++i2) {
+      const int nl = wave * NPW + i2;                       // (every tile has all its TNV nodes)
+      write_out(dt + ((it + 1) & 1) * (B * ts), i2);
+      __builtin_amdgcn_sched_barrier(0);
+      const int off0 = rlane(rp, wave * NPW + i2) - s.a, off1 = rlane(rp, wave * NPW + i2 + 1) - s.a;
       f32x4 acc[NBTM];
 #pragma unroll
       for (int tb2 = 0; tb2 < NBTM; ++tb2) acc[tb2] = f32x4{0.f, 0.f, 0.f, 0.f};
-      Idx c_x = x;
-      for (int g0 = 0; g0 < s.n && !FBT_ABL(1); g0 += 16) {
-        const int n16 = min(16, s.n - g0);
-        if (g0) {
-          if ((g0 & 63) == 0) {
-            c_x = idx_load(e_dst, e_rel, e_val, s.a + g0, last, lane);
-            FBT_ARRIVED(c_x.es); FBT_ARRIVED(c_x.er); FBT_ARRIVED(c_x.ev);
-          }
+      for (int g0 = off0; g0 < off1 && !FBT_ABL(1); g0 += 16) {
+        const int n16 = min(16, off1 - g0);
+        if (g0 + n16 > cb0 + 64) {                          // past the 64 prefetched indices: the next 64, on demand
+          cb0 = g0;
+          c_x = idx_load(e_dst, e_rel, e_val, s.a + cb0, last, lane);
+          FBT_ARRIVED(c_x.es); FBT_ARRIVED(c_x.er); FBT_ARRIVED(c_x.ev);
+        }
+        if (g0 + n16 > sb0 + 16) {                          // past the 16 prefetched rows
+          sb0 = g0;
+          const int nrow = min(16, min(s.n, cb0 + 64) - g0);  // a whole window (the next node's group may start inside it)
           float gq[GQ] = {};
-          gather_rows_at(gq, G, c_x.es, g0 & 63, n16, d, lane);
-          strip_store<GS>(gs, gq, n16, lane);
+          gather_rows_at(gq, G, c_x.es, g0 - cb0, nrow, d, lane);
+          strip_store<GS>(gs, gq, nrow, lane);
         }
         for (int j0 = 0; j0 < n16; j0 += 4) {               // four messages per step: k = the message
-          const int jm = min(j0 + k, n16 - 1), src = (g0 & 63) + jm;
+          const int jm = min(j0 + k, n16 - 1), src = g0 - cb0 + jm;
           const int r = __shfl(c_x.er, src, 64);
           const float vs = __shfl(c_x.ev, src, 64);
           const float v = (j0 + k < n16) ? vs : 0.f;
-          const float bv = gs[jm * GS + min(c, GS - 1)];
+          const float bv = gs[(g0 - sb0 + jm) * GS + min(c, GS - 1)];
 #pragma unroll
           for (int tb2 = 0; tb2 < NBTM; ++tb2)
             if (tb2 < nbt) acc[tb2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ctab[r * B + min(16 * tb2 + c, B - 1)] * v, bv, acc[tb2], 0, 0, 0);
@@ -930,9 +966,11 @@ __global__ __launch_bounds__(TW) void fbn_dbases_kernel(
       }
     }
     t_out = t;
+#pragma unroll
+    for (int k2 = 0; k2 < KLD; ++k2) FBT_KEEP(kept[k2]);
     lds_barrier();
     if (!has1) {
-      write_out(dtc);
+      write_out(dtc, -1);
       break;
     }
     t += Gd;
@@ -946,7 +984,7 @@ inline int pow2_at_least(int v, int lo) {
   while (p < v) p <<= 1;
   return p;
 }
-struct TileShape { int dp, nreg, bp, kld, ts_f, ts_b, dpb, nks; size_t lds_fwd, lds_dc, lds_db, lds_fwd_n, lds_db_n; };
+struct TileShape { int dp, nreg, bp, kld, ts_f, ts_b, dpb, nks, kld2; size_t lds_fwd, lds_dc, lds_db, lds_fwd_n, lds_db_n, lds_db_n2; };
 inline bool tile_shape(int R, int B, int d, long long N, TileShape &s) {
   if (R <= 0 || B < 1 || B > 64 || d < 1 || d > 16 || N < TN) return false;
   s.dp = pow2_at_least(d, 4);
@@ -967,6 +1005,10 @@ inline bool tile_shape(int R, int B, int d, long long N, TileShape &s) {
   s.nks = (B + 3) / 4;                                      // one wave per node (mode 1): K steps of the forward's MFMAs
   s.lds_fwd_n = ((size_t)((R * 4 * s.nks + 3) & ~3) + 2 * (size_t)B * s.ts_f + (size_t)TWV * 16 * 16) * 4;
   s.lds_db_n = 2 * (size_t)B * s.ts_f * 4 + strips + (size_t)R * B * 4;
+  // dbases with 32-node tiles (two nodes per wave): row stride 32 d + 4, B x 8 d pieces
+  s.lds_db_n2 = 2 * (size_t)B * (2 * TN * d + 4) * 4 + strips + (size_t)R * B * 4;
+  s.kld2 = 2 * pieces <= 2 * TW ? 2 : 4;
+  if (2 * pieces > 4 * TW || N < 2 * TN) s.lds_db_n2 = (size_t)LDS_MAX + 1;
   return true;
 }
 int n_cus() {
@@ -1118,8 +1160,28 @@ extern "C" int rgcn_fbasis_tile_bwd_f32(const float *bases, const float *comps, 
 #define FBN_BWD1(KERNEL, LDSB, ...)                                                                                         \
   { if (s.dpb == 4) FBN_BWD2(KERNEL, LDSB, 1, __VA_ARGS__) else if (s.dpb == 8) FBN_BWD2(KERNEL, LDSB, 2, __VA_ARGS__)        \
     else if (s.dpb == 12) FBN_BWD2(KERNEL, LDSB, 3, __VA_ARGS__) else FBN_BWD2(KERNEL, LDSB, 4, __VA_ARGS__) }
-    if (dbases)
-      FBN_BWD1(fbn_dbases_kernel, s.lds_db_n, comps, G, dbases, rowptr, e_dst, e_rel, e_val, n_tiles, (int)n_nodes, R, B, d, s.ts_f, last, abl)
+    if (dbases) {
+      const bool two = s.lds_db_n2 <= (size_t)LDS_MAX;      // 32-node tiles when they fit the LDS
+      const int tiles_db = two ? (int)((n_nodes + 2 * TN - 1) / (2 * TN)) : n_tiles;
+      const int ts_db = two ? 2 * TN * d + 4 : s.ts_f;
+      const size_t lds_db = two ? s.lds_db_n2 : s.lds_db_n;
+      const int kld_db = two ? s.kld2 : s.kld;
+      const dim3 grid_db((unsigned)std::min<int64_t>(tiles_db, n_cus()));
+#define FBN_DB3(NK_, KL_, VE_, NP_)                                                                                               \
+  {                                                                                                                               \
+    HIP_TRY(raise_lds(fbn_dbases_kernel<NK_, KL_, VE_, NP_>, lds_db));                                                             \
+    hipLaunchKernelGGL((fbn_dbases_kernel<NK_, KL_, VE_, NP_>), grid_db, dim3(TW), lds_db, st, comps, G, dbases, rowptr, e_dst, e_rel, e_val, \
+                       tiles_db, (int)n_nodes, R, B, d, ts_db, last, abl);                                                         \
+  }
+#define FBN_DB2(NK_, KL_, VE_) { if (two) FBN_DB3(NK_, KL_, VE_, 2) else FBN_DB3(NK_, KL_, VE_, 1) }
+#define FBN_DB1(NK_, KL_) { if (vec) FBN_DB2(NK_, KL_, true) else FBN_DB2(NK_, KL_, false) }
+#define FBN_DB0(NK_) { if (kld_db == 2) FBN_DB1(NK_, 2) else FBN_DB1(NK_, 4) }
+      if (s.dpb == 4) FBN_DB0(1) else if (s.dpb == 8) FBN_DB0(2) else if (s.dpb == 12) FBN_DB0(3) else FBN_DB0(4)
+#undef FBN_DB0
+#undef FBN_DB1
+#undef FBN_DB2
+#undef FBN_DB3
+    }
     if (dcomps) {
       HIP_TRY(zero_async(dcomps, (size_t)R * B * sizeof(float), st));
       FBN_BWD1(fbn_dcomps_kernel, s.lds_dc, bases, G, dcomps, rowptr, e_dst, e_rel, e_val, n_tiles, (int)n_nodes, R, B, d, s.ts_b, last, abl)
