@@ -94,3 +94,26 @@ def test_shipped_library_has_no_wrong_result_switch():
     assert L.rgcn_set_option(b"no_such_option", ctypes.c_int32(1)) != 0
     syms = subprocess.run(["nm", "-D", "--defined-only", lib_path], capture_output=True, text=True).stdout
     assert "rgcn_blk_debug_read" not in syms and "abl" not in syms.lower().replace("available", ""), "ablation entry points in the shipped library"
+
+
+def test_tile_kernel_mode_follows_the_largest_source_degree(monkeypatch):
+    """featureless basis layer on tables beyond the caches (rgcn_fbasis_tile.hip): one wave per node on the matrix cores unless a source
+    node is a hub (its messages would be ONE wave's loop) -- then a tile's messages are dealt over the waves; routes force either form or
+    turn the tile kernels off; shapes outside the LDS budget fall back (host logic only: no GPU needed)"""
+    from torch_rgcn import _native, routes
+    am = dict(R=267, B=40, d=10, n_nodes=1_666_764)          # AM as shipped
+    assert _native.fbasis_tile_ok(**am, max_degree=25) == (True, 1)
+    assert _native.fbasis_tile_ok(**am, max_degree=_native.TILE_NODE_MODE_MAX_DEGREE + 1) == (True, 0)
+    assert _native.fbasis_tile_ok(**am, max_degree=None) == (True, 0)
+    routes.patch(monkeypatch, "fbasis_tile", "ranges")
+    assert _native.fbasis_tile_ok(**am, max_degree=25) == (True, 0)
+    routes.patch(monkeypatch, "fbasis_tile", "nodes")
+    assert _native.fbasis_tile_ok(**am, max_degree=10 ** 6) == (True, 1)
+    routes.patch(monkeypatch, "fbasis_tile", "0")
+    assert _native.fbasis_tile_ok(**am, max_degree=25)[0] is False
+    routes.patch(monkeypatch, "fbasis_tile", None)
+    routes.patch(monkeypatch, "deterministic", "1")
+    assert _native.fbasis_tile_ok(**am, max_degree=25)[0] is False
+    routes.patch(monkeypatch, "deterministic", None)
+    assert _native.fbasis_tile_ok(R=2000, B=64, d=16, n_nodes=10 ** 6, max_degree=5)[0] is False      # R x B doubles beyond the LDS
+    assert _native.fbasis_tile_ok(R=13, B=5, d=10, n_nodes=8, max_degree=5)[0] is False               # fewer nodes than a tile
