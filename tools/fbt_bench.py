@@ -55,12 +55,18 @@ res = {"mode": mode, "max_degree": plan.max_src_degree,
 L = _native.lib()
 if hasattr(L, "rgcn_fbt_debug_read"):
     import ctypes
-    buf = (ctypes.c_ulonglong * 6)()
+    buf = (ctypes.c_ulonglong * 8)()
     L.rgcn_fbt_debug_read(buf, 1)
     _native.fbasis_tile_fwd(bases, comps, bias, plan, mode=0)
     L.rgcn_fbt_debug_read(buf, 1)
     w = max(buf[5], 1)
     res["fwd_us_per_wave"] = {k: round(buf[i] / w / 100.0, 1) for i, k in enumerate(("arrive+store+flush", "issue", "messages", "barrier", "rotate"))}
+    if mode == 1:
+        _native.fbasis_tile_bwd(bases, comps, g, plan, True, False, mode=1)
+        L.rgcn_fbt_debug_read(buf, 1)
+        w = max(buf[6], 1)
+        res["dbases_cycles_per_wave_and_tile"] = {k: round(buf[i] / w / (plan.n_nodes / 16 / 512), 0) for i, k in
+                                                  enumerate(("issue", "message loops", "barrier 1", "write-out", "barrier 2", "rotate"))}
 _native.profile_start()
 _native.fbasis_tile_fwd(bases, comps, bias, plan, mode=mode)
 prof = _native.profile_stop()

@@ -86,11 +86,11 @@ __device__ __forceinline__ int node_of(int rp, int lane, int p) {
 template <int KLD>
 struct Geo { long long goff[KLD]; int loff[KLD], pos[KLD]; bool act[KLD]; };
 template <int KLD>
-__device__ __forceinline__ void geo_init(Geo<KLD> &g, int tid, int B, int d, long long N, int ts, int tn = TN) {
+__device__ __forceinline__ void geo_init(Geo<KLD> &g, int tid, int B, int d, long long N, int ts, int tn = TN, int nthreads = TW) {
   const int q4 = tn * d / 4;                                // pieces per basis (tn nodes per tile)
 #pragma unroll
   for (int k = 0; k < KLD; ++k) {
-    const int idx = tid + k * TW;
+    const int idx = tid + k * nthreads;
     g.act[k] = idx < B * q4;                                 // (an inactive piece aliases piece 0: its loads stay unconditional)
     const int b = g.act[k] ? idx / q4 : 0, q = g.act[k] ? idx - b * q4 : 0;
     g.goff[k] = (long long)b * N * d + 4 * q;
@@ -326,11 +326,11 @@ __device__ __forceinline__ void gather_rows(float (&gp)[GQ], const float *__rest
       gp[q] = G[(size_t)s * d + c];
     }
 }
-template <int GS>
-__device__ __forceinline__ void strip_store(float *gs, const float (&gp)[GQ], int n, int lane) {
+template <int GS, int NQ>
+__device__ __forceinline__ void strip_store(float *gs, const float (&gp)[NQ], int n, int lane) {
   const int m = lane >> 4, c = lane & 15;
 #pragma unroll
-  for (int q = 0; q < GQ; ++q)
+  for (int q = 0; q < NQ; ++q)
     if (4 * q < n && c < GS) gs[(4 * q + m) * GS + c] = gp[q];          // (rows n .. 4 ceil(n / 4) hold duplicates of row n - 1)
 }
 
@@ -610,10 +610,11 @@ __device__ __forceinline__ NodeRange node_range(int rp, int wave, bool valid) {
   return r;
 }
 // rows of up to 16 messages starting at entry `off` of the wave's 64 prefetched indices -> packed registers (see gather_rows)
-__device__ __forceinline__ void gather_rows_at(float (&gp)[GQ], const float *__restrict__ G, int es, int off, int n, int d, int lane) {
+template <int NQ>
+__device__ __forceinline__ void gather_rows_at(float (&gp)[NQ], const float *__restrict__ G, int es, int off, int n, int d, int lane) {
   const int m = lane >> 4, c = min(lane & 15, d - 1);
 #pragma unroll
-  for (int q = 0; q < GQ; ++q)
+  for (int q = 0; q < NQ; ++q)
     if (4 * q < n) {
       const int s = __shfl(es, off + min(4 * q + m, n - 1), 64);
       gp[q] = G[(size_t)s * d + c];
@@ -622,10 +623,11 @@ __device__ __forceinline__ void gather_rows_at(float (&gp)[GQ], const float *__r
 
 // the first rows of the wave's run, ALWAYS four loads (a run shorter than 16 re-reads its last row, an empty one entry 0 of the indices):
 // a fixed number of loads per iteration lets the compiler count them (s_waitcnt vmcnt(n)) instead of draining everything
-__device__ __forceinline__ void gather_rows_all(float (&gp)[GQ], const float *__restrict__ G, int es, int n, int d, int lane) {
+template <int NQ>
+__device__ __forceinline__ void gather_rows_all(float (&gp)[NQ], const float *__restrict__ G, int es, int n, int d, int lane) {
   const int m = lane >> 4, c = min(lane & 15, d - 1);
 #pragma unroll
-  for (int q = 0; q < GQ; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     const int s = __shfl(es, min(4 * q + m, max(n - 1, 0)), 64);
     gp[q] = G[(size_t)s * d + c];
   }
@@ -852,22 +854,26 @@ __global__ __launch_bounds__(TW) void fbn_dcomps_kernel(
 
 // NPW nodes per wave (tiles of 16 NPW nodes): with 32-node tiles the per-tile costs (write-out, issue, barrier, the wait for the loads) are paid
 // half as often and a tile's message loops are as long as the memory latency they have to cover
-template <int NKD, int KLD, bool VEC, int NPW>
-__global__ __launch_bounds__(TW) void fbn_dbases_kernel(
+// NW waves per workgroup: 16 (one workgroup per CU, the tile gradient double-buffered) or 8 (512 threads, ONE tile buffer, 75 KB of LDS: two
+// workgroups per CU -- one's stores and loads fly under the other's message loops; a single workgroup's waves are all in the same phase)
+template <int NKD, int KLD, bool VEC, int NPW, int NW>
+__global__ __launch_bounds__(64 * NW) void fbn_dbases_kernel(
     const float *__restrict__ comps, const float *__restrict__ G, float *__restrict__ dbases, const int *__restrict__ rowptr,
     const int *__restrict__ e_dst, const int *__restrict__ e_rel, const float *__restrict__ e_val, int n_tiles, int N, int R, int B,
     int d, int ts, int last, int abl) {
-  constexpr int GS = 4 * NKD, NBTM = 4, TNV = TN * NPW;
+  constexpr int GS = 4 * NKD, NBTM = 4, TNV = NW * NPW, NTH = 64 * NW;
+  constexpr bool TWO = NW == 16;                           // two tile buffers
+  constexpr int SR = 16 * NPW, NQ = SR / 4;                // rows of the wave's strip = gradient rows gathered ahead: the wave's nodes send ~8 NPW messages
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k = lane >> 4, c = lane & 15;
   const int nbt = (B + 15) >> 4;
-  float *dt = lds;                                          // 2 x [B][ts] floats: every entry is stored by the wave that owns its node
-  float *gs = lds + 2 * B * ts + wave * (PERB * GS);
-  float *ctab = lds + 2 * B * ts + TWV * PERB * GS;         // [R][B]
-  for (int j = tid; j < R * B; j += TW) ctab[j] = comps[j];
+  float *dt = lds;                                          // (2 x) [B][ts] floats: every entry is stored by the wave that owns its node
+  float *gs = lds + (TWO ? 2 : 1) * B * ts + wave * (SR * GS);
+  float *ctab = lds + (TWO ? 2 : 1) * B * ts + NW * SR * GS;        // [R][B]
+  for (int j = tid; j < R * B; j += NTH) ctab[j] = comps[j];
   Geo<KLD> g;
-  geo_init(g, tid, B, d, N, ts, TNV);
+  geo_init(g, tid, B, d, N, ts, TNV, NTH);
   const int Gd = gridDim.x;
   int t = blockIdx.x;
   // tile tt = nodes first_of(tt) .. + TNV; the LAST tile is nodes N - TNV .. N whatever N: where it overlaps the tile before, both workgroups
@@ -887,9 +893,9 @@ __global__ __launch_bounds__(TW) void fbn_dbases_kernel(
   Idx x = idx_load(e_dst, e_rel, e_val, s.a, last, lane);
   NodeRange s1 = range_of(rp1, t + Gd < n_tiles);
   Idx x1 = idx_load(e_dst, e_rel, e_val, s1.a, last, lane);
-  float gp1[GQ] = {};
-  gather_rows_at(gp1, G, x.es, 0, min(16, s.n), d, lane);
-  strip_store<GS>(gs, gp1, min(16, s.n), lane);
+  float gp1[NQ] = {};
+  gather_rows_at(gp1, G, x.es, 0, min(SR, s.n), d, lane);
+  strip_store<GS>(gs, gp1, min(SR, s.n), lane);
   // the tile whose gradient waits in the other buffer.  Before the first tile: the workgroup's own first tile -- whatever the LDS holds goes out
   // and is overwritten one iteration later by the same threads: every iteration then issues the same number of stores, which lets the
   // compiler wait for the iteration's LOADS with an exact count and leave the stores in flight
@@ -906,25 +912,28 @@ __global__ __launch_bounds__(TW) void fbn_dbases_kernel(
         else { o[0] = kept[k2][0]; o[1] = kept[k2][1]; o[2] = kept[k2][2]; o[3] = kept[k2][3]; }
       }
   };
+  FBT_DBG(long long dbg[6] = {0, 0, 0, 0, 0, 0};)
   lds_barrier();
   for (int it = 0;; ++it) {
     const bool has1 = t + Gd < n_tiles, has2 = t + 2 * Gd < n_tiles;
-    float *dtc = dt + (it & 1) * (B * ts);
+    float *dtc = dt + (TWO ? (it & 1) * (B * ts) : 0);
+    FBT_DBG(const long long T0 = FBT_T();)
     const int rp3 = rp_of(t + 3 * Gd);
     const NodeRange s2 = range_of(rp2, has2);
     const Idx x2 = idx_load(e_dst, e_rel, e_val, s2.a, last, lane);
-    if (!FBT_ABL(4)) gather_rows_all(gp1, G, x1.es, min(16, s1.n), d, lane);
+    if (!FBT_ABL(4)) gather_rows_all(gp1, G, x1.es, min(SR, s1.n), d, lane);
     __builtin_amdgcn_sched_barrier(0);
     // the stores of the tile before go out AFTER this iteration's loads (the wait for those loads at the bottom -- vmcnt counts in order -- then
     // leaves the stores a whole iteration to drain) and in NPW shares, one ahead of each node's message loops: 51 KB per tile and CU take
     // ~3 us to leave the CU, and a store blocks at issue once the write queue is full
     __builtin_amdgcn_sched_barrier(0);
+    FBT_DBG(const long long T1 = FBT_T();)
     // ---- nodes wave * NPW .. of tile t: the wave owns their B x d gradients (zero for a node without messages)
     Idx c_x = x;
-    int cb0 = 0, sb0 = 0;                                   // windows over the wave's messages: 64 indices from cb0, 16 strip rows from sb0
+    int cb0 = 0, sb0 = 0;                                   // windows over the wave's messages: 64 indices from cb0, SR strip rows from sb0
     for (int i2 = 0; i2 < NPW; ++i2) {
       const int nl = wave * NPW + i2;                       // (every tile has all its TNV nodes)
-      write_out(dt + ((it + 1) & 1) * (B * ts), i2);
+      if (TWO) write_out(dt + ((it + 1) & 1) * (B * ts), i2);
       __builtin_amdgcn_sched_barrier(0);
       const int off0 = rlane(rp, wave * NPW + i2) - s.a, off1 = rlane(rp, wave * NPW + i2 + 1) - s.a;
       f32x4 acc[NBTM];
@@ -937,10 +946,10 @@ __global__ __launch_bounds__(TW) void fbn_dbases_kernel(
           c_x = idx_load(e_dst, e_rel, e_val, s.a + cb0, last, lane);
           FBT_ARRIVED(c_x.es); FBT_ARRIVED(c_x.er); FBT_ARRIVED(c_x.ev);
         }
-        if (g0 + n16 > sb0 + 16) {                          // past the 16 prefetched rows
+        if (g0 + n16 > sb0 + SR) {                          // past the prefetched rows
           sb0 = g0;
-          const int nrow = min(16, min(s.n, cb0 + 64) - g0);  // a whole window (the next node's group may start inside it)
-          float gq[GQ] = {};
+          const int nrow = min(SR, min(s.n, cb0 + 64) - g0);  // a whole window (the next node's group may start inside it)
+          float gq[NQ] = {};
           gather_rows_at(gq, G, c_x.es, g0 - cb0, nrow, d, lane);
           strip_store<GS>(gs, gq, nrow, lane);
         }
@@ -966,17 +975,30 @@ __global__ __launch_bounds__(TW) void fbn_dbases_kernel(
       }
     }
     t_out = t;
+    if (TWO) {
 #pragma unroll
-    for (int k2 = 0; k2 < KLD; ++k2) FBT_KEEP(kept[k2]);
+      for (int k2 = 0; k2 < KLD; ++k2) FBT_KEEP(kept[k2]);
+    }
+    FBT_DBG(const long long T2 = FBT_T();)
     lds_barrier();
-    if (!has1) {
+    FBT_DBG(const long long T3 = FBT_T(); dbg[0] += T1 - T0; dbg[1] += T2 - T1; dbg[2] += T3 - T2;)
+    if (!TWO) {                                             // one buffer: out it goes, and nobody sums the next tile into it before everybody has read it
+      write_out(dtc, -1);
+      FBT_DBG(const long long T4 = FBT_T();)
+      lds_barrier();
+      FBT_DBG(dbg[3] += T4 - T3; dbg[4] += FBT_T() - T4;)
+      if (!has1) break;
+    } else if (!has1) {
       write_out(dtc, -1);
       break;
     }
     t += Gd;
+    FBT_DBG(const long long T5 = FBT_T();)
     rp = rp1; rp1 = rp2; rp2 = rp3; s = s1; s1 = s2; x = x1; x1 = x2;
-    strip_store<GS>(gs, gp1, min(16, s.n), lane);
+    strip_store<GS>(gs, gp1, min(SR, s.n), lane);
+    FBT_DBG(dbg[5] += FBT_T() - T5;)
   }
+  FBT_DBG(if (lane == 0) { unsigned long long *o = rgcn_fbt_dbg + 8 * ((blockIdx.x & 255) * 16 + wave); for (int q = 0; q < 6; ++q) o[q] += dbg[q]; o[6] += 1; })
 }
 
 inline int pow2_at_least(int v, int lo) {
@@ -984,7 +1006,7 @@ inline int pow2_at_least(int v, int lo) {
   while (p < v) p <<= 1;
   return p;
 }
-struct TileShape { int dp, nreg, bp, kld, ts_f, ts_b, dpb, nks, kld2; size_t lds_fwd, lds_dc, lds_db, lds_fwd_n, lds_db_n, lds_db_n2; };
+struct TileShape { int dp, nreg, bp, kld, ts_f, ts_b, dpb, nks, kld2, kld8; size_t lds_fwd, lds_dc, lds_db, lds_fwd_n, lds_db_n, lds_db_n2, lds_db_n8; };
 inline bool tile_shape(int R, int B, int d, long long N, TileShape &s) {
   if (R <= 0 || B < 1 || B > 64 || d < 1 || d > 16 || N < TN) return false;
   s.dp = pow2_at_least(d, 4);
@@ -1006,9 +1028,13 @@ inline bool tile_shape(int R, int B, int d, long long N, TileShape &s) {
   s.lds_fwd_n = ((size_t)((R * 4 * s.nks + 3) & ~3) + 2 * (size_t)B * s.ts_f + (size_t)TWV * 16 * 16) * 4;
   s.lds_db_n = 2 * (size_t)B * s.ts_f * 4 + strips + (size_t)R * B * 4;
   // dbases with 32-node tiles (two nodes per wave): row stride 32 d + 4, B x 8 d pieces
-  s.lds_db_n2 = 2 * (size_t)B * (2 * TN * d + 4) * 4 + strips + (size_t)R * B * 4;
+  s.lds_db_n2 = 2 * (size_t)B * (2 * TN * d + 4) * 4 + 2 * strips + (size_t)R * B * 4;       // (strips of 32 rows)
   s.kld2 = 2 * pieces <= 2 * TW ? 2 : 4;
   if (2 * pieces > 4 * TW || N < 2 * TN) s.lds_db_n2 = (size_t)LDS_MAX + 1;
+  // dbases in 512-thread workgroups, two per CU: 16-node tiles, two nodes per wave, one tile buffer
+  s.lds_db_n8 = (size_t)B * s.ts_f * 4 + strips + (size_t)R * B * 4;                        // (8 waves, strips of 32 rows)
+  s.kld8 = pieces <= 2 * 512 ? 2 : 4;
+  if (pieces > 4 * 512) s.lds_db_n8 = (size_t)LDS_MAX + 1;
   return true;
 }
 int n_cus() {
@@ -1030,13 +1056,13 @@ hipError_t raise_lds(K kernel, size_t bytes) {
 #ifdef RGCN_ABLATIONS
 /* ablation library only: 100 MHz ticks summed over the waves of all forward tile launches since the last reset:
  * {arrival + tile store + Y flush, issue of the next loads, message loops, barrier, rotation, waves} */
-extern "C" __attribute__((visibility("default"))) int rgcn_fbt_debug_read(unsigned long long *out6, int reset) {
+extern "C" __attribute__((visibility("default"))) int rgcn_fbt_debug_read(unsigned long long *out8, int reset) {
   static unsigned long long h[8 * 256 * 16];
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(rgcn_fbt_dbg), sizeof(h)));
-  for (int i = 0; i < 6; ++i) out6[i] = 0;
+  for (int i = 0; i < 8; ++i) out8[i] = 0;
   for (int w = 0; w < 256 * 16; ++w)
-    for (int i = 0; i < 6; ++i) out6[i] += h[8 * w + i];
+    for (int i = 0; i < 8; ++i) out8[i] += h[8 * w + i];
   if (reset) { memset(h, 0, sizeof(h)); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rgcn_fbt_dbg), h, sizeof(h))); }
   return RGCN_OK;
 }
@@ -1161,19 +1187,22 @@ extern "C" int rgcn_fbasis_tile_bwd_f32(const float *bases, const float *comps, 
   { if (s.dpb == 4) FBN_BWD2(KERNEL, LDSB, 1, __VA_ARGS__) else if (s.dpb == 8) FBN_BWD2(KERNEL, LDSB, 2, __VA_ARGS__)        \
     else if (s.dpb == 12) FBN_BWD2(KERNEL, LDSB, 3, __VA_ARGS__) else FBN_BWD2(KERNEL, LDSB, 4, __VA_ARGS__) }
     if (dbases) {
-      const bool two = s.lds_db_n2 <= (size_t)LDS_MAX;      // 32-node tiles when they fit the LDS
+      // form: two 512-thread workgroups per CU (16-node tiles, one buffer) when two of them fit the LDS; else 32-node tiles, one workgroup
+      // per CU; else 16-node tiles.  (Ablation build: bwd_abl bit 64 skips the first form, bit 128 the second too.)
+      const bool pair = 2 * s.lds_db_n8 <= (size_t)LDS_MAX && !(abl & 64);
+      const bool two = !pair && s.lds_db_n2 <= (size_t)LDS_MAX && !(abl & 128);
       const int tiles_db = two ? (int)((n_nodes + 2 * TN - 1) / (2 * TN)) : n_tiles;
       const int ts_db = two ? 2 * TN * d + 4 : s.ts_f;
-      const size_t lds_db = two ? s.lds_db_n2 : s.lds_db_n;
-      const int kld_db = two ? s.kld2 : s.kld;
-      const dim3 grid_db((unsigned)std::min<int64_t>(tiles_db, n_cus()));
-#define FBN_DB3(NK_, KL_, VE_, NP_)                                                                                               \
+      const size_t lds_db = pair ? s.lds_db_n8 : (two ? s.lds_db_n2 : s.lds_db_n);
+      const int kld_db = pair ? s.kld8 : (two ? s.kld2 : s.kld);
+      const dim3 grid_db((unsigned)std::min<int64_t>(tiles_db, (int64_t)n_cus() * (pair ? 2 : 1)));
+#define FBN_DB3(NK_, KL_, VE_, NP_, NW_)                                                                                          \
   {                                                                                                                               \
-    HIP_TRY(raise_lds(fbn_dbases_kernel<NK_, KL_, VE_, NP_>, lds_db));                                                             \
-    hipLaunchKernelGGL((fbn_dbases_kernel<NK_, KL_, VE_, NP_>), grid_db, dim3(TW), lds_db, st, comps, G, dbases, rowptr, e_dst, e_rel, e_val, \
-                       tiles_db, (int)n_nodes, R, B, d, ts_db, last, abl);                                                         \
+    HIP_TRY(raise_lds(fbn_dbases_kernel<NK_, KL_, VE_, NP_, NW_>, lds_db));                                                        \
+    hipLaunchKernelGGL((fbn_dbases_kernel<NK_, KL_, VE_, NP_, NW_>), grid_db, dim3(64 * NW_), lds_db, st, comps, G, dbases, rowptr, e_dst, e_rel, \
+                       e_val, tiles_db, (int)n_nodes, R, B, d, ts_db, last, abl);                                                  \
   }
-#define FBN_DB2(NK_, KL_, VE_) { if (two) FBN_DB3(NK_, KL_, VE_, 2) else FBN_DB3(NK_, KL_, VE_, 1) }
+#define FBN_DB2(NK_, KL_, VE_) { if (pair) FBN_DB3(NK_, KL_, VE_, 2, 8) else if (two) FBN_DB3(NK_, KL_, VE_, 2, 16) else FBN_DB3(NK_, KL_, VE_, 1, 16) }
 #define FBN_DB1(NK_, KL_) { if (vec) FBN_DB2(NK_, KL_, true) else FBN_DB2(NK_, KL_, false) }
 #define FBN_DB0(NK_) { if (kld_db == 2) FBN_DB1(NK_, 2) else FBN_DB1(NK_, 4) }
       if (s.dpb == 4) FBN_DB0(1) else if (s.dpb == 8) FBN_DB0(2) else if (s.dpb == 12) FBN_DB0(3) else FBN_DB0(4)
