@@ -42,6 +42,31 @@ def test_classify_nodes_hipgraph_replay_matches_eager():
         assert abs(hist[mode][0][0] - hist[False][0][0]) < 1e-4 * abs(hist[False][0][0]), "epoch 1 starts from the same state"
 
 
+@pytest.mark.parametrize("tile_mode", ["nodes", "ranges"])
+def test_classify_nodes_capture_with_the_in_place_tile_kernels(monkeypatch, tile_mode):
+    """the same with the featureless basis layer on the in-place tile kernels (rgcn_fbasis_tile.hip: the route of tables beyond the caches --
+    AM as shipped --, forced here on the MUTAG-shaped model), both forms: the captured step replays them (LDS above 64 KB, persistent
+    workgroups, the plan's largest source degree read before the capture) and follows the eager trajectory"""
+    sys.path.insert(0, os.path.join(PKG, "experiments"))
+    import classify_nodes
+    import torch
+    from torch_rgcn import _native, routes
+    routes.patch(monkeypatch, "fbasis_inplace_mb", "0")
+    routes.patch(monkeypatch, "fbasis_tile", tile_mode)
+    hist = {}
+    for mode in (False, None):
+        torch.manual_seed(0)
+        if mode is False:                       # (the per-kernel timers record events: not inside a capture)
+            _native.profile_start()
+        hist[mode] = classify_nodes.run(cfg("nc-MUTAG.yaml"), epochs=6, quiet=True, hipgraph=mode, synthetic=True)
+        if mode is False:
+            prof = _native.profile_stop()
+            assert "fbasis_tile_fwd" in prof and "fbasis_tile_bwd" in prof, sorted(prof)
+    assert hist[None][-1][0] < hist[None][0][0]
+    for k in range(6):
+        assert abs(hist[None][k][0] - hist[False][k][0]) < 2e-2 * abs(hist[False][k][0]), (k, hist[None][k][0], hist[False][k][0])
+
+
 def test_experiments_default_to_the_captured_step(monkeypatch):
     """the default run of both experiments replays a captured hipGraph (route capture=0 / --eager: the reference's loop)"""
     sys.path.insert(0, os.path.join(PKG, "experiments"))

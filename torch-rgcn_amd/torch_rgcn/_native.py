@@ -129,7 +129,8 @@ class _Timed:
 
 
 def _timed(name):
-    return _NOCTX if _PROF is None else _Timed(name)
+    # (no events inside a stream capture: recording them there is an error -- a captured step is timed as a whole, by its replay)
+    return _NOCTX if (_PROF is None or torch.cuda.is_current_stream_capturing()) else _Timed(name)
 
 
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
