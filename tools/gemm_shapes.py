@@ -28,7 +28,10 @@ def timed(fn, iters=20, warm=5):
 
 for tag, M, N, K, ta, tb in (("X @ W", 14545, 500, 500, False, False), ("g @ W^T", 14545, 500, 500, False, True),
                              ("X^T @ g", 500, 500, 14545, True, False), ("X @ W (WN18 N)", 40943, 200, 200, False, False),
-                             ("X^T @ g (WN18 N)", 200, 200, 40943, True, False), ("square 4096", 4096, 4096, 4096, False, False)):
+                             ("X^T @ g (WN18 N)", 200, 200, 40943, True, False), ("square 4096", 4096, 4096, 4096, False, False),
+                             # the WN18 step's three products: ag @ flat(bases), g @ flat^T, ag^T @ g
+                             ("WN18 ag @ flat", 40943, 200, 400, False, False), ("WN18 g @ flat^T", 40943, 400, 200, False, True),
+                             ("WN18 ag^T @ g", 400, 200, 40943, True, False)):
     A = torch.randn((K, M) if ta else (M, K), device=dev)
     B = torch.randn((N, K) if tb else (K, N), device=dev)
     sk = _split_k(K, M, N) if ta else 1
