@@ -162,8 +162,14 @@ def test_mutag_full_shape_node_classifier_matches_oracle_composition():
     for n, gv in l2["grads"].items():
         assert rel_err(getattr(model.rgc2, n).grad, gv) < TOL, n
     assert rel_err(model.rgc2.bias.grad, l2["db"]) < TOL
+    # the ReLU's mask as the GPU saw it: a pre-activation within rounding of 0 may come out on the other side there (this seed has ONE such
+    # entry, -2.98e-8 against +2.98e-8 with the tile kernels' summation order) -- then the two gradients legitimately differ by that row
+    with torch.no_grad():
+        mask = model.rgc1.forward_activated(None, "relu").cpu().numpy() > 0
+    flipped = mask != (l1["out"] > 0)
+    assert flipped.sum() <= 3 and (np.abs(l1["out"][flipped]) < 1e-6).all(), (int(flipped.sum()), l1["out"][flipped])
     l1b = oracle.nc_layer(tp, N, R, None, {"bases": P["rgc1.bases"], "comps": P["rgc1.comps"]}, "basis", P["rgc1.bias"], False,
-                          (l2["dX"] * (l1["out"] > 0)).astype(np.float32))
+                          (l2["dX"] * mask).astype(np.float32))
     for n, gv in l1b["grads"].items():
         assert rel_err(getattr(model.rgc1, n).grad, gv) < TOL, n
 

@@ -646,9 +646,11 @@ class _FeaturelessBasisMP(torch.autograd.Function):
         # gradient back): a node's B rows are ONE contiguous run -- what a table far beyond the caches needs (AM as shipped: 2.7 GB,
         # rows of 40 bytes: reading them in place, 40 half-used lines per node, cost 33.5 ms per step against 24).  Basis-major
         # [B, N, d] = the parameter itself, no copies: wins while the table stays cache-resident (MUTAG: 45 MB, step 0.56 -> 0.51 ms).
-        ctx.in_place = ctx.src_major and B * N * d * 4 <= int(routes.get("fbasis_inplace_mb", "256")) << 20
+        ctx.in_place = ctx.src_major and B * N * d * 4 <= int(routes.get("fbasis_inplace_mb", "32")) << 20      # (round 4: 256 -> 32 MB, see below)
         # Round 4: tables beyond the caches are walked in place too, by the tile kernels (rgcn_fbasis_tile.hip: 16 source nodes per tile,
-        # staged through LDS with aligned 16-byte accesses, software-pipelined) -- no transposed copy, no transposed gradient.
+        # staged through LDS with aligned 16-byte accesses, software-pipelined) -- no transposed copy, no transposed gradient.  They also
+        # beat the wave-per-node kernels on a cache-resident table of MUTAG's size (45 MB: forward 42 -> 40 us, backward 65 -> 49 us), hence
+        # the 32 MB threshold.
         tiled, ctx.tile_mode = _native.fbasis_tile_ok(comps.shape[0], B, d, N, graph.fbasis_plan().max_src_degree) \
             if (ctx.src_major and not ctx.in_place) else (False, 0)
         ctx.tile_bwd = tiled
