@@ -241,8 +241,9 @@ def line_node_classifier(tag, N, R0, E, nhid, ncls, decomp, labelled, baseline_c
     # featureless first layer: one weight-table row (basis: the node's B x d block) per message + index, one output row per node
     row = (B or 1) * nhid * 4
     fwd = M * (row + 8) + N * nhid * 4
-    alg = {"featureless_fwd": fwd, "fbasis_fwd": fwd, "featureless_wgrad": M * (nhid * 4 + 8) + (2 * R0 + 1) * N * nhid * 4,
-           "fbasis_bwd": M * (nhid * 4 + 8) + 2 * N * row}.get(name, fwd)
+    bwd_basis = M * (nhid * 4 + 8) + 2 * N * row
+    alg = {"featureless_fwd": fwd, "fbasis_fwd": fwd, "fbasis_tile_fwd": fwd, "featureless_wgrad": M * (nhid * 4 + 8) + (2 * R0 + 1) * N * nhid * 4,
+           "fbasis_bwd": bwd_basis, "fbasis_tile_bwd": bwd_basis}.get(name, fwd)
     return {"baseline_config": baseline_config, "workload": tag, "N": N, "R0": R0, "E": E, "params": sum(p.numel() for p in model.parameters()),
             "step": "NodeClassifier forward + cross-entropy + backward + Adam",
             # the experiments replay the captured step by default (experiments/classify_nodes.py); the eager loop's time is the host's
