@@ -1,6 +1,7 @@
 // Random gather of 64-byte rows (S1's X / G gather: 21 M rows out of a 64 MB table): does any load flavour make the L2 ask the fabric for
 // 64 bytes instead of a whole 128-byte line?  Variants: 0 plain global_load_dwordx4, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc0, 5 sc1 nt, 6 sc0 sc1 nt.
 // Prints ms per pass; run under rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum for the request sizes.
+// build: hipcc -O2 --offload-arch=gfx950 -o tools/micro/gather64.bin tools/micro/gather64.hip   (run on the GPU box: gpurun -- tools/micro/gather64.bin)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,4 +1,5 @@
 // what v_permlane32_swap / v_permlane16_swap do on gfx950 (x = lane, y = 100 + lane): prints both results per lane
+// build: hipcc -O2 --offload-arch=gfx950 -o tools/micro/permlane_swap.bin tools/micro/permlane_swap.hip   (run on the GPU box: gpurun -- tools/micro/permlane_swap.bin)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 __global__ void k(unsigned *o) {

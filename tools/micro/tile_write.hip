@@ -1,5 +1,6 @@
 // How fast can a [B][N][d] table (AM as shipped: 40 x 1,666,764 x 10 floats = 2.67 GB) be WRITTEN tile by tile -- TN consecutive nodes per
 // tile = B runs of TN d floats at a stride of N d floats, 16 bytes per thread -- and read the same way?  The floor of the tile kernels' stores / loads.
+// build: hipcc -O2 --offload-arch=gfx950 -o tools/micro/tile_write.bin tools/micro/tile_write.hip   (run on the GPU box: gpurun -- tools/micro/tile_write.bin)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
