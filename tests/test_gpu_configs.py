@@ -179,3 +179,16 @@ def test_more_than_2_31_relation_node_cells_vs_oracle():
     tables, 64-bit cell indices; also past the 24-bit source id of the packed slots -> unpacked slot arrays): one featured
     layer, forward and backward, against the oracle"""
     run_layer_vs_oracle(N=27_000_000, R0=40, E=3_000_000, d_in=16, d_out=16, mode="none", seed=77)
+
+
+@pytest.mark.parametrize("tile_mode", ["1", "ranges"])
+def test_am_as_shipped_tenth_scale_first_layer_vs_oracle(monkeypatch, tile_mode):
+    """AM as the reference ships it (nc-AM.yaml: featureless first layer, basis 40, hidden 10) at 1/10 scale -- 166,676 nodes, 267
+    relations, a 267 MB table: the in-place tile kernels (one wave per node on the matrix cores by default on this hub-free graph;
+    `ranges`: a tile's messages dealt over the waves), ~650 tiles per workgroup pipeline, against the oracle: output and both gradients"""
+    from torch_rgcn import _native, routes
+    routes.patch(monkeypatch, "fbasis_tile", tile_mode)
+    _native.profile_start()
+    run_layer_vs_oracle(N=AM["N"] // 10, R0=AM["R0"], E=AM["E"] // 10, d_in=None, d_out=10, mode="basis", featureless=True, num_bases=40, seed=410)
+    prof = _native.profile_stop()
+    assert "fbasis_tile_fwd" in prof and "fbasis_tile_bwd" in prof, sorted(prof)
