@@ -20,9 +20,12 @@ ap.add_argument("--e", type=int, default=5_988_321)
 ap.add_argument("--bases", type=int, default=40)
 ap.add_argument("--d", type=int, default=10)
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--hub", type=int, default=0, help="make node 7 the object of the first HUB triples (a hub source of the layer)")
 a = ap.parse_args()
 dev = torch.device("cuda")
 T = torch.from_numpy(np.asarray(_native.synthetic_triples_host(a.n, a.r0, a.e, 1)))
+if a.hub:
+    T[: a.hub, 2] = 7
 from torch_rgcn.utils import add_inverse_and_self  # noqa: E402
 tp = add_inverse_and_self(T, a.n, a.r0)
 layer = RelationalGraphConvolutionNC(triples=tp, num_nodes=a.n, num_relations=2 * a.r0 + 1, in_features=None, out_features=a.d,
