@@ -159,7 +159,7 @@ def make_step(l1, l2, X):
     def step():
         for p in (X, l1.weights, l1.bias, l2.weights, l2.bias):
             p.grad = None
-        out = l2(l1.forward_activated(X, "relu"))
+        out = l2(l1.forward_activated(X, "relu", private=True))
         loss = _MeanSquare.apply(out)
         loss.backward()
         return loss
@@ -270,6 +270,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-s1", action="store_true", help="CPU baseline at 1/10 scale only")
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary lines for BASELINE configs 1-4")
+    ap.add_argument("--check-unsharded", action="store_true", help="N > 1, strong mode: rank 0 also runs the step on the whole graph and the line "
+                    "reports the largest relative difference of loss / dX / dW (tests; not part of the timed region)")
     ap.add_argument("--sustained-steps", type=int, default=400,
                     help="N = 1: untimed-for-the-headline extra leg after the K timed steps (clocks / thermals over ~1 s); 0: skip")
     args = ap.parse_args()
@@ -383,6 +385,25 @@ def main():
     elapsed = t.item()
     ms = 1e3 * elapsed / args.steps
 
+    shard_check = None
+    if group is not None and args.check_unsharded and mode == "strong":
+        # sharded == unsharded on the very step that was timed: dX is complete on every rank after the join, the weight rows live on
+        # their owners (disjoint: their sum over ranks is the whole gradient); rank 0 repeats the step on the whole graph
+        loss_s = step().detach().clone()
+        got = [X.grad.detach().clone(), l1.weights.grad.detach().clone(), l2.weights.grad.detach().clone()]
+        for gr in got[1:]:
+            dist.all_reduce(gr)
+        if rank == 0:
+            u1, u2, _ = build_layers(N, R0, E, d, seed=0, device=device, group=None, keep="all")
+            Xu = X.detach().clone().requires_grad_(True)
+            loss_u = make_step(u1, u2, Xu)().detach()
+            ref = [Xu.grad, u1.weights.grad, u2.weights.grad]
+            errs = {n: float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) for n, a, b in zip(("dX", "dW1", "dW2"), got, ref)}
+            errs["loss"] = float((loss_s - loss_u).abs() / loss_u.abs().clamp_min(1e-30))
+            shard_check = {"max_rel_err": max(errs.values()), **{k: float(f"{v:.3e}") for k, v in errs.items()}}
+            del u1, u2, Xu
+        fence()
+
     if group is not None:
         # what the collectives cost: (a) the step without them (RGCN_DIST_COMM=none: same kernels, wrong numbers),
         # (b) the four N x d collectives of one step on their own
@@ -414,6 +435,10 @@ def main():
                      "exposed_ms_per_step": round(ms - compute_ms, 4),
                      "allreduce_algbw_GBs": round(4 * bytes_per_coll / (comm_ms * 1e-3) / 1e9, 1) if comm_ms > 0 else None,
                      "messages_per_rank": [int(c) for c in counts.tolist()],
+                     # what the backend itself saw (the driver's SCALE record can be checked for "RCCL ran with N ranks")
+                     "world_size_seen_by_backend": dist.get_world_size(group), "backend": str(dist.get_backend(group)),
+                     "backend_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else f"gloo (torch {torch.__version__})"),
+                     "overlap": "side-stream" if chosen[1] > 0 else "none",
                      "model": "per step 4 x all-reduce of N x d fp32 (2 forward outputs, 2 feature gradients); a ring moves "
                               "2(G-1)/G x 64 MB over each rank's slowest link, a direct reduce-scatter + all-gather "
                               "2(G-1)/G x 64 MB spread over G-1 links (DESIGN.md section 6)"})
@@ -523,6 +548,8 @@ def main():
                "roofline": roof}
         if comm is not None:
             res["comm"] = comm
+        if shard_check is not None:
+            res["sharded_vs_unsharded"] = shard_check
         if world == 1 and group is None and not args.no_configs:
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))

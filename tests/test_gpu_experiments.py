@@ -146,3 +146,50 @@ def test_predict_links_training_step_as_hipgraph_learns():
     hist, metrics = predict_links.run(c, epochs=40, quiet=True, max_test=50, synthetic=True, hipgraph=True)
     assert len(hist) == 40 and all(np.isfinite(hist)) and np.mean(hist[-5:]) < np.mean(hist[:5])
     assert 0.0 < metrics["mrr"] <= 1.0
+
+
+def _replay_safe_in_a_fresh_process(prelude, env_value):
+    """REPLAY_SAFE as a fresh interpreter sees it: `prelude` runs before `import torch_rgcn`; env_value: the variable at exec time (None: unset)"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    if env_value is not None:
+        env["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = env_value
+    code = f"import sys; sys.path.insert(0, {PKG!r}); import torch\n{prelude}\nimport torch_rgcn; print('SAFE', torch_rgcn.REPLAY_SAFE)"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1500:]
+    return out.stdout.strip().splitlines()[-1] == "SAFE True"
+
+
+def test_replay_safe_is_not_inferred_from_a_variable_set_too_late():
+    """captured steps are the default only when the runtime's graph packet capture is REALLY off.  The runtime reads
+    DEBUG_CLR_GRAPH_PACKET_CAPTURE once, when it starts -- torch.cuda.is_available() / device_count() start it without setting torch's
+    lazy-init flag, and a setdefault after that does nothing: REPLAY_SAFE must then be False (the experiments fall back to the eager loop)
+    unless the variable was 0 in the environment the process started with."""
+    assert _replay_safe_in_a_fresh_process("", None) is True                                   # import first: the module switches it off in time
+    assert _replay_safe_in_a_fresh_process("torch.cuda.is_available()", None) is False         # runtime already up: too late
+    assert _replay_safe_in_a_fresh_process("torch.zeros(1, device='cuda')", None) is False
+    assert _replay_safe_in_a_fresh_process("torch.cuda.is_available()", "0") is True           # off from the start: safe whenever we look
+    assert _replay_safe_in_a_fresh_process("", "1") is False                                   # the user asked for the feature
+    late = "torch.cuda.is_available(); import os; os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')"
+    assert _replay_safe_in_a_fresh_process(late, None) is False                                # somebody else's setdefault after the start
+
+
+def test_classify_nodes_eager_fallback_starts_from_the_initial_state(monkeypatch):
+    """when the capture fails the eager loop must start epoch 1 from the initial parameters and a fresh optimiser, not after
+    the warm-up's three steps: same first-epoch loss and trajectory as hipgraph=False"""
+    sys.path.insert(0, os.path.join(PKG, "experiments"))
+    import classify_nodes
+    import torch
+    torch.manual_seed(0)
+    ref = classify_nodes.run(cfg("nc-MUTAG.yaml"), epochs=4, quiet=True, hipgraph=False, synthetic=True)
+
+    class Broken:
+        def __init__(self, *a, **k):
+            raise RuntimeError("capture is broken in this test")
+    monkeypatch.setattr(torch.cuda, "CUDAGraph", Broken)
+    torch.manual_seed(0)
+    with pytest.warns(UserWarning, match="capture of the training step failed"):
+        got = classify_nodes.run(cfg("nc-MUTAG.yaml"), epochs=4, quiet=True, hipgraph=None, synthetic=True)
+    assert abs(got[0][0] - ref[0][0]) < 1e-4 * abs(ref[0][0]), (got[0][0], ref[0][0])
+    for k in range(4):
+        assert abs(got[k][0] - ref[k][0]) < 2e-2 * abs(ref[k][0])

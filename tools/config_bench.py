@@ -19,9 +19,12 @@ from torch_rgcn.layers import DistMult, RelationalGraphConvolutionLP, Relational
 from torch_rgcn.models import NodeClassifier  # noqa: E402
 
 DEV = torch.device("cuda:0")
+QUICK = False      # --quick: few iterations (profiling runs under rocprofv3: tools/prof.sh lines)
 
 
 def timed(fn, iters=10, warm=3):
+    if QUICK:
+        iters, warm = min(iters, 3), 1
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -279,7 +282,7 @@ def line_featured(tag, N, R0, E, d, decomposition, seed, baseline_config):
     def step():
         for p in [X] + list(l1.parameters()) + list(l2.parameters()):
             p.grad = None
-        _MeanSquare.apply(l2(l1.forward_activated(X, "relu"))).backward()
+        _MeanSquare.apply(l2(l1.forward_activated(X, "relu", private=True))).backward()
     ms = timed(step, iters=10, warm=3)
     name, kms, per_step, allk = _dominant(step)
     M = 2 * E + N
@@ -405,7 +408,7 @@ def line_s2(baseline_config):
     def step():
         for p in list(l1.parameters()) + list(l2.parameters()):
             p.grad = None
-        _MeanSquare.apply(l2(l1.forward_activated(None, "relu"))).backward()
+        _MeanSquare.apply(l2(l1.forward_activated(None, "relu", private=True))).backward()
     ms = timed(step, iters=10, warm=3)
     name, kms, per_step, allk = _dominant(step)
     counts = _launch_counts(step)
@@ -504,7 +507,9 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     ap.add_argument("--lines", default="", help="bench.py's secondary lines by name: s2,amshipped,s1ii,s1iii (JSON, one per line)")
+    ap.add_argument("--quick", action="store_true", help="few iterations per measurement (profiling runs)")
     a = ap.parse_args()
+    QUICK = a.quick
     if a.lines:
         for nm in a.lines.split(","):
             fn = {"s2": lambda: line_s2("S2"), "amshipped": lambda: line_am_shipped("AM shipped"),

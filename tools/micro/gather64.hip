@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void gather_kernel(const float *__restrict__ X
 }
 
 int main(int argc, char **argv) {
-  const long long N = 1000000, M = 21000000;
+  // gather64.bin [variant | -1] [N rows of the table] [M rows gathered]: S1's shape by default; AM's is 1666764 13643406
+  const long long N = argc > 2 ? atoll(argv[2]) : 1000000, M = argc > 3 ? atoll(argv[3]) : 21000000;
   const int only = argc > 1 ? atoi(argv[1]) : -1;
   std::vector<int> h(M);
   unsigned long long s = 88172645463325252ull;
@@ -60,7 +61,7 @@ int main(int argc, char **argv) {
     for (int w = 0; w < 5; ++w) hipLaunchKernelGGL(gather_kernel<V>, dim3(4096), dim3(256), 0, 0, X, idx, out, M); \
     hipEventRecord(b); hipEventSynchronize(b);                                                          \
     float ms; hipEventElapsedTime(&ms, a, b);                                                           \
-    printf("variant %d (%s): %.3f ms per pass of 21 M rows\n", V, names[V], ms / 5);                    \
+    printf("variant %d (%s): %.3f ms per pass of %.1f M rows out of %.2f M (%.0f MB)\n", V, names[V], ms / 5, M / 1e6, N / 1e6, N * 64 / 1e6);                    \
   }
   RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6)
   return 0;

@@ -26,7 +26,7 @@ if which == "am":
     def step():
         for p in [X] + list(l1.parameters()) + list(l2.parameters()):
             p.grad = None
-        l2(l1.forward_activated(X, "relu")).pow(2).mean().backward()
+        l2(l1.forward_activated(X, "relu", private=True)).pow(2).mean().backward()
 else:
     N, R0, E, nhid, ncls, decomp, lab = {"aifb": (8285, 45, 29_043, 16, 4, None, 140),
                                          "mutag": (23_644, 23, 74_227, 16, 2, {"type": "basis", "num_bases": 30}, 272)}[which]

@@ -45,23 +45,27 @@ def _capture(fn, warmup=3, model=None, optimiser=None):
     (model / optimiser given) the warm-up runs are real optimiser steps: parameters and optimiser state are put back afterwards, in
     place (the captured graph holds their addresses) -- a captured run starts epoch 1 from the same state as the eager one."""
     saved = [p.detach().clone() for p in model.parameters()] if model is not None else None
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(warmup):
-            fn()
-    torch.cuda.current_stream().wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        out = fn()
-    if saved is not None:
-        with torch.no_grad():
-            for p, q in zip(model.parameters(), saved):
-                p.copy_(q)
-            for st in optimiser.state.values():              # Adam state after zero steps: all zeros (step counter included)
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        v.zero_()
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = fn()
+    finally:
+        # also when the capture FAILS (ADVICE r4): the eager fallback must start epoch 1 from the initial state, not after the warm-up's steps
+        if saved is not None:
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                for p, q in zip(model.parameters(), saved):
+                    p.copy_(q)
+                for st in optimiser.state.values():              # Adam state after zero steps: all zeros (step counter included)
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
     return graph, out
 
 
@@ -151,6 +155,10 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, hipgraph=None, synthetic=N
             warnings.warn(f"hipGraph capture of the training step failed ({type(exc).__name__}: {exc}); running the eager loop")
             torch.cuda.synchronize()
             hipgraph = False
+            # a fresh optimiser without capturable=True (its device-side step counters are the captured step's business); parameters
+            # were put back by _capture
+            optimiser = OPTIMISERS[opt_cfg["algorithm"]](model.parameters(), lr=opt_cfg["learn_rate"], weight_decay=opt_cfg["weight_decay"],
+                                                          **({"fused": True} if adam_like else {}))
 
     history = []
     for epoch in range(1, epochs + 1):

@@ -11,7 +11,40 @@ import torch as _torch
 # switched off here -- before this process makes its first HIP call -- unless the user has set the variable himself.  Cost: replays of
 # the small configs get ~10 % slower (AIFB 0.40 -> 0.45 ms), eager execution is not affected.
 _VAR = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
-if not _torch.cuda.is_initialized():
+
+
+def _exec_environment():
+    """the environment this process was STARTED with (what the runtime sees whenever it initialises)"""
+    try:
+        with open("/proc/self/environ", "rb") as f:
+            return dict(kv.split(b"=", 1) for kv in f.read().split(b"\0") if b"=" in kv)
+    except OSError:
+        return None
+
+
+def _hip_runtime_started():
+    """has this process initialised the HIP runtime already (after which the variable is no longer read)?  torch's own lazy-init flag is
+    not the answer: torch.cuda.is_available() / device_count() start the runtime without setting it.  The runtime opens
+    /dev/kfd when it initialises and never before, so an open descriptor on it is the evidence; unknown (no /proc) counts as started."""
+    if _torch.cuda.is_initialized():
+        return True
+    try:
+        for fd in _os.listdir("/proc/self/fd"):
+            try:
+                if _os.readlink("/proc/self/fd/" + fd) == "/dev/kfd":
+                    return True
+            except OSError:
+                continue
+        return False
+    except OSError:
+        return True
+
+
+_at_exec = (_exec_environment() or {}).get(_VAR.encode())
+_started = _hip_runtime_started()
+if not _started:
     _os.environ.setdefault(_VAR, "0")
-REPLAY_SAFE = _os.environ.get(_VAR) == "0"
-"""True when captured steps may be replayed in this process (experiments capture by default only then)"""
+REPLAY_SAFE = _at_exec == b"0" or (not _started and _os.environ.get(_VAR) == "0")
+"""True when captured steps may be replayed in this process (experiments capture by default only then): the variable was "0" in the
+environment the process started with, or it is "0" now and the HIP runtime had not started when this module looked (so the runtime
+will read it).  A "0" that somebody put into os.environ AFTER the runtime started does not count."""

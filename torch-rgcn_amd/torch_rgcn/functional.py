@@ -135,11 +135,18 @@ class _ReluToken:
     (aten.threshold_backward) only when the gradient it receives is that very tensor object, unmodified (same Python object
     through a weak reference, same version counter).  Anything else -- H had other consumers and autograd summed their
     gradients (a new tensor, or an in-place add that bumps the version), a hook replaced the tensor, the consumer took
-    another route -- falls back to masking, which is idempotent on the pre-masked part: always exact."""
-    __slots__ = ("ref", "version", "consumer_input")
+    another route -- falls back to masking, which is idempotent on the pre-masked part: always exact.
 
-    def __init__(self):
-        self.ref, self.version, self.consumer_input = None, -1, None
+    OPT-IN (round 5).  What the consumer hands autograd for H is then dL/d(pre-activation), not dL/dH -- they differ exactly where
+    H == 0 -- and `torch.autograd.grad(loss, H)` (or a grad_fn pre-hook) reads that value without leaving any trace the backward could
+    see.  So the consumer pre-masks only when the PRODUCER was told that H is private: `layer.forward_activated(x, "relu",
+    private=True)` = "H goes into layers of this library and nobody asks autograd for its gradient" (models.py, whose hidden
+    activation never leaves forward(), and bench.py do).  A bare `l2(l1.forward_activated(x, "relu"))` -- like the reference's
+    `F.relu(self.rgc1(...))` -- returns the exact dL/dH; the producer masks in its own backward (one elementwise launch)."""
+    __slots__ = ("ref", "version", "consumer_input", "private")
+
+    def __init__(self, private=False):
+        self.ref, self.version, self.consumer_input, self.private = None, -1, None, bool(private)
 
     def observed(self):
         """someone can SEE the gradient that arrives at H -- H.retain_grad() or a tensor hook on H: then it has to be dL/dH, not the
@@ -194,7 +201,8 @@ class _RelationalMP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, W, bias, graph, relu=False, blocks=None, in_token=None):
         ctx.in_token = in_token                      # X = relu(...) of a layer that fused the activation (see _ReluToken)
-        ctx.out_token = _ReluToken() if relu else None
+        ctx.out_token = _ReluToken(private=relu == "private") if relu else None
+        relu = bool(relu)
         X, W, bias, ctx.dims = _pad_blocks(X, W, bias, graph)
         X = dense(X)
         W = dense(W)
@@ -262,7 +270,7 @@ class _RelationalMP(torch.autograd.Function):
         blk_sparse = sparse and routes.get("bwd", "fused") != "split" and \
             _native.bwd_blk_rows(graph.num_nodes, graph.num_rels, deterministic(), graph.device, ctx.diag4, True) > 0
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and (not sparse or blk_sparse):
-            both = _fused_backward(X, W, g, graph, relu_in=ctx.in_token is not None and (ctx.dims is None or ctx.dims[0] % 16 == 0) and not ctx.in_token.observed(),
+            both = _fused_backward(X, W, g, graph, relu_in=ctx.in_token is not None and ctx.in_token.private and (ctx.dims is None or ctx.dims[0] % 16 == 0) and not ctx.in_token.observed(),
                                    want_db=ctx.has_bias and ctx.needs_input_grad[2], diag4=ctx.diag4, sparse=sparse)
             if both is not None:
                 both, masked, db = both[:2], both[2], both[3]
@@ -415,7 +423,7 @@ def _relu_epilogue(ctx, res, relu):
     """res: what a native forward returned for relu=True -- (out, applied in the kernel's epilogue) -- or the plain output; finishes the
     activation where the kernel could not, and keeps what the backward needs (see _ReluToken)"""
     ctx.relu = bool(relu)
-    ctx.out_token = _ReluToken() if relu else None
+    ctx.out_token = _ReluToken(private=relu == "private") if relu else None
     if not relu:
         return res
     out, applied = res if isinstance(res, tuple) else (res, False)
@@ -436,7 +444,7 @@ class _FeaturelessMP(torch.autograd.Function):
         b = None if bias is None else dense(bias)
         ctx.csr = _featureless_csr(graph, table.shape[2])
         if ctx.csr:
-            out = _relu_epilogue(ctx, _native.featureless_csr_fwd(table, b, graph.csr("fwd"), relu=relu), relu)
+            out = _relu_epilogue(ctx, _native.featureless_csr_fwd(table, b, graph.csr("fwd"), relu=bool(relu)), relu)
         else:
             out = _relu_epilogue(ctx, _native.featureless_fwd(table, b, graph.fwd_plan(table.shape[2])), relu)
         if relu:
@@ -646,31 +654,33 @@ class _FeaturelessBasisMP(torch.autograd.Function):
         # gradient back): a node's B rows are ONE contiguous run -- what a table far beyond the caches needs (AM as shipped: 2.7 GB,
         # rows of 40 bytes: reading them in place, 40 half-used lines per node, cost 33.5 ms per step against 24).  Basis-major
         # [B, N, d] = the parameter itself, no copies: wins while the table stays cache-resident (MUTAG: 45 MB, step 0.56 -> 0.51 ms).
-        ctx.in_place = ctx.src_major and B * N * d * 4 <= int(routes.get("fbasis_inplace_mb", "32")) << 20      # (round 4: 256 -> 32 MB, see below)
         # Round 4: tables beyond the caches are walked in place too, by the tile kernels (rgcn_fbasis_tile.hip: 16 source nodes per tile,
         # staged through LDS with aligned 16-byte accesses, software-pipelined) -- no transposed copy, no transposed gradient.  They also
         # beat the wave-per-node kernels on a cache-resident table of MUTAG's size (45 MB: forward 42 -> 40 us, backward 65 -> 49 us), hence
-        # the 32 MB threshold.
-        tiled, ctx.tile_mode = _native.fbasis_tile_ok(comps.shape[0], B, d, N, graph.fbasis_plan().max_src_degree) \
-            if (ctx.src_major and not ctx.in_place) else (False, 0)
+        # the 32 MB threshold -- which only holds where the tile kernels can take over: a shape or mode they refuse (deterministic mode,
+        # B > 64 ...) keeps round 3's 256 MB before it pays for the transposed copy.
+        tile_ok, tile_mode = _native.fbasis_tile_ok(comps.shape[0], B, d, N, graph.fbasis_plan().max_src_degree) if ctx.src_major else (False, 0)
+        limit_mb = int(routes.get("fbasis_inplace_mb")) if routes.is_set("fbasis_inplace_mb") else (32 if tile_ok else 256)
+        ctx.in_place = ctx.src_major and B * N * d * 4 <= limit_mb << 20
+        tiled, ctx.tile_mode = (tile_ok, tile_mode) if (ctx.src_major and not ctx.in_place) else (False, 0)
         ctx.tile_bwd = tiled
         if tiled:
             comps, bases = dense(comps), dense(bases)
             ctx.graph, ctx.has_bias = graph, bias is not None
             ctx.in_place = True
             ctx.to_save = (bases, comps)
-            return _relu_epilogue(ctx, _native.fbasis_tile_fwd(bases, comps, bias, graph.fbasis_plan(), relu=relu, mode=ctx.tile_mode), relu)
+            return _relu_epilogue(ctx, _native.fbasis_tile_fwd(bases, comps, bias, graph.fbasis_plan(), relu=bool(relu), mode=ctx.tile_mode), relu)
         if ctx.src_major and ctx.in_place:
             comps, bases = dense(comps), dense(bases)
             ctx.graph, ctx.has_bias = graph, bias is not None
             ctx.to_save = (bases, comps)
-            return _relu_epilogue(ctx, _native.fbasis_fwd(bases, comps, bias, graph.fbasis_plan(), basis_major=True, relu=relu), relu)
+            return _relu_epilogue(ctx, _native.fbasis_fwd(bases, comps, bias, graph.fbasis_plan(), basis_major=True, relu=bool(relu)), relu)
         table = bases.permute(1, 0, 2).contiguous()                   # [N, B, d]: one contiguous block per source node
         if ctx.src_major:   # every node's B x d block is read once
             comps = dense(comps)
             ctx.graph, ctx.has_bias = graph, bias is not None
             ctx.to_save = (table, comps)
-            return _relu_epilogue(ctx, _native.fbasis_fwd(table, comps, bias, graph.fbasis_plan(), relu=relu), relu)
+            return _relu_epilogue(ctx, _native.fbasis_fwd(table, comps, bias, graph.fbasis_plan(), relu=bool(relu)), relu)
         comps = dense(comps)
         out = _native.basis_aggregate(table.view(N, B * d), comps, graph.csr("fwd"), B, d, B)
         if bias is not None:
@@ -730,7 +740,9 @@ def use_basis_path(num_bases, d_in, d_out, graph):
 
 def relational_mp(features, weights, bias, graph, relu=False, blocks=None):
     """features [N, d_in], weights [R, d_in, d_out] (dense), bias [d_out] or None -> [N, d_out]; relu=True applies the
-    activation in the kernel's epilogue (the backward masks the upstream gradient with the stored output); blocks: the
+    activation in the kernel's epilogue (the backward masks the upstream gradient with the stored output), relu="private" also lets
+    the layer that consumes the output mask on this layer's behalf (see _ReluToken: the caller promises that nobody asks autograd for
+    the output's gradient); blocks: the
     [R, nb, bi, bo] parameter when weights = block_diag(blocks) (a hint: lets the forward skip the zero entries)"""
     # features = the output of a layer that applied ReLU in its kernel's epilogue: its backward node carries the token
     in_token = getattr(getattr(features, "grad_fn", None), "out_token", None)
@@ -835,6 +847,9 @@ class MaskedCrossEntropy(torch.nn.Module):
         super().__init__()
         idx, labels = idx.reshape(-1).long(), labels.reshape(-1).long()
         assert idx.numel() == labels.numel() and idx.numel() > 0 and torch.unique(idx).numel() == idx.numel(), "labelled nodes: one label each"
+        # (one read-back at construction) the kernel indexes a row of logits with the label: checked against the class count in forward,
+        # as ATen's CrossEntropyLoss device-asserts
+        self._label_range = (int(labels.min().item()), int(labels.max().item()))
         row_label = torch.full((num_nodes,), -1, dtype=torch.int32, device=idx.device)
         row_label[idx] = labels.to(torch.int32)
         self.register_buffer("row_label", row_label, persistent=False)
@@ -843,4 +858,7 @@ class MaskedCrossEntropy(torch.nn.Module):
     def forward(self, logits):
         assert logits.dim() == 2 and logits.shape[0] == self.row_label.shape[0]
         assert int(logits.shape[1]) <= 64, "at most 64 classes"
+        lo, hi = self._label_range
+        if lo < 0 or hi >= int(logits.shape[1]):
+            raise IndexError(f"MaskedCrossEntropy: labels span {lo} .. {hi} but the logits have {int(logits.shape[1])} classes")
         return _MaskedCE.apply(logits, self.row_label, self.lab_rows)

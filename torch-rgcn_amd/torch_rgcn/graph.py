@@ -77,7 +77,11 @@ class RelGraph:
 
     # -- plans are built lazily and cached per tile height
     def _plan(self, kind, tile_rows, max_item_chunks=64):
-        key = (kind, tile_rows, max_item_chunks)
+        # RGCN_DETERMINISTIC=1: no hub pieces (a tile cut into several work units merges its pieces with fp32 atomics, in
+        # arrival order): a hub tile is one long unit for one wave -- slow on skewed graphs, bit-reproducible.  Part of the cache
+        # key: switching the route after a first forward must not reuse plans of the other kind.
+        whole = routes.get("deterministic", "0") == "1"
+        key = (kind, tile_rows, max_item_chunks, whole)
         if key not in self._plans and self._dev is not None:
             N, R = self.num_nodes, self.num_rels
             s, p, o, val, alive = self._dev
@@ -86,9 +90,6 @@ class RelGraph:
             # graphs that live for one step (upper-bound sizes: at most 16 slots per message; one work unit per tile, no hub
             # splitting -- a sampled graph's hub is a few thousand messages).  Static (NC) graphs keep the exact path.
             nosync = self.sync_free or getattr(self, "per_call", False)
-            # RGCN_DETERMINISTIC=1: no hub pieces (a tile cut into several work units merges its pieces with fp32 atomics, in
-            # arrival order): a hub tile is one long unit for one wave -- slow on skewed graphs, bit-reproducible
-            whole = routes.get("deterministic", "0") == "1"
             self._plans[key] = _native.build_plan_device(dst, src, p, val, alive, N, N, R, tile_rows, self.num_messages,
                                                          max_item_chunks, want_runs=True, want_pack=True, sync_free=nosync,
                                                          **({"max_unit_chunks": 1 << 30} if whole else {}))
@@ -96,10 +97,10 @@ class RelGraph:
             N, R = self.num_nodes, self.num_rels
             if kind == "fwd":
                 hp = _native.build_plan_host(self._s, self._o, self._p, self._val, N, N, R, tile_rows, max_item_chunks,
-                                             want_runs=True, want_pack=True)
+                                             want_runs=True, want_pack=True, **({"max_unit_chunks": 1 << 30} if whole else {}))
             elif kind == "bwd":
                 hp = _native.build_plan_host(self._o, self._s, self._p, self._val, N, N, R, tile_rows, max_item_chunks,
-                                             want_runs=True, want_pack=True)
+                                             want_runs=True, want_pack=True, **({"max_unit_chunks": 1 << 30} if whole else {}))
             else:
                 raise KeyError(kind)
             self._plans[key] = _native.DevicePlan(hp, self.device)

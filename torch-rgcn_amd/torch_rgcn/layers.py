@@ -205,22 +205,30 @@ class RelationalGraphConvolutionNC(_RGCBase):
         return self._graph
 
     def forward(self, features=None):
-        return self._forward_impl(features, self.__dict__.pop("_fused_activation", None))
+        return self._forward_impl(features, self.__dict__.pop("_fused_activation", None), self.__dict__.pop("_fused_private", False))
 
-    def forward_activated(self, features=None, activation=None):
+    def forward_activated(self, features=None, activation=None, private=False):
         """forward() plus the activation the models apply right after this layer (reference models.py:194,235,290
         `F.relu(self.rgc1(...))`), run in the kernel's epilogue.  activation: None or "relu".  A separate method so that
         forward() keeps the reference's exact signature; it goes through nn.Module.__call__ (forward / pre-forward hooks
         registered on the layer fire exactly as for `F.relu(self.rgc1(...))`), the activation rides along as a transient
-        attribute."""
+        attribute.
+
+        private=True is a promise by the caller: the returned activation H is only fed to layers of this library and nobody asks
+        autograd for ITS gradient (no torch.autograd.grad(loss, H), no grad_fn pre-hook; retain_grad() and tensor hooks are seen and
+        honoured).  The consuming layer's backward kernel may then apply the ReLU's mask in its own epilogue and hand autograd
+        dL/d(pre-activation) in the place of dL/dH -- one elementwise launch less per step (functional._ReluToken).  Without the
+        promise (the default, and what `F.relu(layer(x))` gives) every gradient autograd can show is exact."""
         assert activation in (None, "relu"), f"unknown activation {activation!r}"
         self._fused_activation = activation
+        self._fused_private = bool(private)
         try:
             return self(features=features)
         finally:
             self.__dict__.pop("_fused_activation", None)
+            self.__dict__.pop("_fused_private", None)
 
-    def _forward_impl(self, features, activation):
+    def _forward_impl(self, features, activation, private=False):
         assert (features is None) == (self.in_features is None), "in_features not provided!"
         assert activation in (None, "relu"), f"unknown activation {activation!r}"
         any_param = self.weights if (self.diag_weight_matrix or self.weight_decomp is None) else \
@@ -266,7 +274,7 @@ class RelationalGraphConvolutionNC(_RGCBase):
                 raise RuntimeError("featureless message passing needs horizontal stacking "
                                    f"(mat1 and mat2 shapes cannot be multiplied: {R * N}x{N} and {R * N}x{out_dim})")
             # the models' F.relu(self.rgc1()) (reference models.py:194) in the kernel's epilogue; the consumer layer's backward masks
-            fuse_act = activation == "relu" and getattr(self, "_shard_group", None) is None
+            fuse_act = activation == "relu" and getattr(self, "_shard_group", None) is None and ("private" if private else True)
             if fl_basis:
                 local = lambda _x, b: F_.featureless_basis_mp(self.bases, self.comps, b, graph, relu=fuse_act)
             else:
@@ -280,13 +288,13 @@ class RelationalGraphConvolutionNC(_RGCBase):
                 local = lambda x, b: F_.diag_mp(x, self.weights, b, graph)
             elif block_path:
                 fuse_act = activation == "relu" and getattr(self, "_shard_group", None) is None
-                local = lambda x, b: F_.block_mp(x, self.blocks, b, graph, relu=fuse_act)
+                local = lambda x, b: F_.block_mp(x, self.blocks, b, graph, relu=bool(fuse_act))
                 if fuse_act:
                     activation = None
             elif self.weight_decomp == 'basis' and not self.diag_weight_matrix and weights is None:
                 local = lambda x, b: F_.basis_mp(x, self.bases, self.comps, b, graph)
             else:
-                fuse_act = activation == "relu" and getattr(self, "_shard_group", None) is None
+                fuse_act = activation == "relu" and getattr(self, "_shard_group", None) is None and ("private" if private else True)
                 hint = self.blocks if (self.weight_decomp == 'block' and not self.diag_weight_matrix) else None
                 local = lambda x, b: F_.relational_mp(x, weights, b, graph, relu=fuse_act, blocks=hint)
                 if fuse_act:

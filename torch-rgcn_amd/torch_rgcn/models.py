@@ -41,7 +41,7 @@ class NodeClassifier(nn.Module):
 
     def forward(self):
         if self.nlayers == 2:      # ReLU in the first layer's epilogue where its kernel has one (reference: F.relu(self.rgc1()))
-            return self.rgc2(features=self.rgc1.forward_activated(None, "relu"))
+            return self.rgc2(features=self.rgc1.forward_activated(None, "relu", private=True))
         return self.rgc1()
 
 
@@ -61,7 +61,7 @@ class EmbeddingNodeClassifier(NodeClassifier):
         nn.init.kaiming_normal_(self.node_embeddings, mode='fan_in')
 
     def forward(self):
-        return self.rgc1(features=self.rgcn_no_hidden.forward_activated(self.node_embeddings, "relu"))
+        return self.rgc1(features=self.rgcn_no_hidden.forward_activated(self.node_embeddings, "relu", private=True))
 
 
 def _init_embedding(tensor, name, gain=1.0):
