@@ -54,7 +54,10 @@ mode = int(os.environ.get("FBT_MODE", "1"))
 res = {"mode": mode, "max_degree": plan.max_src_degree,
        "fwd+gather": timed(lambda: _native.fbasis_tile_fwd(bases, comps, bias, plan, mode=mode)),
        "dbases": timed(lambda: _native.fbasis_tile_bwd(bases, comps, g, plan, True, False, mode=mode)),
-       "dcomps": timed(lambda: _native.fbasis_tile_bwd(bases, comps, g, plan, False, True, mode=mode))}
+       "dcomps": timed(lambda: _native.fbasis_tile_bwd(bases, comps, g, plan, False, True, mode=mode)),
+       # both gradients: ONE walk in mode 1 when its LDS image fits (round 5: fbn_bwd_kernel), the two kernels in mode 3
+       "bwd_both": timed(lambda: _native.fbasis_tile_bwd(bases, comps, g, plan, True, True, mode=mode)),
+       "fused_strip_rows": int(_native.lib().rgcn_fbasis_tile_bwd_fused_gn(2 * a.r0 + 1, a.bases, a.d, a.n))}
 L = _native.lib()
 if hasattr(L, "rgcn_fbt_debug_read"):
     import ctypes
@@ -70,6 +73,15 @@ if hasattr(L, "rgcn_fbt_debug_read"):
         w = max(buf[6], 1)
         res["dbases_cycles_per_wave_and_tile"] = {k: round(buf[i] / w / (plan.n_nodes / 16 / 512), 0) for i, k in
                                                   enumerate(("issue", "message loops", "barrier 1", "write-out", "barrier 2", "rotate"))}
+if hasattr(L, "rgcn_fbt_debug_read") and mode == 1 and res["fused_strip_rows"]:
+    import ctypes
+    buf = (ctypes.c_ulonglong * 8)()
+    L.rgcn_fbt_debug_read(buf, 1)
+    _native.fbasis_tile_bwd(bases, comps, g, plan, True, True, mode=1)
+    L.rgcn_fbt_debug_read(buf, 1)
+    w = max(buf[6], 1)          # (s_memtime ticks at 100 MHz)
+    res["bwd_fused_us_per_wave_and_tile"] = {k: round(buf[i] / w / 100.0, 3) for i, k in
+                                             enumerate(("issue", "messages", "wait for the loads", "barrier 1", "hand-over", "barrier 2"))}
 _native.profile_start()
 _native.fbasis_tile_fwd(bases, comps, bias, plan, mode=mode)
 prof = _native.profile_stop()

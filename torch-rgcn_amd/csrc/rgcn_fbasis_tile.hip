@@ -317,13 +317,13 @@ __device__ __forceinline__ Idx idx_load(const int *__restrict__ e_dst, const int
   return x;
 }
 // lanes (m, c >= d) re-read column d - 1 and messages past n the wave's last one: finite duplicates that no sum ever uses
-__device__ __forceinline__ void gather_rows(float (&gp)[GQ], const float *__restrict__ G, int es, int n, int d, int lane) {
+__device__ __forceinline__ void gather_rows(float (&gp)[GQ], const float *__restrict__ G, int es, int n, int d, int lane, int gstride) {
   const int m = lane >> 4, c = min(lane & 15, d - 1);
 #pragma unroll
   for (int q = 0; q < GQ; ++q)
     if (4 * q < n) {                                       // wave-uniform
       const int s = __shfl(es, min(4 * q + m, n - 1), 64);
-      gp[q] = G[(size_t)s * d + c];
+      gp[q] = G[(size_t)s * gstride + c];
     }
 }
 template <int GS, int NQ>
@@ -339,7 +339,7 @@ template <int DPB, int KLD, bool VEC>
 __global__ __launch_bounds__(TW) void fbt_dcomps_kernel(
     const float *__restrict__ bases, const float *__restrict__ G, float *__restrict__ dC, const int *__restrict__ rowptr,
     const int *__restrict__ e_dst, const int *__restrict__ e_rel, const float *__restrict__ e_val, int n_tiles, int N, int R, int B,
-    int d, int ts, int last, int abl) {
+    int d, int ts, int last, int gstride, int abl) {
   constexpr int GS = DPB;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(TW) void fbt_dcomps_kernel(
   Share s1 = share_of<PERB>(rp1, wave, t + Gd < n_tiles);
   Idx x1 = idx_load(e_dst, e_rel, e_val, s1.a, last, lane);
   float gp1[GQ] = {};
-  gather_rows(gp1, G, x.es, s.n, d, lane);
+  gather_rows(gp1, G, x.es, s.n, d, lane, gstride);
   strip_store<GS>(gs, gp1, s.n, lane);
   stage_store<KLD, false>(tb, st, g);
   stage_load<KLD, VEC>(st, g, bases, base_of(t + Gd));
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(TW) void fbt_dcomps_kernel(
     const int rp3 = rp_of(t + 3 * Gd);
     const Share s2 = share_of<PERB>(rp2, wave, has2);
     const Idx x2 = idx_load(e_dst, e_rel, e_val, s2.a, last, lane);
-    if (!FBT_ABL(4)) gather_rows(gp1, G, x1.es, s1.n, d, lane);
+    if (!FBT_ABL(4)) gather_rows(gp1, G, x1.es, s1.n, d, lane, gstride);
     __builtin_amdgcn_sched_barrier(0);
     // ---- tile t
     const int shift = t * TN - min(t * TN, N - TN);
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(TW) void fbt_dcomps_kernel(
       c_n = max(0, min(s.per, min(c0 + TWV * s.per, s.me) - c_a));
       c_x = idx_load(e_dst, e_rel, e_val, c_a, last, lane);
       float gq[GQ] = {};
-      gather_rows(gq, G, c_x.es, c_n, d, lane);
+      gather_rows(gq, G, c_x.es, c_n, d, lane, gstride);
       FBT_ARRIVED(c_x.er); FBT_ARRIVED(c_x.ev);
       strip_store<GS>(gs, gq, c_n, lane);
     }
@@ -469,7 +469,7 @@ template <int DPB, int KLD, bool VEC>
 __global__ __launch_bounds__(TW) void fbt_dbases_kernel(
     const float *__restrict__ comps, const float *__restrict__ G, float *__restrict__ dbases, const int *__restrict__ rowptr,
     const int *__restrict__ e_dst, const int *__restrict__ e_rel, const float *__restrict__ e_val, int n_tiles, int N, int R, int B,
-    int d, int ts, int last, int abl) {
+    int d, int ts, int last, int gstride, int abl) {
   constexpr int GS = DPB, NT = 4;                           // NT 16-row tiles of bases (B <= 64)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(TW) void fbt_dbases_kernel(
   Share s1 = share_of<PERB>(rp1, wave, t + Gd < n_tiles);
   Idx x1 = idx_load(e_dst, e_rel, e_val, s1.a, last, lane);
   float gp1[GQ] = {};
-  gather_rows(gp1, G, x.es, s.n, d, lane);
+  gather_rows(gp1, G, x.es, s.n, d, lane, gstride);
   strip_store<GS>(gs, gp1, s.n, lane);
   int t_out = -1;                                           // the tile whose gradient waits in dt[(k - 1) & 1]
   auto write_out = [&](double *src) {
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(TW) void fbt_dbases_kernel(
     const int rp3 = rp_of(t + 3 * Gd);
     const Share s2 = share_of<PERB>(rp2, wave, has2);
     const Idx x2 = idx_load(e_dst, e_rel, e_val, s2.a, last, lane);
-    if (!FBT_ABL(4)) gather_rows(gp1, G, x1.es, s1.n, d, lane);
+    if (!FBT_ABL(4)) gather_rows(gp1, G, x1.es, s1.n, d, lane, gstride);
     __builtin_amdgcn_sched_barrier(0);
     // ---- tile t (never the overlapped part of the last tile: local node = tile-relative + shift)
     const int shift = t * TN - min(t * TN, N - TN);
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(TW) void fbt_dbases_kernel(
       c_n = max(0, min(s.per, min(c0 + TWV * s.per, s.me) - c_a));
       c_x = idx_load(e_dst, e_rel, e_val, c_a, last, lane);
       float gq[GQ] = {};
-      gather_rows(gq, G, c_x.es, c_n, d, lane);
+      gather_rows(gq, G, c_x.es, c_n, d, lane, gstride);
       FBT_ARRIVED(c_x.er); FBT_ARRIVED(c_x.ev);
       strip_store<GS>(gs, gq, c_n, lane);
     }
@@ -611,25 +611,25 @@ __device__ __forceinline__ NodeRange node_range(int rp, int wave, bool valid) {
 }
 // rows of up to 16 messages starting at entry `off` of the wave's 64 prefetched indices -> packed registers (see gather_rows)
 template <int NQ>
-__device__ __forceinline__ void gather_rows_at(float (&gp)[NQ], const float *__restrict__ G, int es, int off, int n, int d, int lane) {
+__device__ __forceinline__ void gather_rows_at(float (&gp)[NQ], const float *__restrict__ G, int es, int off, int n, int d, int lane, int gstride) {
   const int m = lane >> 4, c = min(lane & 15, d - 1);
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
     if (4 * q < n) {
       const int s = __shfl(es, off + min(4 * q + m, n - 1), 64);
-      gp[q] = G[(size_t)s * d + c];
+      gp[q] = G[(size_t)s * gstride + c];
     }
 }
 
 // the first rows of the wave's run, ALWAYS four loads (a run shorter than 16 re-reads its last row, an empty one entry 0 of the indices):
 // a fixed number of loads per iteration lets the compiler count them (s_waitcnt vmcnt(n)) instead of draining everything
 template <int NQ>
-__device__ __forceinline__ void gather_rows_all(float (&gp)[NQ], const float *__restrict__ G, int es, int n, int d, int lane) {
+__device__ __forceinline__ void gather_rows_all(float (&gp)[NQ], const float *__restrict__ G, int es, int n, int d, int lane, int gstride) {
   const int m = lane >> 4, c = min(lane & 15, d - 1);
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int s = __shfl(es, min(4 * q + m, max(n - 1, 0)), 64);
-    gp[q] = G[(size_t)s * d + c];
+    gp[q] = G[(size_t)s * gstride + c];
   }
 }
 
@@ -742,7 +742,7 @@ template <int NKD, int KLD, bool VEC>
 __global__ __launch_bounds__(TW) void fbn_dcomps_kernel(
     const float *__restrict__ bases, const float *__restrict__ G, float *__restrict__ dC, const int *__restrict__ rowptr,
     const int *__restrict__ e_dst, const int *__restrict__ e_rel, const float *__restrict__ e_val, int n_tiles, int N, int R, int B,
-    int d, int ts, int last, int abl) {
+    int d, int ts, int last, int gstride, int abl) {
   constexpr int GS = 4 * NKD, NBTM = 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(TW) void fbn_dcomps_kernel(
   NodeRange s1 = node_range(rp1, wave, t + Gd < n_tiles);
   Idx x1 = idx_load(e_dst, e_rel, e_val, s1.a, last, lane);
   float gp1[GQ] = {};
-  gather_rows_at(gp1, G, x.es, 0, min(16, s.n), d, lane);
+  gather_rows_at(gp1, G, x.es, 0, min(16, s.n), d, lane, gstride);
   strip_store<GS>(gs, gp1, min(16, s.n), lane);
   stage_store<KLD, false>(tb, st, g);
   stage_load<KLD, VEC>(st, g, bases, base_of(t + Gd));
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(TW) void fbn_dcomps_kernel(
     const int rp3 = rp_of(t + 3 * Gd);
     const NodeRange s2 = node_range(rp2, wave, has2);
     const Idx x2 = idx_load(e_dst, e_rel, e_val, s2.a, last, lane);
-    if (!FBT_ABL(4)) gather_rows_at(gp1, G, x1.es, 0, min(16, s1.n), d, lane);
+    if (!FBT_ABL(4)) gather_rows_at(gp1, G, x1.es, 0, min(16, s1.n), d, lane, gstride);
     __builtin_amdgcn_sched_barrier(0);
     // ---- node `wave` of tile t
     const int nl = wave + t * TN - min(t * TN, N - TN);
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(TW) void fbn_dcomps_kernel(
             FBT_ARRIVED(c_x.es); FBT_ARRIVED(c_x.er); FBT_ARRIVED(c_x.ev);
           }
           float gq[GQ] = {};
-          gather_rows_at(gq, G, c_x.es, g0 & 63, n16, d, lane);
+          gather_rows_at(gq, G, c_x.es, g0 & 63, n16, d, lane, gstride);
           strip_store<GS>(gs, gq, n16, lane);
         }
         float av[NKD];
@@ -860,7 +860,7 @@ template <int NKD, int KLD, bool VEC, int NPW, int NW>
 __global__ __launch_bounds__(64 * NW) void fbn_dbases_kernel(
     const float *__restrict__ comps, const float *__restrict__ G, float *__restrict__ dbases, const int *__restrict__ rowptr,
     const int *__restrict__ e_dst, const int *__restrict__ e_rel, const float *__restrict__ e_val, int n_tiles, int N, int R, int B,
-    int d, int ts, int last, int abl) {
+    int d, int ts, int last, int gstride, int abl) {
   constexpr int GS = 4 * NKD, NBTM = 4, TNV = NW * NPW, NTH = 64 * NW;
   constexpr bool TWO = NW == 16;                           // two tile buffers
   constexpr int SR = 16 * NPW, NQ = SR / 4;                // rows of the wave's strip = gradient rows gathered ahead: the wave's nodes send ~8 NPW messages
@@ -894,7 +894,7 @@ __global__ __launch_bounds__(64 * NW) void fbn_dbases_kernel(
   NodeRange s1 = range_of(rp1, t + Gd < n_tiles);
   Idx x1 = idx_load(e_dst, e_rel, e_val, s1.a, last, lane);
   float gp1[NQ] = {};
-  gather_rows_at(gp1, G, x.es, 0, min(SR, s.n), d, lane);
+  gather_rows_at(gp1, G, x.es, 0, min(SR, s.n), d, lane, gstride);
   strip_store<GS>(gs, gp1, min(SR, s.n), lane);
   // the tile whose gradient waits in the other buffer.  Before the first tile: the workgroup's own first tile -- whatever the LDS holds goes out
   // and is overwritten one iteration later by the same threads: every iteration then issues the same number of stores, which lets the
@@ -921,7 +921,7 @@ __global__ __launch_bounds__(64 * NW) void fbn_dbases_kernel(
     const int rp3 = rp_of(t + 3 * Gd);
     const NodeRange s2 = range_of(rp2, has2);
     const Idx x2 = idx_load(e_dst, e_rel, e_val, s2.a, last, lane);
-    if (!FBT_ABL(4)) gather_rows_all(gp1, G, x1.es, min(SR, s1.n), d, lane);
+    if (!FBT_ABL(4)) gather_rows_all(gp1, G, x1.es, min(SR, s1.n), d, lane, gstride);
     __builtin_amdgcn_sched_barrier(0);
     // the stores of the tile before go out AFTER this iteration's loads (the wait for those loads at the bottom -- vmcnt counts in order -- then
     // leaves the stores a whole iteration to drain) and in NPW shares, one ahead of each node's message loops: 51 KB per tile and CU take
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(64 * NW) void fbn_dbases_kernel(
           sb0 = g0;
           const int nrow = min(SR, min(s.n, cb0 + 64) - g0);  // a whole window (the next node's group may start inside it)
           float gq[NQ] = {};
-          gather_rows_at(gq, G, c_x.es, g0 - cb0, nrow, d, lane);
+          gather_rows_at(gq, G, c_x.es, g0 - cb0, nrow, d, lane, gstride);
           strip_store<GS>(gs, gq, nrow, lane);
         }
         for (int j0 = 0; j0 < n16; j0 += 4) {               // four messages per step: k = the message
@@ -1001,6 +1001,255 @@ __global__ __launch_bounds__(64 * NW) void fbn_dbases_kernel(
   FBT_DBG(if (lane == 0) { unsigned long long *o = rgcn_fbt_dbg + 8 * ((blockIdx.x & 255) * 16 + wave); for (int q = 0; q < 6; ++q) o[q] += dbg[q]; o[6] += 1; })
 }
 
+// ---- both gradients from ONE walk (round 5).  The two kernels above each stream a [B, N, d] array once (dcomps READS the table, dbases WRITES
+// its gradient) and each gathers the upstream rows of all messages: 5.3 + 4.9 GB of fabric traffic per backward on AM as shipped (PMC,
+// profiles/r05_*), both at ~4.1 TB/s -- at the rate of their access pattern, so the only thing left to remove was traffic.  Here wave w OWNS
+// node w of the tile for both sums, which makes the tile's LDS image private to the wave slot by slot: ONE buffer serves as the staged
+// table tile on the way in and as the gradient tile on the way out (the wave takes its node's block into registers -- the B operand of the
+// dcomps product -- and later lays the node's gradient over it), the rows of G are gathered once, the indices read once:
+//   dcomps  D[m][b] = sum_i G[s_m, i] bases[b, o, i]     -> val_m D[m][b] added to the workgroup's R x B doubles (ds_add_f64)
+//   dbases  D[b][i] = sum_m (val_m comps[r_m, b]) G[s_m, i]   four messages per MFMA step, accumulated in registers over the node's messages
+// LDS: R x B doubles + R x B floats (coefficients) + ONE tile (AM: 85.4 + 42.7 + 26.2 KB of 160; the two kernels otherwise).  No strips of
+// gradient rows: the wave transposes them through its own slot of the tile (B >= 16: sixteen runs of d floats).
+// Per iteration two LDS-only barriers: gradients complete -> [every thread: its pieces of the gradient out to HBM, the next tile's pieces (requested
+// one hand-over earlier: a whole iteration in flight) into the buffer, the tile after that requested] -> staged.
+// NK consecutive floats at any 4-byte alignment (gfx950 takes unaligned LDS accesses: the compiler may use one wide ds_read / ds_write)
+template <int NK>
+struct __attribute__((packed, aligned(4))) FK { float f[NK]; };
+struct __attribute__((packed, aligned(4))) F2U { float f[2]; };
+
+template <int NKD, int KLD, bool VEC, int NBTM>
+__global__ __launch_bounds__(TW) void fbn_bwd_kernel(
+    const float *__restrict__ bases, const float *__restrict__ comps, const float *__restrict__ G, float *__restrict__ dbases,
+    float *__restrict__ dC, const int *__restrict__ rowptr, const int *__restrict__ e_dst, const int *__restrict__ e_rel,
+    const float *__restrict__ e_val, int n_tiles, int N, int R, int B, int d, int ts, int last, int gstride, int gn, int abl) {
+  constexpr int GS = 4 * NKD;                               // NBTM = ceil(B / 16): the 16-row tiles of bases, a template parameter (registers)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k = lane >> 4, c = lane & 15;
+  constexpr int nbt = NBTM;
+  double *dcl = reinterpret_cast<double *>(lds);            // [R][B]
+  float *ctab = lds + ((2 * R * B + 3) & ~3);               // [R][B]
+  float *xt = ctab + ((R * B + 3) & ~3);                    // [B][ts]: the staged tile, then its gradient
+  for (int j = tid; j < R * B; j += TW) { dcl[j] = 0.0; ctab[j] = comps[j]; }
+  // the thread's 16-byte pieces of a tile, packed (b << 16 | q: registers are what this kernel is short of); piece = floats 4 q .. 4 q + 3 of
+  // basis b's run; a thread without a k-th piece aliases piece 0 for its loads (they stay unconditional) and skips the LDS / store side
+  const int q4 = TN * d / 4;
+  int bq[KLD];
+#pragma unroll
+  for (int k2 = 0; k2 < KLD; ++k2) {
+    const int idx = tid + k2 * TW;
+    const bool act = idx < B * q4;
+    const int b = act ? idx / q4 : 0;
+    bq[k2] = (b << 16) | (act ? idx - b * q4 : 0);
+  }
+  const long long Nd = (long long)N * d;
+  auto piece_act = [&](int k2) { return tid + k2 * TW < B * q4; };
+  auto tile_load = [&](f32x4 (&st)[KLD], long long base) {
+#pragma unroll
+    for (int k2 = 0; k2 < KLD; ++k2) {
+      const float *p = bases + (bq[k2] >> 16) * Nd + 4 * (bq[k2] & 0xffff) + base;
+      if (VEC) st[k2] = *reinterpret_cast<const f32x4 *>(p);
+      else st[k2] = f32x4{p[0], p[1], p[2], p[3]};
+    }
+  };
+  const int Gd = gridDim.x;
+  int t = blockIdx.x;
+  auto rp_of = [&](int tt) {
+    tt = min(tt, n_tiles - 1);
+    return rowptr[min((long long)tt * TN + min(lane, TN), (long long)N)];
+  };
+  auto base_of = [&](int tt) { return (long long)min(min(tt, n_tiles - 1) * TN, N - TN) * d; };
+  auto rows_first = [&](float (&gp)[GQ], int es, int n) {    // the first rows of the wave's run: always GQ loads (see gather_rows_all)
+    const int m = lane >> 4, cc = min(lane & 15, d - 1);
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) {
+      const int sidx = __shfl(es, min(4 * q + m, max(n - 1, 0)), 64);
+      gp[q] = G[(size_t)sidx * gstride + cc];
+    }
+  };
+  auto rows_at = [&](float (&gp)[GQ], int es, int off, int n) {
+    const int m = lane >> 4, cc = min(lane & 15, d - 1);
+#pragma unroll
+    for (int q = 0; q < GQ; ++q)
+      if (4 * q < n) {
+        const int sidx = __shfl(es, off + min(4 * q + m, n - 1), 64);
+        gp[q] = G[(size_t)sidx * gstride + cc];
+      }
+  };
+
+  f32x4 st[KLD], kept[KLD];
+  int rp = rp_of(t), rp1 = rp_of(t + Gd), rp2 = rp_of(t + 2 * Gd);
+  tile_load(st, base_of(t));
+  NodeRange s = node_range(rp, wave, true);
+  Idx x = idx_load(e_dst, e_rel, e_val, s.a, last, lane);
+  NodeRange s1 = node_range(rp1, wave, t + Gd < n_tiles);
+  Idx x1 = idx_load(e_dst, e_rel, e_val, s1.a, last, lane);
+  float gp[GQ], gp1[GQ];                                    // rows of the current tile's messages, of the next tile's
+  rows_first(gp, x.es, min(gn, s.n));
+#pragma unroll
+  for (int k2 = 0; k2 < KLD; ++k2)
+    if (piece_act(k2)) *reinterpret_cast<f32x4 *>(xt + (bq[k2] >> 16) * ts + 4 * (bq[k2] & 0xffff)) = st[k2];
+  tile_load(st, base_of(t + Gd));
+#pragma unroll
+  for (int k2 = 0; k2 < KLD; ++k2) kept[k2] = f32x4{0.f, 0.f, 0.f, 0.f};
+  lds_barrier();
+
+  // one tile per iteration; st = tile t + Gd, requested one hand-over ago and laid down at this iteration's hand-over
+  FBT_DBG(long long dbg[7] = {0, 0, 0, 0, 0, 0, 0};)
+  for (;;) {
+    const bool has1 = t + Gd < n_tiles, has2 = t + 2 * Gd < n_tiles;
+    FBT_DBG(const long long T0 = FBT_T();)
+    int rp3 = rp_of(t + 3 * Gd);
+    const NodeRange s2 = node_range(rp2, wave, has2);
+    const Idx x2 = idx_load(e_dst, e_rel, e_val, s2.a, last, lane);
+    if (!FBT_ABL(4)) rows_first(gp1, x1.es, min(gn, s1.n));
+    __builtin_amdgcn_sched_barrier(0);
+    FBT_DBG(const long long T1 = FBT_T();)
+    // ---- node `wave` of tile t: slot nl of the staged tile (the last tile is staged from node N - 16: its first `shift` slots belong to the tile before)
+    const int shift = t * TN - min(t * TN, N - TN);
+    const int nl = wave + shift;
+    f32x4 accD[NBTM];
+#pragma unroll
+    for (int tb2 = 0; tb2 < NBTM; ++tb2) accD[tb2] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (s.n > 0 && !FBT_ABL(1)) {
+      // the node's block transposed: B operand lane (k, c) = bases[16 tb + c][o][feature of K index (ks, k)].  The contraction runs over the
+      // features in ANY order as long as both operands agree: K index (ks, k) <-> feature NKD k + ks, so that a lane's NKD features are
+      // consecutive floats -- ONE LDS read per 16-row tile (and per message row below) instead of NKD: the message loops are bound by the
+      // CU's LDS instruction rate (~55 wave-level LDS instructions per node before, phase timers of the ablation build)
+      float bt[NBTM][NKD];
+#pragma unroll
+      for (int tb2 = 0; tb2 < NBTM; ++tb2) {
+        FK<NKD> v = *reinterpret_cast<const FK<NKD> *>(xt + min(16 * tb2 + c, B - 1) * ts + nl * d + min(NKD * k, d - 1));
+#pragma unroll
+        for (int ks = 0; ks < NKD; ++ks) bt[tb2][ks] = (16 * tb2 + c < B && NKD * k + ks < d) ? v.f[ks] : 0.f;
+      }
+      Idx c_x = x;
+      int cb0 = 0;                                          // c_x holds the 64 indices from message cb0 of the node
+      for (int g0 = 0; g0 < s.n; g0 += gn) {
+        const int n16 = min(gn, s.n - g0);
+        if (g0) {                                           // more than gn messages (rare): this pass' indices and rows on demand -- the
+          cb0 = g0;                                         // prefetched destination ids are not kept for it (registers)
+          c_x = idx_load(e_dst, e_rel, e_val, s.a + cb0, last, lane);
+          FBT_ARRIVED(c_x.es); FBT_ARRIVED(c_x.er); FBT_ARRIVED(c_x.ev);
+          rows_at(gp, c_x.es, g0 - cb0, n16);
+#pragma unroll
+          for (int q = 0; q < GQ; ++q) FBT_ARRIVED(gp[q]);   // (the wait belongs HERE: left to the compiler, every later use of gp -- and of the registers
+        }                                                   //  it shares -- waits for ALL outstanding loads, the next tile's included)
+        const int w0 = g0 - cb0;
+        // dcomps: A operand lane (k, m) = G row of message m, feature 4 ks + k
+        // The A operand wants the same rows transposed (lane (k, m) = feature 4 ks + k of message m).  The transposition strip is the wave's
+        // OWN slot of the tile: its block sits in registers by now (bt) and its gradient is laid down only after the last pass, so in between
+        // the slot's first 16 runs of d floats are 16 rows of scratch -- the LDS has no room for strips next to the tables (same wave, LDS
+        // operations in order: no barrier)
+#pragma unroll
+        for (int q = 0; q < GQ; ++q)
+          if (4 * q < n16 && c < d) xt[(4 * q + k) * ts + nl * d + c] = gp[q];
+        float av[NKD];
+        {
+          const float vm = __shfl(c_x.ev, w0 + min(c, n16 - 1), 64);       // val of message c rides on the A operand: D[m][b] comes out scaled
+          const FK<NKD> v = *reinterpret_cast<const FK<NKD> *>(xt + min(c, n16 - 1) * ts + nl * d + min(NKD * k, d - 1));
+#pragma unroll
+          for (int ks = 0; ks < NKD; ++ks) av[ks] = vm * v.f[ks];                                    // (features past d meet zeros of bt)
+        }
+        int rq[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rq[e] = __shfl(c_x.er, w0 + min(4 * k + e, n16 - 1), 64);       // D's rows of this lane: messages 4 k + e
+#pragma unroll
+        for (int tb2 = 0; tb2 < NBTM; ++tb2)
+          if (tb2 < nbt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKD; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bt[tb2][ks], acc, 0, 0, 0);
+            if (16 * tb2 + c < B && !FBT_ABL(8)) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (4 * k + e < n16)
+                  __hip_atomic_fetch_add(dcl + rq[e] * B + 16 * tb2 + c, (double)acc[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+        // dbases: four messages per step, k = the message of the step
+#pragma unroll
+        for (int q = 0; q < GQ; ++q)
+          if (4 * q < n16) {                                  // (uniform) step q: messages 4 q .. 4 q + 3, B operand = the gathered rows as they are
+            const int jm = min(4 * q + k, n16 - 1);
+            const int r = __shfl(c_x.er, w0 + jm, 64);
+            const float vs = __shfl(c_x.ev, w0 + jm, 64);
+            const float v = (4 * q + k < n16) ? vs : 0.f;
+#pragma unroll
+            for (int tb2 = 0; tb2 < NBTM; ++tb2)
+              if (tb2 < nbt) accD[tb2] = __builtin_amdgcn_mfma_f32_16x16x4f32(gp[q], ctab[r * B + min(16 * tb2 + c, B - 1)] * v, accD[tb2], 0, 0, 0);
+          }
+      }
+    }
+    // the node's gradient over the node's block (the wave is the only reader and the only writer of slot nl).  The product is taken
+    // transposed (A = the gathered rows, B = the scaled coefficients): D lane (q, column b) holds features 4 q .. 4 q + 3 of basis row
+    // 16 tb + b -- consecutive floats, two 8-byte LDS writes per tile of bases instead of four scattered ones; a node without messages writes zeros
+    if (nl < TN) {
+#pragma unroll
+      for (int tb2 = 0; tb2 < NBTM; ++tb2)
+        if (16 * tb2 + c < B) {
+          float *o = xt + (16 * tb2 + c) * ts + nl * d + 4 * k;
+          if (4 * k + 1 < d) *reinterpret_cast<F2U *>(o) = F2U{{accD[tb2][0], accD[tb2][1]}};
+          else if (4 * k < d) o[0] = accD[tb2][0];
+          if (4 * k + 3 < d) *reinterpret_cast<F2U *>(o + 2) = F2U{{accD[tb2][2], accD[tb2][3]}};
+          else if (4 * k + 2 < d) o[2] = accD[tb2][2];
+        }
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < KLD; ++k2) FBT_KEEP(kept[k2]);      // (the registers of the tile before's stores stay untouched until here)
+    // Rotate everything that was LOADED (next tile's indices and rows) BEFORE this tile's stores are issued: vmcnt counts in order, so a
+    // register move of a loaded value placed after the stores waits for the stores to COMPLETE -- every iteration then paid its own
+    // write latency before it could start the next tile (round 5, found in the ISA: s_waitcnt vmcnt(2) ahead of these moves)
+    FBT_DBG(const long long T2 = FBT_T();)
+    const NodeRange s_next = s1;
+    x = x1; x1 = x2;
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) gp[q] = gp1[q];
+    FBT_ARRIVED(x.er); FBT_ARRIVED(x.ev); FBT_ARRIVED(x1.es); FBT_ARRIVED(x1.er); FBT_ARRIVED(x1.ev);
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) FBT_ARRIVED(gp[q]);
+    FBT_ARRIVED(rp3);
+    FBT_DBG(const long long T3 = FBT_T();)
+    lds_barrier();
+    FBT_DBG(const long long T4 = FBT_T();)
+    // hand-over: every thread takes its pieces of the gradient out and puts the next tile's pieces in
+    {
+      const long long base = base_of(t);
+      const int lo = shift * d;                             // the last tile: positions below `lo` are the tile before's
+#pragma unroll
+      for (int k2 = 0; k2 < KLD; ++k2)
+        if (piece_act(k2)) {
+          const int pos = 4 * (bq[k2] & 0xffff);
+          float *p = xt + (bq[k2] >> 16) * ts + pos;
+          kept[k2] = *reinterpret_cast<const f32x4 *>(p);
+          float *o = dbases + (bq[k2] >> 16) * Nd + pos + base;
+          if (!FBT_ABL(32)) {
+            if (VEC && pos >= lo) *reinterpret_cast<f32x4 *>(o) = kept[k2];
+            else {
+#pragma unroll
+              for (int cc = 0; cc < 4; ++cc)
+                if (pos + cc >= lo) o[cc] = kept[k2][cc];
+            }
+          }
+          if (has1) *reinterpret_cast<f32x4 *>(p) = st[k2];
+        }
+      if (!FBT_ABL(2)) tile_load(st, base_of(t + 2 * Gd));     // (past the end: the last tile again, never laid down)
+    }
+    FBT_DBG(const long long T5 = FBT_T();)
+    lds_barrier();
+    FBT_DBG(dbg[0] += T1 - T0; dbg[1] += T2 - T1; dbg[2] += T3 - T2; dbg[3] += T4 - T3; dbg[4] += T5 - T4; dbg[5] += FBT_T() - T5; dbg[6] += 1;)
+    if (!has1) break;
+    t += Gd;
+    rp = rp1; rp1 = rp2; rp2 = rp3; s = s_next; s1 = s2;
+  }
+  for (int j = tid; j < R * B; j += TW) {
+    const float v = (float)dcl[j];
+    if (v != 0.f) atomicAdd(dC + j, v);
+  }
+  FBT_DBG(if (lane == 0) { unsigned long long *o = rgcn_fbt_dbg + 8 * ((blockIdx.x & 255) * 16 + wave); for (int q = 0; q < 7; ++q) o[q] += dbg[q]; })
+}
+
 inline int pow2_at_least(int v, int lo) {
   int p = lo;
   while (p < v) p <<= 1;
@@ -1036,6 +1285,10 @@ inline bool tile_shape(int R, int B, int d, long long N, TileShape &s) {
   s.kld8 = pieces <= 2 * 512 ? 2 : 4;
   if (pieces > 4 * 512) s.lds_db_n8 = (size_t)LDS_MAX + 1;
   return true;
+}
+// LDS image of the one-walk backward (fbn_bwd_kernel): R x B doubles, R x B floats, one tile
+inline size_t fused_lds(const TileShape &s, int R, int B, int /*gn*/) {
+  return ((size_t)((2 * R * B + 3) & ~3) + (size_t)((R * B + 3) & ~3) + (size_t)B * s.ts_f) * 4;
 }
 int n_cus() {
   static int n_cu = 0;
@@ -1150,10 +1403,22 @@ extern "C" int rgcn_gather_rows_sum4_f32(const float *Y, int32_t ys, const int32
   return RGCN_OK;
 }
 
-extern "C" int rgcn_fbasis_tile_bwd_f32(const float *bases, const float *comps, const float *G, float *dbases, float *dcomps,
+extern "C" int rgcn_fbasis_tile_bwd_fused_gn(int32_t R, int32_t B, int32_t d, int64_t n_nodes) {
+  TileShape s;
+  if (!tile_shape(R, B, d, n_nodes, s)) return 0;
+  // the instantiations that keep their state in 128 registers (1024 threads): two pieces per thread, and not four 16-row tiles of bases next
+  // to three or four K steps -- the others spill into scratch inside the pipeline and stay on the two kernels
+  const int nbt = (B + 15) / 16, nkd = s.dpb / 4;
+  if (s.kld != 2 || nbt * nkd > 9 || (nbt == 4 && nkd >= 2) || B < 16) return 0;     // (B >= 16: the slot doubles as a 16-row strip)
+  return fused_lds(s, R, B, 16) <= (size_t)LDS_MAX ? 16 : 0;      // messages of a node per pass
+}
+
+extern "C" int rgcn_fbasis_tile_bwd_f32(const float *bases, const float *comps, const float *G, int32_t g_stride, float *dbases, float *dcomps,
                                         const int32_t *rowptr, const int32_t *e_dst, const int32_t *e_rel, const float *e_val,
                                         int64_t n_messages, int64_t n_nodes, int32_t R, int32_t B, int32_t d, int32_t mode, void *stream) {
   TileShape s;
+  const int gstride = g_stride;
+  if (g_stride < d) { rgcn_set_error("fbasis_tile_bwd: row stride of the upstream gradient below its width"); return RGCN_EINVAL; }
   if (!bases || !comps || !G || !rowptr || !e_dst || !e_rel || !e_val || (!dbases && !dcomps) || n_messages < 0 || n_messages > INT32_MAX) { rgcn_set_error("fbasis_tile_bwd: bad argument"); return RGCN_EINVAL; }
   if (n_messages == 0) {                                    // no messages: both gradients are zero
     if (dbases) HIP_TRY(zero_async(dbases, (size_t)B * n_nodes * d * sizeof(float), (hipStream_t)stream));
@@ -1162,7 +1427,7 @@ extern "C" int rgcn_fbasis_tile_bwd_f32(const float *bases, const float *comps, 
   }
   const int last = (int)(n_messages - 1);
   const int abl = rgcn_option_value(RGCN_OPT_BWD_ABL);      // 0 in the shipped library (rgcn_set_option refuses it)
-  if (!tile_shape(R, B, d, n_nodes, s) || s.lds_dc > (size_t)LDS_MAX || (mode ? s.lds_db_n : s.lds_db) > (size_t)LDS_MAX || (mode != 0 && mode != 1)) { rgcn_set_error("fbasis_tile_bwd: shape outside the tile kernels (rgcn_fbasis_tile_supported)"); return RGCN_EUNSUPPORTED; }
+  if (!tile_shape(R, B, d, n_nodes, s) || s.lds_dc > (size_t)LDS_MAX || (mode ? s.lds_db_n : s.lds_db) > (size_t)LDS_MAX || (mode != 0 && mode != 1 && mode != 3)) { rgcn_set_error("fbasis_tile_bwd: shape outside the tile kernels (rgcn_fbasis_tile_supported)"); return RGCN_EUNSUPPORTED; }
   const int n_tiles = (int)((n_nodes + TN - 1) / TN);
   const bool vec = ((n_nodes * d) % 4 == 0) && (reinterpret_cast<uintptr_t>(bases) % 16 == 0) && (!dbases || reinterpret_cast<uintptr_t>(dbases) % 16 == 0);
   const dim3 grid((unsigned)std::min<int64_t>(n_tiles, n_cus()));
@@ -1181,7 +1446,29 @@ extern "C" int rgcn_fbasis_tile_bwd_f32(const float *bases, const float *comps, 
 #define FBT_BWD1(KERNEL, LDSB, ...)                                                                                        \
   { if (s.dpb == 4) FBT_BWD2(KERNEL, LDSB, 4, __VA_ARGS__) else if (s.dpb == 8) FBT_BWD2(KERNEL, LDSB, 8, __VA_ARGS__)       \
     else if (s.dpb == 12) FBT_BWD2(KERNEL, LDSB, 12, __VA_ARGS__) else FBT_BWD2(KERNEL, LDSB, 16, __VA_ARGS__) }
-  if (mode == 1) {                                          // one wave per node, MFMA: template on the K steps over the features (d / 4)
+  // mode 1 and both gradients wanted: ONE walk (fbn_bwd_kernel) when its LDS image fits; mode 3 = mode 1 on the two kernels (tests, comparisons)
+  const int gn_fused = (mode == 1 && dbases && dcomps) ? rgcn_fbasis_tile_bwd_fused_gn(R, B, d, n_nodes) : 0;
+  if (gn_fused) {
+    HIP_TRY(zero_async(dcomps, (size_t)R * B * sizeof(float), st));
+    const size_t lds_f = fused_lds(s, R, B, gn_fused);
+#define FBN_F4(NK_, KL_, VE_, NB_)                                                                                                  \
+  {                                                                                                                                 \
+    HIP_TRY(raise_lds(fbn_bwd_kernel<NK_, KL_, VE_, NB_>, lds_f));                                                                  \
+    hipLaunchKernelGGL((fbn_bwd_kernel<NK_, KL_, VE_, NB_>), grid, dim3(TW), lds_f, st, bases, comps, G, dbases, dcomps, rowptr, e_dst, e_rel, e_val, \
+                       n_tiles, (int)n_nodes, R, B, d, s.ts_f, last, gstride, gn_fused, abl);                                        \
+  }
+#define FBN_F3(NK_, KL_, VE_) { if (B <= 16) FBN_F4(NK_, KL_, VE_, 1) else if (B <= 32) FBN_F4(NK_, KL_, VE_, 2) else if (B <= 48) FBN_F4(NK_, KL_, VE_, 3) else FBN_F4(NK_, KL_, VE_, 4) }
+#define FBN_F2(NK_, KL_) { if (vec) FBN_F3(NK_, KL_, true) else FBN_F3(NK_, KL_, false) }
+#define FBN_F1(NK_) { FBN_F2(NK_, 2) }
+    if (s.dpb == 4) FBN_F1(1) else if (s.dpb == 8) FBN_F1(2) else if (s.dpb == 12) FBN_F1(3) else FBN_F1(4)
+#undef FBN_F1
+#undef FBN_F2
+#undef FBN_F3
+#undef FBN_F4
+    HIP_TRY(hipGetLastError());
+    return RGCN_OK;
+  }
+  if (mode != 0) {                                          // one wave per node, MFMA: template on the K steps over the features (d / 4)
 #define FBN_BWD2(KERNEL, LDSB, NK_, ...) { if (s.kld == 2) FBT_BWD3(KERNEL, LDSB, NK_, 2, __VA_ARGS__) else FBT_BWD3(KERNEL, LDSB, NK_, 4, __VA_ARGS__) }
 #define FBN_BWD1(KERNEL, LDSB, ...)                                                                                         \
   { if (s.dpb == 4) FBN_BWD2(KERNEL, LDSB, 1, __VA_ARGS__) else if (s.dpb == 8) FBN_BWD2(KERNEL, LDSB, 2, __VA_ARGS__)        \
@@ -1200,7 +1487,7 @@ extern "C" int rgcn_fbasis_tile_bwd_f32(const float *bases, const float *comps, 
   {                                                                                                                               \
     HIP_TRY(raise_lds(fbn_dbases_kernel<NK_, KL_, VE_, NP_, NW_>, lds_db));                                                        \
     hipLaunchKernelGGL((fbn_dbases_kernel<NK_, KL_, VE_, NP_, NW_>), grid_db, dim3(64 * NW_), lds_db, st, comps, G, dbases, rowptr, e_dst, e_rel, \
-                       e_val, tiles_db, (int)n_nodes, R, B, d, ts_db, last, abl);                                                  \
+                       e_val, tiles_db, (int)n_nodes, R, B, d, ts_db, last, gstride, abl);                                                  \
   }
 #define FBN_DB2(NK_, KL_, VE_) { if (pair) FBN_DB3(NK_, KL_, VE_, 2, 8) else if (two) FBN_DB3(NK_, KL_, VE_, 2, 16) else FBN_DB3(NK_, KL_, VE_, 1, 16) }
 #define FBN_DB1(NK_, KL_) { if (vec) FBN_DB2(NK_, KL_, true) else FBN_DB2(NK_, KL_, false) }
@@ -1213,16 +1500,16 @@ extern "C" int rgcn_fbasis_tile_bwd_f32(const float *bases, const float *comps, 
     }
     if (dcomps) {
       HIP_TRY(zero_async(dcomps, (size_t)R * B * sizeof(float), st));
-      FBN_BWD1(fbn_dcomps_kernel, s.lds_dc, bases, G, dcomps, rowptr, e_dst, e_rel, e_val, n_tiles, (int)n_nodes, R, B, d, s.ts_b, last, abl)
+      FBN_BWD1(fbn_dcomps_kernel, s.lds_dc, bases, G, dcomps, rowptr, e_dst, e_rel, e_val, n_tiles, (int)n_nodes, R, B, d, s.ts_b, last, gstride, abl)
     }
 #undef FBN_BWD1
 #undef FBN_BWD2
   } else {
   if (dbases)
-    FBT_BWD1(fbt_dbases_kernel, s.lds_db, comps, G, dbases, rowptr, e_dst, e_rel, e_val, n_tiles, (int)n_nodes, R, B, d, s.ts_b, last, abl)
+    FBT_BWD1(fbt_dbases_kernel, s.lds_db, comps, G, dbases, rowptr, e_dst, e_rel, e_val, n_tiles, (int)n_nodes, R, B, d, s.ts_b, last, gstride, abl)
   if (dcomps) {
     HIP_TRY(zero_async(dcomps, (size_t)R * B * sizeof(float), st));
-    FBT_BWD1(fbt_dcomps_kernel, s.lds_dc, bases, G, dcomps, rowptr, e_dst, e_rel, e_val, n_tiles, (int)n_nodes, R, B, d, s.ts_b, last, abl)
+    FBT_BWD1(fbt_dcomps_kernel, s.lds_dc, bases, G, dcomps, rowptr, e_dst, e_rel, e_val, n_tiles, (int)n_nodes, R, B, d, s.ts_b, last, gstride, abl)
   }
   }
 #undef FBT_BWD1

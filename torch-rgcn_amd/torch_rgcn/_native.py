@@ -657,6 +657,8 @@ def fbasis_tile_ok(R, B, d, n_nodes, max_degree=None):
     ranges, nodes = (m & 3) == 3, (m & 12) == 12
     if route == "nodes":
         return nodes, 1
+    if route == "nodes2":           # one wave per node, dbases and dcomps as two kernels (rounds 4's backward; comparisons)
+        return nodes, 3
     if route == "ranges":
         return ranges, 0
     if nodes and max_degree is not None and max_degree <= TILE_NODE_MODE_MAX_DEGREE:
@@ -674,7 +676,7 @@ def fbasis_tile_fwd(bases, comps, bias, plan, relu=False, mode=0):
     out = torch.empty(N, d, device=dev, dtype=torch.float32)
     with _on(dev), _timed("fbasis_tile_fwd"):
         _check(lib().rgcn_fbasis_tile_fwd_f32(_dp(bases), _dp(comps), _dp(Y), _dp(plan.rowptr_src), _dp(plan.e_rel), _dp(plan.e_val),
-                                              c_i64(plan.n_messages), c_i64(N), c_i32(comps.shape[0]), c_i32(B), c_i32(d), c_i32(mode), _stream(dev)),
+                                              c_i64(plan.n_messages), c_i64(N), c_i32(comps.shape[0]), c_i32(B), c_i32(d), c_i32(1 if mode else 0), _stream(dev)),
                "fbasis_tile_fwd")
     units, n_units, n_split = plan.units_dst
     fused = bool(relu) and n_split == 0
@@ -685,9 +687,15 @@ def fbasis_tile_fwd(bases, comps, bias, plan, relu=False, mode=0):
 
 
 def fbasis_tile_bwd(bases, comps, g, plan, need_bases=True, need_comps=True, mode=0):
-    """-> (dbases [B, N, d] in the parameter's layout, dcomps [R, B])"""
-    _req(bases, "bases"); _req(comps, "comps"); _req(g, "grad")
+    """-> (dbases [B, N, d] in the parameter's layout, dcomps [R, B]); g [N, d], rows contiguous or at a stride of 16 k floats (the
+    first columns of the zero-padded rows a width-16 layer hands back: taken in place)"""
+    _req(bases, "bases"); _req(comps, "comps")
     B, N, d = bases.shape
+    if g.dim() == 2 and g.stride(1) == 1 and g.stride(0) >= g.shape[1] and g.data_ptr() % 16 == 0 and not g.is_contiguous():
+        g_stride = int(g.stride(0))
+    else:
+        _req(g, "grad")
+        g_stride = d
     R = comps.shape[0]
     dev = bases.device
     dB = torch.empty_like(bases) if need_bases else None
@@ -695,7 +703,7 @@ def fbasis_tile_bwd(bases, comps, g, plan, need_bases=True, need_comps=True, mod
     if dB is None and dC is None:
         return None, None
     with _on(dev), _timed("fbasis_tile_bwd"):
-        _check(lib().rgcn_fbasis_tile_bwd_f32(_dp(bases), _dp(comps), _dp(g), _dp(dB), _dp(dC), _dp(plan.rowptr_src), _dp(plan.e_dst),
+        _check(lib().rgcn_fbasis_tile_bwd_f32(_dp(bases), _dp(comps), _dp(g), c_i32(g_stride), _dp(dB), _dp(dC), _dp(plan.rowptr_src), _dp(plan.e_dst),
                                               _dp(plan.e_rel), _dp(plan.e_val), c_i64(plan.n_messages), c_i64(N), c_i32(R), c_i32(B), c_i32(d), c_i32(mode),
                                               _stream(dev)), "fbasis_tile_bwd")
     return dB, dC
