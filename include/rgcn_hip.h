@@ -472,7 +472,8 @@ RGCN_API int rgcn_gather_rows_sum_f32(const float *Y, const int32_t *perm, const
  *   rgcn_fbasis_tile_supported -> bit 0: forward, bit 1: backward, bits 2 / 3: the same in mode 1 (LDS budget: forward R x 64 floats + 2 tiles; backward R x B doubles + 2 tiles
  *                                 and 2 tiles of doubles + R x B floats; B <= 64, d <= 16, N >= 16)
  *   rgcn_fbasis_tile_fwd_f32:     Y[e, 0..ys) = val_e * comps[r_e,:] . bases[:,o,:], zero padded to ys = rgcn_fbasis_tile_ystride(d) = pow2(d) >= 4 columns
- *   rgcn_gather_rows_sum4_f32:    out[row, 0..w) = (bias) + sum over the row's units of Y[perm[j], 0..w); Y rows ys = 4 / 8 / 16 floats
+ *   rgcn_gather_rows_sum4_f32:    out[row, 0..w) = (bias) + sum over the row's units of Y[perm[j], 0..w); Y rows ys = 4 / 8 / 16 floats; out rows
+ *                                 out_stride floats apart (w <= out_stride <= ys), columns w .. out_stride written as zeros
  *   rgcn_fbasis_tile_bwd_f32:     dbases [B, N, d] (written once, no pre-zeroing) and / or dcomps [R, B] (either may be NULL); sums in LDS
  *                                 doubles (ds_add_f64): not bit-reproducible.  G [N, >= d] with a row stride of g_stride floats (the zero-padded
  *                                 [N, 16] rows the width-16 kernels of the next layer hand back are taken as they are).  Round 5: in mode 1
@@ -485,8 +486,8 @@ RGCN_API int rgcn_fbasis_tile_fwd_f32(const float *bases, const float *comps, fl
                                       const float *e_val, int64_t n_messages, int64_t n_nodes, int32_t R, int32_t B, int32_t d,
                                       int32_t mode, void *stream);
 RGCN_API int rgcn_gather_rows_sum4_f32(const float *Y, int32_t ys, const int32_t *perm, const int32_t *units, int64_t n_units,
-                                       int64_t n_split, const float *bias, float *out, int64_t n_rows, int32_t w, int32_t relu,
-                                       void *stream);
+                                       int64_t n_split, const float *bias, float *out, int64_t n_rows, int32_t w, int32_t out_stride,
+                                       int32_t relu, void *stream);
 RGCN_API int rgcn_fbasis_tile_bwd_f32(const float *bases, const float *comps, const float *G, int32_t g_stride, float *dbases, float *dcomps,
                                       const int32_t *rowptr, const int32_t *e_dst, const int32_t *e_rel, const float *e_val,
                                       int64_t n_messages, int64_t n_nodes, int32_t R, int32_t B, int32_t d, int32_t mode, void *stream);

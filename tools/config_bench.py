@@ -441,9 +441,13 @@ def line_am_shipped(baseline_config):
     y = torch.randint(0, ncls, (labelled,), device=DEV)
     opt = torch.optim.Adam(model.parameters(), lr=0.01, fused=True)
 
+    from torch_rgcn.functional import MaskedCrossEntropy, unit_gradient
+    head = MaskedCrossEntropy(idx, y, N)        # what experiments/classify_nodes.py uses (one launch for loss + gradient)
+    unit = unit_gradient(DEV)
+
     def fwd_bwd():
         opt.zero_grad(set_to_none=True)
-        torch.nn.functional.cross_entropy(model()[idx], y).backward()
+        head(model()).backward(gradient=unit)
 
     def step():
         fwd_bwd()

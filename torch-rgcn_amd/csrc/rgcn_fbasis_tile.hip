@@ -269,7 +269,7 @@ __global__ __launch_bounds__(TW) void fbt_fwd_kernel(
 template <int LPR>
 __global__ __launch_bounds__(256) void gather_rows_sum4_kernel(const float *__restrict__ Y, const int *__restrict__ perm,
                                                                const int4 *__restrict__ units, const float *__restrict__ bias,
-                                                               float *__restrict__ out, long long n_units, int w, int relu_out) {
+                                                               float *__restrict__ out, long long n_units, int w, int ow, int relu_out) {
   const int q = threadIdx.x % LPR;
   for (long long u = ((long long)blockIdx.x * 256 + threadIdx.x) / LPR; u < n_units; u += ((long long)gridDim.x * 256) / LPR) {
     const int4 unit = units[u];
@@ -289,12 +289,13 @@ __global__ __launch_bounds__(256) void gather_rows_sum4_kernel(const float *__re
     }
     if (e < e1) a += *reinterpret_cast<const f32x4 *>(Y + (size_t)perm[e] * (4 * LPR) + 4 * q);
     a += b;
-    float *o = out + (size_t)unit.x * w + 4 * q;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
+    float *o = out + (size_t)unit.x * ow + 4 * q;           // rows of ow >= w floats: columns w .. ow are written as zeros (a zero-padded
+#pragma unroll                                              // [N, 16] row is what the width-16 kernels of the next layer read in place)
+    for (int c = 0; c < 4; ++c) {
       if (4 * q + c < w) {
         if (shared) atomicAdd(o + c, a[c]); else o[c] = relu_out ? fmaxf(a[c], 0.f) : a[c];
-      }
+      } else if (4 * q + c < ow && !shared) o[c] = 0.f;
+    }
   }
 }
 
@@ -1383,22 +1384,23 @@ extern "C" int rgcn_fbasis_tile_fwd_f32(const float *bases, const float *comps, 
 }
 
 extern "C" int rgcn_gather_rows_sum4_f32(const float *Y, int32_t ys, const int32_t *perm, const int32_t *units, int64_t n_units,
-                                         int64_t n_split, const float *bias, float *out, int64_t n_rows, int32_t w, int32_t relu,
-                                         void *stream) {
-  if (n_units < 0 || n_rows < 0 || w <= 0 || w > ys || (ys != 4 && ys != 8 && ys != 16) || (n_units && (!Y || !perm || !units || !out))) {
+                                         int64_t n_split, const float *bias, float *out, int64_t n_rows, int32_t w, int32_t out_stride,
+                                         int32_t relu, void *stream) {
+  const int ow = out_stride;
+  if (n_units < 0 || n_rows < 0 || w <= 0 || w > ys || ow < w || ow > ys || (ys != 4 && ys != 8 && ys != 16) || (n_units && (!Y || !perm || !units || !out))) {
     rgcn_set_error("gather_rows_sum4: bad argument");
     return RGCN_EINVAL;
   }
   if (relu && n_split) { rgcn_set_error("gather_rows_sum4: relu in the epilogue needs rows that are not cut into shared pieces"); return RGCN_EUNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
-  if (n_split) HIP_TRY(zero_async(out, (size_t)n_rows * w * sizeof(float), st));
+  if (n_split) HIP_TRY(zero_async(out, (size_t)n_rows * ow * sizeof(float), st));
   if (n_units == 0) return RGCN_OK;
   const int lpr = ys / 4;
   const dim3 grid((unsigned)std::min<int64_t>((n_units * lpr + 255) / 256, (int64_t)n_cus() * 32));
   const int4 *un = reinterpret_cast<const int4 *>(units);
-  if (lpr == 1) hipLaunchKernelGGL(gather_rows_sum4_kernel<1>, grid, dim3(256), 0, st, Y, perm, un, bias, out, (long long)n_units, w, relu ? 1 : 0);
-  else if (lpr == 2) hipLaunchKernelGGL(gather_rows_sum4_kernel<2>, grid, dim3(256), 0, st, Y, perm, un, bias, out, (long long)n_units, w, relu ? 1 : 0);
-  else hipLaunchKernelGGL(gather_rows_sum4_kernel<4>, grid, dim3(256), 0, st, Y, perm, un, bias, out, (long long)n_units, w, relu ? 1 : 0);
+  if (lpr == 1) hipLaunchKernelGGL(gather_rows_sum4_kernel<1>, grid, dim3(256), 0, st, Y, perm, un, bias, out, (long long)n_units, w, ow, relu ? 1 : 0);
+  else if (lpr == 2) hipLaunchKernelGGL(gather_rows_sum4_kernel<2>, grid, dim3(256), 0, st, Y, perm, un, bias, out, (long long)n_units, w, ow, relu ? 1 : 0);
+  else hipLaunchKernelGGL(gather_rows_sum4_kernel<4>, grid, dim3(256), 0, st, Y, perm, un, bias, out, (long long)n_units, w, ow, relu ? 1 : 0);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

@@ -666,14 +666,17 @@ def fbasis_tile_ok(R, B, d, n_nodes, max_degree=None):
     return ranges, 0
 
 
-def fbasis_tile_fwd(bases, comps, bias, plan, relu=False, mode=0):
-    """bases [B, N, d] (the parameter itself) -> out [N, d]; relu: as fbasis_fwd; mode: fbasis_tile_ok"""
+def fbasis_tile_fwd(bases, comps, bias, plan, relu=False, mode=0, padded=False):
+    """bases [B, N, d] (the parameter itself) -> out [N, d]; relu: as fbasis_fwd; mode: fbasis_tile_ok.  padded: the rows are written into
+    a zero-padded [N, 16 k] buffer and its first d columns returned as a VIEW (row stride 16 k: what the width-16 kernels of the next
+    layer read in place -- no pad copy there, no crop copy of its feature gradient on the way back)"""
     _req(bases, "bases"); _req(comps, "comps"); _req(bias, "bias")
     B, N, d = bases.shape
     dev = bases.device
     ys = int(lib().rgcn_fbasis_tile_ystride(c_i32(d)))
     Y = torch.empty(max(plan.n_messages, 1), ys, device=dev, dtype=torch.float32)
-    out = torch.empty(N, d, device=dev, dtype=torch.float32)
+    ow = d + (-d % 16) if (padded and d % 16 and d + (-d % 16) <= ys) else d
+    out = torch.empty(N, ow, device=dev, dtype=torch.float32)
     with _on(dev), _timed("fbasis_tile_fwd"):
         _check(lib().rgcn_fbasis_tile_fwd_f32(_dp(bases), _dp(comps), _dp(Y), _dp(plan.rowptr_src), _dp(plan.e_rel), _dp(plan.e_val),
                                               c_i64(plan.n_messages), c_i64(N), c_i32(comps.shape[0]), c_i32(B), c_i32(d), c_i32(1 if mode else 0), _stream(dev)),
@@ -682,7 +685,10 @@ def fbasis_tile_fwd(bases, comps, bias, plan, relu=False, mode=0):
     fused = bool(relu) and n_split == 0
     with _on(dev), _timed("gather_rows_sum4"):
         _check(lib().rgcn_gather_rows_sum4_f32(_dp(Y), c_i32(ys), _dp(plan.perm_dst), _dp(units), c_i64(n_units), c_i64(n_split),
-                                               _dp(bias), _dp(out), c_i64(N), c_i32(d), c_i32(1 if fused else 0), _stream(dev)), "gather_rows_sum4")
+                                               _dp(bias), _dp(out), c_i64(N), c_i32(d), c_i32(ow), c_i32(1 if fused else 0), _stream(dev)), "gather_rows_sum4")
+    if ow != d:
+        out = out[:, :d]
+        out._rgcn_zero_padded = True
     return (out, fused) if relu else out
 
 

@@ -51,7 +51,10 @@ def _pad_blocks(X, W, bias, graph=None):
             (graph is not None and _wide_gemm_path(graph, d_in, d_out)):       # (the gather-GEMM takes ragged widths as they are)
         return X, W, bias, None
     # one launch for W and the bias together (torch.nn.functional.pad: a fill and a copy each)
-    Xp = X if pi == 0 else _native.resize3(dense(X), (X.shape[0], d_in + pi))
+    if pi and _zero_padded_rows(X, d_in + pi):
+        Xp = torch.as_strided(X, (X.shape[0], d_in + pi), (d_in + pi, 1))      # the producer wrote the padded rows already: no copy
+    else:
+        Xp = X if pi == 0 else _native.resize3(dense(X), (X.shape[0], d_in + pi))
     if bias is None:
         Wp, bp = _native.resize3(dense(W), (d_in + pi, d_out + po)), None
     else:
@@ -93,12 +96,21 @@ def _spmm_blocked(X, W, bias, plan_of, relu=False, graph=None, kind="fwd"):
     return torch.cat(cols, dim=1)
 
 
-def _unpad_blocks(dims, dX, dW, db):
+def _zero_padded_rows(t, wide):
+    """t = the first columns of a contiguous, 16-byte aligned [N, wide] buffer whose other columns are ZERO (the producer said so)?"""
+    return getattr(t, "_rgcn_zero_padded", False) and _rows16(t) and t.stride(0) == wide
+
+
+def _unpad_blocks(dims, dX, dW, db, dx_view=False):
     if dims is None:
         return dX, dW, db
     d_in, d_out = dims
     if dX is not None and dX.shape[1] != d_in:
-        dX = _native.resize3(dense(dX), (dX.shape[0], d_in))
+        if dx_view:       # X was an intermediate that arrived as the first columns of zero-padded rows: its gradient goes back the same way
+            dX = dX[:, :d_in]                                  # (the padded columns of dX are exact zeros: W's padding rows are)
+            dX._rgcn_zero_padded = True
+        else:
+            dX = _native.resize3(dense(dX), (dX.shape[0], d_in))
     if dW is not None and (dW.shape[1] != d_in or dW.shape[2] != d_out):      # contiguous gradients in one launch (a sliced view costs
         if db is not None:                                                     # AccumulateGrad a strided copy per tensor)
             dW, db = _native.resize3(dense(dW), (d_in, d_out), dense(db), d_out)
@@ -203,7 +215,11 @@ class _RelationalMP(torch.autograd.Function):
         ctx.in_token = in_token                      # X = relu(...) of a layer that fused the activation (see _ReluToken)
         ctx.out_token = _ReluToken(private=relu == "private") if relu else None
         relu = bool(relu)
+        x_padded_view = W.shape[1] % 16 != 0 and _zero_padded_rows(X, W.shape[1] + (-W.shape[1] % 16))
         X, W, bias, ctx.dims = _pad_blocks(X, W, bias, graph)
+        # the feature gradient of such an input returns as a view of the padded rows too (no crop launch) -- to an intermediate only: a
+        # leaf's .grad stays a dense tensor of its own shape
+        ctx.dx_view = bool(x_padded_view and ctx.dims is not None and routes.get("pad16_view", "1") != "0")
         X = dense(X)
         W = dense(W)
         b = None if bias is None else dense(bias)
@@ -293,7 +309,7 @@ class _RelationalMP(torch.autograd.Function):
             db = _native.colsum(g)
         if masked:
             ctx.in_token.mark(dX)                     # dX already is the gradient BEFORE the producer's ReLU
-        return (*_unpad_blocks(ctx.dims, dX, dW, db), None, None, None, None)
+        return (*_unpad_blocks(ctx.dims, dX, dW, db, getattr(ctx, "dx_view", False)), None, None, None, None)
 
 
 def _join_shards(partial, group, mode="allreduce"):
@@ -641,6 +657,7 @@ class _FeaturelessBasisMP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, bases, comps, bias, graph, relu=False):
         out = _FeaturelessBasisMP._forward(ctx, bases, comps, bias, graph, relu)
+        ctx.out_padded = bool(getattr(out, "_rgcn_zero_padded", False))     # (the saved copy comes back as another Python object)
         to_save = ctx.to_save
         del ctx.to_save
         ctx.save_for_backward(*to_save, *((out,) if relu else ()))
@@ -669,7 +686,8 @@ class _FeaturelessBasisMP(torch.autograd.Function):
             ctx.graph, ctx.has_bias = graph, bias is not None
             ctx.in_place = True
             ctx.to_save = (bases, comps)
-            return _relu_epilogue(ctx, _native.fbasis_tile_fwd(bases, comps, bias, graph.fbasis_plan(), relu=bool(relu), mode=ctx.tile_mode), relu)
+            return _relu_epilogue(ctx, _native.fbasis_tile_fwd(bases, comps, bias, graph.fbasis_plan(), relu=bool(relu), mode=ctx.tile_mode,
+                                                               padded=routes.get("pad16_view", "1") != "0"), relu)
         if ctx.src_major and ctx.in_place:
             comps, bases = dense(comps), dense(bases)
             ctx.graph, ctx.has_bias = graph, bias is not None
@@ -691,6 +709,22 @@ class _FeaturelessBasisMP(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if getattr(ctx, "tile_bwd", False) and g.dim() == 2 and g.shape[1] % 16 and _zero_padded_rows(g, g.shape[1] + (-g.shape[1] % 16)):
+            # the consumer handed its feature gradient back as the first columns of zero-padded [N, 16] rows: the tile kernels gather those rows
+            # in place (64-byte aligned: one line per row instead of 40-byte rows straddling two), the ReLU's mask and the bias' column sum run
+            # on the padded buffer (its extra columns stay zero)
+            wide = g.stride(0)
+            g16 = torch.as_strided(g, (g.shape[0], wide), (wide, 1))
+            if ctx.relu and not ctx.out_token.premasked(g):
+                out = ctx.saved_tensors[2]
+                out16 = torch.as_strided(out, (out.shape[0], wide), (wide, 1)) if (ctx.out_padded and _rows16(out) and out.stride(0) == wide) else \
+                    _native.resize3(dense(out), (out.shape[0], wide))
+                g16 = torch.ops.aten.threshold_backward(g16, out16, 0.0)
+            table, comps = ctx.saved_tensors[:2]
+            dB, dC = _native.fbasis_tile_bwd(table, comps, g16[:, :g.shape[1]], ctx.graph.fbasis_plan(), ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                             mode=ctx.tile_mode)
+            db = _native.colsum(g16)[:g.shape[1]].contiguous() if ctx.has_bias and ctx.needs_input_grad[2] else None
+            return dB, dC, db, None, None
         g = dense(g)
         if ctx.relu:
             g = _relu_backward(ctx, g, ctx.saved_tensors[2])
