@@ -197,6 +197,17 @@ RGCN_API int rgcn_basis_dcomps_f32(const float *X, const float *D, float *dcomps
                                    const int32_t *p_dst, const float *p_val, const int32_t *chunk_rel,
                                    const int32_t *items, int64_t n_items, int32_t R, int32_t B, int32_t d,
                                    int32_t n_copies, void *stream);
+/* The same sum on the destination-major CSR of the forward walk (rows = destinations; entries: source, relation, val), without the
+ * relation-major plan: one wave per row, D's row in registers, dcomps summed in an LDS table of doubles per workgroup (round 5: per-call
+ * LP graphs no longer build a relation-major plan for this one kernel).  B <= 8, d a multiple of 4, R x B doubles within 60 KB. */
+RGCN_API int rgcn_basis_dcomps_csr_supported(int32_t R, int32_t B, int32_t d);
+RGCN_API int rgcn_basis_dcomps_csr_f32(const float *X, const float *D, float *dcomps, const int32_t *rowptr, const int32_t *p_src,
+                                       const int32_t *p_rel, const float *p_val, int64_t n_rows, int32_t R, int32_t B, int32_t d,
+                                       void *workspace, void *stream);
+/* workspace of rgcn_basis_dcomps_csr_f32 (a kernel that sums an R x B table per workgroup): bytes for one row of doubles (whole 128-byte
+ * lines) per workgroup + a ticket; its first 128 bytes ZEROED once by the caller and left zeroed by every launch.  The workgroups' tables
+ * meet in a fixed order (agent-scope atomic exchanges into the rows, the last workgroup adds them up): bit-reproducible, no zeroing launch. */
+RGCN_API int64_t rgcn_basis_sum_workspace_bytes(int32_t R, int32_t B);
 
 /* ------------------------------------------------------------------ device kernels */
 
@@ -449,7 +460,7 @@ RGCN_API int rgcn_fbasis_bwd_f32(const float *bases, const float *comps, const f
 RGCN_API int rgcn_fbasis_small_supported(int32_t R, int32_t B, int32_t d);
 RGCN_API int rgcn_fbasis_small_bwd_f32(const float *G, const float *table, const float *comps, float *dbases, float *dcomps,
                                        const int32_t *rowptr, const int32_t *p_src, const int32_t *p_rel, const float *p_val,
-                                       int64_t n_rows, int32_t R, int32_t B, int32_t d, void *stream);
+                                       int64_t n_rows, int32_t R, int32_t B, int32_t d, int32_t basis_major, void *stream);
 /* rgcn_fbasis_bwd_f32 with dcomps finished on the chip (round 4): no T scratch, no relation-major pass 2 -- t_e[b] is added to a per-workgroup
  * LDS table of doubles (R x B x 8 bytes <= 120 KiB: rgcn_fbasis_bwd_dc_supported) and every workgroup flushes once into dcomps (zeroed here). */
 RGCN_API int rgcn_fbasis_bwd_dc_supported(int32_t R, int32_t B, int32_t d);
@@ -500,6 +511,15 @@ RGCN_API int rgcn_fbasis_tile_bwd_fused_gn(int32_t R, int32_t B, int32_t d, int6
  * zero-padded output read in place; columns C .. ld of dlogits are written 0). */
 RGCN_API int rgcn_ce_head_f32(const float *logits, const int32_t *row_label, const int32_t *lab_rows, float *loss, float *dlogits,
                               int64_t N, int32_t C, int32_t ld, int32_t n_lab, void *stream);
+
+/* Loss head of the link-prediction experiments, one launch: loss = mean binary cross-entropy with logits over the T scored triples and
+ * dscores [T] = d loss / d scores = (sigmoid(score) - label) / T.  Replaces F.binary_cross_entropy_with_logits(predictions, train_lbl)
+ * and its autograd graph (reference experiments/predict_links.py:152-153).  workspace: rgcn_bce_head_workspace_bytes() bytes, ZEROED
+ * once by the caller before the first call and kept between calls (the launch leaves it zeroed again); partial sums in double, added in
+ * block order by the last block to finish: bit-reproducible. */
+RGCN_API int rgcn_bce_head_workspace_bytes(void);
+RGCN_API int rgcn_bce_head_f32(const float *scores, const float *labels, float *loss, float *dscores, void *workspace, int64_t T,
+                               void *stream);
 
 /* Zero-padding / cropping of the two trailing dimensions of a [A][B][C] tensor into [A][Bd][Cd], with an optional 1-D tensor (n1 -> n1d
  * elements) in the same launch: how widths that are no multiple of 16 (classifier outputs: layers.py weights [R, 16, 4], bias [4]) reach

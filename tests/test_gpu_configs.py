@@ -269,6 +269,8 @@ def test_wn18_full_shape_train_step_vs_oracle(self_loop_type):
     T = oracle.synthetic_triples(N, R0, WN18["train_graph"], seed=3)
     batch = oracle.synthetic_triples(N, R0, WN18["scored"], seed=4)
     X = (torch.randn(N, d, device=DEV) * 0.5).requires_grad_(True)
+    from torch_rgcn import _native
+    _native.profile_start()
     torch.manual_seed(321)
     H = layer(torch.from_numpy(T), X)
     torch.manual_seed(321)      # the layer's Bernoulli draw again: which self loops it kept
@@ -279,6 +281,8 @@ def test_wn18_full_shape_train_step_vs_oracle(self_loop_type):
     scores = dm(torch.from_numpy(batch).to(DEV), H)
     gs = torch.randn(WN18["scored"], device=DEV) / WN18["scored"]
     scores.backward(gs)
+    prof = _native.profile_stop()
+    assert "basis_dcomps_csr" in prof and "basis_dcomps" not in prof, sorted(prof)      # per-step graph: dcomps on the forward's CSR, no relation-major plan
     # decoder against the oracle on the GPU's own encoder output ...
     Hn, rel = H.detach().cpu().numpy(), dm.relations.detach().cpu().numpy()
     s_ref = oracle.distmult_forward(batch, Hn, rel)

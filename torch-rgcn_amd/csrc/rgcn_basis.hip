@@ -689,8 +689,7 @@ extern "C" int rgcn_basis_aggregate_f32(const float *X, const float *comps, floa
   (void)R;
   if (!X || !comps || !out || !rowptr || n_rows < 0 || B <= 0 || d <= 0 || (n_b_in != 1 && n_b_in != B)) { rgcn_set_error("basis_aggregate: bad argument"); return RGCN_EINVAL; }
   if (!n_rows) return RGCN_OK;
-  const int vec_mode = rgcn_option_value(RGCN_OPT_BASIS_VEC4);
-  if (vec_mode && (d & 3) == 0 && d >= 16 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+  if ((d & 3) == 0 && d >= 16 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
     int lpm = 1;
     while (lpm < 64 && 4 * lpm < d) lpm *= 2;
     if (n_b_in == 1)
@@ -716,12 +715,77 @@ extern "C" int rgcn_basis_aggregate_f32(const float *X, const float *comps, floa
 // gathers G[s] once per message, accumulates dbases[o] in registers (written once, no atomics) and adds t_e[b] = val <block[b], G[s]>
 // to an LDS table dcomps[R][B] kept in DOUBLES (ds_add_f64: the LDS float atomic that is native on gfx950); every workgroup
 // flushes its table once.  lpm = d / 4 lanes per message (16-byte loads), 64 / lpm messages of a row in flight per wave.
+// The workgroups' LDS tables of doubles -> out[0..n) as floats, without n atomics per workgroup on the same few addresses (R x B = 74 on WN18:
+// 2048 workgroups x 74 fp32 atomics serialise at the L2 -- most of the kernel's time) and in a FIXED order: every workgroup writes its table
+// to its row of `scratch`, the one that finishes last adds the rows in workgroup order.  ticket: one zeroed word, left zeroed.
+namespace {
+constexpr int TBW = 1024;      // threads of the persistent workgroups that end with this flush
+__device__ __forceinline__ void table_flush_ordered(const double *dcl, int n, double *__restrict__ scratch, unsigned *__restrict__ ticket,
+                                                    float *__restrict__ out) {
+  __shared__ bool last;
+  // rows of whole 128-byte lines: a line shared by two workgroups' rows lives half-written in the L2s of two XCDs, and the reader's own L2
+  // then serves the neighbour's half from what it holds -- LAST launch's values (found as a gradient one step stale on a 2-workgroup launch)
+  const size_t ns = ((size_t)n + 15) & ~(size_t)15;
+  double *mine = scratch + (size_t)blockIdx.x * ns;
+  // The row goes out with agent-scope atomic EXCHANGES: read-modify-write atomics are performed where all XCDs see them (that is what makes
+  // the fp32 atomics of the other kernels add up across the chip), a plain or even an "atomic" store sits in the writer's L2 until that L2 is
+  // written back -- and a __threadfence() per workgroup (an L2 write-back each, 512 of them) cost more than the kernel.  The ticket is taken
+  // once the exchanges have returned (they return the old value: waiting for it IS the acknowledgement).
+  double seen = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) seen += __hip_atomic_exchange(mine + i, dcl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("" ::"v"(seen));                             // (the returned values are waited for, not used)
+  __syncthreads();
+  if (threadIdx.x == 0) last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  // consecutive threads read consecutive entries of one workgroup's row; the rows are dealt over S slices of threads (workgroup b -> slice
+  // b % S), every thread keeps eight loads in flight, the slices' partial sums meet in LDS in slice order: a fixed order, ~nb / S round trips
+  // instead of nb (a lone thread per entry walking 512 rows took longer than the kernel's own work)
+  __shared__ double slice_sum[TBW];
+  const int nb = (int)gridDim.x;
+  for (int i0 = 0; i0 < n; i0 += TBW) {
+    const int cols = min(n - i0, TBW);
+    const int S = max(TBW / cols, 1), sl = (int)threadIdx.x / cols, i = i0 + (int)threadIdx.x % cols;
+    double t = 0.0;
+    if (sl < S) {
+      int b = sl;
+      for (; b + 7 * S < nb; b += 8 * S) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __hip_atomic_load(scratch + (size_t)(b + u * S) * ns + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += v[u];
+      }
+      for (; b < nb; b += S) t += __hip_atomic_load(scratch + (size_t)b * ns + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      slice_sum[sl * cols + (i - i0)] = t;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < cols) {
+      double tot = 0.0;
+      for (int q = 0; q < S; ++q) tot += slice_sum[q * cols + threadIdx.x];
+      out[i0 + threadIdx.x] = (float)tot;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *ticket = 0u;
+}
+inline unsigned persistent_grid(int64_t n_rows, int n_cu) {
+  return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_rows * 64 + TBW - 1) / TBW, (int64_t)n_cu * 2));
+}
+}  // namespace
+
+extern "C" int64_t rgcn_basis_sum_workspace_bytes(int32_t R, int32_t B) {
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+  return (int64_t)2 * v * (((int64_t)R * B + 15) & ~(int64_t)15) * (int64_t)sizeof(double) + 256;     // (rows of whole lines; ticket + alignment slack)
+}
+
 namespace {
 template <int B>
 __global__ __launch_bounds__(TB) void fbasis_small_bwd_kernel(
     const float *__restrict__ G, const float *__restrict__ table, const float *__restrict__ comps, float *__restrict__ dB,
     float *__restrict__ dC, const int *__restrict__ rowptr, const int *__restrict__ p_src, const int *__restrict__ p_rel,
-    const float *__restrict__ p_val, long long n_rows, int R, int d, int lpm) {
+    const float *__restrict__ p_val, long long n_rows, int R, int d, int lpm, long long bstride) {
   extern __shared__ __attribute__((aligned(16))) double dcl[];          // [R][B]
   for (int i = threadIdx.x; i < R * B; i += TB) dcl[i] = 0.0;
   __syncthreads();
@@ -736,7 +800,8 @@ __global__ __launch_bounds__(TB) void fbasis_small_bwd_kernel(
     f32x4 blk[B], a[B];
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-      blk[b] = on ? *reinterpret_cast<const f32x4 *>(table + ((size_t)row * B + b) * d + f) : f32x4{0.f, 0.f, 0.f, 0.f};
+      // bstride: floats between a node's consecutive bases -- d for the node-major table [N, B, d], N d for the parameter's own [B, N, d]
+      blk[b] = on ? *reinterpret_cast<const f32x4 *>(table + (bstride == d ? ((size_t)row * B + b) * d : (size_t)b * bstride + (size_t)row * d) + f) : f32x4{0.f, 0.f, 0.f, 0.f};
       a[b] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (int eb = e0 + sub; eb < e1; eb += ngrp * MB) {
@@ -769,10 +834,12 @@ __global__ __launch_bounds__(TB) void fbasis_small_bwd_kernel(
       for (int c = 0; c < 4; ++c) a[b][c] = group_sum(a[b][c], lpm);
     if (sub == 0 && on) {
 #pragma unroll
-      for (int b = 0; b < B; ++b) *reinterpret_cast<f32x4 *>(dB + ((size_t)row * B + b) * d + f) = a[b];
+      for (int b = 0; b < B; ++b) *reinterpret_cast<f32x4 *>(dB + (bstride == d ? ((size_t)row * B + b) * d : (size_t)b * bstride + (size_t)row * d) + f) = a[b];
     }
   }
   __syncthreads();
+  // (atomics on the zeroed table: this kernel wants many small workgroups -- 1024-thread persistent ones with the ordered flush of the
+  // CSR dcomps kernel below were 15 % slower at S2 --, and 2048 tables cannot meet in one workgroup's time)
   for (int i = threadIdx.x; i < R * B; i += TB) {
     const float t = (float)dcl[i];
     if (t != 0.f) atomicAdd(dC + i, t);
@@ -780,13 +847,94 @@ __global__ __launch_bounds__(TB) void fbasis_small_bwd_kernel(
 }
 }  // namespace
 
+// dcomps of the aggregate-then-contract basis layer on the DESTINATION-major CSR the forward already walks (round 5; the relation-major
+// form above needs the relation-major plan: a dozen launches to build per call on a per-step LP graph -- more than the kernel itself on
+// the WN18-shaped step).  dcomps[r,b] = sum_e val_e <X[src_e], D[dst_e, b, :]>: one wave per destination row holds the row's B blocks of D
+// in registers (read once), gathers X[src] once per message, and adds the B dot products to an LDS table [R][B] of DOUBLES (ds_add_f64);
+// persistent workgroups, one flush each.  lpm lanes per message (16-byte loads), 64 / lpm messages of a row in flight.
+namespace {
+template <int NB>
+__global__ __launch_bounds__(TBW) void basis_dcomps_csr_kernel(
+    const float *__restrict__ X, const float *__restrict__ D, float *__restrict__ dC, const int *__restrict__ rowptr,
+    const int *__restrict__ p_src, const int *__restrict__ p_rel, const float *__restrict__ p_val, long long n_rows, int R, int B, int d,
+    int lpm, double *__restrict__ scratch, unsigned *__restrict__ ticket) {
+  extern __shared__ __attribute__((aligned(16))) double dcl[];          // [R][B]
+  for (int i = threadIdx.x; i < R * B; i += TBW) dcl[i] = 0.0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / lpm, il = lane % lpm, ngrp = 64 / lpm;
+  const long long wave0 = ((long long)blockIdx.x * TBW + threadIdx.x) >> 6, nw = ((long long)gridDim.x * TBW) >> 6;
+  for (long long row = wave0; row < n_rows; row += nw) {
+    const int e0 = rowptr[row], e1 = rowptr[row + 1];
+    if (e0 == e1) continue;
+    for (int f0 = 0; f0 < d; f0 += 4 * lpm) {
+      const int f = f0 + 4 * il;
+      const bool on = f < d;
+      f32x4 blk[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        blk[b] = (on && b < B) ? *reinterpret_cast<const f32x4 *>(D + ((size_t)row * B + b) * d + f) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int eb = e0 + sub; eb < e1 + sub; eb += ngrp) {            // (every group runs the same trips: the shuffles below are wave-wide)
+        const bool live = eb < e1;
+        const int e = min(eb, e1 - 1);
+        const float v = live ? p_val[e] : 0.f;
+        const int r = p_rel[e];
+        const f32x4 x = on ? *reinterpret_cast<const f32x4 *>(X + (size_t)p_src[e] * d + f) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          float dot = blk[b][0] * x[0] + blk[b][1] * x[1] + blk[b][2] * x[2] + blk[b][3] * x[3];
+          for (int off = 1; off < lpm; off <<= 1) dot += __shfl_xor(dot, off, 64);
+          if (il == 0 && b < B && v != 0.f)
+            __hip_atomic_fetch_add(dcl + r * B + b, (double)(v * dot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  table_flush_ordered(dcl, R * B, scratch, ticket, dC);
+}
+}  // namespace
+
+extern "C" int rgcn_basis_dcomps_csr_supported(int32_t R, int32_t B, int32_t d) {
+  return B >= 1 && B <= 8 && d >= 4 && (d & 3) == 0 && d <= 1024 && (size_t)R * B * sizeof(double) <= 60 * 1024;
+}
+
+extern "C" int rgcn_basis_dcomps_csr_f32(const float *X, const float *D, float *dcomps, const int32_t *rowptr, const int32_t *p_src,
+                                         const int32_t *p_rel, const float *p_val, int64_t n_rows, int32_t R, int32_t B, int32_t d,
+                                         void *workspace, void *stream) {
+  if (!X || !D || !dcomps || !rowptr || !workspace || n_rows < 0 || R <= 0) { rgcn_set_error("basis_dcomps_csr: bad argument"); return RGCN_EINVAL; }
+  if (!rgcn_basis_dcomps_csr_supported(R, B, d)) { rgcn_set_error("basis_dcomps_csr: B = %d (1..8), d = %d (multiple of 4), R = %d", B, d, R); return RGCN_EUNSUPPORTED; }
+  if (((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(D)) & 15) != 0) { rgcn_set_error("basis_dcomps_csr: X / D must be 16-byte aligned"); return RGCN_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  if (!n_rows) { HIP_TRY(zero_async(dcomps, (size_t)R * B * sizeof(float), st)); return RGCN_OK; }
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0, v = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+    n_cu = v > 0 ? v : 256;
+  }
+  const unsigned grid = persistent_grid(n_rows, n_cu);
+  const size_t lds = (size_t)R * B * sizeof(double);
+  int lpm = 1;
+  while (lpm < 64 && 4 * lpm < d) lpm *= 2;
+  unsigned *ticket = reinterpret_cast<unsigned *>(workspace);            // (the first bytes: zeroed by the caller once, left zeroed)
+  double *scratch = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(workspace) + 128 + 127) & ~(uintptr_t)127);   // line-aligned rows
+#define RGCN_BDC(NB_) hipLaunchKernelGGL(basis_dcomps_csr_kernel<NB_>, dim3(grid), dim3(TBW), lds, st, X, D, dcomps, rowptr, p_src, p_rel, p_val, \
+                                         (long long)n_rows, R, B, d, lpm, scratch, ticket)
+  if (B <= 2) RGCN_BDC(2); else if (B <= 4) RGCN_BDC(4); else RGCN_BDC(8);
+#undef RGCN_BDC
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
 extern "C" int rgcn_fbasis_small_supported(int32_t R, int32_t B, int32_t d) {
   return B >= 1 && B <= 4 && d >= 4 && d <= 64 && (d & 3) == 0 && (d & (d - 1)) == 0 && (size_t)R * B * sizeof(double) <= 60 * 1024;
 }
 
 extern "C" int rgcn_fbasis_small_bwd_f32(const float *G, const float *table, const float *comps, float *dbases, float *dcomps,
                                          const int32_t *rowptr, const int32_t *p_src, const int32_t *p_rel, const float *p_val,
-                                         int64_t n_rows, int32_t R, int32_t B, int32_t d, void *stream) {
+                                         int64_t n_rows, int32_t R, int32_t B, int32_t d, int32_t basis_major, void *stream) {
   if (!G || !table || !comps || !dbases || !dcomps || !rowptr || n_rows < 0 || R <= 0) { rgcn_set_error("fbasis_small_bwd: bad argument"); return RGCN_EINVAL; }
   if (!rgcn_fbasis_small_supported(R, B, d)) { rgcn_set_error("fbasis_small_bwd: B = %d (1..4), d = %d (power of two, 4..64), R = %d", B, d, R); return RGCN_EUNSUPPORTED; }
   if (((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(dbases)) & 15) != 0) {
@@ -807,7 +955,7 @@ extern "C" int rgcn_fbasis_small_bwd_f32(const float *G, const float *table, con
   const size_t lds = (size_t)R * B * sizeof(double);
   const int lpm = d / 4;
 #define RGCN_FBS(BB) hipLaunchKernelGGL(fbasis_small_bwd_kernel<BB>, dim3(grid), dim3(TB), lds, st, G, table, comps, dbases, dcomps, rowptr, p_src, \
-                                        p_rel, p_val, (long long)n_rows, R, d, lpm)
+                                        p_rel, p_val, (long long)n_rows, R, d, lpm, basis_major ? (long long)n_rows * d : (long long)d)
   if (B == 1) RGCN_FBS(1); else if (B == 2) RGCN_FBS(2); else if (B == 3) RGCN_FBS(3); else RGCN_FBS(4);
 #undef RGCN_FBS
   HIP_TRY(hipGetLastError());

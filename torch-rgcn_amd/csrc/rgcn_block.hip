@@ -422,9 +422,8 @@ extern "C" int rgcn_block_spmm_f32(const float *X, const float *blocks, const fl
   const int4 *un = reinterpret_cast<const int4 *>(units);
   // table in LDS: worth it when the graph is large enough to amortise 512 table loads (and the table fits)
   const size_t table_bytes = (size_t)n_rel_blocks * nb * bi * bo * sizeof(float);
-  const int lds_mode = rgcn_option_value(RGCN_OPT_BLOCK_LDS);
   const size_t lds_bytes = table_bytes + (size_t)n_rel_blocks * 4 * sizeof(float);          // + the per-relation pad
-  if (bi == 4 && bo == 4 && lds_mode && lds_bytes <= LDS_TABLE_BYTES && n_units >= 64 * 1024) {
+  if (bi == 4 && bo == 4 && lds_bytes <= LDS_TABLE_BYTES && n_units >= 64 * 1024) {
     const dim3 pgrid((unsigned)std::min<int64_t>(512, (n_units * lr + BIG_WG - 1) / BIG_WG));
     auto launch = [&](auto kern, bool &raised) -> hipError_t {
       if (lds_bytes > 64 * 1024 && !raised) {     // once per process and kernel (not a stream operation: keep it out of captures)
@@ -438,8 +437,7 @@ extern "C" int rgcn_block_spmm_f32(const float *X, const float *blocks, const fl
       return hipGetLastError();
     };
     static bool raised_t = false, raised_n = false, raised_pt = false, raised_pn = false;
-    const int pipe = rgcn_option_value(RGCN_OPT_BLOCK_PIPE);
-    if (pipe && nb == 4 && un) {          // width 16: the software-pipelined form
+    if (nb == 4 && un) {          // width 16: the software-pipelined form
       const dim3 pg((unsigned)std::min<int64_t>(512, (n_units + BIG_WG / 16 - 1) / (BIG_WG / 16)));
       auto launch_p = [&](auto kern, bool &raised) -> hipError_t {
         if (lds_bytes > 64 * 1024 && !raised) {

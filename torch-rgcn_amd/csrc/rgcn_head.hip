@@ -80,7 +80,67 @@ __global__ __launch_bounds__(HB) void resize3_kernel(const float *__restrict__ s
     }
   }
 }
+
+// Loss head of the link-prediction experiments: loss = mean over the scored triples of the binary cross-entropy with logits, and
+// dscores = (sigmoid(x) - y) / T, one launch (reference experiments/predict_links.py:152-153: F.binary_cross_entropy_with_logits --
+// ATen: ~13 elementwise / reduction launches around 330 k scalars).  Every block writes its pieces of dscores and a partial sum in
+// double; the block that finishes LAST adds the partials in block order: one launch, bit-reproducible.
+constexpr int BCE_BLOCKS = HB;       // (the last block adds one partial per thread)
+__global__ __launch_bounds__(HB) void bce_head_kernel(const float *__restrict__ x, const float *__restrict__ y, float *__restrict__ loss,
+                                                       float *__restrict__ dx, double *__restrict__ partial, unsigned *__restrict__ ticket,
+                                                       long long T) {
+  __shared__ double part[HB];
+  __shared__ bool is_last;
+  double acc = 0.0;
+  const float inv = 1.f / (float)T;
+  for (long long i = (long long)blockIdx.x * HB + threadIdx.x; i < T; i += (long long)gridDim.x * HB) {
+    const float v = x[i], t = y[i];
+    const float e = expf(-fabsf(v));                         // the stable form ATen uses: max(x, 0) - x y + log1p(exp(-|x|))
+    acc += (double)(fmaxf(v, 0.f) - v * t + log1pf(e));
+    const float sg = v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    dx[i] = (sg - t) * inv;
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = HB / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    // one 128-byte line per block, by an agent-scope atomic exchange whose return is awaited before the ticket: see table_flush_ordered (rgcn_basis.hip)
+    const double seen = __hip_atomic_exchange(partial + 16 * blockIdx.x, part[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(seen));
+    is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (is_last) {                                            // the partials in block order, by the whole block (a lone thread's 256 dependent
+                                                            // round trips took longer than the rest of the kernel)
+    part[threadIdx.x] = threadIdx.x < gridDim.x ? __hip_atomic_load(partial + 16 * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    __syncthreads();
+    for (int off = HB / 2; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      loss[0] = (float)(part[0] / (double)T);
+      *ticket = 0u;                                          // ready for the next launch (a captured step replays this kernel)
+    }
+  }
+}
 }  // namespace
+
+extern "C" int rgcn_bce_head_workspace_bytes(void) { return (int)(BCE_BLOCKS * 128 + 256); }
+
+extern "C" int rgcn_bce_head_f32(const float *scores, const float *labels, float *loss, float *dscores, void *workspace, int64_t T,
+                                 void *stream) {
+  if (!scores || !labels || !loss || !dscores || !workspace || T <= 0) { rgcn_set_error("bce_head: bad argument"); return RGCN_EINVAL; }
+  const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((T + HB - 1) / HB, BCE_BLOCKS));
+  unsigned *ticket = reinterpret_cast<unsigned *>(workspace);
+  double *partial = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(workspace) + 128 + 127) & ~(uintptr_t)127);
+  hipLaunchKernelGGL(bce_head_kernel, dim3(grid), dim3(HB), 0, (hipStream_t)stream, scores, labels, loss, dscores, partial, ticket, (long long)T);
+  if (hipGetLastError() != hipSuccess) { rgcn_set_error("bce_head: launch failed"); return RGCN_EHIP; }
+  return RGCN_OK;
+}
 
 extern "C" int rgcn_resize3_f32(const float *src, float *dst, int64_t A, int32_t B, int32_t C, int32_t Bd, int32_t Cd, const float *src1,
                                 float *dst1, int32_t n1, int32_t n1d, void *stream) {

@@ -34,21 +34,12 @@ extern "C" const char *rgcn_csrc_sha(void) { return RGCN_CSRC_SHA; }
 namespace {
 struct OptEntry { const char *name; int32_t value; };
 OptEntry g_options[] = {
-    {"basis_vec4", 1},            // rgcn_basis_aggregate_f32: 16-byte loads when d % 4 == 0, d >= 16
-    {"block_lds", 1},             // rgcn_block_spmm_f32: block table in LDS
-    {"block_pipe", 1},            //   software-pipelined 4 x 4 kernel
     {"bwd_nw", 16},               // rgcn_bwd_lean_f32: waves per workgroup (16 / 8)
-    {"bwd_d", 4},                 // rgcn_bwd_fused_f32 (staging kernel): relations per barrier interval
-    {"bwd_waves", 0},             //   tiles per workgroup (0: 4 atomic / 8 deterministic)
-    {"bwd_u", 4},                 //   chunks in flight
     {"gemm_bm", 0},               // rgcn_gemm_f32: 0 auto, 64 / 128 rows per tile
     {"spmm_u", 4},                // rgcn_spmm_f32 hidden-16 kernel: chunks per loop iteration
     {"wgrad_rg", 1},              // rgcn_wgrad_tiled_f32 variants
     {"wgrad_u", 2},
-    {"distmult_one_launch", 0},   // rgcn_distmult_bwd_all_f32: one launch for the three gradients
-    {"rank_tile", 1},             // rgcn_distmult_score_all_f32: 1 LDS-staged; 22 / 24 / 42 / 44 register tiles
     {"bwd_abl", 0},               // ablation build only: timing experiments with WRONG results
-    {"rank_ablate", 0},
 };
 static_assert(sizeof(g_options) / sizeof(g_options[0]) == RGCN_OPT_COUNT, "option table out of step with enum RgcnOpt (rgcn_device.h)");
 }  // namespace
@@ -59,7 +50,7 @@ extern "C" int rgcn_set_option(const char *name, int32_t value) {
   for (auto &o : g_options)
     if (name && !strcmp(o.name, name)) {
 #ifndef RGCN_ABLATIONS
-      if ((!strcmp(name, "bwd_abl") || !strcmp(name, "rank_ablate")) && value) {
+      if (!strcmp(name, "bwd_abl") && value) {
         rgcn_set_error("set_option: %s exists in the ablation build only (make -C torch-rgcn_amd/csrc abl)", name);
         return RGCN_EUNSUPPORTED;
       }

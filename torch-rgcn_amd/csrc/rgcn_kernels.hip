@@ -1802,11 +1802,7 @@ extern "C" int rgcn_distmult_bwd_all_f32(const int32_t *rowptr_s, const int32_t 
   if (!n_nodes) return RGCN_OK;
   const unsigned gx = (unsigned)std::min<int64_t>((n_nodes + 3) / 4, 512);
   const size_t lds = (size_t)4 * ((size_t)n_rel * d + n_rel) * sizeof(float);
-  const int one_launch = rgcn_option_value(RGCN_OPT_DISTMULT_ONE_LAUNCH);
-  if (one_launch) {
-    hipLaunchKernelGGL(distmult_bwd_all_kernel<3>, dim3(gx), dim3(WG), lds, st, rowptr_s, other_s, rel_s, g_s, rowptr_o, other_o, rel_o,
-                       g_o, nodes, rel, dnodes, drel, dsbias, dpbias, dobias, (long long)n_nodes, n_rel, d);
-  } else {
+  {     // two launches (object side without LDS at full occupancy, then subject side + relation table): the one-launch form was measured slower
     const unsigned gx2 = (unsigned)std::min<int64_t>((n_nodes + 3) / 4, 256 * 32);
     hipLaunchKernelGGL(distmult_bwd_all_kernel<2>, dim3(gx2), dim3(WG), 0, st, rowptr_s, other_s, rel_s, g_s, rowptr_o, other_o, rel_o,
                        g_o, nodes, rel, dnodes, drel, dsbias, dpbias, dobias, (long long)n_nodes, n_rel, d);

@@ -72,103 +72,6 @@ __device__ __forceinline__ f32x4 mask_k4(f32x4 v, int k, int d) {
   return v;
 }
 
-// scores tile per workgroup: (32 TA) queries x (32 TB) candidates, a (16 TA) x (16 TB) block of MFMA tiles per wave.
-// Full K steps (all of k .. k+15 inside the row) run unmasked from two ping-pong operand buffers: while the MFMAs of one
-// step execute, the loads of the next are in flight and nothing but pointer bumps competes for the VALU.
-template <bool VEC, int TA, int TB>
-__global__ __launch_bounds__(WG) void score_all_kernel(
-    const float *__restrict__ qvec, const float *__restrict__ qb, const float *__restrict__ nodes,
-    const float *__restrict__ cbias, float *__restrict__ scores, int Q, long long N, int d, int head, int q_blocks, int ablate_arg) {
-#ifdef RGCN_ABLATIONS
-  const int ablate = ablate_arg;      // timing experiments (wrong results): ablation build only
-#else
-  constexpr int ablate = 0;
-  (void)ablate_arg;
-#endif
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = lane & 15, kq = lane >> 4;
-  // query block fastest: workgroups that are resident together share one slab of the entity table (L2), and the whole
-  // query matrix (Q x d) stays cached
-  const int q0 = (blockIdx.x % q_blocks) * (32 * TA) + (wave >> 1) * (16 * TA);
-  const long long c0 = (long long)(blockIdx.x / q_blocks) * (32 * TB) + (wave & 1) * (16 * TB);
-  const float *ap[TA], *bp[TB];
-#pragma unroll
-  for (int a = 0; a < TA; ++a) ap[a] = qvec + (size_t)min(q0 + 16 * a + i, Q - 1) * d;
-#pragma unroll
-  for (int b = 0; b < TB; ++b) bp[b] = nodes + (size_t)min(c0 + 16 * b + i, N - 1) * d;
-  f32x4 acc[TA][TB];
-#pragma unroll
-  for (int a = 0; a < TA; ++a)
-#pragma unroll
-    for (int b = 0; b < TB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 a0[TA], b0[TB], a1[TA], b1[TB];
-  if (ablate & 4) {
-    for (int a = 0; a < TA; ++a) a1[a] = f32x4{1.f, 2.f, 3.f, 4.f};
-    for (int b = 0; b < TB; ++b) b1[b] = f32x4{1.f, 2.f, 3.f, 4.f};
-  }
-  auto fetch = [&](f32x4 (&av)[TA], f32x4 (&bv)[TB], int k) {
-#pragma unroll
-    for (int a = 0; a < TA; ++a) av[a] = load_k4<VEC>(ap[a], k, d);
-#pragma unroll
-    for (int b = 0; b < TB; ++b) bv[b] = load_k4<VEC>(bp[b], k, d);
-  };
-  auto multiply = [&](const f32x4 (&av)[TA], const f32x4 (&bv)[TB]) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int a = 0; a < TA; ++a)
-#pragma unroll
-        for (int b = 0; b < TB; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][c], bv[b][c], acc[a][b], 0, 0, 0);
-  };
-  const int full = d / 16, k0 = 4 * kq;
-  if (full > 0) {
-    fetch(a0, b0, k0);
-    int t = 0;
-    for (; t + 2 <= full; t += 2) {
-      if (!(ablate & 4)) fetch(a1, b1, (ablate & 1) ? k0 : 16 * (t + 1) + k0);
-      __builtin_amdgcn_sched_barrier(0);   // loads stay above the MFMAs (hipcc would sink them to their first use)
-      multiply(a0, b0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (!(ablate & 4)) fetch(a0, b0, (ablate & 1) ? k0 : 16 * min(t + 2, full - 1) + k0);
-      __builtin_amdgcn_sched_barrier(0);
-      multiply(a1, b1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (t < full) multiply(a0, b0);        // odd number of full steps: a0/b0 hold the last one
-  }
-  if (d % 16) {                            // tail: k >= d zeroed
-    const int k = 16 * full + k0;
-    fetch(a0, b0, k);
-#pragma unroll
-    for (int a = 0; a < TA; ++a) a0[a] = mask_k4<VEC>(a0[a], k, d);
-#pragma unroll
-    for (int b = 0; b < TB; ++b) b0[b] = mask_k4<VEC>(b0[b], k, d);
-    multiply(a0, b0);
-  }
-  // D: lane 16*kq + i holds query rows 4kq..4kq+3 of the tile, candidate column i
-#pragma unroll
-  for (int a = 0; a < TA; ++a)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int qrow = q0 + 16 * a + 4 * kq + r;
-      if (qrow >= Q) continue;
-      float s1 = 0.f, s2 = 0.f;
-      if (qb) { s1 = qb[2 * qrow]; s2 = qb[2 * qrow + 1]; }
-#pragma unroll
-      for (int b = 0; b < TB; ++b) {
-        const long long col = c0 + 16 * b + i;
-        if (col >= N) continue;
-        float sc = acc[a][b][r];
-        if (qb) {   // layers.py:96: scores + (sbias[s] + pbias[p] + obias[o]), same association
-          const float cb = cbias[col];
-          sc += head ? ((cb + s1) + s2) : ((s2 + s1) + cb);
-        }
-        if (!(ablate & 2)) scores[(size_t)qrow * N + col] = sc;
-      }
-    }
-}
-
 // Same product with the operands staged through LDS: a workgroup owns 128 queries x 128 candidates (a 64 x 64 block
 // per wave), every K step's two 128 x 16 operand slabs are fetched from L2 ONCE per workgroup (the register-only kernel
 // fetches each slab twice, and 16 rows x 64 B per instruction is a poor shape for the L1), written to a double-buffered
@@ -318,14 +221,7 @@ extern "C" int rgcn_distmult_score_all_f32(const int64_t *batch, int64_t Q, int3
   hipLaunchKernelGGL(rank_query_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(WG), 0, st,
                      reinterpret_cast<const long long *>(batch), (int)Q, head, nodes, rel, sbias, pbias, obias, qvec,
                      qbias, d);
-  #ifdef RGCN_ABLATIONS
-  const int ablate = rgcn_option_value(RGCN_OPT_RANK_ABLATE);   // measurement only (ablation build)
-#else
-  constexpr int ablate = 0;
-#endif
-  const int tile_env = rgcn_option_value(RGCN_OPT_RANK_TILE);   // 1 = LDS-staged (default); TA*10 + TB = register-only variant
-  const int tile = (tile_env == 22 || tile_env == 24 || tile_env == 42 || tile_env == 44) ? tile_env : 1;
-  if (tile == 1) {
+  {     // (round 5: the register-only tile variants behind RGCN_RANK_TILE -- measured slower than this LDS-staged kernel in round 1 -- are gone)
     const int qbl = (int)((Q + 127) / 128);
     const int64_t nwg = ((n_nodes + 127) / 128) * qbl;
     if (nwg > INT32_MAX) { rgcn_set_error("distmult_score_all: too many scores in one call; split the batch"); return RGCN_EUNSUPPORTED; }
@@ -339,23 +235,6 @@ extern "C" int rgcn_distmult_score_all_f32(const int64_t *batch, int64_t Q, int3
     HIP_TRY(hipGetLastError());
     return RGCN_OK;
   }
-  const int TAv = tile / 10, TBv = tile % 10;
-  const int q_blocks = (int)((Q + 32 * TAv - 1) / (32 * TAv));
-  const int64_t n_wg = ((n_nodes + 32 * TBv - 1) / (32 * TBv)) * q_blocks;
-  if (n_wg > INT32_MAX) { rgcn_set_error("distmult_score_all: %lld x %lld scores in one call is too many; split the batch", (long long)Q, (long long)n_nodes); return RGCN_EUNSUPPORTED; }
-  const dim3 grid((unsigned)n_wg);
-  const float *qb = sbias ? qbias : nullptr, *cb = sbias ? (head ? sbias : obias) : nullptr;
-#define RGCN_SCORE(VECV, TAC, TBC)                                                                                   \
-  hipLaunchKernelGGL((score_all_kernel<VECV, TAC, TBC>), grid, dim3(WG), 0, st, qvec, qb, nodes, cb, scores, (int)Q, \
-                     (long long)n_nodes, d, head, q_blocks, ablate)
-  if (d % 4 == 0) {
-    if (tile == 22) RGCN_SCORE(true, 2, 2); else if (tile == 42) RGCN_SCORE(true, 4, 2); else if (tile == 24) RGCN_SCORE(true, 2, 4); else RGCN_SCORE(true, 4, 4);
-  } else {
-    if (tile == 22) RGCN_SCORE(false, 2, 2); else if (tile == 42) RGCN_SCORE(false, 4, 2); else if (tile == 24) RGCN_SCORE(false, 2, 4); else RGCN_SCORE(false, 4, 4);
-  }
-#undef RGCN_SCORE
-  HIP_TRY(hipGetLastError());
-  return RGCN_OK;
 }
 
 extern "C" int rgcn_rank_filter_f32(float *scores, int64_t Q, int64_t n_nodes, const int32_t *filt_q,

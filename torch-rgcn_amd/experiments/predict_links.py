@@ -15,13 +15,12 @@ import time
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 import yaml
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch_rgcn  # noqa: E402
 from torch_rgcn import routes  # noqa: E402
-from torch_rgcn.functional import unit_gradient  # noqa: E402
+from torch_rgcn.functional import bce_with_logits, unit_gradient  # noqa: E402
 from torch_rgcn.models import CompressionRelationPredictor, LinkPredictor  # noqa: E402
 from utils.data import load_link_prediction_data  # noqa: E402
 from utils.misc import evaluate, generate_true_dict, negative_sampling, select_sampling  # noqa: E402
@@ -130,7 +129,7 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None, synthetic=N
     def train_step(graph, batch_idx, train_lbl):
         optimiser.zero_grad(set_to_none=False)
         predictions, penalty = model(graph, batch_idx)
-        loss = F.binary_cross_entropy_with_logits(predictions, train_lbl) + decoder_l2_penalty * penalty
+        loss = bce_with_logits(predictions, train_lbl) + decoder_l2_penalty * penalty
         loss.backward(gradient=unit_gradient(loss.device))      # (no ones_like() fill per step; MaskedCrossEntropy skips the multiplication)
         optimiser.step()
         return loss
@@ -186,7 +185,7 @@ def run(cfg, data_dir=None, epochs=None, quiet=False, max_test=None, synthetic=N
             optimiser.zero_grad()
             graph, batch_idx, train_lbl = sample_inputs()
             predictions, penalty = model(graph, batch_idx)
-            loss = F.binary_cross_entropy_with_logits(predictions, train_lbl) + decoder_l2_penalty * penalty
+            loss = bce_with_logits(predictions, train_lbl) + decoder_l2_penalty * penalty
             t2 = time.time()
             loss.backward(gradient=unit_gradient(loss.device))
             optimiser.step()

@@ -42,6 +42,7 @@ def lib():
         L.rgcn_bwd_blk_rec_bytes.restype = ctypes.c_int64
         L.rgcn_colsum_scratch_floats.restype = ctypes.c_int64
         L.rgcn_gemm_scratch_floats.restype = ctypes.c_int64
+        L.rgcn_basis_sum_workspace_bytes.restype = ctypes.c_int64
         L.rgcn_last_error.restype = ctypes.c_char_p
         _lib = L
         defaults = {}
@@ -729,16 +730,18 @@ def fbasis_small_ok(R, B, d):
     return bool(lib().rgcn_fbasis_small_supported(c_i32(R), c_i32(B), c_i32(d)))
 
 
-def fbasis_small_bwd(G, table, comps, csr, B, d):
+def fbasis_small_bwd(G, table, comps, csr, B, d, basis_major=False):
     """featureless basis layer with small blocks (B <= 4), both gradients from ONE walk of the source-major CSR
-    (rgcn_fbasis_small_bwd_f32): table [N, B, d] node-major -> (dbases [N, B, d], dcomps [R, B])"""
+    (rgcn_fbasis_small_bwd_f32): table [N, B, d] node-major -> (dbases [N, B, d], dcomps [R, B]); basis_major: table and its gradient in
+    the parameter's own [B, N, d] layout (a node's B blocks are then B sequential streams: no transposed copy of the gradient)"""
     _req(G, "grad_output"); _req(table, "bases"); _req(comps, "comps")
     R = comps.shape[0]
-    dB = torch.empty((csr.n_rows, B, d), device=G.device, dtype=torch.float32)
+    dB = torch.empty_like(table)
     dC = torch.empty((R, B), device=G.device, dtype=torch.float32)
     with _on(G.device), _timed("fbasis_small_bwd"):
         _check(lib().rgcn_fbasis_small_bwd_f32(_dp(G), _dp(table), _dp(comps), _dp(dB), _dp(dC), _dp(csr.rowptr), _dp(csr.src), _dp(csr.rel),
-                                               _dp(csr.val), c_i64(csr.n_rows), c_i32(R), c_i32(B), c_i32(d), _stream(G.device)),
+                                               _dp(csr.val), c_i64(csr.n_rows), c_i32(R), c_i32(B), c_i32(d), c_i32(1 if basis_major else 0),
+                                               _stream(G.device)),
                "fbasis_small_bwd")
     return dB, dC
 
@@ -756,6 +759,36 @@ def basis_dcomps(X, D, plan, R, B, d, swap=False):
                                            _dp(plan.chunk_rel), _dp(plan.items), c_i64(plan.n_items), c_i32(R), c_i32(B),
                                            c_i32(d), c_i32(copies), _stream(X.device)), "basis_dcomps")
     return dc.sum(0) if copies > 1 else dc[0]
+
+
+_TABLE_WS = {}
+
+
+def _table_workspace(dev, R, B):
+    """workspace of the kernels that reduce per-workgroup R x B tables in a fixed order: one per device (launches that use it are ordered
+    on the step's stream; a capture's warm-up runs create it before the capture), zeroed at creation (every launch leaves its ticket
+    zeroed), grown when a larger table comes along"""
+    key = dev
+    need = int(lib().rgcn_basis_sum_workspace_bytes(c_i32(R), c_i32(B)))
+    ws = _TABLE_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _TABLE_WS[key] = torch.zeros(need, dtype=torch.uint8, device=dev)
+    return ws
+
+
+def basis_dcomps_csr_ok(R, B, d):
+    return bool(lib().rgcn_basis_dcomps_csr_supported(c_i32(R), c_i32(B), c_i32(d)))
+
+
+def basis_dcomps_csr(X, D, csr, R, B, d):
+    """dcomps[r,b] = sum_e val <X[src_e], D[dst_e, b, :]> on the destination-major CSR (rgcn_basis_dcomps_csr_f32): X [N, d], D [N, B*d]"""
+    _req(X, "features"); _req(D, "grad")
+    dc = torch.empty((R, B), device=X.device, dtype=torch.float32)
+    with _on(X.device), _timed("basis_dcomps_csr"):
+        _check(lib().rgcn_basis_dcomps_csr_f32(_dp(X), _dp(D), _dp(dc), _dp(csr.rowptr), _dp(csr.src), _dp(csr.rel), _dp(csr.val),
+                                               c_i64(csr.n_rows), c_i32(R), c_i32(B), c_i32(d), _dp(_table_workspace(X.device, R, B)),
+                                               _stream(X.device)), "basis_dcomps_csr")
+    return dc
 
 
 G_TRANS_A, G_TRANS_B = 1, 2
@@ -1469,6 +1502,24 @@ def ce_head(logits, row_label, lab_rows):
         _check(lib().rgcn_ce_head_f32(_dp(logits), _dp(row_label), _dp(lab_rows), _dp(loss), _dp(full), c_i64(N), c_i32(C), c_i32(ld),
                                       c_i32(lab_rows.shape[0]), _stream(logits.device)), "ce_head")
     return (loss, full, None) if ld == C else (loss, full[:, :C], full)
+
+
+_BCE_WS = {}
+
+
+def bce_head(scores, labels):
+    """(loss [1], dscores [T]) of the mean binary cross-entropy with logits (rgcn_bce_head_f32: one launch)"""
+    _req(scores, "scores"); _req(labels, "labels")
+    assert scores.dim() == 1 and labels.shape == scores.shape
+    dev = scores.device
+    ws = _BCE_WS.get(dev)
+    if ws is None:        # zeroed once; every launch leaves it zeroed (allocated outside any capture: the first call is the warm-up's)
+        ws = _BCE_WS[dev] = torch.zeros(int(lib().rgcn_bce_head_workspace_bytes()), dtype=torch.uint8, device=dev)
+    loss = torch.empty(1, device=dev, dtype=torch.float32)
+    ds = torch.empty_like(scores)
+    with _on(dev), _timed("bce_head"):
+        _check(lib().rgcn_bce_head_f32(_dp(scores), _dp(labels), _dp(loss), _dp(ds), _dp(ws), c_i64(scores.shape[0]), _stream(dev)), "bce_head")
+    return loss, ds
 
 
 def distmult_fwd(triples, nodes, rel, sbias, pbias, obias):

@@ -644,7 +644,11 @@ class _BasisMP(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dX = _native.basis_aggregate(d_ag, comps, ctx.graph.csr("bwd"), B, d_in, B)
         if ctx.needs_input_grad[2]:
-            dC = _native.basis_dcomps(X, d_ag, ctx.graph.wgt_plan(), comps.shape[0], B, d_in)
+            if getattr(ctx.graph, "per_call", False) and not deterministic() and _native.basis_dcomps_csr_ok(comps.shape[0], B, d_in):
+                # per-step (LP) graphs: on the CSR the forward walked -- building a relation-major plan for this one kernel costs a dozen launches
+                dC = _native.basis_dcomps_csr(X, d_ag, ctx.graph.csr("fwd"), comps.shape[0], B, d_in)
+            else:
+                dC = _native.basis_dcomps(X, d_ag, ctx.graph.wgt_plan(), comps.shape[0], B, d_in)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             db = _native.colsum(g)
         return dX, dB, dC, db, None
@@ -704,7 +708,11 @@ class _FeaturelessBasisMP(torch.autograd.Function):
         if bias is not None:
             out += bias
         ctx.graph, ctx.has_bias = graph, bias is not None
-        ctx.to_save = (table, comps)
+        # small blocks (S2: B = 2): the backward walks the sources in order and reads / writes their blocks as B sequential streams -- straight
+        # from the PARAMETER's [B, N, d] layout and into a gradient of that layout (round 5: no strided view for AccumulateGrad to copy);
+        # only the forward's per-message gather wants the node-major copy (one 128-byte line per message instead of B half-used ones)
+        ctx.small_in_place = (not deterministic()) and _native.fbasis_small_ok(comps.shape[0], B, d)
+        ctx.to_save = (dense(bases), comps) if ctx.small_in_place else (table, comps)
         return _relu_epilogue(ctx, out, relu)
 
     @staticmethod
@@ -740,14 +748,15 @@ class _FeaturelessBasisMP(torch.autograd.Function):
             db = _native.colsum(g) if ctx.has_bias and ctx.needs_input_grad[2] else None
             return dB, dC, db, None, None
         table, comps = ctx.saved_tensors[:2]
-        N, B, d = table.shape
         dB = dC = db = None
-        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not deterministic() and _native.fbasis_small_ok(comps.shape[0], B, d):
-            # small blocks (S2: B = 2, d = 16): one walk of the source-major CSR for both gradients (one gather per message)
-            dB, dC = _native.fbasis_small_bwd(g, table, comps, ctx.graph.csr("bwd"), B, d)
+        if getattr(ctx, "small_in_place", False):
+            # small blocks (S2: B = 2, d = 16): one walk of the source-major CSR for both gradients (one gather per message), in the parameter's layout
+            B, N, d = table.shape
+            dB, dC = _native.fbasis_small_bwd(g, table, comps, ctx.graph.csr("bwd"), B, d, basis_major=True)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = _native.colsum(g)
-            return dB.permute(1, 0, 2), dC, db, None, None
+            return (dB if ctx.needs_input_grad[0] else None), (dC if ctx.needs_input_grad[1] else None), db, None, None
+        N, B, d = table.shape
         if ctx.needs_input_grad[0]:
             dB = _native.basis_aggregate(g, comps, ctx.graph.csr("bwd"), B, d, 1).view(N, B, d).permute(1, 0, 2)
         if ctx.needs_input_grad[1]:
@@ -870,6 +879,26 @@ class _MaskedCE(torch.autograd.Function):
         if ctx.dl_full:      # dl = the first columns of a zero-padded [N, 16] buffer: the layer's backward takes the buffer as it is
             dl._rgcn_zero_padded = True
         return dl, None, None
+
+
+class _BCEWithLogits(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scores, labels):
+        loss, ds = _native.bce_head(dense(scores.reshape(-1)), dense(labels.reshape(-1).to(torch.float32)))
+        ctx.save_for_backward(ds)
+        ctx.shape = scores.shape
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        ds, = ctx.saved_tensors
+        return (ds if _is_unit(g) else ds * g).view(ctx.shape), None
+
+
+def bce_with_logits(scores, labels):
+    """`F.binary_cross_entropy_with_logits(scores, labels)` (mean reduction; reference experiments/predict_links.py:152-153) as ONE kernel for the
+    loss and its gradient instead of ATen's ~13 launches around a few hundred thousand scalars (rgcn_bce_head_f32); labels get no gradient"""
+    return _BCEWithLogits.apply(scores, labels)
 
 
 class MaskedCrossEntropy(torch.nn.Module):
