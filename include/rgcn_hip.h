@@ -288,17 +288,16 @@ RGCN_API int rgcn_wgrad_tiled_f32(const float *X, const float *G, float *dW, con
 #define RGCN_F_TRANSPOSE_W 8   /* rgcn_block_spmm_f32: multiply by the transposed blocks */
 #define RGCN_F_DIAG4 16        /* rgcn_bwd_blk_f32: W_r is block-diagonal with 4 x 4 blocks; only the diagonal blocks of dW_r are computed */
 RGCN_API int64_t rgcn_bwd_fused_scratch_floats(int64_t n_tiles, int32_t R);
-RGCN_API int rgcn_bwd_fused_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW,
-                                float *scratch, const int32_t *p_pack, const int32_t *chunk_rel,
-                                const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R,
-                                int32_t flags, void *stream);
+/* (rgcn_bwd_fused_f32 itself -- round 2's staging kernel, four wave-owned tiles per workgroup -- was the fallback of rounds 3-4 for
+ * wave-owned tiles of 65 .. 160 rows; nothing selected it by default and round 5 removed it.  The argument conventions above are those
+ * of the two kernels that follow.) */
 /* The same backward on a reformatted plan (round 3, "lean" kernel): per-chunk bookkeeping -- unpacking, duplicate / tail flags of the
  * fold, LDS row offsets -- is done once per plan instead of once per launch.
  *   rgcn_bwd_lean_slot_bytes(n_chunks)   size of the slot array (12 bytes per slot: source row << 6 | flags, val, tile row << 6)
  *   rgcn_bwd_lean_prepare_f32            p_pack / chunk_rel of the transposed plan (n_chunks = m_pad / 16) -> slots, hdr [n_chunks]
  *                                        (relation | fold flags); once per static graph, per call for per-call graphs
  *   rgcn_bwd_lean_supported(tile_rows)   1 when the kernel's LDS (dX tile + X tile + scratch per wave, 8 or 16 waves) fits
- *   rgcn_bwd_lean_f32                    arguments as rgcn_bwd_fused_f32 with (slots, hdr) in place of (p_pack, chunk_rel);
+ *   rgcn_bwd_lean_f32                    arguments as described above with (slots, hdr) in place of (p_pack, chunk_rel);
  *                                        flags RGCN_F_DW_ATOMIC, RGCN_F_RELU (dX masked with X > 0: X is a ReLU's output and
  *                                        dX is wanted before it -- the caller's F.relu backward, models.py:196 / autograd)
  * Same autograd duals of layers.py:293-301 as above; R < 65536. */
@@ -531,15 +530,7 @@ RGCN_API int rgcn_resize3_f32(const float *src, float *dst, int64_t A, int32_t B
 /* ------------------------------------------------------------------ dense contractions on the matrix cores
  * Basis decomposition (layers.py:241-242, :468-469: W_r = sum_b comps[r,b] bases[b]) at large width: the layer is
  * out = ag @ flat(bases) + bias with ag[s, b, :] = sum_e comps[r_e, b] val_e X[o_e, :].
- * rgcn_basis_fused_fwd_f32 (opt-in; the default forward is rgcn_basis_aggregate_f32 + rgcn_gemm_f32, measured faster at
- * WN18 size): aggregation of a 32-row destination tile into LDS, then the (B d_in) x d_out contraction with
- * v_mfma_f32_16x16x4_f32 straight from LDS -- ag is not written to HBM unless ag_out != NULL (training keeps it for the
- * backward's dbases = ag^T g).  CSR arguments as rgcn_basis_aggregate_f32; bases [B, d_in, d_out]; needs
- * 32 * (B d_in + pad) floats of LDS (RGCN_EUNSUPPORTED beyond 64 KiB: callers then aggregate + rgcn_gemm_f32). */
-RGCN_API int rgcn_basis_fused_fwd_f32(const float *X, const float *comps, const float *bases, const float *bias, float *out,
-                                      float *ag_out, const int32_t *rowptr, const int32_t *p_src, const int32_t *p_rel,
-                                      const float *p_val, int64_t n_rows, int32_t R, int32_t B, int32_t d_in, int32_t d_out,
-                                      void *stream);
+ * Forward = rgcn_basis_aggregate_f32 + rgcn_gemm_f32 (the fused aggregate-in-LDS kernel of rounds 1-4 was measured slower and is gone). */
 /* C[M,N] = op(A) op(B) (+ bias[n]); fp32 MFMA, LDS-tiled (128 x 128 x 16).  A is [M,K] (lda) or, with RGCN_G_TRANS_A,
  * stored [K,M]; B is [K,N] (ldb) or, with RGCN_G_TRANS_B, stored [N,K].  split_k > 1 cuts K into slices whose partial
  * products go to `scratch` (rgcn_gemm_scratch_floats) and are summed in a fixed order.  The backward of the basis path

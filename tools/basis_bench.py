@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The dense step of the basis path at WN18 size (N = 40,943, d = 200, B = 2): kernel times (HIP events) and achieved
 TFLOP/s of the fused aggregate-in-LDS + MFMA forward and of the two backward GEMMs (d_ag = g flat^T, dbases = ag^T g).
-Run under `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` for the matrix-core utilisation (tools/pmc_basis.sh)."""
+Run under `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` for the matrix-core utilisation (tools/prof.sh pmc)."""
 import json
 import os
 import sys
@@ -42,9 +42,7 @@ for tag, E in (("train graph (15,000 triples)", 15_000), ("eval graph (141,442 t
     flops = 2.0 * N * (B * d) * d
     M = int(csr.rowptr[-1].item())
     r = {"messages": M}
-    for name, fn, fl in (("basis_fused_fwd (aggregate in LDS + MFMA contract)", lambda: _native.basis_fused_fwd(X, comps, bases, bias, csr, False), flops),
-                         ("basis_fused_fwd, ag kept for the backward", lambda: _native.basis_fused_fwd(X, comps, bases, bias, csr, True), flops),
-                         ("basis_aggregate (to HBM) + gemm NN", lambda: _native.gemm(_native.basis_aggregate(X, comps, csr, B, d, 1), flat, bias=bias), flops),
+    for name, fn, fl in (("basis_aggregate (to HBM) + gemm NN", lambda: _native.gemm(_native.basis_aggregate(X, comps, csr, B, d, 1), flat, bias=bias), flops),
                          ("gemm NN alone: ag @ flat", lambda: _native.gemm(ag, flat, bias=bias), flops),
                          ("torch (rocBLAS) addmm: ag @ flat", lambda: torch.addmm(bias, ag, flat), flops),
                          ("gemm NT: d_ag = g @ flat^T", lambda: _native.gemm(G, flat, trans_b=True), flops),

@@ -41,175 +41,16 @@
 
 namespace {
 
-// BW_D = relations per barrier interval (<= 4 = waves per workgroup: wave w reduces relation BW_D iv + w), template parameter
 constexpr int BW_SCR = 16 * 20;      // floats of transposition scratch per wave (row stride 20: conflict-free b128 writes)
 
-template <int U>
-struct BwdStage {
-  int s[U];        // source row (of G) of slot m
-  float v[U];      // adjacency value of slot m
-  int d[U];        // destination row of slot m (-1: pad)
-  int dl[U];       // destination row inside the tile (0xFF: pad)
-  int r[U];        // relation (wave-uniform)
-  float4 g[U];     // gathered G[s_m][4k..4k+3]
-  float4 w[U];     // W_r^T fragment
-  float4 xn[U];    // X[o_m][4k..4k+3] (tile-local row of the destination)
-};
-
-template <int U, bool ATOMIC, int BW_D, int NW = 4>      // NW = waves (= tiles) per workgroup
-__global__ __launch_bounds__(64 * NW, 16 / NW) void bwd_fused_d16_kernel(
-    const float *__restrict__ G, const float *__restrict__ X, const float *__restrict__ Wtp, float *__restrict__ dX,
-    float *__restrict__ dWout, const int2 *__restrict__ p_pack, const int *__restrict__ chunk_rel,
-    const int *__restrict__ run_ptr, int n_tiles, int n_blocks, int tile_rows, int n_dst, int R) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int t = blockIdx.x * NW + wave;
-  const bool valid = t < n_tiles;
-  float *tile = lds + wave * tile_rows * 16;
-  float *xs = lds + NW * tile_rows * 16 + wave * BW_SCR;
-  float *stage = lds + NW * tile_rows * 16 + NW * BW_SCR;      // [wave][BW_D][256], fragment order
-  float *my_stage = stage + wave * (BW_D * 256);
-  const int row0 = t * tile_rows;
-  const int nrows = valid ? min(tile_rows, n_dst - row0) : 0;
-  for (int i = lane; i < nrows * 4; i += 64) reinterpret_cast<float4 *>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int q = 0; q < BW_D; ++q) reinterpret_cast<f32x4 *>(my_stage + q * 256)[lane] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int my0 = valid ? run_ptr[(size_t)t * (R + 1)] : 0, my1 = valid ? run_ptr[(size_t)t * (R + 1) + R] : 0;
-  const int m = lane & 15, k = lane >> 4;
-  const int n_iv = (R + BW_D - 1) / BW_D;
-  int iv = 0;                 // current interval: relations [BW_D iv, BW_D iv + BW_D)
-  int cur = -1;               // relation accumulating in acc_w (-1: none)
-  f32x4 acc_w = {0.f, 0.f, 0.f, 0.f};
-
-  // close the current interval: park the open partial, meet the other waves, reduce one relation, meet again
-  auto close_interval = [&]() {
-    if (cur >= 0) {
-      reinterpret_cast<f32x4 *>(my_stage + (cur - iv * BW_D) * 256)[lane] = acc_w;
-      cur = -1;
-      acc_w = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    __syncthreads();
-    const int r = iv * BW_D + wave;
-    if (wave < BW_D && r < R) {
-      f32x4 sum = reinterpret_cast<const f32x4 *>(stage + (0 * BW_D + wave) * 256)[lane];
-#pragma unroll
-      for (int w2 = 1; w2 < NW; ++w2) sum += reinterpret_cast<const f32x4 *>(stage + (w2 * BW_D + wave) * 256)[lane];
-      if (ATOMIC) {       // D: lane 16q+j holds rows 4q..4q+3 (input feature), column j (output feature)
-        float *wr = dWout + (size_t)r * 256 + (4 * k) * 16 + m;
-        atomicAdd(wr, sum[0]); atomicAdd(wr + 16, sum[1]); atomicAdd(wr + 32, sum[2]); atomicAdd(wr + 48, sum[3]);
-      } else {
-        reinterpret_cast<f32x4 *>(dWout + ((size_t)r * n_blocks + blockIdx.x) * 256)[lane] = sum;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < BW_D; ++q) reinterpret_cast<f32x4 *>(my_stage + q * 256)[lane] = f32x4{0.f, 0.f, 0.f, 0.f};
-    ++iv;
-  };
-
-  if (my0 < my1) {
-    const int last = my1 - 1;
-    // index data (packed slots + relations) of the NEXT group of U chunks is requested while the current group's gathers
-    // are in flight: a wave's iteration is then gather latency + compute, not index latency + gather latency + compute
-    // (0.77 -> 0.72 ms at S1)
-    int2 pk_n[U];
-    int relv_n;
-    auto request_idx = [&](int c) {
-      relv_n = chunk_rel[min(c + (lane & (U - 1)), last)];
-#pragma unroll
-      for (int j = 0; j < U; ++j) pk_n[j] = p_pack[min(c + j, last) * RGCN_CHUNK + m];
-    };
-    request_idx(my0);
-    for (int c = my0; c < my1; c += U) {
-      BwdStage<U> A;
-      // stage 1: unpack the slots requested one iteration ago (chunks past the range re-read the last chunk with val = 0);
-      // the U relations come from ONE vector load (a scalar load per chunk makes hipcc wait for each in turn)
-      const int relv = relv_n;
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        const int2 pk = pk_n[j];
-        A.s[j] = pk.x & 0xFFFFFF;
-        A.dl[j] = (int)((unsigned)pk.x >> 24);
-        A.d[j] = A.dl[j] == 0xFF ? -1 : row0 + A.dl[j];
-        A.v[j] = (c + j <= last) ? __builtin_bit_cast(float, pk.y) : 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < U; ++j) A.r[j] = __builtin_amdgcn_readlane(relv, j);
-#pragma unroll
-      for (int j = 0; j < U; ++j) asm volatile("" : "+v"(A.d[j]), "+v"(A.v[j]));   // pin the index data here
-      __builtin_amdgcn_sched_barrier(0);
-      // stage 2: the random gather, the W_r^T fragment, and the tile-local X rows in operand order
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        // 32-bit byte offsets from the uniform base pointers (packed slots: source ids < 2^24, so row << 6 fits): the loads take
-        // the scalar-base + vector-offset form instead of a 64-bit address per lane
-        const unsigned og = ((unsigned)A.s[j] << 6) | ((unsigned)k << 4);
-        const unsigned ox = ((unsigned)(row0 + (A.dl[j] == 0xFF ? 0 : A.dl[j])) << 6) | ((unsigned)k << 4);
-        A.g[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(G) + og);
-        A.w[j] = reinterpret_cast<const float4 *>(Wtp)[(size_t)A.r[j] * 64 + lane];
-        A.xn[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(X) + ox);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      request_idx(c + U);                  // behind the gathers in the (in-order) memory pipeline; used next iteration
-      __builtin_amdgcn_sched_barrier(0);
-      // stage 3: matrix cores
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        const float v = A.v[j];
-        const bool live = v != 0.f;
-        const f32x4 sc = {live ? A.g[j].x * v : 0.f, live ? A.g[j].y * v : 0.f, live ? A.g[j].z * v : 0.f,
-                          live ? A.g[j].w * v : 0.f};
-        // ---- dX
-        f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A.w[j].x, sc[0], acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A.w[j].y, sc[1], acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A.w[j].z, sc[2], acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A.w[j].w, sc[3], acc[0], 0, 0, 0);
-        if (fold_segments<1>(acc, A.d[j])) {
-          f32x4 *p = reinterpret_cast<f32x4 *>(tile + A.dl[j] * 16 + 4 * (k ^ ((A.dl[j] >> 2) & 3)));   // swizzled: see tile_swz
-          *p += acc[0];
-        }
-        // ---- dW: relation / interval bookkeeping (wave-uniform), then K over the chunk's 16 messages
-        const int rj = __builtin_amdgcn_readfirstlane(A.r[j]);
-        while (rj >= (iv + 1) * BW_D) close_interval();
-        if (rj != cur) {
-          if (cur >= 0) reinterpret_cast<f32x4 *>(my_stage + (cur - iv * BW_D) * 256)[lane] = acc_w;
-          acc_w = f32x4{0.f, 0.f, 0.f, 0.f};
-          cur = rj;
-        }
-        // both operands go through the wave's LDS scratch into K-over-messages layout (written as rows of a slot, read as
-        // one feature of four slots); the LDS pipeline is in order, so one scratch serves both
-        float bv[4], av[4];
-        asm volatile("" ::: "memory");
-        *reinterpret_cast<f32x4 *>(xs + m * 20 + 4 * k) = sc;                    // xs[slot m][4k..4k+3] = val G[s_m][4k..]
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) bv[t4] = xs[(4 * t4 + k) * 20 + m];       // B[mu][j = m], mu = 4 t4 + k
-        asm volatile("" ::: "memory");
-        const bool pad = A.dl[j] == 0xFF;                                        // pads contribute nothing (B is 0; keep A finite)
-        *reinterpret_cast<f32x4 *>(xs + m * 20 + 4 * k) = f32x4{pad ? 0.f : A.xn[j].x, pad ? 0.f : A.xn[j].y,
-                                                                pad ? 0.f : A.xn[j].z, pad ? 0.f : A.xn[j].w};
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) av[t4] = xs[(4 * t4 + k) * 20 + m];       // A[i = m][mu] = X[o_mu][m]
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) acc_w = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4], bv[t4], acc_w, 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  while (iv < n_iv) close_interval();
-
-  float4 *o4 = reinterpret_cast<float4 *>(dX + (size_t)row0 * 16);
-  for (int i = lane; i < nrows * 4; i += 64) o4[i] = reinterpret_cast<const float4 *>(tile)[tile_swz(i)];
-}
+// (Round 2's staging kernel described in the header -- bwd_fused_d16_kernel, rgcn_bwd_fused_f32: four wave-owned tiles per workgroup, the dW
+// partials parked in LDS staging slots and reduced across the waves at workgroup barriers -- was the fallback of rounds 3-4 for wave-owned
+// tiles of 65..160 rows and RGCN_BWD_KERNEL=stage; nothing selected it by default and round 5 removed it: such plans take the two-pass
+// backward.  Its measurements stay in profiles/r02_*; the byte ledger below is what led from it to the kernels that follow.)
 
 // ---- round 3: the same walk with everything tile-local ON the CU and no workgroup barrier in the loop.
 //
-// Byte ledger of the kernel above at S1 (profiles/r02_pmc_kernels.json: 4.18 GB of fabric traffic per launch for 1.64 GB
+// Byte ledger of round 2's staging kernel at S1 (profiles/r02_pmc_kernels.json: 4.18 GB of fabric traffic per launch for 1.64 GB
 // of algorithmic bytes, the kernel sits at the ~6.3 TB/s fabric ceiling): G gathers 2.69 GB + packed slots 0.24 GB are
 // inherent; the rest is (a) the tile's X rows re-fetched through the fabric (the random gathers evict them from L1 / L2
 // between a wave's chunks) and (b) the dW flush -- 3,906 workgroups x 101 relations x 1 KiB of fp32 atomics = 394 MB.
@@ -737,37 +578,6 @@ __global__ __launch_bounds__(WG) void pack_w16_pair_kernel(const float *__restri
   Wtp[i] = W[r * 256 + o * 16 + (4 * kk + c)];
 }
 
-struct BwdLaunch {
-  const float *G, *X, *Wtp;
-  float *dX, *dWout;
-  const int2 *pk;
-  const int *chunk_rel, *run_ptr;
-  int n_tiles, n_blocks, tile_rows, n_dst, R;
-  size_t lds;
-  hipStream_t st;
-};
-
-template <int U, bool AT, int D>
-void launch_bwd(const BwdLaunch &a) {
-  hipLaunchKernelGGL((bwd_fused_d16_kernel<U, AT, D>), dim3((unsigned)a.n_blocks), dim3(WG), a.lds, a.st, a.G, a.X, a.Wtp,
-                     a.dX, a.dWout, a.pk, a.chunk_rel, a.run_ptr, a.n_tiles, a.n_blocks, a.tile_rows, a.n_dst, a.R);
-}
-
-// 8 tiles per workgroup (512 threads, 2 workgroups per CU): half the dW flushes of the 4-tile form; needs > 64 KiB of LDS
-template <bool AT>
-hipError_t launch_bwd8(const BwdLaunch &a) {
-  auto kern = bwd_fused_d16_kernel<4, AT, 4, 8>;
-  static bool raised = false;                    // once per process (not a stream operation: keep it out of captures)
-  if (a.lds > 64 * 1024 && !raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (e != hipSuccess) return e;
-    raised = true;
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)a.n_blocks), dim3(512), a.lds, a.st, a.G, a.X, a.Wtp, a.dX, a.dWout, a.pk, a.chunk_rel,
-                     a.run_ptr, a.n_tiles, a.n_blocks, a.tile_rows, a.n_dst, a.R);
-  return hipGetLastError();
-}
-
 template <int NW, int NG>
 size_t bwd_lean_lds(int tile_rows) {
   return ((size_t)2 * NW * tile_rows * 16 + NW * BW_SCR2 + NG * WIN_GS * 256) * sizeof(float) + 4 * NG * sizeof(int);
@@ -811,13 +621,6 @@ hipError_t launch_bwd_lean_f(const LeanLaunch &a, bool relu) {
   }
 #endif
   return relu ? launch_bwd_lean<NW, NG, AT, true>(a) : launch_bwd_lean<NW, NG, AT, false>(a);
-}
-
-template <int U, bool AT>
-void launch_bwd_d(const BwdLaunch &a, int D) {
-  if (D == 4) launch_bwd<U, AT, 4>(a);
-  else if (D == 2) launch_bwd<U, AT, 2>(a);
-  else launch_bwd<U, AT, 1>(a);
 }
 
 }  // namespace
@@ -908,53 +711,6 @@ extern "C" int rgcn_bwd_lean_f32(const float *G, const float *X, const float *Wt
     hipLaunchKernelGGL(dw_reduce_b_kernel, dim3((unsigned)R), dim3(WG), 0, st, tmp, dW, S);
     HIP_TRY(hipGetLastError());
   }
-  return RGCN_OK;
-}
-
-extern "C" int rgcn_bwd_fused_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW,
-                                  float *scratch, const int32_t *p_pack, const int32_t *chunk_rel,
-                                  const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R,
-                                  int32_t flags, void *stream) {
-  if (!G || !X || !Wt_packed || !dX || !dW || !p_pack || !chunk_rel || !run_ptr || n_tiles <= 0 || tile_rows <= 0 ||
-      tile_rows > 255 || n_dst <= 0 || R <= 0) {
-    rgcn_set_error("bwd_fused: bad argument");
-    return RGCN_EINVAL;
-  }
-  const bool atomic = (flags & RGCN_F_DW_ATOMIC) != 0;
-  const bool relu = (flags & RGCN_F_RELU) != 0;
-  if (!atomic && !scratch) { rgcn_set_error("bwd_fused: the deterministic reduction needs a scratch buffer"); return RGCN_EINVAL; }
-  // round 2's staging kernel: the fallback for wave-owned tiles the lean kernel's LDS does not hold (65..160 rows) and
-  // RGCN_BWD_KERNEL=stage; rgcn_bwd_blk_f32 / rgcn_bwd_lean_f32 are the round-3 kernels
-  if (relu) { rgcn_set_error("bwd_fused: RGCN_F_RELU is implemented by rgcn_bwd_blk_f32 / rgcn_bwd_lean_f32 only (tile_rows = %d)", tile_rows); return RGCN_EUNSUPPORTED; }
-  const int DSEL = rgcn_option_value(RGCN_OPT_BWD_D);
-  const int Dv = DSEL >= 4 ? 4 : (DSEL >= 2 ? 2 : 1);
-  // tiles per workgroup: 8 halve the number of dW partials -- measured at S1 (profiles/r02_bwd_fused_ablation.txt): atomic flush
-  // 0.719 -> 0.740 ms (the barrier now waits for the slowest of 8 waves, which costs more than the saved atomics), plain-store
-  // flush of the deterministic mode 0.798 -> 0.769 ms (half the partial bytes) -- so 8 only there
-  const int NWSEL = rgcn_option_value(RGCN_OPT_BWD_WAVES);
-  const int NWwant = NWSEL ? NWSEL : (atomic ? 4 : 8);
-  const int NWv = (NWwant >= 8 && Dv == 4 && tile_rows <= 64) ? 8 : 4;
-  const size_t lds = ((size_t)NWv * tile_rows * 16 + NWv * BW_SCR + NWv * Dv * 256) * sizeof(float);
-  if (lds > (NWv == 8 ? 80 : 64) * 1024) { rgcn_set_error("bwd_fused: tile_rows = %d needs %zu bytes of LDS per workgroup", tile_rows, lds); return RGCN_EUNSUPPORTED; }
-  hipStream_t st = (hipStream_t)stream;
-  const int n_blocks = (int)((n_tiles + NWv - 1) / NWv);
-  const int USEL = rgcn_option_value(RGCN_OPT_BWD_U);
-  const int2 *pk = reinterpret_cast<const int2 *>(p_pack);
-  const BwdLaunch L{G, X, Wt_packed, dX, atomic ? dW : scratch, pk, chunk_rel, run_ptr, (int)n_tiles, n_blocks, tile_rows,
-                    (int)n_dst, R, lds, st};
-  if (atomic) {
-    HIP_TRY(zero_async(dW, (size_t)R * 256 * sizeof(float), st));
-    if (NWv == 8) HIP_TRY(launch_bwd8<true>(L));
-    else if (USEL >= 4) launch_bwd_d<4, true>(L, Dv); else launch_bwd_d<2, true>(L, Dv);
-  } else {
-    if (NWv == 8) HIP_TRY(launch_bwd8<false>(L));
-    else if (USEL >= 4) launch_bwd_d<4, false>(L, Dv); else launch_bwd_d<2, false>(L, Dv);
-    const int S = (int)std::max<int64_t>(1, std::min<int64_t>(16, n_blocks / 64));
-    float *tmp = scratch + (size_t)n_blocks * R * 256;
-    hipLaunchKernelGGL(dw_reduce_a_kernel, dim3((unsigned)R, (unsigned)S), dim3(WG), 0, st, scratch, tmp, n_blocks, S);
-    hipLaunchKernelGGL(dw_reduce_b_kernel, dim3((unsigned)R), dim3(WG), 0, st, tmp, dW, S);
-  }
-  HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
 

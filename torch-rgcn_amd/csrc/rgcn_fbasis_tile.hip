@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(TW) void fbn_bwd_kernel(
     const float *__restrict__ bases, const float *__restrict__ comps, const float *__restrict__ G, float *__restrict__ dbases,
     float *__restrict__ dC, const int *__restrict__ rowptr, const int *__restrict__ e_dst, const int *__restrict__ e_rel,
     const float *__restrict__ e_val, int n_tiles, int N, int R, int B, int d, int ts, int last, int gstride, int gn, int abl) {
-  constexpr int GS = 4 * NKD;                               // NBTM = ceil(B / 16): the 16-row tiles of bases, a template parameter (registers)
+  // (NBTM = ceil(B / 16): the 16-row tiles of bases, a template parameter -- registers)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k = lane >> 4, c = lane & 15;

@@ -5,13 +5,6 @@
 //     out[s] = sum_b ( sum_e comps[r_e,b] val_e X[o_e] ) bases[b] + bias  =  ag[s, :] @ flat(bases) + bias,
 // ag[N, B d_in] the per-basis aggregation and flat(bases) [B d_in, d_out]: the "(B V) H" contraction north_star assigns to
 // MFMA.  Here:
-//   basis_fused_fwd_kernel   (opt-in, RGCN_BASIS_FUSED=1: measured slower than aggregate + gemm at WN18 size, 0.20 vs 0.17 ms,
-//                            but needs no N x (B d_in) buffer) one workgroup per tile of 32 destination rows: phase 1
-//                            aggregates the tile's ag rows into LDS
-//                            (one wave per row at a time, registers -> one LDS row write), phase 2 multiplies the 32 x (B d_in)
-//                            LDS tile by flat(bases) with v_mfma_f32_16x16x4_f32 (A operand: ds_read_b128 from the tile,
-//                            B operand: L2-resident bases) and writes out + bias.  ag never goes to HBM unless the caller
-//                            wants it kept for the backward (training).
 //   gemm_kernel              LDS-tiled fp32 MFMA GEMM, 128 x 128 x 16 tiles, double-buffered, either operand K-inner or
 //                            K-outer, optional split-K with a fixed-order reduction: the backward's two products
 //                            d_ag = g flat^T  and  dbases = ag^T g  (and the wide-block / generic fallbacks).
@@ -449,133 +442,6 @@ __global__ __launch_bounds__(WG) void segment_gather_sum_wide_kernel(const float
   }
 }
 
-// ------------------------------------------------------------------ fused basis forward
-// LDS: ag tile [FT rows][ldk] with ldk = B d_in rounded up so that (ldk % 32) == 4 (16 rows x 4 k-groups of a ds_read_b128
-// spread over the banks).  K = B d_in is padded with zeros to a multiple of 16.
-constexpr int FT = 32;
-
-__global__ __launch_bounds__(WG) void basis_fused_fwd_kernel(
-    const float *__restrict__ X, const float *__restrict__ comps, const float *__restrict__ flat /* [B d_in][d_out] */,
-    const float *__restrict__ bias, float *__restrict__ out, float *__restrict__ ag_out /* [N][B d_in] or NULL */,
-    const int *__restrict__ rowptr, const int *__restrict__ p_src, const int *__restrict__ p_rel,
-    const float *__restrict__ p_val, int n_rows, int B, int d_in, int d_out, int ldk) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];      // [FT][ldk]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int row0 = blockIdx.x * FT;
-  const int K = B * d_in, Kp = (K + 15) & ~15;
-
-  // ---- phase 1: ag[row][b][:] = sum_e comps[rel_e][b] val_e X[src_e][:]      (wave w: rows w, w + 4, ...)
-  for (int rl = wave; rl < FT; rl += 4) {
-    const int row = row0 + rl;
-    float *trow = tile + (size_t)rl * ldk;
-    for (int kx = K + lane; kx < ldk; kx += 64) trow[kx] = 0.f;          // K tail / padding columns
-    if (row >= n_rows) {
-      for (int kx = lane; kx < K; kx += 64) trow[kx] = 0.f;
-      continue;
-    }
-    const int e0 = rowptr[row], e1 = rowptr[row + 1];
-    for (int f0 = 0; f0 < d_in; f0 += 256) {                            // a lane carries 4 features; 256 per pass
-      const int f = f0 + 4 * lane;
-      const bool on = f < d_in;
-      for (int b0 = 0; b0 < B; b0 += 4) {                               // up to 4 bases per pass in registers
-        f32x4 a[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int eb = e0; eb < e1; eb += 4) {                           // 4 messages' loads in flight together
-          f32x4 x[4];
-          float c[4][4];
-#pragma unroll
-          for (int mm = 0; mm < 4; ++mm) {
-            const int e = min(eb + mm, e1 - 1);
-            const float v = (eb + mm < e1) ? p_val[e] : 0.f;
-            const float *xr = X + (size_t)p_src[e] * d_in;
-            if (on && f + 3 < d_in && (d_in & 3) == 0) {
-              x[mm] = *reinterpret_cast<const f32x4 *>(xr + f);
-            } else {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) x[mm][q] = (f + q < d_in) ? xr[f + q] : 0.f;
-            }
-            const float *cp = comps + (size_t)p_rel[e] * B + b0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) c[mm][q] = (b0 + q < B) ? cp[q] * v : 0.f;
-          }
-#pragma unroll
-          for (int mm = 0; mm < 4; ++mm)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] += x[mm] * c[mm][q];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (b0 + q < B && on) {
-            float *dst = trow + (size_t)(b0 + q) * d_in + f;
-#pragma unroll
-            for (int z = 0; z < 4; ++z)
-              if (f + z < d_in) dst[z] = a[q][z];
-          }
-      }
-    }
-  }
-  __syncthreads();
-  if (ag_out) {     // training: the backward's dbases = ag^T g needs the aggregation again -- keep it (coalesced rows)
-    for (int idx = tid; idx < FT * K; idx += WG) {
-      const int rl = idx / K, kx = idx - rl * K;
-      if (row0 + rl < n_rows) ag_out[(size_t)(row0 + rl) * K + kx] = tile[(size_t)rl * ldk + kx];
-    }
-  }
-
-  // ---- phase 2: out[32, d_out] = tile[32, Kp] @ flat[Kp, d_out]: wave w takes the 16-column tiles w, w + 4, ... (both
-  // 16-row halves: the B operand, read from L2 in operand layout, feeds two MFMAs).  Measured alternative: staging the B
-  // operand through a double-buffered LDS slab shared by the four waves -- 0.24 ms against 0.20 ms at WN18 size (a barrier
-  // per 16 MFMAs of a wave); see profiles/r02_basis_bench.json.
-  const int i = lane & 15, kq = lane >> 4;
-  const int n_ct = (d_out + 15) / 16;
-  for (int ct0 = wave; ct0 < n_ct; ct0 += 16) {          // up to 4 column tiles per pass
-    f32x4 acc[2][4];
-    int col[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      col[j] = (ct0 + 4 * j) * 16 + i;
-      acc[0][j] = acc[1][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    for (int k0 = 0; k0 < Kp; k0 += GK) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4 *>(tile + (size_t)i * ldk + k0 + 4 * kq);
-      const f32x4 a1 = *reinterpret_cast<const f32x4 *>(tile + (size_t)(16 + i) * ldk + k0 + 4 * kq);
-      float bv[4][4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int kx = k0 + 4 * kq + c;
-          bv[j][c] = (ct0 + 4 * j < n_ct && col[j] < d_out && kx < K) ? flat[(size_t)kx * d_out + col[j]] : 0.f;
-        }
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c], bv[j][c], acc[0][j], 0, 0, 0);
-          acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c], bv[j][c], acc[1][j], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = row0 + 16 * h + 4 * kq + r;
-        if (row >= n_rows) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (ct0 + 4 * j < n_ct && col[j] < d_out)
-            out[(size_t)row * d_out + col[j]] = acc[h][j][r] + (bias ? bias[col[j]] : 0.f);
-      }
-  }
-}
-
-int fused_ldk(int K) {
-  int ldk = (K + 15) & ~15;
-  while ((ldk & 31) != 4) ldk += 4;
-  return ldk;
-}
-
 }  // namespace
 
 extern "C" int64_t rgcn_gemm_scratch_floats(int64_t M, int64_t N, int64_t K, int32_t split_k) {
@@ -629,25 +495,6 @@ extern "C" int rgcn_gemm_f32(const float *A, const float *B, const float *bias, 
     hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)std::min<long long>((n + WG - 1) / WG, 4096)), dim3(WG), 0, st, scratch,
                        bias, C, n, (int)N, S, (long long)ldc);
   }
-  HIP_TRY(hipGetLastError());
-  return RGCN_OK;
-}
-
-extern "C" int rgcn_basis_fused_fwd_f32(const float *X, const float *comps, const float *bases, const float *bias, float *out,
-                                        float *ag_out, const int32_t *rowptr, const int32_t *p_src, const int32_t *p_rel,
-                                        const float *p_val, int64_t n_rows, int32_t R, int32_t B, int32_t d_in, int32_t d_out,
-                                        void *stream) {
-  (void)R;
-  if (!X || !comps || !bases || !out || !rowptr || n_rows < 0 || B <= 0 || d_in <= 0 || d_out <= 0) {
-    rgcn_set_error("basis_fused_fwd: bad argument");
-    return RGCN_EINVAL;
-  }
-  const int ldk = fused_ldk(B * d_in);
-  const size_t lds = (size_t)FT * ldk * sizeof(float);
-  if (lds > 64 * 1024) { rgcn_set_error("basis_fused_fwd: B * d_in = %d is too wide for the LDS tile", B * d_in); return RGCN_EUNSUPPORTED; }
-  if (!n_rows) return RGCN_OK;
-  hipLaunchKernelGGL(basis_fused_fwd_kernel, dim3((unsigned)((n_rows + FT - 1) / FT)), dim3(WG), lds, (hipStream_t)stream, X,
-                     comps, bases, bias, out, ag_out, rowptr, p_src, p_rel, p_val, (int)n_rows, B, d_in, d_out, ldk);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

@@ -623,7 +623,7 @@ def fbasis_bwd(table, comps, g, plan, need_bases=True, need_comps=True, basis_ma
     dB = torch.empty_like(bases) if need_bases else None
     dC = torch.empty(R, B, device=dev, dtype=torch.float32) if need_comps else None
     units, n_units, n_split = plan.units_src
-    if need_comps and routes.get("fbasis_dc", "1") != "0" and not routes.flag("deterministic") and \
+    if need_comps and not routes.flag("deterministic") and \
             lib().rgcn_fbasis_bwd_dc_supported(c_i32(R), c_i32(B), c_i32(d)):
         # dcomps summed in an LDS table of doubles inside the walk: no [M, B] scratch, no second pass
         with _on(dev), _timed("fbasis_bwd"):
@@ -817,28 +817,6 @@ def gemm(A, B, bias=None, trans_a=False, trans_b=False, split_k=1):
     return C
 
 
-def basis_fused_supported(B, d_in):
-    """the 32-row ag tile of the fused basis kernel must fit 64 KiB of LDS"""
-    ldk = (B * d_in + 15) & ~15
-    while ldk & 31 != 4:
-        ldk += 4
-    return 32 * ldk * 4 <= 64 * 1024
-
-
-def basis_fused_fwd(X, comps, bases, bias, csr, keep_ag):
-    """out = ag @ flat(bases) + bias with the aggregation tile kept in LDS (rgcn_basis_fused_fwd_f32) -> (out, ag or None)"""
-    _req(X, "features"); _req(comps, "comps"); _req(bases, "bases"); _req(bias, "bias")
-    Bn, d_in, d_out = bases.shape
-    out = torch.empty((csr.n_rows, d_out), device=X.device, dtype=torch.float32)
-    ag = torch.empty((csr.n_rows, Bn * d_in), device=X.device, dtype=torch.float32) if keep_ag else None
-    with _on(X.device), _timed("basis_fused_fwd"):
-        _check(lib().rgcn_basis_fused_fwd_f32(_dp(X), _dp(comps), _dp(bases), _dp(bias), _dp(out), _dp(ag), _dp(csr.rowptr),
-                                              _dp(csr.src), _dp(csr.rel), _dp(csr.val), c_i64(csr.n_rows),
-                                              c_i32(comps.shape[0]), c_i32(Bn), c_i32(d_in), c_i32(d_out), _stream(X.device)),
-               "basis_fused_fwd")
-    return out, ag
-
-
 def _req(t, name, dtype=torch.float32):
     if t is None:
         return
@@ -936,7 +914,7 @@ def _spmm_prepare(X, W, bias, plan):
     assert X.shape == (plan.n_src, d_in), f"features {tuple(X.shape)} vs ({plan.n_src}, {d_in})"
     assert R == plan.num_rels
     flags = 0
-    if plan.pack is not None and not routes.get("no_pack"):
+    if plan.pack is not None:
         if d_in == 16 and d_out == 16:
             W = pack_w16(W)
             flags |= F_WPACKED
@@ -1133,7 +1111,7 @@ def pack_w16t(W):
 
 
 def bwd_route():
-    """RGCN_BWD_KERNEL: blk (default: block-tile kernel where it applies, else lean) | lean | stage -- DESIGN.md 4.2"""
+    """RGCN_BWD_KERNEL: blk (default: block-tile kernel where it applies, else lean) | lean -- DESIGN.md 4.2"""
     return routes.get("bwd_kernel", "blk")
 
 
@@ -1171,7 +1149,10 @@ def bwd_fused_ok(plan, diag4=False):
         return False
     if _bwd_blk_plan(plan, diag4):
         return True             # (tiles above 255 rows have no packed slots: the lean slots are made from the unpacked arrays)
-    return plan.pack is not None and plan.n_split == 0 and plan.n_units == plan.n_tiles and plan.tile_rows <= 160
+    # (the lean window kernel: its LDS holds the dX tile + X tile + scratch of at least 8 waves; round 2's staging kernel, which took the
+    # taller wave-owned tiles up to 160 rows, is gone -- such plans only come from experimental routes and take the two-pass backward)
+    return plan.pack is not None and plan.n_split == 0 and plan.n_units == plan.n_tiles and \
+        bool(lib().rgcn_bwd_lean_supported(c_i32(plan.tile_rows))) and plan.num_rels < 65536
 
 
 def _blk_units(plan):
@@ -1230,15 +1211,13 @@ def _blk_rec(plan):
 
 
 def bwd_fused_relu_ok(plan, diag4=False):
-    """RGCN_F_RELU of rgcn_bwd_fused_f32 (dX masked with X > 0 in the epilogue) exists in the window kernel only: its LDS
-    (dX tile + X tile + scratch per wave, 8 waves at least) has to fit"""
-    return _bwd_blk_plan(plan, diag4) or (bwd_route() != "stage" and
-                                   (2 * 8 * plan.tile_rows * 16 + 8 * 256 + 4 * 256) * 4 + 4 <= 160 * 1024)
+    """RGCN_F_RELU (dX masked with X > 0 in the epilogue): both fused kernels have it"""
+    return bool(_bwd_blk_plan(plan, diag4)) or bwd_fused_ok(plan, diag4)
 
 
 def bwd_fused(G, X, W, plan, atomic=False, relu=False, want_db=False, diag4=False):
-    """(dX [n, 16], dW [R, 16, 16]) of the hidden-16 layer from one walk of the transposed plan (rgcn_bwd_fused_f32):
-    G upstream gradient, X the layer's input, W [R, 16, 16].  relu: X is the output of a ReLU and dX is wanted BEFORE it
+    """(dX [n, 16], dW [R, 16, 16]) of the hidden-16 layer from one walk of the transposed plan:
+    G upstream gradient, X the layer's input, W [R, 16, 16] (rgcn_bwd_blk_f32 on a plan of tall tiles, rgcn_bwd_lean_f32 on wave-owned ones).  relu: X is the output of a ReLU and dX is wanted BEFORE it
     (rows masked with X > 0 in the kernel's epilogue).  want_db: returns (dX, dW, db) -- db [16] = column sums of G when the
     kernel that ran computes them on the side (block-tile kernel), else None (the caller launches colsum).  diag4: W is
     block_diag() of 4 x 4 blocks and only the diagonal blocks of dW are wanted (block-tile kernel only: up to 447 relations)."""
@@ -1261,7 +1240,6 @@ def bwd_fused(G, X, W, plan, atomic=False, relu=False, want_db=False, diag4=Fals
     if not atomic:
         n = int(lib().rgcn_bwd_fused_scratch_floats(c_i64(plan.n_tiles), c_i32(W.shape[0])))
         scratch = torch.empty(n, device=dev, dtype=torch.float32)
-    route = bwd_route()
     if blk:     # a plan of tall tiles (graph.bwd_plan asked bwd_blk_rows): one tile per workgroup
         if not atomic:
             raise NativeLibraryError("bwd_fused: the block-tile plan (tall tiles) has no bit-reproducible kernel")
@@ -1273,19 +1251,14 @@ def bwd_fused(G, X, W, plan, atomic=False, relu=False, want_db=False, diag4=Fals
                                           c_i32((F_RELU if relu else 0) | (F_DIAG4 if diag4 else 0)), _dp(db), c_i64(plan.n_src),
                                           _dp(units), c_i64(n_units), c_i64(n_split), _stream(dev)), "bwd_blk")
         return ret()
-    if route in ("lean", "blk") and lib().rgcn_bwd_lean_supported(c_i32(plan.tile_rows)) and W.shape[0] < 65536:
-        slots, hdr = _lean_plan(plan)
-        with _on(dev), _timed("bwd_fused"):
-            _check(lib().rgcn_bwd_lean_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(scratch), _dp(slots), _dp(hdr),
-                                           _dp(plan.run_ptr), c_i64(plan.n_tiles), c_i32(plan.tile_rows), c_i64(plan.n_dst),
-                                           c_i32(W.shape[0]), c_i32((F_DW_ATOMIC if atomic else 0) | (1 if relu else 0)),
-                                           _stream(dev)), "bwd_lean")
-        return ret()
+    if not (lib().rgcn_bwd_lean_supported(c_i32(plan.tile_rows)) and W.shape[0] < 65536):
+        raise NativeLibraryError(f"bwd_fused: no fused kernel for wave-owned tiles of {plan.tile_rows} rows (bwd_fused_ok)")
+    slots, hdr = _lean_plan(plan)
     with _on(dev), _timed("bwd_fused"):
-        _check(lib().rgcn_bwd_fused_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(scratch), _dp(plan.pack),
-                                        _dp(plan.chunk_rel), _dp(plan.run_ptr), c_i64(plan.n_tiles), c_i32(plan.tile_rows),
-                                        c_i64(plan.n_dst), c_i32(W.shape[0]), c_i32((F_DW_ATOMIC if atomic else 0) | (1 if relu else 0)),
-                                        _stream(dev)), "bwd_fused")
+        _check(lib().rgcn_bwd_lean_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(scratch), _dp(slots), _dp(hdr),
+                                       _dp(plan.run_ptr), c_i64(plan.n_tiles), c_i32(plan.tile_rows), c_i64(plan.n_dst),
+                                       c_i32(W.shape[0]), c_i32((F_DW_ATOMIC if atomic else 0) | (1 if relu else 0)),
+                                       _stream(dev)), "bwd_lean")
     return ret()
 
 

@@ -68,15 +68,13 @@ _BLOCKED_MAX = 512     # widest layer that is cut into 64-wide blocks of the MFM
 def _wide_gemm_path(graph, d_in, d_out):
     """undecomposed weights above width 64: relation-grouped gather-GEMM on the matrix cores + per-destination row sum
     (csrc/rgcn_gemm.hip); needs the device-side graph and host-known message counts (not the sync-free per-call build)"""
-    return (max(d_in, d_out) > 64 and getattr(graph, "_dev", None) is not None and not getattr(graph, "sync_free", False)
-            and routes.get("wide", "gemm") == "gemm")
+    return max(d_in, d_out) > 64 and getattr(graph, "_dev", None) is not None and not getattr(graph, "sync_free", False)
 
 
 def _spmm_blocked(X, W, bias, plan_of, relu=False, graph=None, kind="fwd"):
     """spmm for any width.  Up to 64 x 64 it is one launch of the block kernels.  Above (undecomposed weights at d = 100,
     200, ...): relation-grouped gather-GEMM (X gathered once per message, every W_r through LDS once per 128 messages) + row
-    sum; RGCN_WIDE=blocks keeps round 1's (d_in / 64) x (d_out / 64) launches of the block kernel, which is also the route
-    of graphs without a device-side build."""
+    sum; graphs without a device-side build keep round 1's (d_in / 64) x (d_out / 64) launches of the block kernel."""
     d_in, d_out = W.shape[1], W.shape[2]
     if graph is not None and _wide_gemm_path(graph, d_in, d_out):
         return _native.spmm_wide_two_pass(X, W, bias, graph.scatter_plan(kind, 8), graph.csr(kind), relu=relu)
@@ -611,8 +609,7 @@ def matmul_mfma(A, B):
 class _BasisMP(torch.autograd.Function):
     """W_r = sum_b comps[r,b] bases[b] at large width: aggregate per basis, then contract (B d_in) x d_out on the matrix
     cores -- never touches an R x d x d weight tensor (reference: layers.py:241-242, :468-469).  Forward: aggregation
-    kernel + hand-written MFMA GEMM (rgcn_gemm_f32; 57 TFLOP/s at WN18 size, rocBLAS addmm 50); RGCN_BASIS_FUSED=1 selects
-    the single fused kernel (aggregation tile in LDS -> MFMA, no N x (B d_in) buffer; 0.20 ms against 0.17 ms).  Backward:
+    kernel + hand-written MFMA GEMM (rgcn_gemm_f32; 57 TFLOP/s at WN18 size, rocBLAS addmm 50).  Backward:
     d_ag = g flat^T and dbases = ag^T g on rgcn_gemm_f32, dX by the same aggregation on the source-major CSR, dcomps by the
     relation-major dot-product kernel."""
 
@@ -621,12 +618,8 @@ class _BasisMP(torch.autograd.Function):
         X, bases, comps = dense(X), dense(bases), dense(comps)
         B, d_in, d_out = bases.shape
         b = None if bias is None else dense(bias)
-        need_bwd = any(ctx.needs_input_grad[:4])
-        if _native.basis_fused_supported(B, d_in) and routes.get("basis_fused", "0") == "1":
-            out, ag = _native.basis_fused_fwd(X, comps, bases, b, graph.csr("fwd"), keep_ag=need_bwd and ctx.needs_input_grad[1])
-        else:
-            ag = _native.basis_aggregate(X, comps, graph.csr("fwd"), B, d_in, 1)          # [N, B*d_in]
-            out = _native.gemm(ag, bases.view(B * d_in, d_out), bias=b)
+        ag = _native.basis_aggregate(X, comps, graph.csr("fwd"), B, d_in, 1)          # [N, B*d_in]
+        out = _native.gemm(ag, bases.view(B * d_in, d_out), bias=b)
         ctx.graph, ctx.has_bias = graph, bias is not None
         ctx.save_for_backward(X, bases, comps, ag)
         return out

@@ -12,20 +12,19 @@ environment is never looked at again -- behaviour does not depend on when somebo
 
 Names are the old variable names without the RGCN_ prefix, lower case; docs: DESIGN.md section 7.  NATIVE names are tuning
 integers of librgcn_hip.so itself: they are pushed through rgcn_set_option (the library has no getenv).  The two
-timing-only switches with WRONG results (bwd_abl, rank_ablate) exist in the ablation build only
+timing-only switch with WRONG results (bwd_abl) exists in the ablation build only
 (make -C torch-rgcn_amd/csrc abl, loaded through RGCN_HIP_LIB by tools/); the shipped library refuses them.
 """
 import contextlib
 import os
 
 NAMES = (
-    "deterministic", "relabel", "tile_rows", "bwd_tile_rows", "bwd", "bwd_kernel", "bwd_blk_cap", "twopass", "wide", "pad16",
-    "featureless_csr", "dist_comm", "dist_slabs", "deferred_checks", "block_path", "block_fwd", "basis_path", "basis_fused",
-    "wgrad_tiles", "wgrad_item_chunks", "wgrad", "spmm_csr", "sparse_path", "no_pack", "graph_build", "fbasis_inplace_mb", "fbasis",
-    "distmult_bwd", "diag_path", "capture", "fbasis_dc", "fbasis_tile", "pad16_view",
+    "deterministic", "relabel", "tile_rows", "bwd_tile_rows", "bwd", "bwd_kernel", "bwd_blk_cap", "twopass", "pad16",
+    "featureless_csr", "dist_comm", "dist_slabs", "deferred_checks", "block_path", "block_fwd", "basis_path",
+    "wgrad_tiles", "wgrad_item_chunks", "wgrad", "spmm_csr", "sparse_path", "graph_build", "fbasis_inplace_mb", "fbasis",
+    "distmult_bwd", "diag_path", "capture", "fbasis_tile", "pad16_view",
 )
-NATIVE = ("basis_vec4", "block_lds", "block_pipe", "bwd_nw", "bwd_d", "bwd_waves", "bwd_u", "gemm_bm", "spmm_u", "wgrad_rg", "wgrad_u",
-          "distmult_one_launch", "rank_tile", "bwd_abl", "rank_ablate")
+NATIVE = ("bwd_nw", "gemm_bm", "spmm_u", "wgrad_rg", "wgrad_u", "bwd_abl")
 
 _values = {}
 _native_sink = None        # set by _native.lib(): callable(name, int) -> pushes one option into the loaded library
