@@ -287,6 +287,8 @@ RGCN_API int rgcn_wgrad_tiled_f32(const float *X, const float *G, float *dW, con
 #define RGCN_F_DW_ATOMIC 4
 #define RGCN_F_TRANSPOSE_W 8   /* rgcn_block_spmm_f32: multiply by the transposed blocks */
 #define RGCN_F_DIAG4 16        /* rgcn_bwd_blk_f32: W_r is block-diagonal with 4 x 4 blocks; only the diagonal blocks of dW_r are computed */
+#define RGCN_F_PARTIAL 32      /* rgcn_bwd_blk_f32: `units` lists SOME whole tiles (a slab): their dX rows are written, dW / dbias zeroed and summed */
+#define RGCN_F_ACCUMULATE 64   /* rgcn_bwd_blk_f32: a further slab of the same backward: as RGCN_F_PARTIAL, but dW / dbias are NOT zeroed first */
 RGCN_API int64_t rgcn_bwd_fused_scratch_floats(int64_t n_tiles, int32_t R);
 /* (rgcn_bwd_fused_f32 itself -- round 2's staging kernel, four wave-owned tiles per workgroup -- was the fallback of rounds 3-4 for
  * wave-owned tiles of 65 .. 160 rows; nothing selected it by default and round 5 removed it.  The argument conventions above are those

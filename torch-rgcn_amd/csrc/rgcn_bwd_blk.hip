@@ -481,10 +481,11 @@ extern "C" int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_
                                 const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R, int32_t flags,
                                 float *dbias, int64_t n_src, const int32_t *units, int64_t n_units, int64_t n_split, void *stream) {
   if (!G || !X || !Wt_packed || !dX || !dW || !rec || !run_ptr || n_tiles <= 0 || tile_rows <= 0 || n_dst <= 0 || R <= 0 ||
-      (units && (n_units < n_tiles || n_split < 0 || n_units > INT32_MAX))) {
+      (units && ((n_units < n_tiles && !(flags & (RGCN_F_ACCUMULATE | RGCN_F_PARTIAL))) || n_split < 0 || n_units > INT32_MAX || n_units <= 0))) {
     rgcn_set_error("bwd_blk: bad argument");
     return RGCN_EINVAL;
   }
+  if ((flags & (RGCN_F_ACCUMULATE | RGCN_F_PARTIAL)) && (!units || n_split)) { rgcn_set_error("bwd_blk: a slab (RGCN_F_PARTIAL / RGCN_F_ACCUMULATE) is an explicit list of whole-tile work units"); return RGCN_EINVAL; }
   if (!units) { n_units = n_tiles; n_split = 0; }
   if (!rgcn_bwd_blk_supported(tile_rows, R, flags)) {
     rgcn_set_error("bwd_blk: tile_rows = %d / R = %d: 192 bytes per row + 16 KiB + R KiB (R / 4 KiB with RGCN_F_DIAG4) of LDS do not fit (at most %d rows)",
@@ -503,7 +504,9 @@ extern "C" int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_
     n_cu = v > 0 ? v : 256;
   }
   if (dbias && (n_src <= 0 || n_src >= (int64_t(1) << 29))) { rgcn_set_error("bwd_blk: dbias needs 0 < n_src < 2^29"); return RGCN_EINVAL; }
-  if (dbias == dW + (size_t)R * 256) {     // one fill for both when the caller laid them out back to back
+  if (flags & RGCN_F_ACCUMULATE) {
+    // a later slab of the same backward (relation-sharded layers: the slab before is being all-reduced while this one runs): dW / dbias keep adding
+  } else if (dbias == dW + (size_t)R * 256) {     // one fill for both when the caller laid them out back to back
     HIP_TRY(zero_async(dW, ((size_t)R * 256 + 16) * sizeof(float), st));
   } else {
     HIP_TRY(zero_async(dW, (size_t)R * 256 * sizeof(float), st));

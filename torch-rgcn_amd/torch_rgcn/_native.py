@@ -835,6 +835,7 @@ def _req(t, name, dtype=torch.float32):
 
 F_RELU, F_WPACKED = 1, 2
 F_DIAG4 = 16      # rgcn_bwd_blk_f32: block-diagonal weights, 4 x 4 blocks
+F_PARTIAL, F_ACCUMULATE = 32, 64      # rgcn_bwd_blk_f32: a slab of whole tiles (first / further slabs of one backward)
 
 
 # Both fragment orders (Wp, Wtp) of a [R,16,16] weight are packed in ONE launch the first time either is asked for.  They are
@@ -1260,6 +1261,38 @@ def bwd_fused(G, X, W, plan, atomic=False, relu=False, want_db=False, diag4=Fals
                                        c_i32(W.shape[0]), c_i32((F_DW_ATOMIC if atomic else 0) | (1 if relu else 0)),
                                        _stream(dev)), "bwd_lean")
     return ret()
+
+
+def bwd_fused_slabs_ok(plan):
+    """the slab-by-slab form of the fused backward: the block-tile kernel on a plan of tall tiles without hub pieces"""
+    return bool(_bwd_blk_plan(plan)) and _blk_units(plan)[2] == 0 and getattr(plan, "tile_ptr", None) is not None
+
+
+def bwd_fused_slabs(G, X, W, plan, n_slabs, after_slab):
+    """bwd_fused launched slab by slab (whole tiles of the transposed plan): dX rows [r0, r1) are complete after slab k's launch and
+    after_slab(dX, r0, r1) is called right there -- the relation-sharded layer starts the asynchronous all-reduce of those rows while
+    slab k + 1's kernel runs; dW and the bias gradient keep accumulating over the slabs (RGCN_F_PARTIAL, then RGCN_F_ACCUMULATE).
+    -> (dX, dW, db)"""
+    _req(G, "grad_output"); _req(X, "features"); _req(W, "weights")
+    assert W.shape[1:] == (16, 16) and bwd_fused_slabs_ok(plan)
+    dev = G.device
+    Wtp = pack_w16t(W)
+    dX = torch.empty((plan.n_dst, 16), device=dev, dtype=torch.float32)
+    buf = torch.empty(W.numel() + 16, device=dev, dtype=torch.float32)
+    dW, db = buf[:W.numel()].view_as(W), buf[W.numel():]
+    rec = _blk_rec(plan)
+    tiles = getattr(plan, "_blk_tile_units", None)
+    if tiles is None:        # one explicit work unit per tile (the default launch lets the kernel read the run pointers itself)
+        tiles = plan._blk_tile_units = row_units(plan.tile_ptr, plan.n_tiles, 1 << 30)[0]
+    cuts = sorted({(plan.n_tiles * k) // n_slabs for k in range(n_slabs + 1)})
+    for i, (ta, tb) in enumerate(zip(cuts[:-1], cuts[1:])):
+        with _on(dev), _timed("bwd_fused"):
+            _check(lib().rgcn_bwd_blk_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(rec), _dp(plan.run_ptr),
+                                          c_i64(plan.n_tiles), c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i32(W.shape[0]),
+                                          c_i32(F_PARTIAL if i == 0 else F_ACCUMULATE), _dp(db) if i == 0 else None, c_i64(plan.n_src),
+                                          c_void_p(tiles.data_ptr() + 16 * ta), c_i64(tb - ta), c_i64(0), _stream(dev)), "bwd_blk")
+        after_slab(dX, ta * plan.tile_rows, min(plan.n_dst, tb * plan.tile_rows))
+    return dX, dW, db
 
 
 def featureless_fwd(table, bias, plan):

@@ -394,7 +394,16 @@ class _ShardedRelationalMP(torch.autograd.Function):
         works = []
         slabbed = ctx.n_slabs > 0 and ctx.comm == "allreduce"
         both = None
-        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not slabbed:
+        joined = False
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and slabbed and not deterministic() and routes.get("bwd", "fused") != "split":
+            # the fused backward slab by slab (round 5): the all-reduce of slab k's dX rows -- RCCL on its own stream -- runs under slab
+            # k + 1's kernel; dW (owner-local rows) keeps adding across the slabs.  Plans with hub pieces keep the unfused slab path below.
+            bp = graph.bwd_blk_plan()
+            if bp is not None and W.shape[1] == 16 and W.shape[2] == 16 and _native.bwd_fused_slabs_ok(bp):
+                dX, dW, _ = _native.bwd_fused_slabs(g, X, W, bp, ctx.n_slabs,
+                                                    lambda o, r0, r1: works.append(dist.all_reduce(o[r0:r1], group=ctx.group, async_op=True)))
+                both, joined = (dX, dW), True
+        if both is None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not slabbed:
             both = _fused_backward(X, W, g, graph)
         if both is not None:
             dX, dW = both[:2]
@@ -410,7 +419,7 @@ class _ShardedRelationalMP(torch.autograd.Function):
                 dW = _weight_gradient(X, W, g, graph)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _native.colsum(g)
-        if dX is not None and not slabbed:
+        if dX is not None and not slabbed and not joined:
             dX = _join_shards(dX, ctx.group, ctx.comm)
         for w in works:
             w.wait()
