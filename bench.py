@@ -47,7 +47,7 @@ import torch.distributed as dist  # noqa: E402
 
 METRIC = "edges/s/GPU (fwd+bwd) 2-layer RGCN, 1M nodes/10M edges/50 rels, h=16"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def fwd_bytes(M, N, d_in, d_out):
@@ -61,7 +61,7 @@ def bwd_bytes(M, N, d_in, d_out, x_needs_grad=True):
 
 
 def _profile_json(name):
-    for rnd in (PROFILE_ROUND, "r03", "r02", "r01"):
+    for rnd in (PROFILE_ROUND, "r04", "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")) as f:
                 return json.load(f), f"profiles/{rnd}_{name}.json"

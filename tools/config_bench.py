@@ -193,15 +193,94 @@ def _count_launches(step):
         return {"failed": f"{type(exc).__name__}: {exc}"[:120]}
 
 
+PROFILE_ROUND = "r05"
+# the kernels behind a timed tag of torch_rgcn._native (HIP-event timers) as rocprofv3 names them: (substrings, kernels per call of the tag)
+TAG_KERNELS = {
+    "fbasis_tile_fwd": (("fbn_fwd_kernel", "fbt_fwd_kernel"), 1), "gather_rows_sum4": (("gather_rows_sum4_kernel",), 1),
+    "fbasis_tile_bwd": (("fbn_bwd_kernel", "fbn_dbases_kernel", "fbn_dcomps_kernel", "fbt_dbases_kernel", "fbt_dcomps_kernel"), None),
+    "spmm": (("spmm_d16_kernel", "spmm_wide_kernel", "spmm_generic_kernel"), 1), "spmm_csr": (("spmm_csr_d16_kernel",), 1),
+    "spmm_scatter": (("spmm_scatter_d16_kernel",), 1), "segment_sum": (("segment_gather_sum", "segment_sum"), 1),
+    "bwd_scatter_dw": (("bwd_scatter_dw_d16_kernel",), 1), "bwd_fused": (("bwd_blk_d16_kernel", "bwd_lean_d16_kernel"), 1),
+    "block_spmm": (("block44_csr_kernel", "block_csr"), 1), "basis_aggregate": (("basis_aggregate",), 1),
+    "fbasis_small_bwd": (("fbasis_small_bwd_kernel",), 1), "fbasis_fwd": (("fbasis_fwd_kernel",), 1), "fbasis_bwd": (("fbasis_bwd",), 1),
+    "featureless_csr_fwd": (("featureless_csr_fwd",), 1), "featureless_csr_wgrad": (("featureless_csr_wgrad",), 1),
+    "gemm": (("gemm_kernel",), 1), "distmult_fwd": (("distmult_fwd_kernel",), 1), "distmult_bwd_all": (("distmult_bwd_all_kernel",), 2),
+    "basis_dcomps_csr": (("basis_dcomps_csr_kernel",), 1), "basis_dcomps": (("basis_dcomps_kernel",), 1),
+    "ce_head": (("ce_head_kernel",), 1), "bce_head": (("bce_head_kernel",), 1), "colsum": (("colsum",), None),
+}
+_PMC_CACHE = {}
+
+
+def _pmc_file(line_key):
+    """the committed counter summary of this line (tools/prof.sh lines -> profiles/r05_<line>_pmc.json), or None"""
+    if line_key not in _PMC_CACHE:
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{line_key}_pmc.json")) as f:
+                _PMC_CACHE[line_key] = json.load(f)
+        except OSError:
+            _PMC_CACHE[line_key] = None
+    return _PMC_CACHE[line_key]
+
+
+def _tag_traffic(line_key, tag):
+    """HBM-side bytes per CALL of a timed tag from the committed rocprofv3 --pmc summary of this line (STATIC: not measured in this run;
+    bytes = (FETCH_SIZE x (1 + share of 128-byte requests) + WRITE_SIZE) x 1024, MI355X_MICROARCH.md) -> dict or None"""
+    data = _pmc_file(line_key)
+    if not data or tag not in TAG_KERNELS:
+        return None
+    subs, kpc = TAG_KERNELS[tag]
+    hits = [(k, v) for k, v in data.items() if k != "_meta" and any(sub in k for sub in subs) and "hbm_bytes_per_launch" in v]
+    if not hits:
+        return None
+    launches = sum(max(v.get("launches_traced", 1), 1) for _, v in hits)
+    if kpc is None:
+        kpc = len(hits) if tag != "colsum" else 1
+    calls = launches / kpc
+    total = sum(v["hbm_bytes_per_launch"] * max(v.get("launches_traced", 1), 1) for _, v in hits)
+    us = sum(v.get("avg_us", 0.0) * max(v.get("launches_traced", 1), 1) for _, v in hits) / calls
+    out = {"traffic": int(total / calls), "kernels": sorted(k.split("(")[0][-60:] for k, _ in hits), "avg_us_under_rocprof": round(us, 1)}
+    for extra in ("l2_hit_rate", "lds_bank_conflict_frac", "mfma_busy_frac", "share_of_128B_read_requests"):
+        vals = [v[extra] for _, v in hits if extra in v]
+        if vals:
+            out[extra] = round(sum(vals) / len(vals), 3)
+    return out
+
+
+def _attach_traffic(line, line_key, models=None):
+    """roofline.traffic of the line's dominant kernel + the traffic of every timed kernel of the step, tagged with the binary it was taken on"""
+    data = _pmc_file(line_key)
+    roof = line.get("roofline")
+    if not data or not isinstance(roof, dict):
+        if isinstance(roof, dict):
+            roof.setdefault("traffic", None)
+        return line
+    meta = data.get("_meta", {})
+    per = {}
+    for tag in line.get("kernels_ms", {}):
+        t = _tag_traffic(line_key, tag)
+        if t:
+            if models and tag in models:
+                t["algorithmic_bytes"] = int(models[tag])
+                t["traffic_over_algorithmic"] = round(t["traffic"] / models[tag], 3)
+            per[tag] = t
+    roof["kernels_traffic"] = per
+    dom = roof.get("dominant_tag")
+    roof["traffic"] = per[dom]["traffic"] if dom in per else (sum(v["traffic"] for v in per.values()) if roof.get("traffic_is_step_sum") else None)
+    roof["traffic_static"] = f"profiles/{PROFILE_ROUND}_{line_key}_pmc.json: rocprofv3 --pmc (separate passes, tools/prof.sh lines {line_key}), NOT measured in this run"
+    roof["traffic_static_csrc_sha"] = meta.get("csrc_sha")
+    roof["traffic_static_csrc_match"] = meta.get("csrc_sha") == _native.csrc_sha()
+    return line
+
+
 def _roof(name, ms, alg_bytes, note):
     if not name or not ms:
         return None
     ach = alg_bytes / (ms * 1e-3) / 1e9
-    return {"kernel": name, "bound": "hbm", "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+    return {"kernel": name, "dominant_tag": name, "bound": "hbm", "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "bytes_model": note}
 
 
-def line_node_classifier(tag, N, R0, E, nhid, ncls, decomp, labelled, baseline_config):
+def line_node_classifier(tag, N, R0, E, nhid, ncls, decomp, labelled, baseline_config, key=None):
     T = _native.synthetic_triples_host(N, R0, E, 1)
     model = NodeClassifier(triples=T, nnodes=N, nrel=R0, nhid=nhid, nclass=ncls, decomposition=decomp).to(DEV)
     idx = torch.arange(labelled, device=DEV)
@@ -247,13 +326,13 @@ def line_node_classifier(tag, N, R0, E, nhid, ncls, decomp, labelled, baseline_c
     bwd_basis = M * (nhid * 4 + 8) + 2 * N * row
     alg = {"featureless_fwd": fwd, "fbasis_fwd": fwd, "fbasis_tile_fwd": fwd, "featureless_wgrad": M * (nhid * 4 + 8) + (2 * R0 + 1) * N * nhid * 4,
            "fbasis_bwd": bwd_basis, "fbasis_tile_bwd": bwd_basis}.get(name, fwd)
-    return {"baseline_config": baseline_config, "workload": tag, "N": N, "R0": R0, "E": E, "params": sum(p.numel() for p in model.parameters()),
+    return _attach_traffic({"baseline_config": baseline_config, "workload": tag, "N": N, "R0": R0, "E": E, "params": sum(p.numel() for p in model.parameters()),
             "step": "NodeClassifier forward + cross-entropy + backward + Adam",
             # the experiments replay the captured step by default (experiments/classify_nodes.py); the eager loop's time is the host's
             "ms_per_step": ms_graph if isinstance(ms_graph, float) else round(ms, 3), "ms_per_step_eager": round(ms, 3),
             "ms_per_step_hipgraph_replay": ms_graph,
             "edges_per_s": round(E / (ms_graph if isinstance(ms_graph, float) else ms) * 1e3), "launches_per_step": _count_launches(step), "kernels_ms": allk, "library_launches_per_step": round(sum(_launch_counts(step).values()), 1),
-            "roofline": _roof(name, kms, alg, "messages x (weight-table row + 8 B index) + node rows written")}
+            "roofline": _roof(name, kms, alg, "messages x (weight-table row + 8 B index) + node rows written")}, key, {name: alg} if name else None)
 
 
 class _MeanSquare(torch.autograd.Function):
@@ -271,7 +350,7 @@ class _MeanSquare(torch.autograd.Function):
         return out * (g * (2.0 / out.numel()))
 
 
-def line_featured(tag, N, R0, E, d, decomposition, seed, baseline_config):
+def line_featured(tag, N, R0, E, d, decomposition, seed, baseline_config, key=None):
     T = _native.synthetic_triples_host(N, R0, E, seed)
     tp = torch.from_numpy(_native.add_inverse_and_self_host(T, N, R0))
     kw = dict(triples=tp, num_nodes=N, num_relations=2 * R0 + 1, in_features=d, out_features=d, decomposition=decomposition)
@@ -319,6 +398,7 @@ def line_featured(tag, N, R0, E, d, decomposition, seed, baseline_config):
     roof = dict(dom) if dom else None
     if roof:
         roof["kernel"] = roof.pop("kernels")
+        roof["dominant_tag"] = name
         roof["avg_launch_ms"] = roof["ms_per_layer"]
         roof["forward"], roof["backward"] = fwd, bwd
         step_alg = 2 * (fwd_alg + bwd_alg)
@@ -331,8 +411,9 @@ def line_featured(tag, N, R0, E, d, decomposition, seed, baseline_config):
             roof["dominant_kernel_own_access_pattern"] = {"kernel": name, "avg_launch_ms": round(kms, 4), "bytes_per_launch": int(own),
                                                           "GBs": round(own / (kms * 1e-3) / 1e9, 1),
                                                           "note": "what this kernel itself moves (two gathered rows / the transformed rows once more), NOT SURVEY 8(d)"}
-    return {"baseline_config": baseline_config, "workload": tag, "N": N, "R0": R0, "E": E, "step": "2 featured layers, forward + backward",
-            "ms_per_step": round(ms, 3), "edges_per_s": round(E / ms * 1e3), "kernels_ms": allk, "roofline": roof}
+    models = {"spmm": fwd_alg, "block_spmm": fwd_alg, "spmm_csr": fwd_alg, "bwd_fused": bwd_alg}
+    return _attach_traffic({"baseline_config": baseline_config, "workload": tag, "N": N, "R0": R0, "E": E, "step": "2 featured layers, forward + backward",
+                            "ms_per_step": round(ms, 3), "edges_per_s": round(E / ms * 1e3), "kernels_ms": allk, "roofline": roof}, key, models)
 
 
 def line_wn18(baseline_config):
@@ -389,13 +470,15 @@ def line_wn18(baseline_config):
         roof["distmult_bwd_all"] = _roof("distmult_bwd_all_kernel", allk["distmult_bwd_all"], dm_alg,       # entity / relation gradient row written once
                                          "scored triples x (three d-wide rows + 28 B) + (entities + relations) x one gradient row")
         roof["distmult_fwd"] = _roof("distmult_fwd_kernel", allk.get("distmult_fwd"), Tn * (3 * d * 4 + 28), "scored triples x (three d-wide rows + 28 B)")
-    return {"baseline_config": baseline_config, "workload": "WN18-shaped: LP layer d=200 basis 2 (graph of 15,000 triples built per step) + "
+    if roof is not None:
+        roof["dominant_tag"] = name
+    return _attach_traffic({"baseline_config": baseline_config, "workload": "WN18-shaped: LP layer d=200 basis 2 (graph of 15,000 triples built per step) + "
             "DistMult on 330,000 triples", "N": N, "R0": R0, "graph_triples": E, "scored_triples": Tn,
             "step": "encoder + decoder forward + BCE + backward (per-step graph build included)", "ms_per_step": round(ms, 3),
             "ms_per_step_sync_free": None if ms_nosync is None else round(ms_nosync, 3),
             "ms_per_step_hipgraph_replay": round(ms_graph, 3) if isinstance(ms_graph, float) else ms_graph,
             "scored_triples_per_s": round(Tn / ms * 1e3), "kernels_ms": allk, "launches_per_step": _count_launches(step),
-            "roofline": roof}
+            "roofline": roof}, "wn18", {"distmult_fwd": Tn * (3 * d * 4 + 28), "distmult_bwd_all": Tn * (3 * d * 4 + 28) + (N + R0) * d * 4})
 
 
 def line_s2(baseline_config):
@@ -428,9 +511,12 @@ def line_s2(baseline_config):
     if roof:
         roof["step_algorithmic_bytes"] = int(step_alg)
         roof["step_frac"] = round(step_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-    return {"baseline_config": baseline_config, "workload": "S2: S1 graph, featureless layer 1 with basis B=2 (no R x N x 16 table), ReLU, layer 2 16->16",
-            "N": N, "R0": R0, "E": E, "step": "2 layers, forward + backward", "ms_per_step": round(ms, 3), "edges_per_s": round(E / ms * 1e3),
-            "kernels_ms": allk, "launches_per_step": counts, "roofline": roof}
+    if roof:
+        roof["dominant_tag"] = name
+    return _attach_traffic({"baseline_config": baseline_config, "workload": "S2: S1 graph, featureless layer 1 with basis B=2 (no R x N x 16 table), ReLU, layer 2 16->16",
+                            "N": N, "R0": R0, "E": E, "step": "2 layers, forward + backward", "ms_per_step": round(ms, 3), "edges_per_s": round(E / ms * 1e3),
+                            "kernels_ms": allk, "launches_per_step": counts, "roofline": roof}, "s2",
+                           {"basis_aggregate": l1_fwd, "fbasis_small_bwd": l1_bwd, "spmm": l2_fwd, "bwd_fused": l2_bwd})
 
 
 def line_am_shipped(baseline_config):
@@ -477,12 +563,18 @@ def line_am_shipped(baseline_config):
             "bytes_model": "torch.optim.Adam(fused=True): param, grad, exp_avg, exp_avg_sq read; param, exp_avg, exp_avg_sq written"}
     roof = dict(fb)
     roof["kernel"] = f"forward + backward (dominant kernel: {name}, {round(kms, 4) if kms else None} ms per launch)"
+    roof["dominant_tag"] = name
     roof["avg_launch_ms"] = fb["ms"]
     roof["adam"] = adam
-    return {"baseline_config": baseline_config, "workload": "AM-shaped NodeClassifier as shipped (featureless L1, basis 40, hidden 10, 11 classes)",
-            "N": N, "R0": R0, "E": E, "params": n_par, "step": "NodeClassifier forward + cross-entropy + backward + Adam",
-            "ms_per_step": round(ms_step, 3), "ms_forward_backward": round(ms_fb, 3), "ms_adam": round(ms_adam, 3),
-            "edges_per_s": round(E / ms_step * 1e3), "kernels_ms": allk, "roofline": roof}
+    # per-kernel models for the wasted-traffic ratios (traffic / model): the tile kernels' own access patterns
+    ys = 16
+    models = {"fbasis_tile_fwd": table + M * 8 + M * ys * 4, "gather_rows_sum4": M * (ys * 4 + 4) + N * 16 * 4,
+              "fbasis_tile_bwd": 2 * table + M * (12 + 64), "spmm_scatter": M * (4 * 16 + 8) + M * 64, "segment_sum": M * (64 + 4) + N * 64,
+              "bwd_scatter_dw": M * (2 * 64 + 12) + M * 64}
+    return _attach_traffic({"baseline_config": baseline_config, "workload": "AM-shaped NodeClassifier as shipped (featureless L1, basis 40, hidden 10, 11 classes)",
+                            "N": N, "R0": R0, "E": E, "params": n_par, "step": "NodeClassifier forward + cross-entropy + backward + Adam",
+                            "ms_per_step": round(ms_step, 3), "ms_forward_backward": round(ms_fb, 3), "ms_adam": round(ms_adam, 3),
+                            "edges_per_s": round(E / ms_step * 1e3), "kernels_ms": allk, "roofline": roof}, "amshipped", models)
 
 
 def secondary_lines():
@@ -490,16 +582,16 @@ def secondary_lines():
     roofline; bounded to a few seconds each"""
     out = []
     for fn in (lambda: line_node_classifier("AIFB-shaped NodeClassifier (featureless L1, hidden 16, 4 classes)", 8285, 45, 29043, 16, 4, None, 176,
-                                            "configs[0] AIFB (reference config nc-AIFB.yaml; here on the GPU, the CPU run is cpu_baseline's business)"),
+                                            "configs[0] AIFB (reference config nc-AIFB.yaml; here on the GPU, the CPU run is cpu_baseline's business)", key="aifb"),
                lambda: line_node_classifier("MUTAG-shaped NodeClassifier (basis 30, hidden 16, 2 classes)", 23644, 23, 74227, 16, 2,
-                                            {"type": "basis", "num_bases": 30}, 340, "configs[1] MUTAG, basis decomposition"),
+                                            {"type": "basis", "num_bases": 30}, 340, "configs[1] MUTAG, basis decomposition", key="mutag"),
                lambda: line_featured("AM-shaped, block-diagonal (nb=4), 2 featured layers d=16 (layer-level, SURVEY 8d)", 1_666_764, 133,
-                                     5_988_321, 16, {"type": "block", "num_blocks": 4}, 2, "configs[2] AM, block-diagonal"),
+                                     5_988_321, 16, {"type": "block", "num_blocks": 4}, 2, "configs[2] AM, block-diagonal", key="am"),
                lambda: line_wn18("configs[3] WN18 link prediction, DistMult decoder"),
                lambda: line_featured("S1(ii): S1 graph, basis decomposition B=10, 2 featured layers d=16", 1_000_000, 50, 10_000_000, 16,
-                                     {"type": "basis", "num_bases": 10}, 0, "SURVEY 8(d) S1 variant (ii)"),
+                                     {"type": "basis", "num_bases": 10}, 0, "SURVEY 8(d) S1 variant (ii)", key="s1ii"),
                lambda: line_featured("S1(iii): S1 graph, block-diagonal nb=4, 2 featured layers d=16", 1_000_000, 50, 10_000_000, 16,
-                                     {"type": "block", "num_blocks": 4}, 0, "SURVEY 8(d) S1 variant (iii)"),
+                                     {"type": "block", "num_blocks": 4}, 0, "SURVEY 8(d) S1 variant (iii)", key="s1iii"),
                lambda: line_s2("SURVEY 8(d) S2 (secondary)"),
                lambda: line_am_shipped("configs[2] AM as the reference ships it (nc-AM.yaml: featureless, basis 40, hidden 10)")):
         try:
@@ -520,11 +612,11 @@ if __name__ == "__main__":
     if a.lines:
         for nm in a.lines.split(","):
             fn = {"s2": lambda: line_s2("S2"), "amshipped": lambda: line_am_shipped("AM shipped"),
-                  "aifb": lambda: line_node_classifier("AIFB-shaped", 8285, 45, 29043, 16, 4, None, 176, "AIFB"),
-                  "mutag": lambda: line_node_classifier("MUTAG-shaped", 23644, 23, 74227, 16, 2, {"type": "basis", "num_bases": 30}, 340, "MUTAG"),
-                  "wn18": lambda: line_wn18("WN18"), "am": lambda: line_featured("AM block", 1_666_764, 133, 5_988_321, 16, {"type": "block", "num_blocks": 4}, 2, "AM"),
-                  "s1ii": lambda: line_featured("S1(ii)", 1_000_000, 50, 10_000_000, 16, {"type": "basis", "num_bases": 10}, 0, "S1(ii)"),
-                  "s1iii": lambda: line_featured("S1(iii)", 1_000_000, 50, 10_000_000, 16, {"type": "block", "num_blocks": 4}, 0, "S1(iii)")}[nm]
+                  "aifb": lambda: line_node_classifier("AIFB-shaped", 8285, 45, 29043, 16, 4, None, 176, "AIFB", key="aifb"),
+                  "mutag": lambda: line_node_classifier("MUTAG-shaped", 23644, 23, 74227, 16, 2, {"type": "basis", "num_bases": 30}, 340, "MUTAG", key="mutag"),
+                  "wn18": lambda: line_wn18("WN18"), "am": lambda: line_featured("AM block", 1_666_764, 133, 5_988_321, 16, {"type": "block", "num_blocks": 4}, 2, "AM", key="am"),
+                  "s1ii": lambda: line_featured("S1(ii)", 1_000_000, 50, 10_000_000, 16, {"type": "basis", "num_bases": 10}, 0, "S1(ii)", key="s1ii"),
+                  "s1iii": lambda: line_featured("S1(iii)", 1_000_000, 50, 10_000_000, 16, {"type": "block", "num_blocks": 4}, 0, "S1(iii)", key="s1iii")}[nm]
             print(json.dumps(fn()), flush=True)
             torch.cuda.empty_cache()
         sys.exit(0)
