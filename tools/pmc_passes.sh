@@ -51,3 +51,4 @@ for key in keys:
               round(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (d["GRBM_GUI_ACTIVE"] / 8 * 1024), 3), "SALU", round(d.get("SQ_INSTS_SALU", 0)),
               "VALU", round(d.get("SQ_INSTS_VALU", 0)))
 PY
+[ "${KEEP_RAW:-0}" = "1" ] || rm -rf "$OUT"/k[0-9]* "$OUT"/kl[0-9]*          # raw counter dumps: tens of MB (gpurun copies back 64 MiB at most)

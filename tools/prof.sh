@@ -101,12 +101,15 @@ case "$MODE" in
       tail -c 400 "$OUT/$L/trace/stdout.txt" | head -c 400; echo
       if [ "${NO_PMC:-0}" != "1" ]; then echo "=== line $L: PMC passes"; pmc_runs "$OUT/$L" $CMD; fi
       summarise "$OUT/$L/trace" "$OUT/$L" "$OUT/${L}_kernel_stats.csv" "$OUT/${L}_pmc.json" "$CMD"
+      tail -c 3000 "$OUT/$L/trace/stdout.txt" > "$OUT/${L}_line_tail.txt" 2>/dev/null
+      [ "${KEEP_RAW:-0}" = "1" ] || rm -rf "$OUT/$L"          # the raw traces run to tens of MB per line: gpurun copies back 64 MiB at most
     done ;;
   bench)
     CMD="python bench.py --no-cpu-baseline --no-configs"
     trace_run "$OUT/trace" $CMD
     cp "$OUT/trace/stdout.txt" "$OUT/bench_under_rocprof.json"
-    summarise "$OUT/trace" "" "$OUT/kernel_stats.csv" "" "$CMD" ;;
+    summarise "$OUT/trace" "" "$OUT/kernel_stats.csv" "" "$CMD"
+    [ "${KEEP_RAW:-0}" = "1" ] || rm -rf "$OUT/trace" ;;
   s1pmc)
     exec bash tools/pmc_passes.sh "$OUT" ;;
   trace)
@@ -118,7 +121,8 @@ case "$MODE" in
     [ "${1:-}" = "--" ] && shift
     trace_run "$OUT/trace" "$@"
     pmc_runs "$OUT" "$@"
-    summarise "$OUT/trace" "$OUT" "$OUT/kernel_stats.csv" "$OUT/pmc.json" "$*" ;;
+    summarise "$OUT/trace" "$OUT" "$OUT/kernel_stats.csv" "$OUT/pmc.json" "$*"
+    [ "${KEEP_RAW:-0}" = "1" ] || rm -rf "$OUT/trace" "$OUT"/k[0-9]* ;;
   seq)
     [ "${1:-}" = "--" ] && shift
     rm -rf "$OUT/seq"; mkdir -p "$OUT/seq"
