@@ -685,14 +685,23 @@ __global__ __launch_bounds__(TW) void fbn_fwd_kernel(
   for (int it = 0;; ++it) {
     const bool has1 = t + G < n_tiles;
     const float *cb = tb + (it & 1) * (B * ts);
+    // The staged pieces are waited for HERE, by every thread, before anything is stored (round 5, found in the ISA): a thread without a second
+    // piece skips that piece's LDS write and with it the wait for its load -- at the join the compiler then has to assume the load still in
+    // flight and, before the next loads may overwrite its registers, waits with vmcnt(0) AFTER the Y flush was issued: every iteration paid the
+    // round trip of its own store before it requested the next tile
+#pragma unroll
+    for (int k2 = 0; k2 < KLD; ++k2) asm volatile("" : "+v"(st[k2]));
     if (has1) stage_store<KLD, true>(tb + ((it + 1) & 1) * (B * ts), st, g);
     f32x4 kept = flush();
     __builtin_amdgcn_sched_barrier(0);
-    if (!FBT_ABL(2)) stage_load<KLD, VEC>(st, g, bases, base_of(t + 2 * G));
+    // the small loads FIRST, the tile two ahead LAST: vmcnt counts in order, so the wait for the indices at the bottom of the iteration then
+    // leaves the tile's loads in flight (issued the other way round it drained them: the tile was never more than one iteration ahead)
     const int rp2 = rp_of(t + 2 * G);
     const NodeRange s1 = node_range(rp1, wave, has1);
     const int er1 = e_rel[min(s1.a + lane, last)];
     const float ev1 = e_val[min(s1.a + lane, last)];
+    __builtin_amdgcn_sched_barrier(0);
+    if (!FBT_ABL(2)) stage_load<KLD, VEC>(st, g, bases, base_of(t + 2 * G));
     __builtin_amdgcn_sched_barrier(0);
     // ---- node `wave` of tile t
     const int nl = wave + t * TN - min(t * TN, N - TN);
@@ -780,13 +789,16 @@ __global__ __launch_bounds__(TW) void fbn_dcomps_kernel(
   for (int it = 0;; ++it) {
     const bool has1 = t + Gd < n_tiles, has2 = t + 2 * Gd < n_tiles;
     const float *cb = tb + (it & 1) * (B * ts);
+#pragma unroll
+    for (int k2 = 0; k2 < KLD; ++k2) asm volatile("" : "+v"(st[k2]));     // (every thread waits for its staged pieces here: see fbn_fwd_kernel)
     if (has1) stage_store<KLD, false>(tb + ((it + 1) & 1) * (B * ts), st, g);
     __builtin_amdgcn_sched_barrier(0);
-    if (!FBT_ABL(2)) stage_load<KLD, VEC>(st, g, bases, base_of(t + 2 * Gd));
     const int rp3 = rp_of(t + 3 * Gd);
     const NodeRange s2 = node_range(rp2, wave, has2);
     const Idx x2 = idx_load(e_dst, e_rel, e_val, s2.a, last, lane);
     if (!FBT_ABL(4)) gather_rows_at(gp1, G, x1.es, 0, min(16, s1.n), d, lane, gstride);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!FBT_ABL(2)) stage_load<KLD, VEC>(st, g, bases, base_of(t + 2 * Gd));      // (the tile LAST: the waits for the small loads leave it in flight)
     __builtin_amdgcn_sched_barrier(0);
     // ---- node `wave` of tile t
     const int nl = wave + t * TN - min(t * TN, N - TN);

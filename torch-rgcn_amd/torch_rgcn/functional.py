@@ -587,7 +587,9 @@ def use_diag_path(graph, d):
 def _split_k(K, M, N):
     """slices of the K dimension so that a skinny product (K = number of nodes, M x N = a weight matrix) still fills the chip"""
     tiles = -(-M // 128) * -(-N // 128)
-    return int(max(1, min(256, (4 * 256) // max(tiles, 1), K // 512)))
+    # (at most 64 slices: past that the partial products' round trip through HBM costs more than the extra workgroups buy --
+    # tools/splitk_probe.py, WN18's dbases = ag^T g, K = 40,943: 64 slices 122.7 us, the former choice of 79 133.7, 128 142.0)
+    return int(max(1, min(64, (4 * 256) // max(tiles, 1), K // 512)))
 
 
 class _MatmulMFMA(torch.autograd.Function):
