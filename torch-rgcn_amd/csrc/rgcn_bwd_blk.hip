@@ -380,6 +380,12 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
     lds_barrier();                                                 // every wave has finished adding to the dX tile (LDS only: the prefetches stay in flight)
     BLK_DBG(dbg_tb = BLK_T(); dbg_wait += dbg_tb - dbg_ta;)
     gs.x += gn.x; gs.y += gn.y; gs.z += gn.z; gs.w += gn.w;
+    // The next tile's X rows (requested before the barrier) are waited for HERE, before the tile's rows are stored (round 5, from the ISA):
+    // they are installed after the stores, vmcnt counts in order and the number of stores differs from thread to thread, so the compiler's
+    // wait at the install was vmcnt(0) -- it also waited for the stores to COMPLETE: one write round trip per tile with nothing in flight.
+    // With the arrival pinned here the stores drain under the re-zeroing, the barrier and the next tile's first gathers.
+#pragma unroll
+    for (int q = 0; q < TQ; ++q) asm volatile("" : "+v"(xn[q].x), "+v"(xn[q].y), "+v"(xn[q].z), "+v"(xn[q].w));
 #pragma unroll
     for (int q = 0; q < TQ; ++q) {
       const int idx = tid + q * NT;
