@@ -182,16 +182,25 @@ __global__ __launch_bounds__(BIG_WG) void block44_csr_kernel(
   long long u = (long long)blockIdx.x * UPW + (threadIdx.x >> 4);
   struct Idx { int rel[MF], src[MF]; float v[MF]; };
   auto load_unit = [&](long long uu) { return uu < n_units ? units[uu] : int4{0, 0, 0, 0}; };
+  // the three index loads of a message are UNCONDITIONAL and their sanitising happens where they are waited for (finish_idx): with
+  // `val = (relation in the table) ? e_val[e] : 0` the val load hung on the relation's arrival -- four dependent round trips per row
+  // (round 5, from the ISA: s_waitcnt vmcnt(1) after every relation load; the kernel ran at ~7 us per workgroup pass of 64 rows)
   auto load_idx = [&](const int4 &un, Idx &ix) {
 #pragma unroll
     for (int q = 0; q < MF; ++q) {
       const int e = un.y + g + 4 * q;
-      const bool have = e < un.z;
-      const int ee = have ? e : 0;
-      const int r = e_rel[ee];
-      ix.rel[q] = r < n_rel_blocks ? r : 0;
+      const int ee = e < un.z ? e : 0;
+      ix.rel[q] = e_rel[ee];
       ix.src[q] = e_src[ee];
-      ix.v[q] = (have && r < n_rel_blocks) ? e_val[ee] : 0.f;   // relations past the block table (LP self loops): not ours
+      ix.v[q] = e_val[ee];
+    }
+  };
+  auto finish_idx = [&](const int4 &un, Idx &ix) {
+#pragma unroll
+    for (int q = 0; q < MF; ++q) {
+      const bool ours = un.y + g + 4 * q < un.z && ix.rel[q] < n_rel_blocks;      // relations past the block table (LP self loops): not ours
+      ix.rel[q] = ix.rel[q] < n_rel_blocks ? ix.rel[q] : 0;
+      ix.v[q] = ours ? ix.v[q] : 0.f;
     }
   };
   auto mac = [&](f32x4 &acc, const f32x4 &x, float v, int rel) {
@@ -210,11 +219,17 @@ __global__ __launch_bounds__(BIG_WG) void block44_csr_kernel(
   int4 un_c = load_unit(u), un_n = load_unit(u + stride);
   Idx ix_c, ix_n;
   load_idx(un_c, ix_c);
+  finish_idx(un_c, ix_c);
+  const f32x4 bias4 = bias ? *reinterpret_cast<const f32x4 *>(bias + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};      // (once: a load ahead of every row's store would be waited for there)
   const long long u_first = (long long)blockIdx.x * UPW;      // uniform loop bound for the whole workgroup (shuffles below)
-  for (long long base = u_first; base < n_units; base += stride, u += stride) {
-    f32x4 x[MF];
+  // The row's gathers are issued at the END of the row before, AHEAD of that row's store (round 5, from the ISA): vmcnt counts in order, so a
+  // wait for loads issued after a store also waits for the store to complete -- with the gathers behind the store every row paid a write
+  // round trip before its first product.  Per iteration now: prefetch (unit two ahead, indices one ahead) | products of this row | wait for
+  // the prefetch | NEXT row's gathers | this row's store.
+  f32x4 x[MF];
 #pragma unroll
-    for (int q = 0; q < MF; ++q) x[q] = *reinterpret_cast<const f32x4 *>(X + (size_t)ix_c.src[q] * 16 + 4 * j);
+  for (int q = 0; q < MF; ++q) x[q] = *reinterpret_cast<const f32x4 *>(X + (size_t)ix_c.src[q] * 16 + 4 * j);
+  for (long long base = u_first; base < n_units; base += stride, u += stride) {
     const int4 un_nn = load_unit(u + 2 * stride);
     load_idx(un_n, ix_n);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -230,11 +245,19 @@ __global__ __launch_bounds__(BIG_WG) void block44_csr_kernel(
     for (int q = 0; q < 4; ++q) { acc[q] += __shfl_xor(acc[q], 4, 64); }
 #pragma unroll
     for (int q = 0; q < 4; ++q) { acc[q] += __shfl_xor(acc[q], 8, 64); }
+    int4 un_nn_p = un_nn;
+    asm volatile("" : "+v"(un_nn_p.x), "+v"(un_nn_p.y), "+v"(un_nn_p.z), "+v"(un_nn_p.w));
+#pragma unroll
+    for (int q = 0; q < MF; ++q) asm volatile("" : "+v"(ix_n.rel[q]), "+v"(ix_n.src[q]), "+v"(ix_n.v[q]));
+    finish_idx(un_n, ix_n);
+#pragma unroll
+    for (int q = 0; q < MF; ++q) x[q] = *reinterpret_cast<const f32x4 *>(X + (size_t)ix_n.src[q] * 16 + 4 * j);      // (past the end: row 0, unused)
+    __builtin_amdgcn_sched_barrier(0);
     if (u < n_units && g == 0) {
       const bool shared = un_c.w & RGCN_U_SHARED;
       const bool add_bias = bias && (!shared || (un_c.w & RGCN_U_FIRST));
       float *orow = out + (size_t)un_c.x * 16 + 4 * j;
-      if (add_bias) acc += *reinterpret_cast<const f32x4 *>(bias + 4 * j);
+      if (add_bias) acc += bias4;
       if (shared) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) atomicAdd(orow + q, acc[q]);
@@ -243,7 +266,7 @@ __global__ __launch_bounds__(BIG_WG) void block44_csr_kernel(
         *reinterpret_cast<f32x4 *>(orow) = acc;
       }
     }
-    un_c = un_n; un_n = un_nn; ix_c = ix_n;
+    un_c = un_n; un_n = un_nn_p; ix_c = ix_n;
   }
 }
 
