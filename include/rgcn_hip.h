@@ -565,10 +565,24 @@ RGCN_API int rgcn_segment_gather_sum_wide_f32(const float *Y, const int32_t *per
  * scores[t] = sum_k nodes[s,k] rel[p,k] nodes[o,k] (+ sbias[s] + pbias[p] + obias[o]);
  * triples int64 [T,3] on the device.  Biases may all be NULL.  Triples whose s / o are outside [0, n_nodes) or whose p
  * is outside [0, n_rel) are NOT touched (the reference's fancy indexing raises IndexError): their score is 0 and
- * *err_flag (device int32, may be NULL) is set to 1 -- the caller turns it into the exception. */
+ * *err_flag (device int32, may be NULL) is set to 1 -- the caller turns it into the exception.
+ * rank_counts / ranks (both NULL or both set): the counting pass of the backward's two CSRs of the scored triples (by subject, by
+ * object) rides along -- rank_counts (2 n_nodes + 3 ints, zeroed here) receives the row sizes (subject row k at [1 + k], object row k at
+ * [n_nodes + 2 + k]) and ranks (2 T ints) each valid triple's rank within its subject row and its object row (one returning atomic
+ * each, hidden behind the wave's row loads); rgcn_distmult_csr_place finishes the CSRs once the score gradients exist. */
 RGCN_API int rgcn_distmult_fwd_f32(const int64_t *triples, int64_t T, const float *nodes, const float *rel,
                                    const float *sbias, const float *pbias, const float *obias, float *scores,
-                                   int64_t n_nodes, int32_t n_rel, int32_t d, int32_t *err_flag, void *stream);
+                                   int64_t n_nodes, int32_t n_rel, int32_t d, int32_t *err_flag, int32_t *rank_counts,
+                                   int32_t *ranks, void *stream);
+/* The two CSRs rgcn_distmult_bwd_all_f32 / rgcn_distmult_bwd_nodes_f32 walk, from the ranks and row sizes the scoring kernel left
+ * (rgcn_distmult_fwd_f32) and the score gradients gs [T]: an exclusive scan of rank_counts in place (scan_tmp: (2 N + 2) / 1024 + 3
+ * ints; NULL = rank_counts already holds the scanned row starts of an earlier call) and one pass over the triples without atomics.
+ * Afterwards rank_counts + 1 is the row pointer by subject (N + 1 ints; entries = (object, predicate, gs)), rank_counts + N + 2 the row
+ * pointer by object (entries = (subject, predicate, gs)), both indexing the same array of 2 T entries of four int32 {other end,
+ * predicate, gs[t] (bit pattern), 0} (16 bytes: one store here, one load per lane in the walk; 16-byte aligned).  Triples outside the
+ * ranges are skipped as the scoring kernel skipped them. */
+RGCN_API int rgcn_distmult_csr_place(const int64_t *triples, int64_t T, int64_t N, int32_t n_rel, const int32_t *ranks,
+                                     int32_t *rank_counts, int32_t *scan_tmp, const float *gs, int32_t *entries, void *stream);
 /* Gradients of sum_t gs[t] * scores[t]; dnodes / drel (and the bias grads when
  * non-NULL) are zeroed first and accumulated with fp32 atomics.  Out-of-range triples are skipped.  dnodes may be NULL
  * (see rgcn_distmult_bwd_nodes_f32). */
@@ -576,24 +590,22 @@ RGCN_API int rgcn_distmult_bwd_f32(const int64_t *triples, int64_t T, const floa
                                    const float *gs, float *dnodes, float *drel, float *dsbias, float *dpbias,
                                    float *dobias, int64_t n_nodes, int32_t n_rel, int32_t d, void *stream);
 /* Entity gradients without atomics: dnodes[n] = sum_{t: s_t = n} g_t rel[p_t] * nodes[o_t] + sum_{t: o_t = n} g_t rel[p_t] *
- * nodes[s_t], one wave per entity over two CSRs of the scored triples (rows = subject, entries = (object, predicate, g);
- * rows = object, entries = (subject, predicate, g) -- rgcn_dev_plan_count / _fill with R = 1, see rgcn_dev_plan_fill).
+ * nodes[s_t], one wave per entity over the two CSRs of the scored triples (rgcn_distmult_csr_place: rows = subject, entries =
+ * (object, predicate, g); rows = object, entries = (subject, predicate, g)).
  * dnodes is fully written.  rgcn_distmult_bwd_f32 with dnodes = NULL then yields the relation / bias gradients only. */
-RGCN_API int rgcn_distmult_bwd_nodes_f32(const int32_t *rowptr_s, const int32_t *other_s, const int32_t *rel_s,
-                                         const float *g_s, const int32_t *rowptr_o, const int32_t *other_o,
-                                         const int32_t *rel_o, const float *g_o, const float *nodes, const float *rel,
-                                         float *dnodes, int64_t n_nodes, int32_t d, void *stream);
+RGCN_API int rgcn_distmult_bwd_nodes_f32(const int32_t *rowptr_s, const int32_t *rowptr_o, const int32_t *entries, const float *nodes,
+                                         const float *rel, float *dnodes, int64_t n_nodes, int32_t d, void *stream);
 
 /* All DistMult gradients from the two CSRs of the scored triples (by subject: entries = (object, predicate, g); by object:
  * entries = (subject, predicate, g)) -- entity gradient as above, relation gradient d_rel[p] += g x_s x_o accumulated in
- * wave-private LDS tables (no predicate sort, no second pass over the triples), bias gradients (d_sbias[n] / d_obias[n] = the
- * row sums of g, d_pbias via the LDS tables) when the three pointers are set.  The autograd dual of layers.py:87-101.
+ * one LDS table of doubles per workgroup (ds_add_f64; no predicate sort, no second pass over the triples), bias gradients
+ * (d_sbias[n] / d_obias[n] = the row sums of g, d_pbias via the LDS table) when the three pointers are set.  The autograd dual of
+ * layers.py:87-101.
  * Needs n_rel (d + 1) <= 4096 (rgcn_distmult_bwd_all_supported); d_rel / d_pbias are zeroed first. */
 RGCN_API int rgcn_distmult_bwd_all_supported(int32_t n_rel, int32_t d);
-RGCN_API int rgcn_distmult_bwd_all_f32(const int32_t *rowptr_s, const int32_t *other_s, const int32_t *rel_s, const float *g_s,
-                                       const int32_t *rowptr_o, const int32_t *other_o, const int32_t *rel_o, const float *g_o,
-                                       const float *nodes, const float *rel, float *dnodes, float *drel, float *dsbias,
-                                       float *dpbias, float *dobias, int64_t n_nodes, int32_t n_rel, int32_t d, void *stream);
+RGCN_API int rgcn_distmult_bwd_all_f32(const int32_t *rowptr_s, const int32_t *rowptr_o, const int32_t *entries, const float *nodes,
+                                       const float *rel, float *dnodes, float *drel, float *dsbias, float *dpbias, float *dobias,
+                                       int64_t n_nodes, int32_t n_rel, int32_t d, void *stream);
 
 /* Ranking evaluator (utils/misc.py:60-110 + torch_rgcn/layers.py:87-98 on the expanded
  * [bn, N, 3] candidate tensor, which is never built here).  For each of the Q test triples in `batch` (int64

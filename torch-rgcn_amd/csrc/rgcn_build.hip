@@ -426,7 +426,41 @@ __global__ void csr2_scatter_kernel(const int *__restrict__ a, const int *__rest
   }
 }
 
+// The two CSRs of a batch of SCORED triples once the scoring kernel has left every triple's rank within its subject row and its object
+// row (distmult_fwd_kernel) and the row sizes: no atomics here, one pass.
+__global__ void triple_csr_place_kernel(const long long *__restrict__ tr, long long T, long long N, int n_rel,
+                                        const int *__restrict__ ranks, const int *__restrict__ C, const float *__restrict__ gs,
+                                        int4 *__restrict__ entries) {
+  for (long long t = (long long)blockIdx.x * TB + threadIdx.x; t < T; t += (long long)gridDim.x * TB) {
+    const long long s = tr[3 * t], p = tr[3 * t + 1], o = tr[3 * t + 2];
+    if (s < 0 || s >= N || o < 0 || o >= N || p < 0 || p >= n_rel) continue;       // the scoring kernel skipped (and flagged) these
+    const int2 rk = *reinterpret_cast<const int2 *>(ranks + 2 * t);
+    const float g = gs[t];
+    const int ps = C[1 + s] + rk.x, po = C[N + 2 + o] + rk.y;
+    entries[ps] = make_int4((int)o, (int)p, __float_as_int(g), 0);      // one 16-byte store per entry, one 16-byte load per lane later
+    entries[po] = make_int4((int)s, (int)p, __float_as_int(g), 0);
+  }
+}
+
 }  // namespace
+
+extern "C" int rgcn_distmult_csr_place(const int64_t *triples, int64_t T, int64_t N, int32_t n_rel, const int32_t *ranks,
+                                       int32_t *rank_counts, int32_t *scan_tmp, const float *gs, int32_t *entries, void *stream) {
+  if (T < 0 || N <= 0 || n_rel <= 0 || !rank_counts || (T && (!triples || !ranks || !gs || !entries))) {
+    rgcn_set_error("distmult_csr_place: bad argument");
+    return RGCN_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const long long n_cells = 2 * (long long)N + 2;                 // C[1 ..]: N subject rows, one dummy, N object rows, the end
+  if (scan_tmp) {                                                 // (NULL: rank_counts was scanned by an earlier call -- a second backward pass)
+    int rc = exclusive_scan(rank_counts + 1, rank_counts + 1, scan_tmp, n_cells, scan_tmp + (n_cells / (TB * 4) + 2), st);
+    if (rc) return rc;
+  }
+  if (T) hipLaunchKernelGGL(triple_csr_place_kernel, dim3(blocks_for(T)), dim3(TB), 0, st, (const long long *)triples, (long long)T,
+                            (long long)N, n_rel, ranks, rank_counts, gs, reinterpret_cast<int4 *>(entries));
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
 
 extern "C" int rgcn_dev_split_triples(const int64_t *triples_plus, int64_t M, int64_t N, int32_t R, int32_t *s, int32_t *p,
                                       int32_t *o, int32_t *err_flag, void *stream) {

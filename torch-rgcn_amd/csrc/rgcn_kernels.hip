@@ -1131,7 +1131,8 @@ __global__ __launch_bounds__(WG) void colsum_b_kernel(const float *__restrict__ 
 __global__ __launch_bounds__(WG) void distmult_fwd_kernel(
     const long long *__restrict__ tr, long long T, const float *__restrict__ nodes, const float *__restrict__ rel,
     const float *__restrict__ sb, const float *__restrict__ pb, const float *__restrict__ ob,
-    float *__restrict__ scores, int d, long long n_nodes, int n_rel, int *__restrict__ err) {
+    float *__restrict__ scores, int d, long long n_nodes, int n_rel, int *__restrict__ err, int *__restrict__ counts,
+    int *__restrict__ ranks) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long long wstride = (long long)gridDim.x * (WG / 64);
   for (long long t = (long long)blockIdx.x * (WG / 64) + wave; t < T; t += wstride) {
@@ -1140,6 +1141,11 @@ __global__ __launch_bounds__(WG) void distmult_fwd_kernel(
       if (lane == 0) { if (err) atomicMax(err, 1); scores[t] = 0.f; }
       continue;
     }
+    // The backward pass walks the scored triples as two CSRs (by subject, by object).  Their counting pass rides here: one returning
+    // atomic per side gives the triple its rank within its row, behind the row loads of this wave instead of in two launches of their
+    // own (28 + 41 us for WN18's 330 k triples, bound by the rate of atomic requests); rgcn_distmult_csr_place finishes the CSRs.
+    int rk_s = 0, rk_o = 0;
+    if (counts && lane == 0) { rk_s = atomicAdd(counts + 1 + s, 1); rk_o = atomicAdd(counts + n_nodes + 2 + o, 1); }
     const float *ns = nodes + (size_t)s * d, *rp = rel + (size_t)p * d, *no = nodes + (size_t)o * d;
     float a = 0.f;
     for (int j = lane; j < d; j += 64) a += ns[j] * rp[j] * no[j];
@@ -1148,6 +1154,7 @@ __global__ __launch_bounds__(WG) void distmult_fwd_kernel(
     if (lane == 0) {
       if (sb) a += sb[s] + pb[p] + ob[o];
       scores[t] = a;
+      if (counts) *reinterpret_cast<int2 *>(ranks + 2 * t) = make_int2(rk_s, rk_o);
     }
   }
 }
@@ -1211,51 +1218,9 @@ __global__ __launch_bounds__(WG) void distmult_bwd_kernel(
 // Entity gradients of DistMult without atomics: the scored triples are indexed twice (CSR by subject, CSR by object --
 // the counting-sort builder of rgcn_build.hip) and one wave per entity sums its rows
 //     dnodes[n] = sum_{t: s_t = n} g_t r[p_t] * nodes[o_t]  +  sum_{t: o_t = n} g_t r[p_t] * nodes[s_t]
-// in registers (4 features per lane and pass, two entries' row loads in flight).  The scatter form it replaces issued
+// in registers (4 features per lane and pass, four entries' row loads in flight).  The scatter form it replaces issued
 // 2 T d fp32 atomics (132 M for a WN18 batch: 0.43 of the kernel's 0.51 ms at 2 cycles per lane and CU).
-__global__ __launch_bounds__(WG) void distmult_bwd_nodes_kernel(
-    const int *__restrict__ rp_s, const int *__restrict__ oth_s, const int *__restrict__ rel_s, const float *__restrict__ g_s,
-    const int *__restrict__ rp_o, const int *__restrict__ oth_o, const int *__restrict__ rel_o, const float *__restrict__ g_o,
-    const float *__restrict__ nodes, const float *__restrict__ rel, float *__restrict__ dnodes, long long N, int d) {
-  const int lane = threadIdx.x & 63;
-  const long long wave0 = ((long long)blockIdx.x * WG + threadIdx.x) >> 6, nw = ((long long)gridDim.x * WG) >> 6;
-  for (long long n = wave0; n < N; n += nw) {
-    for (int f0 = 0; f0 < d; f0 += 256) {
-      const int f = f0 + 4 * lane;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int side = 0; side < 2; ++side) {
-        const int *rp = side ? rp_o : rp_s, *oth = side ? oth_o : oth_s, *rl = side ? rel_o : rel_s;
-        const float *gv = side ? g_o : g_s;
-        const int e0 = rp[n], e1 = rp[n + 1];
-        for (int e = e0; e < e1; e += 2) {
-          const int ea = e, eb = min(e + 1, e1 - 1);
-          const float ga = gv[ea], gb = (e + 1 < e1) ? gv[eb] : 0.f;
-          const float *na = nodes + (size_t)oth[ea] * d, *nb = nodes + (size_t)oth[eb] * d;
-          const float *ra = rel + (size_t)rl[ea] * d, *rb = rel + (size_t)rl[eb] * d;
-          if (f + 3 < d && (d & 3) == 0) {
-            const f32x4 xa = *reinterpret_cast<const f32x4 *>(na + f), xb = *reinterpret_cast<const f32x4 *>(nb + f);
-            const f32x4 wa = *reinterpret_cast<const f32x4 *>(ra + f), wb = *reinterpret_cast<const f32x4 *>(rb + f);
-            acc += xa * wa * ga + xb * wb * gb;
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (f + q < d) acc[q] += na[f + q] * ra[f + q] * ga + nb[f + q] * rb[f + q] * gb;
-          }
-        }
-      }
-      float *o = dnodes + (size_t)n * d + f;
-      if (f + 3 < d && (d & 3) == 0) {
-        *reinterpret_cast<f32x4 *>(o) = acc;
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (f + q < d) o[q] = acc[q];
-      }
-    }
-  }
-}
-
+// (distmult_bwd_all_kernel<3, VEC, false> below: both sides in one launch, no relation table.)
 // All of DistMult's gradients from the two CSRs, no sort and no second pass over the triples: the entity walk above already
 // holds, for every triple of the subject-side CSR, the row of the object; with the entity's own row it is the triple's
 // contribution to the RELATION gradient, d_rel[p] += g * x_s * x_o.  Each wave keeps a private [n_rel][d] table (+ the
@@ -1265,96 +1230,112 @@ __global__ __launch_bounds__(WG) void distmult_bwd_nodes_kernel(
 // by predicate (rocPRIM merge sort, 0.15 ms for 330 k triples) + two index gathers + distmult_bwd_kernel (0.12 ms).
 // (One table per WORKGROUP with ds_add_f32 -- 4x less LDS, twice the resident waves -- measured 0.37 ms against 0.21: LDS float
 // atomics are slow on gfx950 even without address conflicts.)
-// SIDES: 3 = both CSRs in one launch; 1 = subject side only (with the LDS tables), ADDING to the dnodes rows a previous launch
-// wrote; 2 = object side only (no LDS: launched with many more resident waves).  Two launches (2, then 1) measured faster than
-// one: the LDS tables hold the one-launch form at 8 waves per CU for ALL of its gathers.
-template <int SIDES>
+// Round 5: ONE table per workgroup after all, in DOUBLES with ds_add_f64 -- the LDS float atomic gfx950 runs at full rate when the lanes
+// of an instruction touch consecutive doubles.  The kernel is a chain of dependent round trips per entity (row pointers -> indices ->
+// rows -> read-modify-write of the entity's row) that only resident waves hide, and four private tables per workgroup (58 KB) held it
+// at 8 waves per CU: 135 us for WN18's subject side where the table-free object side takes 48.  29 KB per workgroup = 20 waves per CU.
+// The table is stored feature-permuted (feature 4 l + q of a relation's row at q * ceil(d / 4) + l) so that instruction q of the 64
+// lanes adds to 64 consecutive doubles.
+// SIDES: 1 = subject side (with the LDS table), ADDING to the dnodes rows the object-side launch wrote; 2 = object side only (no LDS:
+// launched first, with many more resident waves).
+// The entries of an entity's row (other end, predicate, score gradient) are loaded by the lanes in ONE round trip -- lane i takes entry i --
+// and handed to the wave four at a time with v_readlane: scalar row addresses, four entity rows and four relation rows in flight per
+// step of the chain instead of two behind a per-pair index load.
+// VEC: d is a multiple of 4 -- every lane loads whole float4s without a branch (lanes past the row's end from feature 0, and keep nothing).
+// TABLE = false: entity gradients only (relation tables too large for the LDS: the predicate-sorted kernel above does the rest); SIDES = 3.
+// Entries: int4 {other end, predicate, score gradient (bits), -} -- one 16-byte load per lane (rgcn_distmult_csr_place writes them).
+template <int SIDES, bool VEC, bool TABLE>
 __global__ __launch_bounds__(WG) void distmult_bwd_all_kernel(
-    const int *__restrict__ rp_s, const int *__restrict__ oth_s, const int *__restrict__ rel_s, const float *__restrict__ g_s,
-    const int *__restrict__ rp_o, const int *__restrict__ oth_o, const int *__restrict__ rel_o, const float *__restrict__ g_o,
-    const float *__restrict__ nodes, const float *__restrict__ rel, float *__restrict__ dnodes, float *__restrict__ drel,
-    float *__restrict__ dsb, float *__restrict__ dpb, float *__restrict__ dob, long long N, int n_rel, int d) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tab_floats = n_rel * d + n_rel;                 // [n_rel][d] + predicate bias [n_rel]
-  float *tab = lds + (size_t)wave * tab_floats, *pb = tab + (size_t)n_rel * d;
-  if (SIDES & 1)
-    for (int i = lane; i < tab_floats; i += 64) tab[i] = 0.f;
-  const bool vec = (d & 3) == 0;
+    const int *__restrict__ rp_s, const int *__restrict__ rp_o, const int4 *__restrict__ entries, const float *__restrict__ nodes,
+    const float *__restrict__ rel, float *__restrict__ dnodes, float *__restrict__ drel, float *__restrict__ dsb,
+    float *__restrict__ dpb, float *__restrict__ dob, long long N, int n_rel, int d) {
+  extern __shared__ __attribute__((aligned(16))) double ldsd[];
+  const int lane = threadIdx.x & 63;
+  const int dq = (d + 3) >> 2, dp = 4 * dq;                 // a relation's row: 4 runs of dq doubles (feature 4 l + q at q * dq + l)
+  const int tab_n = n_rel * dp + n_rel;                     // [n_rel][dp] + predicate bias [n_rel]
+  double *tab = ldsd, *pb = tab + (size_t)n_rel * dp;
+  if (TABLE && (SIDES & 1)) {
+    for (int i = threadIdx.x; i < tab_n; i += WG) tab[i] = 0.0;
+    __syncthreads();
+  }
   const long long wave0 = ((long long)blockIdx.x * WG + threadIdx.x) >> 6, nw = ((long long)gridDim.x * WG) >> 6;
   for (long long n = wave0; n < N; n += nw) {
     for (int f0 = 0; f0 < d; f0 += 256) {
       const int f = f0 + 4 * lane;
-      const bool full = vec && f + 3 < d;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, xn = {0.f, 0.f, 0.f, 0.f};
-      if (full) {
-        xn = *reinterpret_cast<const f32x4 *>(nodes + (size_t)n * d + f);
-      } else {
+      const bool act = f < d;
+      const int fc = act ? f : 0;
+      auto load4 = [&](const float *row) -> f32x4 {
+        if (VEC) return *reinterpret_cast<const f32x4 *>(row + fc);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          if (f + q < d) xn[q] = nodes[(size_t)n * d + f + q];
-      }
+          if (f + q < d) v[q] = row[f + q];
+        return v;
+      };
+      float *o = dnodes + (size_t)n * d;
+      const f32x4 xn = load4(nodes + (size_t)n * d);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (SIDES == 1) acc = load4(o);                  // the object-side launch wrote this row
 #pragma unroll
       for (int side = 0; side < 2; ++side) {
         if (!((SIDES >> side) & 1)) continue;
-        const int *rp = side ? rp_o : rp_s, *oth = side ? oth_o : oth_s, *rl = side ? rel_o : rel_s;
-        const float *gv = side ? g_o : g_s;
-        const int e0 = rp[n], e1 = rp[n + 1];
+        const int *rp = side ? rp_o : rp_s;
+        const int e0 = __builtin_amdgcn_readfirstlane(rp[n]), e1 = __builtin_amdgcn_readfirstlane(rp[n + 1]);
         float gsum = 0.f;
-        for (int e = e0; e < e1; e += 2) {
-          const int ea = e, eb = min(e + 1, e1 - 1);
-          const bool hb = e + 1 < e1;
-          const float ga = gv[ea], gb = hb ? gv[eb] : 0.f;
-          const int pa = rl[ea], pbi = rl[eb];
-          const float *na = nodes + (size_t)oth[ea] * d, *nb = nodes + (size_t)oth[eb] * d;
-          const float *ra = rel + (size_t)pa * d, *rb = rel + (size_t)pbi * d;
-          f32x4 xa = {0.f, 0.f, 0.f, 0.f}, xb = xa, wa = xa, wb = xa;
-          if (full) {
-            xa = *reinterpret_cast<const f32x4 *>(na + f); xb = *reinterpret_cast<const f32x4 *>(nb + f);
-            wa = *reinterpret_cast<const f32x4 *>(ra + f); wb = *reinterpret_cast<const f32x4 *>(rb + f);
-          } else {
+        for (int c0 = e0; c0 < e1; c0 += 64) {
+          const int cnt = min(64, e1 - c0);
+          const int4 me = entries[c0 + min(lane, cnt - 1)];      // lanes past the row's end repeat its last entry, with a zero gradient
+          const int mo = me.x, mr = me.y, mg = lane < cnt ? me.z : 0;
+          for (int j = 0; j < cnt; j += 4) {
+            f32x4 xe[4], we[4];
+            float ge[4];
+            int pe[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (f + q < d) { xa[q] = na[f + q]; xb[q] = nb[f + q]; wa[q] = ra[f + q]; wb[q] = rb[f + q]; }
-          }
-          acc += xa * wa * ga + xb * wb * gb;
-          gsum += ga + gb;
-          if (side == 0 && f < d) {            // relation gradient: this wave's LDS table, plain RMW (the LDS pipeline is in order)
-            float *ta = tab + (size_t)pa * d + f, *tb = tab + (size_t)pbi * d + f;
-            const f32x4 ca = xn * xa * ga, cb = xn * xb * gb;
-            if (full) {
-              *reinterpret_cast<f32x4 *>(ta) += ca;
-              if (hb) *reinterpret_cast<f32x4 *>(tb) += cb;
-            } else {
-#pragma unroll
-              for (int q = 0; q < 4; ++q)
-                if (f + q < d) { ta[q] += ca[q]; if (hb) tb[q] += cb[q]; }
+            for (int u = 0; u < 4; ++u) {
+              const int oe = __builtin_amdgcn_readlane(mo, j + u);
+              pe[u] = __builtin_amdgcn_readlane(mr, j + u);
+              ge[u] = __int_as_float(__builtin_amdgcn_readlane(mg, j + u));
+              xe[u] = load4(nodes + (size_t)oe * d);
+              we[u] = load4(rel + (size_t)pe[u] * d);
             }
-            if (f0 == 0 && lane == 0 && dpb) { pb[pa] += ga; if (hb) pb[pbi] += gb; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              acc += xe[u] * we[u] * ge[u];
+              gsum += ge[u];
+              if (TABLE && side == 0 && act && j + u < cnt) {   // relation gradient: the workgroup's LDS table of doubles (ds_add_f64, consecutive doubles per instruction)
+                double *ta = tab + (size_t)pe[u] * dp + (f >> 2);
+                const f32x4 ca = xn * xe[u] * ge[u];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                  if (VEC || f + q < d) __hip_atomic_fetch_add(ta + q * dq, (double)ca[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (f0 == 0 && lane == 0 && dpb) __hip_atomic_fetch_add(pb + pe[u], (double)ge[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+            }
           }
         }
         if (f0 == 0 && lane == 0 && dsb) (side ? dob : dsb)[n] = gsum;
       }
-      float *o = dnodes + (size_t)n * d + f;
-      if (full) {
-        if (SIDES == 1) acc += *reinterpret_cast<const f32x4 *>(o);      // the object-side launch wrote this row
-        *reinterpret_cast<f32x4 *>(o) = acc;
+      if (VEC) {
+        if (act) *reinterpret_cast<f32x4 *>(o + f) = acc;
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          if (f + q < d) o[q] = acc[q] + (SIDES == 1 ? o[q] : 0.f);
+          if (f + q < d) o[f + q] = acc[q];
       }
     }
   }
-  if (!(SIDES & 1)) return;
+  if (!TABLE || !(SIDES & 1)) return;
   __syncthreads();
-  for (int i = threadIdx.x; i < tab_floats; i += WG) {
-    const float t = (lds[i] + lds[tab_floats + i]) + (lds[2 * tab_floats + i] + lds[3 * tab_floats + i]);
-    if (t != 0.f) {
-      if (i < n_rel * d) atomicAdd(drel + i, t);
-      else if (dpb) atomicAdd(dpb + (i - n_rel * d), t);
-    }
+  for (int i = threadIdx.x; i < n_rel * d; i += WG) {       // un-permute: drel[r][j] = tab[r][(j & 3) * dq + (j >> 2)]
+    const int r = i / d, j = i - r * d;
+    const float t = (float)tab[(size_t)r * dp + (j & 3) * dq + (j >> 2)];
+    if (t != 0.f) atomicAdd(drel + i, t);
   }
+  if (dpb)
+    for (int i = threadIdx.x; i < n_rel; i += WG) {
+      const float t = (float)pb[i];
+      if (t != 0.f) atomicAdd(dpb + i, t);
+    }
 }
 
 int pow2_lanes(int d) {
@@ -1752,15 +1733,18 @@ extern "C" int rgcn_colsum_f32(const float *G, float *db, float *scratch, int64_
 
 extern "C" int rgcn_distmult_fwd_f32(const int64_t *triples, int64_t T, const float *nodes, const float *rel,
                                      const float *sbias, const float *pbias, const float *obias, float *scores,
-                                     int64_t n_nodes, int32_t n_rel, int32_t d, int32_t *err_flag, void *stream) {
-  if (T < 0 || d <= 0 || (T && (!triples || !nodes || !rel || !scores))) { rgcn_set_error("distmult_fwd: bad argument"); return RGCN_EINVAL; }
+                                     int64_t n_nodes, int32_t n_rel, int32_t d, int32_t *err_flag, int32_t *rank_counts,
+                                     int32_t *ranks, void *stream) {
+  if (T < 0 || d <= 0 || (T && (!triples || !nodes || !rel || !scores)) || (rank_counts != nullptr) != (ranks != nullptr) ||
+      (rank_counts && (n_nodes <= 0 || 2 * T > INT32_MAX))) { rgcn_set_error("distmult_fwd: bad argument"); return RGCN_EINVAL; }
   if ((sbias != nullptr) != (pbias != nullptr) || (sbias != nullptr) != (obias != nullptr)) { rgcn_set_error("distmult_fwd: biases must be all set or all NULL"); return RGCN_EINVAL; }
   if (err_flag) HIP_TRY(zero_async(err_flag, sizeof(int32_t), (hipStream_t)stream));
+  if (rank_counts) HIP_TRY(zero_async(rank_counts, (size_t)(2 * n_nodes + 3) * sizeof(int32_t), (hipStream_t)stream));
   if (T == 0) return RGCN_OK;
   const unsigned gx = (unsigned)std::min<int64_t>((T + 3) / 4, 256 * 32);
   hipLaunchKernelGGL(distmult_fwd_kernel, dim3(gx), dim3(WG), 0, (hipStream_t)stream,
                      reinterpret_cast<const long long *>(triples), (long long)T, nodes, rel, sbias, pbias, obias,
-                     scores, d, (long long)n_nodes, n_rel, err_flag);
+                     scores, d, (long long)n_nodes, n_rel, err_flag, rank_counts, ranks);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
@@ -1789,39 +1773,45 @@ extern "C" int rgcn_distmult_bwd_f32(const int64_t *triples, int64_t T, const fl
 
 extern "C" int rgcn_distmult_bwd_all_supported(int32_t n_rel, int32_t d) { return n_rel > 0 && d > 0 && (int64_t)n_rel * (d + 1) <= 4096; }
 
-extern "C" int rgcn_distmult_bwd_all_f32(const int32_t *rowptr_s, const int32_t *other_s, const int32_t *rel_s, const float *g_s,
-                                         const int32_t *rowptr_o, const int32_t *other_o, const int32_t *rel_o, const float *g_o,
-                                         const float *nodes, const float *rel, float *dnodes, float *drel, float *dsbias,
-                                         float *dpbias, float *dobias, int64_t n_nodes, int32_t n_rel, int32_t d, void *stream) {
+extern "C" int rgcn_distmult_bwd_all_f32(const int32_t *rowptr_s, const int32_t *rowptr_o, const int32_t *entries, const float *nodes,
+                                         const float *rel, float *dnodes, float *drel, float *dsbias, float *dpbias, float *dobias,
+                                         int64_t n_nodes, int32_t n_rel, int32_t d, void *stream) {
   if (!rowptr_s || !rowptr_o || !nodes || !rel || !dnodes || !drel || n_nodes < 0 || d <= 0 || n_rel <= 0) { rgcn_set_error("distmult_bwd_all: bad argument"); return RGCN_EINVAL; }
   if ((dsbias != nullptr) != (dpbias != nullptr) || (dsbias != nullptr) != (dobias != nullptr)) { rgcn_set_error("distmult_bwd_all: bias gradients must be all set or all NULL"); return RGCN_EINVAL; }
-  if (!rgcn_distmult_bwd_all_supported(n_rel, d)) { rgcn_set_error("distmult_bwd_all: n_rel (d + 1) = %lld floats do not fit a wave's LDS table (4096)", (long long)n_rel * (d + 1)); return RGCN_EUNSUPPORTED; }
+  if (!rgcn_distmult_bwd_all_supported(n_rel, d)) { rgcn_set_error("distmult_bwd_all: n_rel (d + 1) = %lld floats do not fit the LDS table (4096)", (long long)n_rel * (d + 1)); return RGCN_EUNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(zero_async(drel, (size_t)n_rel * d * sizeof(float), st));
   if (dpbias) HIP_TRY(zero_async(dpbias, (size_t)n_rel * sizeof(float), st));
   if (!n_nodes) return RGCN_OK;
-  const unsigned gx = (unsigned)std::min<int64_t>((n_nodes + 3) / 4, 512);
-  const size_t lds = (size_t)4 * ((size_t)n_rel * d + n_rel) * sizeof(float);
-  {     // two launches (object side without LDS at full occupancy, then subject side + relation table): the one-launch form was measured slower
-    const unsigned gx2 = (unsigned)std::min<int64_t>((n_nodes + 3) / 4, 256 * 32);
-    hipLaunchKernelGGL(distmult_bwd_all_kernel<2>, dim3(gx2), dim3(WG), 0, st, rowptr_s, other_s, rel_s, g_s, rowptr_o, other_o, rel_o,
-                       g_o, nodes, rel, dnodes, drel, dsbias, dpbias, dobias, (long long)n_nodes, n_rel, d);
-    hipLaunchKernelGGL(distmult_bwd_all_kernel<1>, dim3(gx), dim3(WG), lds, st, rowptr_s, other_s, rel_s, g_s, rowptr_o, other_o, rel_o,
-                       g_o, nodes, rel, dnodes, drel, dsbias, dpbias, dobias, (long long)n_nodes, n_rel, d);
-  }
+  const unsigned gx = (unsigned)std::min<int64_t>((n_nodes + 3) / 4, 1024);        // (29 KB of LDS per workgroup at WN18's size: up to 5 per CU)
+  const size_t lds = ((size_t)n_rel * 4 * ((d + 3) / 4) + n_rel) * sizeof(double);
+  const unsigned gx2 = (unsigned)std::min<int64_t>((n_nodes + 3) / 4, 256 * 32);
+  const int4 *en = reinterpret_cast<const int4 *>(entries);
+  // two launches (object side without LDS at full occupancy, then subject side + relation table): the one-launch form was measured slower
+  auto go = [&](auto k2, auto k1) {
+    hipLaunchKernelGGL(k2, dim3(gx2), dim3(WG), 0, st, rowptr_s, rowptr_o, en, nodes, rel, dnodes, drel, dsbias, dpbias, dobias,
+                       (long long)n_nodes, n_rel, d);
+    hipLaunchKernelGGL(k1, dim3(gx), dim3(WG), lds, st, rowptr_s, rowptr_o, en, nodes, rel, dnodes, drel, dsbias, dpbias, dobias,
+                       (long long)n_nodes, n_rel, d);
+  };
+  if (d % 4 == 0) go(distmult_bwd_all_kernel<2, true, true>, distmult_bwd_all_kernel<1, true, true>);
+  else go(distmult_bwd_all_kernel<2, false, true>, distmult_bwd_all_kernel<1, false, true>);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
 
-extern "C" int rgcn_distmult_bwd_nodes_f32(const int32_t *rowptr_s, const int32_t *other_s, const int32_t *rel_s,
-                                           const float *g_s, const int32_t *rowptr_o, const int32_t *other_o,
-                                           const int32_t *rel_o, const float *g_o, const float *nodes, const float *rel,
-                                           float *dnodes, int64_t n_nodes, int32_t d, void *stream) {
+extern "C" int rgcn_distmult_bwd_nodes_f32(const int32_t *rowptr_s, const int32_t *rowptr_o, const int32_t *entries, const float *nodes,
+                                           const float *rel, float *dnodes, int64_t n_nodes, int32_t d, void *stream) {
   if (!rowptr_s || !rowptr_o || !nodes || !rel || !dnodes || n_nodes < 0 || d <= 0) { rgcn_set_error("distmult_bwd_nodes: bad argument"); return RGCN_EINVAL; }
   if (!n_nodes) return RGCN_OK;
   const unsigned gx = (unsigned)std::min<int64_t>((n_nodes + 3) / 4, 256 * 32);
-  hipLaunchKernelGGL(distmult_bwd_nodes_kernel, dim3(gx), dim3(WG), 0, (hipStream_t)stream, rowptr_s, other_s, rel_s, g_s, rowptr_o,
-                     other_o, rel_o, g_o, nodes, rel, dnodes, (long long)n_nodes, d);
+  const int4 *en = reinterpret_cast<const int4 *>(entries);
+  auto go = [&](auto k) {
+    hipLaunchKernelGGL(k, dim3(gx), dim3(WG), 0, (hipStream_t)stream, rowptr_s, rowptr_o, en, nodes, rel, dnodes, (float *)nullptr,
+                       (float *)nullptr, (float *)nullptr, (float *)nullptr, (long long)n_nodes, 0, d);
+  };
+  if (d % 4 == 0) go(distmult_bwd_all_kernel<3, true, false>);
+  else go(distmult_bwd_all_kernel<3, false, false>);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

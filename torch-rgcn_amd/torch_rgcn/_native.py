@@ -1528,20 +1528,26 @@ def bce_head(scores, labels):
     return loss, ds
 
 
-def distmult_fwd(triples, nodes, rel, sbias, pbias, obias):
+def distmult_fwd(triples, nodes, rel, sbias, pbias, obias, ranks=False):
+    """scores [T]; ranks=True: (scores, [row sizes, ranks]) -- the counting pass of the backward's two CSRs done by the scoring kernel
+    (see distmult_csrs; the list is consumed by it)"""
     _req(nodes, "nodes"); _req(rel, "relations"); _req(triples, "triples", torch.int64)
     for b, n in ((sbias, "sbias"), (pbias, "pbias"), (obias, "obias")):
         _req(b, n)
     T = triples.shape[0]
     scores = torch.empty(T, device=nodes.device, dtype=torch.float32)
     err = _i32(1, nodes.device)
+    counts = rk = None
+    if ranks and T:
+        counts, rk = _i32(2 * nodes.shape[0] + 3, nodes.device), _i32(2 * T, nodes.device)
     with _on(nodes.device), _timed("distmult_fwd"):
         _check(lib().rgcn_distmult_fwd_f32(_dp(triples), c_i64(T), _dp(nodes), _dp(rel), _dp(sbias), _dp(pbias),
                                            _dp(obias), _dp(scores), c_i64(nodes.shape[0]), c_i32(rel.shape[0]),
-                                           c_i32(nodes.shape[1]), _dp(err), _stream(nodes.device)), "distmult_fwd")
+                                           c_i32(nodes.shape[1]), _dp(err), _dp(counts), _dp(rk), _stream(nodes.device)),
+               "distmult_fwd")
     # the reference indexes nodes[s], relations[p], nodes[o] (layers.py:89-93) and raises IndexError on a bad index
     dev_check_err(err, "DistMult triples (s, o < num_nodes, p < num_relations)", IndexError)
-    return scores
+    return (scores, [counts, rk, False]) if ranks else scores
 
 
 def distmult_score_all(batch, head, nodes, rel, sbias=None, pbias=None, obias=None, out=None):
@@ -1614,45 +1620,50 @@ def distmult_bwd_all_supported(n_rel, d):
     return bool(lib().rgcn_distmult_bwd_all_supported(c_i32(n_rel), c_i32(d)))
 
 
-def distmult_bwd_all(triples, nodes, rel, gs, with_bias):
+def distmult_csrs(triples, ranks, nodes, rel, gs):
+    """(rowptr by subject, rowptr by object, entries): the two CSRs of the scored triples the backward kernels walk, 16-byte entries
+    {other end, predicate, gs[t], -}, from the row sizes and ranks the scoring kernel left (distmult_fwd(..., ranks=True)): a scan
+    and one pass without atomics (rgcn_distmult_csr_place).  The row sizes are scanned in place, once: ranks[2] remembers."""
+    counts, rk, scanned = ranks
+    N, R, T = nodes.shape[0], rel.shape[0], triples.shape[0]
+    dev = nodes.device
+    scan_tmp = None if scanned else _i32((2 * N + 2) // 1024 + 4, dev)
+    ranks[2] = True
+    entries = torch.empty((max(2 * T, 1), 4), dtype=torch.int32, device=dev)
+    with _on(dev):
+        _check(lib().rgcn_distmult_csr_place(_dp(triples), c_i64(T), c_i64(N), c_i32(R), _dp(rk), _dp(counts), _dp(scan_tmp), _dp(gs),
+                                             _dp(entries), _stream(dev)), "distmult_csr_place")
+    return counts[1: N + 2], counts[N + 2: 2 * N + 3], entries
+
+
+def distmult_bwd_all(triples, ranks, nodes, rel, gs, with_bias):
     """(dnodes, drel, dsbias, dpbias, dobias) of DistMult from two CSRs of the scored triples -- no predicate sort, no atomics on
     the entity rows (rgcn_distmult_bwd_all_f32); bias gradients None unless with_bias"""
     _req(gs, "grad_scores"); _req(nodes, "nodes"); _req(rel, "relations")
     N, d = nodes.shape
     R = rel.shape[0]
     dev = nodes.device
-    s, p, o, _err = dev_split_triples(triples, N, R)
-    alive = None
-    if _deferred_mode():     # the forward's range check may not have been looked at yet: bad triples must not reach the sort
-        alive = ((triples >= 0).all(dim=1) & (triples[:, 0] < N) & (triples[:, 2] < N) & (triples[:, 1] < R)).to(torch.uint8)
-    by_s, by_o = build_csr_pair_device(s, o, p, gs, alive, N)
+    rp_s, rp_o, entries = distmult_csrs(triples, ranks, nodes, rel, gs)
     dn, dr = torch.empty_like(nodes), torch.empty_like(rel)
     dsb = dpb = dob = None
     if with_bias:
         dsb, dob = torch.empty(N, device=dev, dtype=torch.float32), torch.empty(N, device=dev, dtype=torch.float32)
         dpb = torch.empty(R, device=dev, dtype=torch.float32)
     with _on(dev), _timed("distmult_bwd_all"):
-        _check(lib().rgcn_distmult_bwd_all_f32(_dp(by_s.rowptr), _dp(by_s.src), _dp(by_s.rel), _dp(by_s.val), _dp(by_o.rowptr),
-                                               _dp(by_o.src), _dp(by_o.rel), _dp(by_o.val), _dp(nodes), _dp(rel), _dp(dn), _dp(dr),
-                                               _dp(dsb), _dp(dpb), _dp(dob), c_i64(N), c_i32(R), c_i32(d), _stream(dev)),
-               "distmult_bwd_all")
+        _check(lib().rgcn_distmult_bwd_all_f32(_dp(rp_s), _dp(rp_o), _dp(entries), _dp(nodes), _dp(rel), _dp(dn), _dp(dr), _dp(dsb),
+                                               _dp(dpb), _dp(dob), c_i64(N), c_i32(R), c_i32(d), _stream(dev)), "distmult_bwd_all")
     return dn, dr, dsb, dpb, dob
 
 
-def distmult_bwd_nodes(triples, nodes, rel, gs):
-    """entity gradients of DistMult without atomics: two CSRs of the scored triples (by subject, by object; device-side
-    counting sort, no host read-back) and one wave per entity (rgcn_distmult_bwd_nodes_f32)"""
+def distmult_bwd_nodes(triples, ranks, nodes, rel, gs):
+    """entity gradients of DistMult without atomics: the two CSRs of the scored triples (distmult_csrs) and one wave per entity
+    (rgcn_distmult_bwd_nodes_f32)"""
     _req(gs, "grad_scores"); _req(nodes, "nodes"); _req(rel, "relations")
     N, d = nodes.shape
     dev = nodes.device
-    s, p, o, _err = dev_split_triples(triples, N, rel.shape[0])
-    alive = None
-    if _deferred_mode():     # the forward's range check may not have been looked at yet: bad triples must not reach the sort
-        alive = ((triples >= 0).all(dim=1) & (triples[:, 0] < N) & (triples[:, 2] < N) & (triples[:, 1] < rel.shape[0])).to(torch.uint8)
-    by_s, by_o = build_csr_pair_device(s, o, p, gs, alive, N)
+    rp_s, rp_o, entries = distmult_csrs(triples, ranks, nodes, rel, gs)
     dn = torch.empty_like(nodes)
     with _on(dev), _timed("distmult_bwd_nodes"):
-        _check(lib().rgcn_distmult_bwd_nodes_f32(_dp(by_s.rowptr), _dp(by_s.src), _dp(by_s.rel), _dp(by_s.val), _dp(by_o.rowptr),
-                                                 _dp(by_o.src), _dp(by_o.rel), _dp(by_o.val), _dp(nodes), _dp(rel), _dp(dn),
-                                                 c_i64(N), c_i32(d), _stream(dev)), "distmult_bwd_nodes")
+        _check(lib().rgcn_distmult_bwd_nodes_f32(_dp(rp_s), _dp(rp_o), _dp(entries), _dp(nodes), _dp(rel), _dp(dn), c_i64(N), c_i32(d),
+                                                 _stream(dev)), "distmult_bwd_nodes")
     return dn

@@ -811,7 +811,13 @@ class _DistMultScore(torch.autograd.Function):
         tr = triples.reshape(-1, 3).contiguous()
         nodes = dense(nodes)
         relations = dense(relations)
-        scores = _native.distmult_fwd(tr, nodes, relations, sbias, pbias, obias)
+        # the backward pass walks the scored triples as two CSRs (unless routed to the atomic scatter): their counting pass rides on
+        # the scoring kernel
+        ctx.ranks = None
+        if any(ctx.needs_input_grad[1:]) and tr.shape[0] and routes.get("distmult_bwd", "csr") != "atomic":
+            scores, ctx.ranks = _native.distmult_fwd(tr, nodes, relations, sbias, pbias, obias, ranks=True)
+        else:
+            scores = _native.distmult_fwd(tr, nodes, relations, sbias, pbias, obias)
         ctx.save_for_backward(tr, nodes, relations)
         ctx.with_bias = sbias is not None
         ctx.shape = shape
@@ -823,16 +829,16 @@ class _DistMultScore(torch.autograd.Function):
         gs = gs.reshape(-1)
         gs = dense(gs)
         mode = routes.get("distmult_bwd", "csr")
-        scatter = mode == "atomic" or tr.shape[0] == 0
+        scatter = ctx.ranks is None
         if not scatter and mode != "split" and _native.distmult_bwd_all_supported(relations.shape[0], nodes.shape[1]):
             # small relation tables (WN18: 18 x 200): every gradient from the two CSR walks, no predicate sort
-            dn, dr, dsb, dpb, dob = _native.distmult_bwd_all(tr, nodes, relations, gs, ctx.with_bias)
+            dn, dr, dsb, dpb, dob = _native.distmult_bwd_all(tr, ctx.ranks, nodes, relations, gs, ctx.with_bias)
             return None, dn, dr, dsb, dpb, dob
         order = torch.argsort(tr[:, 1], stable=True)   # predicate runs -> relation gradient accumulates in registers
         dn, dr, dsb, dpb, dob = _native.distmult_bwd(tr[order].contiguous(), nodes, relations, gs[order].contiguous(),
                                                      ctx.with_bias, nodes_grad=scatter)
         if not scatter:      # entity gradients: CSR by subject / by object, one wave per entity, no atomics
-            dn = _native.distmult_bwd_nodes(tr, nodes, relations, gs)
+            dn = _native.distmult_bwd_nodes(tr, ctx.ranks, nodes, relations, gs)
         return None, dn, dr, dsb, dpb, dob
 
 
