@@ -781,60 +781,107 @@ extern "C" int64_t rgcn_basis_sum_workspace_bytes(int32_t R, int32_t B) {
 }
 
 namespace {
-template <int B>
+// LPM: lanes per message when known at compile time (4: d = 16, the models' hidden width), 0 = the run-time value lpm_rt
+template <int B, int LPM>
 __global__ __launch_bounds__(TB) void fbasis_small_bwd_kernel(
     const float *__restrict__ G, const float *__restrict__ table, const float *__restrict__ comps, float *__restrict__ dB,
     float *__restrict__ dC, const int *__restrict__ rowptr, const int *__restrict__ p_src, const int *__restrict__ p_rel,
-    const float *__restrict__ p_val, long long n_rows, int R, int d, int lpm, long long bstride) {
+    const float *__restrict__ p_val, long long n_rows, int R, int d, int lpm_rt, long long bstride) {
+  const int lpm = LPM ? LPM : lpm_rt;
   extern __shared__ __attribute__((aligned(16))) double dcl[];          // [R][B]
   for (int i = threadIdx.x; i < R * B; i += TB) dcl[i] = 0.0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int sub = lane / lpm, il = lane % lpm, ngrp = 64 / lpm;
-  const int f = 4 * il;
-  const bool on = f < d;
+  const bool on = 4 * il < d;
+  const int f = on ? 4 * il : 0;          // (lanes past the row's end load feature 0 without a branch and keep nothing)
   const long long wave0 = ((long long)blockIdx.x * TB + threadIdx.x) >> 6, nw = ((long long)gridDim.x * TB) >> 6;
   constexpr int MB = 2;      // messages in flight per lane group
-  for (long long row = wave0; row < n_rows; row += nw) {
-    const int e0 = rowptr[row], e1 = rowptr[row + 1];
-    f32x4 blk[B], a[B];
+  // A row is a chain of three dependent round trips (row pointers -> the messages' indices -> the upstream rows and coefficients) and the
+  // average row (21 messages at S2) fits ONE trip of the message loop: nothing inside a row overlaps them.  So the rows are software-
+  // pipelined -- while row k is summed, the indices of row k + 1 are in flight, and its gathers are issued (behind the row pointers of
+  // row k + 2) BEFORE row k's gradient block is stored: s_waitcnt vmcnt counts loads and stores in order, loads issued after the store
+  // would wait for the store to complete.  (Two rows of gathers in flight per wave, in two register sets: 107 VGPRs = 4 waves per SIMD
+  // instead of 6, measured 0.645 ms at S2 against 0.618 for this form; before the pipelining 0.750.)
+  struct Idx { int src[MB], rel[MB]; float v[MB]; };
+  const size_t n_floats_row = (size_t)d;
+  auto load_idx = [&](int e0, int e1, int base, Idx &ix) {
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
-      // bstride: floats between a node's consecutive bases -- d for the node-major table [N, B, d], N d for the parameter's own [B, N, d]
-      blk[b] = on ? *reinterpret_cast<const f32x4 *>(table + (bstride == d ? ((size_t)row * B + b) * d : (size_t)b * bstride + (size_t)row * d) + f) : f32x4{0.f, 0.f, 0.f, 0.f};
-      a[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MB; ++m) {
+      const int eb = base + sub + m * ngrp;
+      const int e = max(min(eb, e1 - 1), 0);
+      ix.src[m] = p_src[e]; ix.rel[m] = p_rel[e];
+      const float pv = p_val[e];
+      ix.v[m] = eb < e1 ? pv : 0.f;
     }
-    for (int eb = e0 + sub; eb < e1; eb += ngrp * MB) {
-      int rel[MB];
-      float v[MB];
-      f32x4 x[MB];
+  };
+  auto tab_at = [&](long long row, int b) -> size_t {
+    // bstride: floats between a node's consecutive bases -- d for the node-major table [N, B, d], N d for the parameter's own [B, N, d]
+    return (bstride == d ? ((size_t)row * B + b) * n_floats_row : (size_t)b * bstride + (size_t)row * n_floats_row) + f;
+  };
+  struct Rows { f32x4 x[MB]; float c[MB][B]; };
+  auto gather = [&](const Idx &ix, Rows &g) {
 #pragma unroll
-      for (int m = 0; m < MB; ++m) {
-        const int e = min(eb + m * ngrp, e1 - 1);
-        v[m] = (eb + m * ngrp < e1) ? p_val[e] : 0.f;
-        rel[m] = p_rel[e];
-        x[m] = on ? *reinterpret_cast<const f32x4 *>(G + (size_t)p_src[e] * d + f) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+    for (int m = 0; m < MB; ++m) {
+      g.x[m] = *reinterpret_cast<const f32x4 *>(G + (size_t)ix.src[m] * d + f);
+      if (!on) g.x[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int m = 0; m < MB; ++m) {
-        const float *cp = comps + (size_t)rel[m] * B;
+      for (int b = 0; b < B; ++b) g.c[m][b] = comps[(size_t)ix.rel[m] * B + b];
+    }
+  };
+  long long row = wave0;
+  if (row < n_rows && p_src) {
+    int e0 = rowptr[row], e1 = rowptr[row + 1];
+    Idx cur;
+    load_idx(e0, e1, e0, cur);
+    int ne0 = rowptr[min(row + nw, n_rows - 1)], ne1 = rowptr[min(row + nw, n_rows - 1) + 1];
+    Rows g;
+    f32x4 blk[B];
+    gather(cur, g);
 #pragma unroll
-        for (int b = 0; b < B; ++b) {
-          a[b] += x[m] * (cp[b] * v[m]);
-          float dot = blk[b][0] * x[m][0] + blk[b][1] * x[m][1] + blk[b][2] * x[m][2] + blk[b][3] * x[m][3];
-          for (int off = 1; off < lpm; off <<= 1) dot += __shfl_xor(dot, off, 64);
-          if (il == 0 && v[m] != 0.f)
-            __hip_atomic_fetch_add(dcl + rel[m] * B + b, (double)(v[m] * dot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int b = 0; b < B; ++b) blk[b] = *reinterpret_cast<const f32x4 *>(table + tab_at(row, b));     // (lanes that are not `on`: multiplied with zeros)
+    for (; row < n_rows; row += nw) {
+      const long long nrow = min(row + nw, n_rows - 1), nnrow = min(row + 2 * nw, n_rows - 1);
+      Idx nxt;
+      load_idx(ne0, ne1, ne0, nxt);                       // (row k + 1's indices: in flight under row k's sums)
+      f32x4 a[B];
+#pragma unroll
+      for (int b = 0; b < B; ++b) a[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      auto sum = [&](const Idx &ix, const Rows &gr) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+#pragma unroll
+          for (int b = 0; b < B; ++b) {
+            a[b] += gr.x[m] * (gr.c[m][b] * ix.v[m]);
+            float dot = blk[b][0] * gr.x[m][0] + blk[b][1] * gr.x[m][1] + blk[b][2] * gr.x[m][2] + blk[b][3] * gr.x[m][3];
+            for (int off = 1; off < lpm; off <<= 1) dot += __shfl_xor(dot, off, 64);
+            if (il == 0 && ix.v[m] != 0.f)
+              __hip_atomic_fetch_add(dcl + ix.rel[m] * B + b, (double)(ix.v[m] * dot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
         }
+      };
+      sum(cur, g);
+      for (int base = e0 + ngrp * MB; base < e1; base += ngrp * MB) {     // rows longer than one trip: their further trips are not pipelined
+        Idx t;
+        Rows gt;
+        load_idx(e0, e1, base, t);
+        gather(t, gt);
+        sum(t, gt);
       }
-    }
 #pragma unroll
-    for (int b = 0; b < B; ++b)
+      for (int b = 0; b < B; ++b)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) a[b][c] = group_sum(a[b][c], lpm);
-    if (sub == 0 && on) {
+        for (int c = 0; c < 4; ++c) a[b][c] = group_sum(a[b][c], lpm);
+      // row k + 2's pointers, then row k + 1's gathers -- all issued before row k's store
+      const int nne0 = rowptr[nnrow], nne1 = rowptr[nnrow + 1];
+      gather(nxt, g);
 #pragma unroll
-      for (int b = 0; b < B; ++b) *reinterpret_cast<f32x4 *>(dB + (bstride == d ? ((size_t)row * B + b) * d : (size_t)b * bstride + (size_t)row * d) + f) = a[b];
+      for (int b = 0; b < B; ++b) blk[b] = *reinterpret_cast<const f32x4 *>(table + tab_at(nrow, b));     // (row k's blocks are spent)
+      if (sub == 0 && on) {
+#pragma unroll
+        for (int b = 0; b < B; ++b) *reinterpret_cast<f32x4 *>(dB + tab_at(row, b)) = a[b];
+      }
+      cur = nxt; e0 = ne0; e1 = ne1; ne0 = nne0; ne1 = nne1;
     }
   }
   __syncthreads();
@@ -954,9 +1001,11 @@ extern "C" int rgcn_fbasis_small_bwd_f32(const float *G, const float *table, con
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_rows * 64 + TB - 1) / TB, (int64_t)n_cu * 8));
   const size_t lds = (size_t)R * B * sizeof(double);
   const int lpm = d / 4;
-#define RGCN_FBS(BB) hipLaunchKernelGGL(fbasis_small_bwd_kernel<BB>, dim3(grid), dim3(TB), lds, st, G, table, comps, dbases, dcomps, rowptr, p_src, \
-                                        p_rel, p_val, (long long)n_rows, R, d, lpm, basis_major ? (long long)n_rows * d : (long long)d)
+#define RGCN_FBS(BB) do { if (lpm == 4) RGCN_FBS2(BB, 4); else RGCN_FBS2(BB, 0); } while (0)
+#define RGCN_FBS2(BB, LL) hipLaunchKernelGGL((fbasis_small_bwd_kernel<BB, LL>), dim3(grid), dim3(TB), lds, st, G, table, comps, dbases, dcomps, rowptr, \
+                                             p_src, p_rel, p_val, (long long)n_rows, R, d, lpm, basis_major ? (long long)n_rows * d : (long long)d)
   if (B == 1) RGCN_FBS(1); else if (B == 2) RGCN_FBS(2); else if (B == 3) RGCN_FBS(3); else RGCN_FBS(4);
+#undef RGCN_FBS2
 #undef RGCN_FBS
   HIP_TRY(hipGetLastError());
   return RGCN_OK;

@@ -280,14 +280,24 @@ __global__ __launch_bounds__(256) void gather_rows_sum4_kernel(const float *__re
       for (int c = 0; c < 4; ++c)
         if (4 * q + c < w) a[c] = bias[4 * q + c];
     }
-    int e = unit.y;
-    const int e1 = unit.z;
-    for (; e + 1 < e1; e += 2) {
-      const int p0 = perm[e], p1 = perm[e + 1];
-      a += *reinterpret_cast<const f32x4 *>(Y + (size_t)p0 * (4 * LPR) + 4 * q);
-      b += *reinterpret_cast<const f32x4 *>(Y + (size_t)p1 * (4 * LPR) + 4 * q);
+    // Four row reads in flight, and the NEXT four indices loaded before this trip's rows are used: a trip of the loop is one round trip
+    // (the rows), not two (indices, then rows).  Entries past the unit's end re-read its last entry (unconditional loads) and add nothing.
+    const int e0 = unit.y, e1 = unit.z;
+    if (e1 > e0) {
+      int p[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p[j] = perm[min(e0 + j, e1 - 1)];
+      for (int e = e0; e < e1; e += 4) {
+        f32x4 y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = *reinterpret_cast<const f32x4 *>(Y + (size_t)p[j] * (4 * LPR) + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = perm[min(e + 4 + j, e1 - 1)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (e + j < e1) { if (j & 1) b += y[j]; else a += y[j]; }
+      }
     }
-    if (e < e1) a += *reinterpret_cast<const f32x4 *>(Y + (size_t)perm[e] * (4 * LPR) + 4 * q);
     a += b;
     float *o = out + (size_t)unit.x * ow + 4 * q;           // rows of ow >= w floats: columns w .. ow are written as zeros (a zero-padded
 #pragma unroll                                              // [N, 16] row is what the width-16 kernels of the next layer read in place)

@@ -336,6 +336,30 @@ __global__ __launch_bounds__(WG) void segment_sum_d16_kernel(const float *__rest
   }
 }
 
+// a, b += the rows Y[perm[e0 .. e1), 4 q .. 4 q + 4): four row reads in flight, and the NEXT four indices loaded before this trip's rows are
+// used -- a trip of the loop is one round trip (the rows), not two (indices, then rows).  Entries past the end re-read the last one
+// (unconditional loads) and add nothing.
+__device__ __forceinline__ void gather_sum4(const float *__restrict__ Y, const int *__restrict__ perm, int e0, int e1, int q, float4 &a,
+                                            float4 &b) {
+  if (e1 <= e0) return;
+  int p[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) p[j] = perm[min(e0 + j, e1 - 1)];
+  for (int e = e0; e < e1; e += 4) {
+    float4 y[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = *reinterpret_cast<const float4 *>(Y + (size_t)p[j] * 16 + 4 * q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = perm[min(e + 4 + j, e1 - 1)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (e + j < e1) {
+        float4 &t = (j & 1) ? b : a;
+        t.x += y[j].x; t.y += y[j].y; t.z += y[j].z; t.w += y[j].w;
+      }
+  }
+}
+
 // ---- pass 2 when pass 1 wrote its rows in slot order: the rows of a destination are gathered through `perm`
 // (destination-major position -> slot).  4 lanes per row, 4 row reads in flight.
 __global__ __launch_bounds__(WG) void segment_gather_sum_d16_kernel(const float *__restrict__ Y, const int *__restrict__ perm,
@@ -347,18 +371,7 @@ __global__ __launch_bounds__(WG) void segment_gather_sum_d16_kernel(const float 
   for (long long row = ((long long)blockIdx.x * WG + threadIdx.x) >> 2; row < n_rows; row += ((long long)gridDim.x * WG) >> 2) {
     const int e0 = rowptr[row], e1 = rowptr[row + 1];
     float4 a = bv, b = make_float4(0.f, 0.f, 0.f, 0.f);
-    int e = e0;
-    for (; e + 1 < e1; e += 2) {
-      const int p0 = perm[e], p1 = perm[e + 1];
-      const float4 y0 = *reinterpret_cast<const float4 *>(Y + (size_t)p0 * 16 + 4 * q);
-      const float4 y1 = *reinterpret_cast<const float4 *>(Y + (size_t)p1 * 16 + 4 * q);
-      a.x += y0.x; a.y += y0.y; a.z += y0.z; a.w += y0.w;
-      b.x += y1.x; b.y += y1.y; b.z += y1.z; b.w += y1.w;
-    }
-    if (e < e1) {
-      const float4 y0 = *reinterpret_cast<const float4 *>(Y + (size_t)perm[e] * 16 + 4 * q);
-      a.x += y0.x; a.y += y0.y; a.z += y0.z; a.w += y0.w;
-    }
+    gather_sum4(Y, perm, e0, e1, q, a, b);
     a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     if (relu_out) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
     *reinterpret_cast<float4 *>(out + (size_t)row * 16 + 4 * q) = a;
@@ -377,19 +390,7 @@ __global__ __launch_bounds__(WG) void segment_gather_sum_units_d16_kernel(const 
     const bool shared = unit.w & RGCN_U_SHARED;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias && (!shared || (unit.w & RGCN_U_FIRST))) a = reinterpret_cast<const float4 *>(bias)[q];
-    int e = unit.y;
-    const int e1 = unit.z;
-    for (; e + 1 < e1; e += 2) {
-      const int p0 = perm[e], p1 = perm[e + 1];
-      const float4 y0 = *reinterpret_cast<const float4 *>(Y + (size_t)p0 * 16 + 4 * q);
-      const float4 y1 = *reinterpret_cast<const float4 *>(Y + (size_t)p1 * 16 + 4 * q);
-      a.x += y0.x; a.y += y0.y; a.z += y0.z; a.w += y0.w;
-      b.x += y1.x; b.y += y1.y; b.z += y1.z; b.w += y1.w;
-    }
-    if (e < e1) {
-      const float4 y0 = *reinterpret_cast<const float4 *>(Y + (size_t)perm[e] * 16 + 4 * q);
-      a.x += y0.x; a.y += y0.y; a.z += y0.z; a.w += y0.w;
-    }
+    gather_sum4(Y, perm, unit.y, unit.z, q, a, b);
     a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     float *o = out + (size_t)unit.x * 16 + 4 * q;
     if (shared) {
