@@ -610,6 +610,99 @@ __global__ __launch_bounds__(TB) void basis_aggregate_vec4_kernel(
   }
 }
 
+// The same for rows of ONE pass (d <= 256) and B <= 4 bases, with the ROWS software-pipelined over persistent waves.  A row is a chain of three
+// dependent round trips (row pointers -> the messages' indices -> the rows and coefficients) and most rows fit one trip of the message
+// loop (21 messages at S2, 2 on the WN18-shaped graph): nothing inside a row overlaps them.  While row k is summed the indices of row
+// k + 1 are in flight, and its gathers are issued (behind the pointers of row k + 2) BEFORE row k's result is stored -- s_waitcnt vmcnt
+// counts loads and stores in order: loads issued after the store would wait for the store to complete.  Every load is unconditional
+// (entries past a row's end re-read its last entry with a zero value; lanes past the row's width read feature 0 and keep nothing).
+// MODE 0: X [N, B, d] (one B x d block per node), out [n_rows, d];  MODE 1: X [N, d], out [n_rows, B, d].
+template <int MODE, int NB>
+__global__ __launch_bounds__(TB) void basis_aggregate_pipe_kernel(
+    const float *__restrict__ X, const float *__restrict__ comps, float *__restrict__ out,
+    const int *__restrict__ rowptr, const int *__restrict__ p_src, const int *__restrict__ p_rel,
+    const float *__restrict__ p_val, long long n_rows, int B, int d, int lpm) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / lpm, il = lane % lpm, ngrp = 64 / lpm;
+  const bool on = 4 * il < d;
+  const int f = on ? 4 * il : 0;
+  const long long wave0 = ((long long)blockIdx.x * TB + threadIdx.x) >> 6, nw = ((long long)gridDim.x * TB) >> 6;
+  constexpr int MB = 2;      // messages in flight per lane group
+  constexpr int NX = MODE ? 1 : NB, NA = MODE ? NB : 1;
+  struct Idx { int src[MB], rel[MB]; float v[MB]; };
+  struct Rows { f32x4 x[MB][NX]; float c[MB][NB]; };
+  auto load_idx = [&](int e0, int e1, int base, Idx &ix) {
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const int eb = base + sub + m * ngrp;
+      const int e = max(min(eb, e1 - 1), 0);
+      ix.src[m] = p_src[e]; ix.rel[m] = p_rel[e];
+      const float pv = p_val[e];
+      ix.v[m] = eb < e1 ? pv : 0.f;
+    }
+  };
+  auto gather = [&](const Idx &ix, Rows &g) {
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) g.c[m][b] = comps[(size_t)ix.rel[m] * B + min(b, B - 1)];
+#pragma unroll
+      for (int b = 0; b < NX; ++b)
+        g.x[m][b] = *reinterpret_cast<const f32x4 *>(X + (MODE ? (size_t)ix.src[m] : (size_t)ix.src[m] * B + min(b, B - 1)) * d + f);
+    }
+  };
+  long long row = wave0;
+  if (row >= n_rows || !p_src) return;
+  int e0 = rowptr[row], e1 = rowptr[row + 1];
+  Idx cur;
+  load_idx(e0, e1, e0, cur);
+  int ne0 = rowptr[min(row + nw, n_rows - 1)], ne1 = rowptr[min(row + nw, n_rows - 1) + 1];
+  Rows g;
+  gather(cur, g);
+  for (; row < n_rows; row += nw) {
+    const long long nnrow = min(row + 2 * nw, n_rows - 1);
+    Idx nxt;
+    load_idx(ne0, ne1, ne0, nxt);                         // (row k + 1's indices: in flight under row k's sums)
+    f32x4 a[NA];
+#pragma unroll
+    for (int q = 0; q < NA; ++q) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto sum = [&](const Idx &ix, const Rows &gr) {
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const float cv = b < B ? gr.c[m][b] * ix.v[m] : 0.f;
+          a[MODE ? b : 0] += gr.x[m][MODE ? 0 : b] * cv;
+        }
+    };
+    sum(cur, g);
+    for (int base = e0 + ngrp * MB; base < e1; base += ngrp * MB) {       // rows longer than one trip: their further trips are not pipelined
+      Idx t;
+      Rows gt;
+      load_idx(e0, e1, base, t);
+      gather(t, gt);
+      sum(t, gt);
+    }
+#pragma unroll
+    for (int q = 0; q < NA; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a[q][c] = group_sum(a[q][c], lpm);
+    // row k + 2's pointers, then row k + 1's gathers -- all issued before row k's store
+    const int nne0 = rowptr[nnrow], nne1 = rowptr[nnrow + 1];
+    gather(nxt, g);
+    if (sub == 0 && on) {
+      if (MODE) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q)
+          if (q < B) *reinterpret_cast<f32x4 *>(out + ((size_t)row * B + q) * d + f) = a[q];
+      } else {
+        *reinterpret_cast<f32x4 *>(out + (size_t)row * d + f) = a[0];
+      }
+    }
+    cur = nxt; e0 = ne0; e1 = ne1; ne0 = nne0; ne1 = nne1;
+  }
+}
+
 // Relation-major work items (chunk ranges of one relation, relation-major plan): per-lane partial sums over the
 // whole item, ONE wave reduction and one atomic per (item piece, basis) -- not per message.  Lane groups of lpr
 // lanes take alternate slots so that narrow rows keep all 64 lanes busy.
@@ -692,6 +785,23 @@ extern "C" int rgcn_basis_aggregate_f32(const float *X, const float *comps, floa
   if ((d & 3) == 0 && d >= 16 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
     int lpm = 1;
     while (lpm < 64 && 4 * lpm < d) lpm *= 2;
+    if (d <= 256 && B <= 4 && p_src) {                   // one pass per row, few bases: the rows pipelined over persistent waves
+      static int n_cu = 0;
+      if (!n_cu) {
+        int dev = 0, v = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+        n_cu = v > 0 ? v : 256;
+      }
+      const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_rows * 64 + TB - 1) / TB, (int64_t)n_cu * 8));
+#define RGCN_BAP(MODE_, NB_) hipLaunchKernelGGL((basis_aggregate_pipe_kernel<MODE_, NB_>), dim3(grid), dim3(TB), 0, (hipStream_t)stream, X, comps, \
+                                                out, rowptr, p_src, p_rel, p_val, (long long)n_rows, B, d, lpm)
+      if (n_b_in == 1) { if (B <= 2) RGCN_BAP(1, 2); else RGCN_BAP(1, 4); }
+      else { if (B <= 2) RGCN_BAP(0, 2); else RGCN_BAP(0, 4); }
+#undef RGCN_BAP
+      HIP_TRY(hipGetLastError());
+      return RGCN_OK;
+    }
     if (n_b_in == 1)
       hipLaunchKernelGGL(basis_aggregate_vec4_kernel<1>, dim3(blocks_for(n_rows * 64)), dim3(TB), 0, (hipStream_t)stream, X, comps, out,
                          rowptr, p_src, p_rel, p_val, (long long)n_rows, B, d, lpm);
