@@ -652,7 +652,13 @@ __global__ __launch_bounds__(TB) void basis_aggregate_pipe_kernel(
     }
   };
   long long row = wave0;
-  if (row >= n_rows || !p_src) return;
+  if (row >= n_rows) return;
+  if (rowptr[n_rows] == 0) {                           // no messages at all (the unconditional index loads would read entry 0 of nothing): zeros
+    for (; row < n_rows; row += nw)
+      if (sub == 0 && on)
+        for (int q = 0; q < (MODE ? B : 1); ++q) *reinterpret_cast<f32x4 *>(out + ((size_t)row * (MODE ? B : 1) + q) * d + f) = f32x4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
   int e0 = rowptr[row], e1 = rowptr[row + 1];
   Idx cur;
   load_idx(e0, e1, e0, cur);
@@ -785,7 +791,7 @@ extern "C" int rgcn_basis_aggregate_f32(const float *X, const float *comps, floa
   if ((d & 3) == 0 && d >= 16 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
     int lpm = 1;
     while (lpm < 64 && 4 * lpm < d) lpm *= 2;
-    if (d <= 256 && B <= 4 && p_src) {                   // one pass per row, few bases: the rows pipelined over persistent waves
+    if (d <= 256 && B <= 4) {                            // one pass per row, few bases: the rows pipelined over persistent waves
       static int n_cu = 0;
       if (!n_cu) {
         int dev = 0, v = 0;
@@ -940,7 +946,12 @@ __global__ __launch_bounds__(TB) void fbasis_small_bwd_kernel(
     }
   };
   long long row = wave0;
-  if (row < n_rows && p_src) {
+  if (row < n_rows && rowptr[n_rows] == 0) {           // no messages at all (the unconditional index loads would read entry 0 of nothing): zeros
+    for (; row < n_rows; row += nw)
+      if (sub == 0 && on)
+        for (int b = 0; b < B; ++b) *reinterpret_cast<f32x4 *>(dB + tab_at(row, b)) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (row < n_rows) {
     int e0 = rowptr[row], e1 = rowptr[row + 1];
     Idx cur;
     load_idx(e0, e1, e0, cur);
