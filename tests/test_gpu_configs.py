@@ -175,10 +175,11 @@ def test_mutag_full_shape_node_classifier_matches_oracle_composition():
 
 
 def test_more_than_2_31_relation_node_cells_vs_oracle():
-    """num_nodes x num_relations past 2^31 (27 M nodes x 81 relations = 2.19e9 cells of the counting
+    """num_nodes x num_relations past 2^31 (17 M nodes x 129 relations = 2.19e9 cells of the counting
     tables, 64-bit cell indices; also past the 24-bit source id of the packed slots -> unpacked slot arrays): one featured
-    layer, forward and backward, against the oracle"""
-    run_layer_vs_oracle(N=27_000_000, R0=40, E=3_000_000, d_in=16, d_out=16, mode="none", seed=77)
+    layer, forward and backward, against the oracle.  (27 M x 81 until round 5: the same two limits crossed with 37 % fewer rows of
+    random numbers, oracle zero-fills and float64 comparisons -- 27 s of the suite's 184.)"""
+    run_layer_vs_oracle(N=17_000_000, R0=64, E=3_000_000, d_in=16, d_out=16, mode="none", seed=77)
 
 
 @pytest.mark.parametrize("tile_mode", ["1", "ranges"])

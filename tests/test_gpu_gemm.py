@@ -17,12 +17,15 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (7, 5, 3), (128, 128, 16), (130, 127, 33), (400, 200, 513), (37, 256, 200),
-                                   (300, 2, 64), (16, 400, 40), (257, 129, 4)])
+                                   (300, 2, 64), (16, 400, 40), (257, 129, 4), (404, 200, 400), (200, 400, 204), (1000, 16, 36),
+                                   (68, 100, 52), (132, 144, 20), (64, 208, 16), (60, 212, 24)])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
-@pytest.mark.parametrize("bm", ["128", "64"])
+@pytest.mark.parametrize("bm", ["128", "64", "0"])
 def test_gemm_layouts_and_edges(monkeypatch, M, N, K, ta, tb, bm):
     """bm: rows of the C tile per workgroup (rgcn_gemm_f32 picks 64-row tiles per launch when they balance better over the
-    CUs; RGCN_GEMM_BM forces either form)"""
+    CUs; RGCN_GEMM_BM forces either form); 0 = the launcher's own choice, which includes the 64-row PANELS of up to 208 columns
+    (gemm_panel_kernel: aligned operands whose N the 128-wide tiles would round up by more than the panels do -- 200, 400, 16, 100,
+    144, 208, 212 here; every operand layout, K tails, rows past M, split-K)"""
     from torch_rgcn import _native
     routes.patch(monkeypatch, "gemm_bm", bm)
     rng = np.random.default_rng(M * 31 + N * 7 + K)

@@ -172,6 +172,129 @@ __global__ __launch_bounds__(WG) void gemm_kernel(const float *__restrict__ A, c
     }
 }
 
+// ------------------------------------------------------------------ row-panel GEMM: (a slice of) N in ONE tile
+// The 128-wide tiles above pay for N rounded up to 128: the WN18 layer's products have N = 200 and 400 (256 / 512 computed: 22 % of the
+// MFMAs wasted), and 640 tiles of 128 x 128 over 256 CUs leave half the chip with 3 tiles and half with 2.  Here a workgroup computes 64 rows
+// x 16 NB columns (NB <= 13: 208 columns = 200 rounded up to MFMA tiles), the four waves side by side along M (16 rows each, NB accumulator
+// tiles per wave): N = 200 is one panel, 400 two of 208, and the 640 row panels are all resident at once.  Slabs keep their operand's
+// orientation in LDS as in gemm_kernel (16-byte stores; K-inner slabs are read with 16-byte LDS reads, K-outer ones with four scalar
+// reads per operand: transposing a K-outer slab in the stash put its 4 scalar writes 16 ways into the same banks -- 0.130 ms per product
+// against gemm_kernel's 0.111).  16-byte global loads only (the launcher falls back to gemm_kernel otherwise).
+template <bool TA, bool TB, int NB>
+__global__ __launch_bounds__(WG) void gemm_panel_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                        const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K,
+                                                        long long lda, long long ldb, long long ldc, int tiles_m, int k_per_split,
+                                                        long long split_stride) {
+  constexpr int BM = 64, BN = 16 * NB;
+  constexpr int NLB = (BN * 4 + WG - 1) / WG;          // float4 loads of the B slab per thread (16 x BN floats)
+  // K-outer slabs [16][LD]: LD = 16 mod 32, so that the four k rows a wave's scalar operand read touches (16 consecutive floats each) fall
+  // into four disjoint groups of 16 banks
+  constexpr int LDA_O = 80, LDB_O = (BN % 32 == 16) ? BN : BN + 16;
+  __shared__ __attribute__((aligned(16))) float sA[2][TA ? GK * LDA_O : BM * LD_IN];
+  __shared__ __attribute__((aligned(16))) float sB[2][TB ? BN * LD_IN : GK * LDB_O];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, kq = lane >> 4;
+  const int m0 = (blockIdx.x % tiles_m) * BM, n0 = (blockIdx.x / tiles_m) * BN;
+  const int kb = blockIdx.y * k_per_split, ke = min(K, kb + k_per_split);
+
+  f32x4 acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  f32x4 ra, rb[NLB];
+  auto fetch = [&](int k0) {
+    if (TA) {          // A stored [K][M]: k row tid >> 4, columns m0 + 4 (tid & 15) ..
+      ra = *reinterpret_cast<const f32x4 *>(A + (size_t)min(k0 + (tid >> 4), ke - 1) * lda + min(m0 + 4 * (tid & 15), M - 4));
+    } else {           // A stored [M][K]: row tid >> 2, k group 4 (tid & 3)
+      ra = *reinterpret_cast<const f32x4 *>(A + (size_t)min(m0 + (tid >> 2), M - 1) * lda + min(k0 + 4 * (tid & 3), K - 4));
+    }
+#pragma unroll
+    for (int h = 0; h < NLB; ++h) {
+      const int idx = min(tid + WG * h, BN * 4 - 1);
+      if (TB) {        // B stored [N][K]: row (a column of C) idx >> 2, k group 4 (idx & 3)
+        rb[h] = *reinterpret_cast<const f32x4 *>(B + (size_t)min(n0 + (idx >> 2), N - 1) * ldb + min(k0 + 4 * (idx & 3), K - 4));
+      } else {         // B stored [K][N]: k row idx / (BN / 4), columns n0 + 4 (idx % (BN / 4)) ..  (columns past N: duplicates, never stored)
+        rb[h] = *reinterpret_cast<const f32x4 *>(B + (size_t)min(k0 + idx / (BN / 4), ke - 1) * ldb + min(n0 + 4 * (idx % (BN / 4)), N - 4));
+      }
+    }
+  };
+  auto stash = [&](int buf, int k0) {
+    if (TA) {
+      const bool live = k0 + (tid >> 4) < ke;
+      *reinterpret_cast<f32x4 *>(&sA[buf][(tid >> 4) * LDA_O + 4 * (tid & 15)]) = live ? ra : f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      const int kk = k0 + 4 * (tid & 3);
+      f32x4 v = ra;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = (kk + c < ke) ? v[c] : 0.f;
+      *reinterpret_cast<f32x4 *>(&sA[buf][(tid >> 2) * LD_IN + 4 * (tid & 3)]) = v;
+    }
+#pragma unroll
+    for (int h = 0; h < NLB; ++h) {
+      const int idx = tid + WG * h;
+      if (idx >= BN * 4) continue;
+      if (TB) {
+        const int kk = k0 + 4 * (idx & 3);
+        f32x4 v = rb[h];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = (kk + c < ke) ? v[c] : 0.f;
+        *reinterpret_cast<f32x4 *>(&sB[buf][(idx >> 2) * LD_IN + 4 * (idx & 3)]) = v;
+      } else {
+        const int kr = idx / (BN / 4), cg = idx % (BN / 4);
+        const bool live = k0 + kr < ke;
+        *reinterpret_cast<f32x4 *>(&sB[buf][kr * LDB_O + 4 * cg]) = live ? rb[h] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+
+  const int steps = (ke - kb + GK - 1) / GK;
+  if (steps > 0) {
+    fetch(kb);
+    stash(0, kb);
+    __syncthreads();
+    for (int t = 0; t < steps; ++t) {
+      const int cur = t & 1;
+      if (t + 1 < steps) fetch(kb + GK * (t + 1));
+      f32x4 av;
+      if (TA) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) av[c] = sA[cur][(4 * kq + c) * LDA_O + 16 * wave + i];
+      } else {
+        av = *reinterpret_cast<const f32x4 *>(&sA[cur][(16 * wave + i) * LD_IN + 4 * kq]);
+      }
+      f32x4 bv[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (TB) {
+          bv[b] = *reinterpret_cast<const f32x4 *>(&sB[cur][(16 * b + i) * LD_IN + 4 * kq]);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) bv[b][c] = sB[cur][(4 * kq + c) * LDB_O + 16 * b + i];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv[b][c], acc[b], 0, 0, 0);
+      if (t + 1 < steps) stash(cur ^ 1, kb + GK * (t + 1));
+      __syncthreads();
+    }
+  }
+  // D: lane 16 q + j holds rows 4 q .. 4 q + 3 (M index), column j (N index) of every 16 x 16 tile
+  float *Cs = C + (size_t)blockIdx.y * split_stride;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = m0 + 16 * wave + 4 * kq + r;
+    if (row >= M) continue;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int col = n0 + 16 * b + i;
+      if (col >= N) continue;
+      Cs[(size_t)row * ldc + col] = acc[b][r] + ((bias && gridDim.y == 1) ? bias[col] : 0.f);
+    }
+  }
+}
+
 // C[i] = bias[i % N] + sum_s partial[s][i]   (fixed order)
 __global__ __launch_bounds__(WG) void sum_slices_kernel(const float *__restrict__ partial, const float *__restrict__ bias,
                                                         float *__restrict__ C, long long n, int N, int S, long long ldc) {
@@ -470,12 +593,43 @@ extern "C" int rgcn_gemm_f32(const float *A, const float *B, const float *bias, 
   const int64_t t128 = (int64_t)tiles_m * tiles_n * S, t64 = ((M + 63) / 64) * tiles_n * S;
   const bool half = bm_env ? bm_env == 64 : ((t64 + 255) / 256 < 2 * ((t128 + 255) / 256) && t128 > 256);
   if (half) tiles_m = (int)((M + 63) / 64);
-  dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)S), block(WG);
   const bool ta = flags & RGCN_G_TRANS_A, tb = flags & RGCN_G_TRANS_B;
   // 16-byte loads when rows / columns are 16-byte aligned (the contiguous extent and the leading dimension multiples of 4): the
   // K tail is then whole groups of 4 and is zeroed by the stash; otherwise element loads with clamped indices
   const bool vec = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (((ta ? M : K) & 3) == 0) &&
                    ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (((tb ? K : N) & 3) == 0);
+  // row panels (64 rows x up to 208 columns) when the 128-wide tiles would compute noticeably more columns than the panels: N = 200 is
+  // 208 instead of 256, 400 is 416 instead of 512, a hidden width of 16 is 64 instead of 128
+  if (vec && !bm_env && M >= 4 && N >= 4 && K >= 4) {
+    const int nt = (int)((N + 15) / 16), n_panels = (nt + 12) / 13, need = (nt + n_panels - 1) / n_panels;
+    const int nb = need <= 4 ? 4 : need <= 7 ? 7 : need <= 10 ? 10 : 13;
+    if ((int64_t)n_panels * nb * 16 * 100 < (int64_t)tiles_n * GT * 95) {
+      const int pm = (int)((M + 63) / 64);
+      dim3 pgrid((unsigned)(pm * n_panels), (unsigned)S);
+#define RGCN_PANEL_ARGS pgrid, dim3(WG), 0, st, A, B, bias, out, (int)M, (int)N, (int)K, (long long)lda, (long long)ldb, ldo, pm, kps > 0 ? kps : GK, sstride
+#define RGCN_PANEL_NB(TAc, TBc)                                                                          \
+  do {                                                                                                   \
+    if (nb == 4) hipLaunchKernelGGL((gemm_panel_kernel<TAc, TBc, 4>), RGCN_PANEL_ARGS);                  \
+    else if (nb == 7) hipLaunchKernelGGL((gemm_panel_kernel<TAc, TBc, 7>), RGCN_PANEL_ARGS);             \
+    else if (nb == 10) hipLaunchKernelGGL((gemm_panel_kernel<TAc, TBc, 10>), RGCN_PANEL_ARGS);           \
+    else hipLaunchKernelGGL((gemm_panel_kernel<TAc, TBc, 13>), RGCN_PANEL_ARGS);                         \
+  } while (0)
+      if (ta && tb) RGCN_PANEL_NB(true, true);
+      else if (ta) RGCN_PANEL_NB(true, false);
+      else if (tb) RGCN_PANEL_NB(false, true);
+      else RGCN_PANEL_NB(false, false);
+#undef RGCN_PANEL_NB
+#undef RGCN_PANEL_ARGS
+      if (S > 1) {
+        const long long n = (long long)M * N;
+        hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)std::min<long long>((n + WG - 1) / WG, 4096)), dim3(WG), 0, st, scratch,
+                           bias, C, n, (int)N, S, (long long)ldc);
+      }
+      HIP_TRY(hipGetLastError());
+      return RGCN_OK;
+    }
+  }
+  dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)S), block(WG);
 #define RGCN_GEMM_ARGS grid, block, 0, st, A, B, bias, out, (int)M, (int)N, (int)K, (long long)lda, (long long)ldb, ldo, tiles_m, kps > 0 ? kps : GK, sstride
 #define RGCN_GEMM_LAUNCH(TAc, TBc)                                                                  \
   do {                                                                                               \
