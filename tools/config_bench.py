@@ -204,7 +204,7 @@ TAG_KERNELS = {
     "block_spmm": (("block44_csr_kernel", "block_csr"), 1), "basis_aggregate": (("basis_aggregate",), 1),
     "fbasis_small_bwd": (("fbasis_small_bwd_kernel",), 1), "fbasis_fwd": (("fbasis_fwd_kernel",), 1), "fbasis_bwd": (("fbasis_bwd",), 1),
     "featureless_csr_fwd": (("featureless_csr_fwd",), 1), "featureless_csr_wgrad": (("featureless_csr_wgrad",), 1),
-    "gemm": (("gemm_kernel",), 1), "distmult_fwd": (("distmult_fwd_kernel",), 1), "distmult_bwd_all": (("distmult_bwd_all_kernel",), 2),
+    "gemm": (("gemm_kernel", "gemm_panel_kernel"), 1), "distmult_fwd": (("distmult_fwd_kernel",), 1), "distmult_bwd_all": (("distmult_bwd_all_kernel",), 2),
     "basis_dcomps_csr": (("basis_dcomps_csr_kernel",), 1), "basis_dcomps": (("basis_dcomps_kernel",), 1),
     "ce_head": (("ce_head_kernel",), 1), "bce_head": (("bce_head_kernel",), 1), "colsum": (("colsum",), None),
 }
@@ -461,7 +461,7 @@ def line_wn18(baseline_config):
     roof = _roof(name, kms, alg, "scored triples x (three d-wide rows + 24 B of indices [+ two gradient rows])")
     if name == "gemm":      # the dense (B d) x d contraction and its two backward products: bound by the matrix cores
         flops = 2.0 * N * 2 * d * d
-        roof = {"kernel": "gemm_kernel (ag @ flat(bases); d_ag = g @ flat^T; dbases = ag^T @ g)", "bound": "mfma", "avg_launch_ms": round(kms, 4),
+        roof = {"kernel": "gemm_panel_kernel (ag @ flat(bases); d_ag = g @ flat^T; dbases = ag^T @ g)", "bound": "mfma", "avg_launch_ms": round(kms, 4),
                 "algorithmic_flops_per_launch": flops, "achieved": round(flops / (kms * 1e-3) / 1e12, 1), "peak": 157.3, "unit": "TFLOP/s",
                 "frac": round(flops / (kms * 1e-3) / 1e12 / 157.3, 4)}
     # the largest single kernel of the step after the GEMMs: all DistMult gradients from one pass (rgcn_distmult_bwd_all_f32)
