@@ -325,7 +325,8 @@ RGCN_API int rgcn_bwd_lean_f32(const float *G, const float *X, const float *Wt_p
  *                                        row << 6, relation)
  *   rgcn_bwd_blk_prepare_f32             the transposed plan -> records, once per plan: p_pack (tiles of up to 255 rows) or, with
  *                                        p_pack == NULL, p_src / p_dst (global destination row, < 0 = pad) / p_val as
- *                                        rgcn_dev_plan_fill wrote them (tiles of up to 512 rows); chunk_rel; n_chunks = m_pad / 16
+ *                                        rgcn_dev_plan_fill wrote them (tiles of up to 1023 rows: 512 for the backward kernel, 1023 for
+ *                                        rgcn_spmm_blk_f32); chunk_rel; n_chunks = m_pad / 16
  * Atomic flush only, sums in arrival order (dX: fp64 sums rounded once, so run-to-run differences are rare but possible;
  * RGCN_DETERMINISTIC=1 takes the lean kernel on 64-row tiles).
  * flags: RGCN_F_RELU; RGCN_F_DIAG4: the weights are block_diag() of 4 x 4 blocks (layers.py:243-244 at width 16) -- only the
@@ -344,6 +345,17 @@ RGCN_API int rgcn_bwd_blk_prepare_f32(const int32_t *p_pack, const int32_t *p_sr
 RGCN_API int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, const void *rec,
                               const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R, int32_t flags,
                               float *dbias, int64_t n_src, const int32_t *units, int64_t n_units, int64_t n_split, void *stream);
+/* The same walk as a FORWARD kernel (round 5): out[dst] = bias + sum val X[src] W_r (layers.py:293-301 at width 16) on the FORWARD plan cut
+ * into tall tiles (one per workgroup, up to rgcn_spmm_blk_max_rows() = 1023 rows: 128 bytes of LDS per row, no weight table) with the chunk
+ * records of rgcn_bwd_blk_prepare_f32.  For layers whose (tile, relation) buckets on the wave-owned tiles of rgcn_spmm_f32 are mostly
+ * padding and whose relations do not fit rgcn_spmm_csr_d16_f32's LDS (AM as shipped, layer 2: R = 267); one launch instead of
+ * rgcn_spmm_scatter_f32 + rgcn_segment_gather_sum_f32.  W_packed: rgcn_pack_w16_f32 fragments; bias may be NULL; flags: RGCN_F_RELU
+ * (the activation in the epilogue; not with hub pieces).  units / n_units / n_split as above (pieces add into a zeroed out; the
+ * RGCN_U_FIRST piece adds the bias). */
+RGCN_API int32_t rgcn_spmm_blk_max_rows(void);
+RGCN_API int rgcn_spmm_blk_f32(const float *X, const float *W_packed, const float *bias, float *out, const void *rec,
+                               const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R, int32_t flags,
+                               const int32_t *units, int64_t n_units, int64_t n_split, void *stream);
 /* The same for graphs whose (tile, relation) buckets are sparse (AM: 267 relations), on the RELATION-major plan of the
  * two-pass path: one wave per work item gathers G[p_src] and X[p_dst] once per message and produces
  *   Y[slot, :] = val G[p_src] W_r^T   (slot order; pass 2 = rgcn_segment_gather_sum_f32 sums them per destination -> dX)

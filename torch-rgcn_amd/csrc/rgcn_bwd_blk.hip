@@ -452,13 +452,189 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
 }
 
 
+// ------------------------------------------------------------------ the same walk as a FORWARD kernel (round 5)
+// out[dst] = bias + sum val X[src] W_r on the forward plan cut into tall tiles: the workgroup owns the destination tile [rows][16] in
+// doubles (ds_add_f64), its chunks are dealt to the 16 waves as above, a chunk is one gather of 16 source rows, one 1 KiB weight fragment out
+// of L2 and four MFMAs.  No X tile, no dW table: 128 bytes of LDS per row, tiles of up to 1023 rows (the records keep a slot's tile row
+// x 64 in 16 bits).  For whom: hidden-16 layers whose (tile, relation) buckets on the wave-owned 32 .. 64-row tiles are mostly padding AND
+// whose relations do not fit the one-pass CSR kernel's LDS (AM as shipped, layer 2: R = 267 -- 31 messages per bucket on 930-row tiles
+// instead of ~2 on 64-row ones); until round 5 that layer's forward was two passes over a [M, 16] intermediate (0.40 + 0.22 ms).
+// TQ = ceil(tile_rows / 256): float4 of the tile a thread converts and stores per tile.
+template <bool RELU, int TQ>
+__global__ __launch_bounds__(64 * BLK_NW) void spmm_blk_d16_kernel(
+    const float *__restrict__ X, const float *__restrict__ Wp, const float *__restrict__ bias, float *__restrict__ out,
+    const char *__restrict__ rec, const int *__restrict__ run_ptr, int n_tiles, int tile_rows, int n_dst, int R,
+    const int4 *__restrict__ units, int n_units) {
+  constexpr int U = 4, NW = BLK_NW, NT = 64 * BLK_NW;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  float4 *tz = reinterpret_cast<float4 *>(lds);                   // the tile [rows][16] doubles as 16-byte units (zeroing)
+  const double2 *td2 = reinterpret_cast<const double2 *>(lds);
+  int *ctl = reinterpret_cast<int *>(lds + (size_t)tile_rows * 128u);      // [0]: next quad of the tile
+
+  auto unit_of = [&](int u) {
+    if (units) return units[u];
+    return int4{u, run_ptr[(size_t)u * (R + 1)], run_ptr[(size_t)u * (R + 1) + R], 0};
+  };
+  auto static_quads = [](int n) { return max(1, min(4, (3 * n) / (4 * BLK_NW))); };
+  int un = blockIdx.x;
+  int4 unit = unit_of(un);
+  int row0 = __builtin_amdgcn_readfirstlane(unit.x) * tile_rows;
+  int nrows = min(tile_rows, n_dst - row0);
+  int c0 = __builtin_amdgcn_readfirstlane(unit.y), c1 = __builtin_amdgcn_readfirstlane(unit.z);
+  int uflags = __builtin_amdgcn_readfirstlane(unit.w);
+  int nq = (c1 - c0 + U - 1) / U;
+  int ns = static_quads(nq);
+  for (int i = tid; i < tile_rows * 8; i += NT) tz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid == 0) ctl[0] = NW * (ns + 1);
+  __syncthreads();
+
+  const int m = lane & 15, k = lane >> 4;
+  const unsigned kofs = (unsigned)k << 4;
+  const unsigned t_lane = (unsigned)m * 8u;                             // LDS byte address of tile [0][m]
+  const unsigned slot_lane = (unsigned)m * 8u;
+  const unsigned rows_lane = (unsigned)BLK_REC_ROWS + (unsigned)k * 8u;
+  const unsigned w_lane = (unsigned)lane * 16u;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) bv = reinterpret_cast<const float4 *>(bias)[tid & 3];       // (a thread's float4 of a tile row: columns 4 (tid & 3) ..)
+
+  uint2 sl_n[U], rw_n[U];
+  int hd_n[U];
+  auto request_idx = [&](int c, int last) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int cc = min(c + j, last);                          // scalar: chunks past the tile re-read its last chunk (val forced to 0)
+      const char *r = rec + (size_t)cc * BLK_REC;
+      sl_n[j] = *reinterpret_cast<const uint2 *>(r + slot_lane);
+      rw_n[j] = *reinterpret_cast<const uint2 *>(r + rows_lane);
+      hd_n[j] = *reinterpret_cast<const int *>(r + BLK_REC_HDR);
+    }
+  };
+  int q_cur = wave * ns, q_nxt = 1 < ns ? wave * ns + 1 : NW * ns + wave, q_pos = 2;
+  if (q_cur < nq) request_idx(c0 + q_cur * U, c1 - 1);
+
+  for (;;) {
+    const int last = c1 - 1;
+    while (q_cur < nq) {
+      const int c = c0 + q_cur * U;
+      unsigned w0_[U];
+      uint2 rw_[U];
+      float v_[U];
+      int hd_[U];
+      float4 g_[U], w_[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        w0_[j] = sl_n[j].x;
+        rw_[j] = rw_n[j];
+        v_[j] = (c + j <= last) ? __builtin_bit_cast(float, sl_n[j].y) : 0.f;
+        hd_[j] = __builtin_amdgcn_readfirstlane(hd_n[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) asm volatile("" : "+v"(w0_[j]), "+v"(v_[j]));   // pin the index data here
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const unsigned og = w0_[j] | kofs;
+        g_[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(X) + og);
+        w_[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Wp) + (size_t)hd_[j] * 1024 + w_lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (q_nxt < nq) request_idx(c0 + q_nxt * U, last);
+      int q_nn = q_pos < ns ? wave * ns + q_pos : NW * ns + wave;
+      if (q_pos > ns && lane == 0) q_nn = __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      ++q_pos;
+      __builtin_amdgcn_sched_barrier(0);
+      // D[slot][o] = sum_f (val X[src_slot][f]) W_r[f][o]: lane (k, m) <- slots 4k .. 4k+3, output feature m
+      f32x4 sc[U], acc[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        sc[j] = f32x4{g_[j].x * v_[j], g_[j].y * v_[j], g_[j].z * v_[j], g_[j].w * v_[j]};
+        acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[j][0], w_[j].x, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[j][1], w_[j].y, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[j][2], w_[j].z, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < U; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[j][3], w_[j].w, acc[j], 0, 0, 0);
+      // the tile update, one ds_add_f64 per slot quarter (the records hold a slot's tile row x 64; a tile row is 128 bytes of doubles)
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const unsigned ro[4] = {rw_[j].x & 0xFFFFu, rw_[j].x >> 16, rw_[j].y & 0xFFFFu, rw_[j].y >> 16};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          __hip_atomic_fetch_add(static_cast<double *>(__builtin_assume_aligned(lds + (t_lane + 2u * ro[e]), 8)), (double)acc[j][e], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      q_cur = q_nxt;
+      q_nxt = __builtin_amdgcn_readfirstlane(q_nn);
+    }
+    // the next unit of this workgroup: this wave's first chunks are requested before the barrier
+    const int unn = un + (int)gridDim.x;
+    int c0n = 0, c1n = 0, nqn = 0, row0n = 0, nrn = 0, flagsn = 0, nsn = 1;
+    if (unn < n_units) {
+      const int4 unx = unit_of(unn);
+      row0n = __builtin_amdgcn_readfirstlane(unx.x) * tile_rows;
+      nrn = min(tile_rows, n_dst - row0n);
+      c0n = __builtin_amdgcn_readfirstlane(unx.y);
+      c1n = __builtin_amdgcn_readfirstlane(unx.z);
+      flagsn = __builtin_amdgcn_readfirstlane(unx.w);
+      nqn = (c1n - c0n + U - 1) / U;
+      nsn = static_quads(nqn);
+      if (wave * nsn < nqn) request_idx(c0n + wave * nsn * U, c1n - 1);
+    }
+    // (the records just requested are pinned as arrived BEFORE the tile's stores: vmcnt counts in order, and the number of stores differs
+    // from thread to thread -- left to the compiler, their first use would wait for the stores to complete)
+    lds_barrier();                                                 // every wave has finished adding to the tile
+#pragma unroll
+    for (int j = 0; j < U; ++j) asm volatile("" : "+v"(sl_n[j].x), "+v"(sl_n[j].y), "+v"(rw_n[j].x), "+v"(rw_n[j].y), "+v"(hd_n[j]));
+    const bool shared = uflags & RGCN_U_SHARED;
+    const bool with_bias = !shared || (uflags & RGCN_U_FIRST);
+#pragma unroll
+    for (int q = 0; q < TQ; ++q) {
+      const int idx = tid + q * NT;
+      if (idx < nrows * 4) {
+        const double2 d0 = td2[2 * idx], d1 = td2[2 * idx + 1];
+        float4 a = make_float4((float)d0.x, (float)d0.y, (float)d1.x, (float)d1.y);
+        if (with_bias) { a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w; }
+        float4 *o = reinterpret_cast<float4 *>(out + (size_t)row0 * 16) + idx;
+        if (shared) {       // a piece of a hub tile: the pieces' rows are summed in memory (out was zeroed; no ReLU on such plans)
+          atomicAdd(&o->x, a.x); atomicAdd(&o->y, a.y); atomicAdd(&o->z, a.z); atomicAdd(&o->w, a.w);
+        } else {
+          if (RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+          *o = a;
+        }
+      }
+    }
+    if (unn >= n_units) break;
+#pragma unroll
+    for (int q = 0; q < TQ; ++q) {
+      const int idx = tid + q * NT;
+      if (idx < tile_rows * 4) {
+        tz[2 * idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+        tz[2 * idx + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    if (tid == 0) ctl[0] = NW * (nsn + 1);
+    lds_barrier();                                                 // the tile is clean again (nobody waits for the stores)
+    un = unn; row0 = row0n; nrows = nrn; c0 = c0n; c1 = c1n; nq = nqn; uflags = flagsn;
+    ns = nsn;
+    q_cur = wave * ns; q_nxt = 1 < ns ? wave * ns + 1 : NW * ns + wave; q_pos = 2;
+  }
+}
+
+
 }  // namespace
 
 extern "C" int64_t rgcn_bwd_blk_rec_bytes(int64_t n_chunks) { return n_chunks * (int64_t)BLK_REC; }
 
 extern "C" int rgcn_bwd_blk_prepare_f32(const int32_t *p_pack, const int32_t *p_src, const int32_t *p_dst, const float *p_val,
                                         int32_t tile_rows, const int32_t *chunk_rel, int64_t n_chunks, void *rec, void *stream) {
-  if (n_chunks < 0 || tile_rows <= 0 || tile_rows > 512 || (!p_pack && n_chunks && (!p_src || !p_dst || !p_val)) ||
+  if (n_chunks < 0 || tile_rows <= 0 || tile_rows > 1023 || (!p_pack && n_chunks && (!p_src || !p_dst || !p_val)) ||
       (p_pack && tile_rows > 255) || (n_chunks && (!chunk_rel || !rec))) {
     rgcn_set_error("bwd_blk_prepare: bad argument");
     return RGCN_EINVAL;
@@ -556,6 +732,57 @@ extern "C" int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_
   else if (relu) HIP_TRY(launch(bwd_blk_d16_kernel<true, false, 1>, r6));
   else HIP_TRY(launch(bwd_blk_d16_kernel<false, false, 1>, r7));
 #endif
+  return RGCN_OK;
+}
+
+extern "C" int32_t rgcn_spmm_blk_max_rows(void) { return 1023; }
+
+extern "C" int rgcn_spmm_blk_f32(const float *X, const float *W_packed, const float *bias, float *out, const void *rec,
+                                 const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R, int32_t flags,
+                                 const int32_t *units, int64_t n_units, int64_t n_split, void *stream) {
+  if (!X || !W_packed || !out || !rec || !run_ptr || n_tiles <= 0 || tile_rows <= 0 || n_dst <= 0 || R <= 0 || n_dst > INT32_MAX ||
+      (units && (n_units < n_tiles || n_split < 0 || n_units > INT32_MAX))) {
+    rgcn_set_error("spmm_blk: bad argument");
+    return RGCN_EINVAL;
+  }
+  if (tile_rows > rgcn_spmm_blk_max_rows()) { rgcn_set_error("spmm_blk: tiles of at most %d rows (got %d)", rgcn_spmm_blk_max_rows(), tile_rows); return RGCN_EUNSUPPORTED; }
+  if (!units) { n_units = n_tiles; n_split = 0; }
+  const bool relu = (flags & RGCN_F_RELU) != 0;
+  if (relu && n_split) { rgcn_set_error("spmm_blk: relu in the epilogue needs tiles that are not cut into shared pieces"); return RGCN_EUNSUPPORTED; }
+  hipStream_t st = (hipStream_t)stream;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0, v = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+    n_cu = v > 0 ? v : 256;
+  }
+  if (n_split) HIP_TRY(zero_async(out, (size_t)n_dst * 16 * sizeof(float), st));          // pieces of hub tiles add their rows
+  const size_t lds = (size_t)tile_rows * 128 + 64;
+  const unsigned n_blocks = (unsigned)std::min<int64_t>(n_units, n_cu);
+  auto launch = [&](auto kern, bool &raised) -> hipError_t {
+    if (lds > 64 * 1024 && !raised) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, BLK_LDS_MAX);
+      if (e != hipSuccess) return e;
+      raised = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64 * BLK_NW), lds, st, X, W_packed, bias, out, static_cast<const char *>(rec), run_ptr, (int)n_tiles,
+                       tile_rows, (int)n_dst, R, reinterpret_cast<const int4 *>(units), (int)n_units);
+    return hipGetLastError();
+  };
+  static bool r[8] = {false, false, false, false, false, false, false, false};
+  const int tq = (tile_rows + 255) / 256;
+  if (relu) {
+    if (tq == 1) HIP_TRY(launch(spmm_blk_d16_kernel<true, 1>, r[0]));
+    else if (tq == 2) HIP_TRY(launch(spmm_blk_d16_kernel<true, 2>, r[1]));
+    else if (tq == 3) HIP_TRY(launch(spmm_blk_d16_kernel<true, 3>, r[2]));
+    else HIP_TRY(launch(spmm_blk_d16_kernel<true, 4>, r[3]));
+  } else {
+    if (tq == 1) HIP_TRY(launch(spmm_blk_d16_kernel<false, 1>, r[4]));
+    else if (tq == 2) HIP_TRY(launch(spmm_blk_d16_kernel<false, 2>, r[5]));
+    else if (tq == 3) HIP_TRY(launch(spmm_blk_d16_kernel<false, 3>, r[6]));
+    else HIP_TRY(launch(spmm_blk_d16_kernel<false, 4>, r[7]));
+  }
   return RGCN_OK;
 }
 

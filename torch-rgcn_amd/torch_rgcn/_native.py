@@ -1137,6 +1137,35 @@ def bwd_blk_rows(n_nodes, num_rels, deterministic=False, device=None, diag4=Fals
     return max(rows, min(cap, 128))      # small graphs: fewer, taller tiles (fuller buckets, fewer dW flushes) rather than one per CU
 
 
+def spmm_blk_rows(n_nodes, device=None):
+    """tile height of the forward plan for the block-tile FORWARD kernel (rgcn_spmm_blk_f32): the tallest tile up to 1000 rows that gives
+    every CU the same number of tiles; 0 for graphs too small to fill the chip with one tile per workgroup"""
+    if n_nodes < _BLK_MIN_NODES or routes.get("spmm_csr", "1") == "0":
+        return 0
+    cap = min(1000, int(lib().rgcn_spmm_blk_max_rows()))
+    n_cu = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).multi_processor_count
+    per_cu = -(-n_nodes // (n_cu * cap))
+    return -(-n_nodes // (n_cu * per_cu))
+
+
+def spmm_blk(X, W, bias, plan, relu=False):
+    """out [n_dst, 16] = bias + sum val X[src] W_r on a forward plan of tall tiles, one launch (rgcn_spmm_blk_f32)"""
+    _req(X, "features"); _req(W, "weights"); _req(bias, "bias")
+    assert W.shape[1:] == (16, 16) and X.shape == (plan.n_src, 16)
+    dev = X.device
+    Wp = pack_w16(W)
+    out = torch.empty((plan.n_dst, 16), device=dev, dtype=torch.float32)
+    rec = _blk_rec(plan)
+    units, n_units, n_split = _blk_units(plan)
+    if relu and n_split:
+        raise NativeLibraryError("spmm_blk: relu in the epilogue needs a plan without hub pieces")
+    with _on(dev), _timed("spmm_blk"):
+        _check(lib().rgcn_spmm_blk_f32(_dp(X), _dp(Wp), _dp(bias), _dp(out), _dp(rec), _dp(plan.run_ptr), c_i64(plan.n_tiles),
+                                       c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i32(W.shape[0]), c_i32(F_RELU if relu else 0),
+                                       _dp(units), c_i64(n_units), c_i64(n_split), _stream(dev)), "spmm_blk")
+    return out
+
+
 def _bwd_blk_plan(plan, diag4=False):
     return (plan.tile_rows > 160 or (plan.tile_rows > 64 and bwd_route() == "blk")) and \
         bool(lib().rgcn_bwd_blk_supported(c_i32(plan.tile_rows), c_i32(plan.num_rels), c_i32(F_DIAG4 if diag4 else 0)))

@@ -39,6 +39,17 @@ def _sparse_buckets(graph, W):
     return graph.max_degree() <= 4096
 
 
+def _fwd_blk(graph, relu):
+    """the forward plan of tall tiles for rgcn_spmm_blk_f32, or None (graph too small, route off, ReLU epilogue on a plan with hub pieces,
+    deterministic mode: the tile is summed in arrival order)"""
+    if deterministic():
+        return None
+    plan = graph.fwd_blk_plan()
+    if plan is None or (relu and _native._blk_units(plan)[2]):
+        return None
+    return plan
+
+
 def _pad_blocks(X, W, bias, graph=None):
     """Widths up to 64 run on the MFMA block kernels (hidden-16 scheme over blocks of 16 features) with operands
     zero-padded to multiples of 16: a 40-byte row costs the same 128-byte fabric request as a 64-byte one, and these
@@ -234,6 +245,10 @@ class _RelationalMP(torch.autograd.Function):
                     _native.spmm_csr_d16_ok(graph.csr("fwd"), W.shape[0]):
                 # sparse buckets, up to 120 relations: ONE pass over the destination-major CSR, messages of mixed relations, W in LDS
                 out = _native.spmm_csr_d16(X, W, b, graph.csr("fwd"), relu=fused_relu)
+            elif _sparse_buckets(graph, W) and _fwd_blk(graph, fused_relu) is not None:
+                # sparse buckets, more relations than the CSR kernel's LDS holds (AM as shipped, layer 2: R = 267): the forward plan cut into
+                # tall workgroup-owned tiles (31 messages per (tile, relation) bucket instead of ~2), one launch, no [M, 16] intermediate
+                out = _native.spmm_blk(X, W, b, _fwd_blk(graph, fused_relu), relu=fused_relu)
             elif _sparse_buckets(graph, W):
                 out = _native.spmm_two_pass(X, W, b, graph.scatter_plan("fwd"), graph.csr("fwd"), relu=fused_relu)
             else:

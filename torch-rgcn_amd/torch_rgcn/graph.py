@@ -131,6 +131,17 @@ class RelGraph:
                                     sparse)
         return self._plan("bwd", rows) if rows else None
 
+    def fwd_blk_plan(self):
+        """FORWARD plan of tall tiles (one per workgroup, up to 1000 rows) for the block-tile forward kernel (rgcn_spmm_blk_f32), or None
+        when it does not apply (small graph, forced tile height, no run pointers)"""
+        if routes.is_set("tile_rows"):
+            return None
+        rows = _native.spmm_blk_rows(self.num_nodes, self.device)
+        if not rows:
+            return None
+        plan = self._plan("fwd", rows)
+        return plan if plan.run_ptr is not None and plan.n_src < (1 << 26) else None
+
     def wgt_plan(self):
         """relation-major (single tile): long runs per relation for the weight gradient"""
         return self._plan("fwd", max(self.num_nodes, 1), int(routes.get("wgrad_item_chunks", "64")))
