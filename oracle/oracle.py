@@ -179,8 +179,10 @@ def expand_weights(params, mode):
     if mode == "none":
         return _f32(params["weights"])
     if mode == "basis":
-        return np.einsum("rb,bio->rio", params["comps"].astype(np.float64),
-                         params["bases"].astype(np.float64)).astype(np.float32)
+        # einsum("rb,bio->rio") spelled as one matrix product [R, B] x [B, i o]: the same float64 sums on BLAS (np.einsum walks this
+        # contraction element by element -- 45 s for AM's table at 1/10 scale against 7)
+        comps, bases = params["comps"].astype(np.float64), params["bases"].astype(np.float64)
+        return (comps @ bases.reshape(bases.shape[0], -1)).reshape((comps.shape[0],) + bases.shape[1:]).astype(np.float32)
     if mode == "block":
         W = block_diag_np(_f32(params["blocks"]))
         if "blocks_self" in params:  # LP variant: dense self-loop weight appended last
@@ -203,8 +205,9 @@ def contract_weight_grads(dW, params, mode):
     if mode == "basis":
         comps = params["comps"].astype(np.float64)
         bases = params["bases"].astype(np.float64)
-        return {"bases": np.einsum("rb,rio->bio", comps, dW64).astype(np.float32),
-                "comps": np.einsum("rio,bio->rb", dW64, bases).astype(np.float32)}
+        flat = dW64.reshape(dW64.shape[0], -1)              # einsum("rb,rio->bio") and ("rio,bio->rb") as matrix products
+        return {"bases": (comps.T @ flat).reshape(bases.shape).astype(np.float32),
+                "comps": (flat @ bases.reshape(bases.shape[0], -1).T).astype(np.float32)}
     if mode == "block":
         blocks = params["blocks"]
         Rb, nb, bi, bo = blocks.shape

@@ -26,10 +26,35 @@
  * Arithmetic: inputs/outputs fp32 (as the reference); sums are carried in double
  * and rounded once, so the oracle sits at or below the reference's own fp32
  * round-off (about 1e-7 relative) from the exact result.
+ *
+ * Threads (round 5): the two layer loops run "owner computes" over a few OpenMP
+ * threads -- thread t walks the WHOLE edge list in order and takes the messages
+ * whose accumulator row it owns (destination row for the forward, source row for
+ * dX, relation -- or table row -- for dW).  Every accumulator still receives its
+ * terms in edge-list order: the results are bit for bit those of the one-thread
+ * loop (ORACLE_THREADS=1 in the environment runs it), the full-size parity tests
+ * just stop waiting 15 s per case for it.
  */
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* threads of the layer loops: min(16, cores), ORACLE_THREADS overrides; small edge lists stay on one */
+static int oracle_threads(int64_t M) {
+#ifdef _OPENMP
+  const char *e = getenv("ORACLE_THREADS");
+  int t = e ? atoi(e) : omp_get_max_threads();
+  if (t > 16) t = 16;
+  if (t < 1 || M < 200000) t = 1;
+  return t;
+#else
+  (void)M;
+  return 1;
+#endif
+}
 
 #define ORACLE_OK 0
 #define ORACLE_EINVAL 1
@@ -202,21 +227,33 @@ int oracle_rgcn_forward(const int64_t *Tp, const float *val, int64_t M,
   double *acc = (double *)calloc(NZ(N * d_out), sizeof(double));
   if (!acc) return ORACLE_ENOMEM;
   int rc = ORACLE_OK;
-  for (int64_t e = 0; e < M; ++e) {
-    int64_t s = Tp[3 * e + 0], p = Tp[3 * e + 1], o = Tp[3 * e + 2];
-    if (s < 0 || s >= N || o < 0 || o >= N || p < 0 || p >= R) { rc = ORACLE_ERANGE; break; }
-    double v = (double)val[e];
-    double *dst = acc + s * d_out;
-    if (!X) {
-      const float *w = W + (p * N + o) * d_out;
-      for (int64_t j = 0; j < d_out; ++j) dst[j] += v * (double)w[j];
-    } else {
-      const float *x = X + o * d_in;
-      const float *w = W + p * d_in * d_out;
-      for (int64_t i = 0; i < d_in; ++i) {
-        double xv = v * (double)x[i];
-        const float *wr = w + i * d_out;
-        for (int64_t j = 0; j < d_out; ++j) dst[j] += xv * (double)wr[j];
+  const int nt = oracle_threads(M);
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nt)
+#endif
+  {
+#ifdef _OPENMP
+    const int me = omp_get_thread_num();
+#else
+    const int me = 0;
+#endif
+    for (int64_t e = 0; e < M; ++e) {
+      int64_t s = Tp[3 * e + 0], p = Tp[3 * e + 1], o = Tp[3 * e + 2];
+      if (s < 0 || s >= N || o < 0 || o >= N || p < 0 || p >= R) { rc = ORACLE_ERANGE; break; }   /* (every thread meets it) */
+      if ((int)(s % nt) != me) continue;            /* owner computes: the destination row */
+      double v = (double)val[e];
+      double *dst = acc + s * d_out;
+      if (!X) {
+        const float *w = W + (p * N + o) * d_out;
+        for (int64_t j = 0; j < d_out; ++j) dst[j] += v * (double)w[j];
+      } else {
+        const float *x = X + o * d_in;
+        const float *w = W + p * d_in * d_out;
+        for (int64_t i = 0; i < d_in; ++i) {
+          double xv = v * (double)x[i];
+          const float *wr = w + i * d_out;
+          for (int64_t j = 0; j < d_out; ++j) dst[j] += xv * (double)wr[j];
+        }
       }
     }
   }
@@ -242,29 +279,44 @@ int oracle_rgcn_backward(const int64_t *Tp, const float *val, int64_t M,
   double *aX = (dX && X) ? (double *)calloc(NZ(N * d_in), sizeof(double)) : NULL;
   if ((dW && !aW) || (dX && X && !aX)) { free(aW); free(aX); return ORACLE_ENOMEM; }
   int rc = ORACLE_OK;
-  for (int64_t e = 0; e < M; ++e) {
-    int64_t s = Tp[3 * e + 0], p = Tp[3 * e + 1], o = Tp[3 * e + 2];
-    if (s < 0 || s >= N || o < 0 || o >= N || p < 0 || p >= R) { rc = ORACLE_ERANGE; break; }
-    double v = (double)val[e];
-    const float *gs = g + s * d_out;
-    if (!X) {
-      if (aW) {
-        double *w = aW + (p * N + o) * d_out;
-        for (int64_t j = 0; j < d_out; ++j) w[j] += v * (double)gs[j];
+  const int nt = oracle_threads(M);
+  /* the one loop of the one-thread form, walked by every thread: a thread adds to dX rows it owns (source row o) and to dW
+   * entries it owns (relation p; featureless: table row o) -- two owners per message, each accumulator filled in edge order */
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nt)
+#endif
+  {
+#ifdef _OPENMP
+    const int me = omp_get_thread_num();
+#else
+    const int me = 0;
+#endif
+    for (int64_t e = 0; e < M; ++e) {
+      int64_t s = Tp[3 * e + 0], p = Tp[3 * e + 1], o = Tp[3 * e + 2];
+      if (s < 0 || s >= N || o < 0 || o >= N || p < 0 || p >= R) { rc = ORACLE_ERANGE; break; }   /* (every thread meets it) */
+      double v = (double)val[e];
+      const float *gs = g + s * d_out;
+      if (!X) {
+        if (aW && (int)(o % nt) == me) {
+          double *w = aW + (p * N + o) * d_out;
+          for (int64_t j = 0; j < d_out; ++j) w[j] += v * (double)gs[j];
+        }
+        continue;
       }
-      continue;
-    }
-    const float *x = X + o * d_in;
-    const float *w = W + p * d_in * d_out;
-    for (int64_t i = 0; i < d_in; ++i) {
-      const float *wr = w + i * d_out;
-      double xv = v * (double)x[i];
-      double dot = 0.0;
-      for (int64_t j = 0; j < d_out; ++j) {
-        dot += (double)gs[j] * (double)wr[j];
-        if (aW) aW[p * d_in * d_out + i * d_out + j] += xv * (double)gs[j];
+      const int own_x = aX && (int)(o % nt) == me, own_w = aW && (int)(p % nt) == me;
+      if (!own_x && !own_w) continue;
+      const float *x = X + o * d_in;
+      const float *w = W + p * d_in * d_out;
+      for (int64_t i = 0; i < d_in; ++i) {
+        const float *wr = w + i * d_out;
+        double xv = v * (double)x[i];
+        double dot = 0.0;
+        for (int64_t j = 0; j < d_out; ++j) {
+          dot += (double)gs[j] * (double)wr[j];
+          if (own_w) aW[p * d_in * d_out + i * d_out + j] += xv * (double)gs[j];
+        }
+        if (own_x) aX[o * d_in + i] += v * dot;
       }
-      if (aX) aX[o * d_in + i] += v * dot;
     }
   }
   if (rc == ORACLE_OK) {

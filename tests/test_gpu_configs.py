@@ -23,39 +23,46 @@ MUTAG = dict(N=23_644, R0=23, E=74_227)
 
 
 @pytest.mark.parametrize("vertical", [False, True])
-@pytest.mark.parametrize("route", ["block", "hybrid", "hybrid_r2", "twopass", "tile"])
+@pytest.mark.parametrize("route", ["block", "hybrid", "hybrid_r2", "fwdblk", "twopass", "tile"])
 def test_am_tenth_scale_block_diagonal_layer_vs_oracle(monkeypatch, route, vertical):
     """1/10 of AM, block-diagonal nb = 4, d = 16, both stackings, every route: out / dX / dblocks / db against the oracle.
       hybrid   the default for sparse (tile, relation) buckets (267 relations): forward on the block CSR kernel (4 x 4 blocks as
                they are), backward on the block-tile kernel (round 3: one 255-row tile per workgroup, dX + the DIAGONAL blocks of
                dW + db from one gather per message; RGCN_F_DIAG4)
       hybrid_r2  round 2's default: the backward on the expanded 16 x 16 weights, relation-major fused pass + row sums
-      twopass  forward too on the expanded weights (transform in relation-major order, sum per destination), round 2's backward
+      fwdblk   forward on the expanded weights in ONE launch of the block-tile forward kernel (round 5, rgcn_spmm_blk_f32: what a dense-weight
+               layer with 267 relations takes), round 2's backward
+      twopass  forward too on the expanded weights in two passes (transform in relation-major order, sum per destination; RGCN_SPMM_CSR=0),
+               round 2's backward
       tile     the (tile, relation) kernels of dense-bucket graphs
       block    forward and backward on the block kernels (RGCN_BLOCK_PATH=2; at width 16 not the default)"""
     from torch_rgcn import _native
     routes.patch(monkeypatch, "block_path", "2" if route == "block" else "0")
     routes.patch(monkeypatch, "block_fwd", "1" if route in ("hybrid", "hybrid_r2") else "0")
-    if route in ("hybrid_r2", "twopass"):
+    if route in ("hybrid_r2", "twopass", "fwdblk"):
         routes.patch(monkeypatch, "bwd_kernel", "lean")       # no block-tile kernel: the sparse graph's backward is the two-pass one
-    if route in ("twopass", "tile"):
-        routes.patch(monkeypatch, "sparse_path", "1" if route == "twopass" else "0")
+    if route in ("twopass", "fwdblk", "tile"):
+        routes.patch(monkeypatch, "sparse_path", "0" if route == "tile" else "1")
+    if route == "twopass":
+        routes.patch(monkeypatch, "spmm_csr", "0")
     _native.profile_start()
     run_layer_vs_oracle(N=166_676, R0=133, E=598_832, d_in=16, d_out=16, mode="block", num_blocks=4, vertical=vertical,
                         seed=301 + int(vertical))
     prof = _native.profile_stop()
     assert ("block_spmm" in prof) == (route in ("block", "hybrid", "hybrid_r2")) and ("block_wgrad" in prof) == (route == "block")
-    assert ("spmm_scatter" in prof) == (route == "twopass")
+    assert ("spmm_scatter" in prof) == (route == "twopass") and ("spmm_blk" in prof) == (route == "fwdblk")
     # backward: relation-major fused pass (dX rows + dW from one walk) on the sparse path, tile-walk fused kernel otherwise
-    assert ("bwd_scatter_dw" in prof) == (route in ("hybrid_r2", "twopass")) and ("bwd_fused" in prof) == (route in ("tile", "hybrid"))
+    assert ("bwd_scatter_dw" in prof) == (route in ("hybrid_r2", "twopass", "fwdblk")) and ("bwd_fused" in prof) == (route in ("tile", "hybrid"))
 
 
 def test_am_tenth_scale_default_path_is_the_sparse_one():
-    """without any switch the 267-relation graph must pick the two-pass path by itself (fill of the 16-slot chunks < 50 %)"""
+    """without any switch the 267-relation graph must pick the sparse-bucket routes by itself (fill of the 16-slot chunks < 50 %): the
+    block-tile forward kernel on tall tiles (more relations than the one-pass CSR kernel holds), the relation-major fused backward"""
     from torch_rgcn import _native
     _native.profile_start()
     run_layer_vs_oracle(N=166_676, R0=133, E=598_832, d_in=16, d_out=16, mode="none", seed=303)
-    assert "spmm_scatter" in _native.profile_stop()
+    prof = _native.profile_stop()
+    assert "spmm_blk" in prof and "bwd_scatter_dw" in prof and "spmm" not in prof, sorted(prof)
 
 
 def _am_graph():
