@@ -262,20 +262,45 @@ __global__ __launch_bounds__(WG) void gemm_panel_kernel(const float *__restrict_
       } else {
         av = *reinterpret_cast<const f32x4 *>(&sA[cur][(16 * wave + i) * LD_IN + 4 * kq]);
       }
-      f32x4 bv[NB];
+      // The B operands are read from LDS one phase AHEAD of the MFMAs that use them, the phases pinned with scheduling barriers.  Left to
+      // itself hipcc kept ONE register pair for all of them: read, s_waitcnt lgkmcnt(0), two MFMAs, read ... -- an LDS round trip exposed
+      // between every two MFMAs of a wave (found in the ISA; the kernel sat at 0.42 of the MFMA peak whatever its tiles and prefetches).
+      if (TB) {          // K-inner slab: a 16-byte read is one column tile's four K values -> phases of four column tiles
+        constexpr int G = 4, NG = (NB + G - 1) / G;
+        f32x4 bg[2][G];
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        if (TB) {
-          bv[b] = *reinterpret_cast<const f32x4 *>(&sB[cur][(16 * b + i) * LD_IN + 4 * kq]);
-        } else {
+        for (int j = 0; j < G; ++j) bg[0][j] = *reinterpret_cast<const f32x4 *>(&sB[cur][(16 * min(j, NB - 1) + i) * LD_IN + 4 * kq]);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) bv[b][c] = sB[cur][(4 * kq + c) * LDB_O + 16 * b + i];
+        for (int g = 0; g < NG; ++g) {
+          if (g + 1 < NG) {
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+              bg[(g + 1) & 1][j] = *reinterpret_cast<const f32x4 *>(&sB[cur][(16 * min((g + 1) * G + j, NB - 1) + i) * LD_IN + 4 * kq]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+              if (g * G + j < NB) acc[g * G + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bg[g & 1][j][c], acc[g * G + j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {           // K-outer slab: a phase is one K value of every column tile
+        float bc[2][NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) bc[0][b] = sB[cur][(4 * kq) * LDB_O + 16 * b + i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (c < 3) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) bc[(c + 1) & 1][b] = sB[cur][(4 * kq + c + 1) * LDB_O + 16 * b + i];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bc[c & 1][b], acc[b], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv[b][c], acc[b], 0, 0, 0);
       if (t + 1 < steps) stash(cur ^ 1, kb + GK * (t + 1));
       __syncthreads();
     }
