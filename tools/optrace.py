@@ -1,3 +1,5 @@
+"""Which ATen / autograd op launched which kernel in one WN18-shaped LP training step (torch.profiler, input shapes recorded): how the two
+float -> bool -> uint8 casts of the dropout mask (8 us each) and the embeddings' ReLU pair were found.  python tools/optrace.py"""
 import sys, torch
 sys.path.insert(0, "torch-rgcn_amd"); sys.path.insert(0, "tools")
 from torch_rgcn import _native
