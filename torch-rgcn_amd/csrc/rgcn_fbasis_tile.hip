@@ -269,7 +269,7 @@ __global__ __launch_bounds__(TW) void fbt_fwd_kernel(
 template <int LPR>
 __global__ __launch_bounds__(256) void gather_rows_sum4_kernel(const float *__restrict__ Y, const int *__restrict__ perm,
                                                                const int4 *__restrict__ units, const float *__restrict__ bias,
-                                                               float *__restrict__ out, long long n_units, int w, int ow, int relu_out) {
+                                                               float *__restrict__ out, long long n_units, int w, int ow, int relu_out, int vec_out) {
   const int q = threadIdx.x % LPR;
   for (long long u = ((long long)blockIdx.x * 256 + threadIdx.x) / LPR; u < n_units; u += ((long long)gridDim.x * 256) / LPR) {
     const int4 unit = units[u];
@@ -300,11 +300,21 @@ __global__ __launch_bounds__(256) void gather_rows_sum4_kernel(const float *__re
     }
     a += b;
     float *o = out + (size_t)unit.x * ow + 4 * q;           // rows of ow >= w floats: columns w .. ow are written as zeros (a zero-padded
-#pragma unroll                                              // [N, 16] row is what the width-16 kernels of the next layer read in place)
-    for (int c = 0; c < 4; ++c) {
-      if (4 * q + c < w) {
-        if (shared) atomicAdd(o + c, a[c]); else o[c] = relu_out ? fmaxf(a[c], 0.f) : a[c];
-      } else if (4 * q + c < ow && !shared) o[c] = 0.f;
+                                                            // [N, 16] row is what the width-16 kernels of the next layer read in place)
+    if (!shared && vec_out) {                               // whole 16-byte pieces: one store per lane (four scalar ones: 0.34 -> 0.30 ms at AM size)
+      if (4 * q < ow) {
+        f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = 4 * q + c < w ? (relu_out ? fmaxf(a[c], 0.f) : a[c]) : 0.f;
+        *reinterpret_cast<f32x4 *>(o) = v;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (4 * q + c < w) {
+          if (shared) atomicAdd(o + c, a[c]); else o[c] = relu_out ? fmaxf(a[c], 0.f) : a[c];
+        } else if (4 * q + c < ow && !shared) o[c] = 0.f;
+      }
     }
   }
 }
@@ -1418,11 +1428,12 @@ extern "C" int rgcn_gather_rows_sum4_f32(const float *Y, int32_t ys, const int32
   if (n_split) HIP_TRY(zero_async(out, (size_t)n_rows * ow * sizeof(float), st));
   if (n_units == 0) return RGCN_OK;
   const int lpr = ys / 4;
-  const dim3 grid((unsigned)std::min<int64_t>((n_units * lpr + 255) / 256, (int64_t)n_cus() * 32));
+  const dim3 grid((unsigned)std::min<int64_t>((n_units * lpr + 255) / 256, (int64_t)n_cus() * 64));
   const int4 *un = reinterpret_cast<const int4 *>(units);
-  if (lpr == 1) hipLaunchKernelGGL(gather_rows_sum4_kernel<1>, grid, dim3(256), 0, st, Y, perm, un, bias, out, (long long)n_units, w, ow, relu ? 1 : 0);
-  else if (lpr == 2) hipLaunchKernelGGL(gather_rows_sum4_kernel<2>, grid, dim3(256), 0, st, Y, perm, un, bias, out, (long long)n_units, w, ow, relu ? 1 : 0);
-  else hipLaunchKernelGGL(gather_rows_sum4_kernel<4>, grid, dim3(256), 0, st, Y, perm, un, bias, out, (long long)n_units, w, ow, relu ? 1 : 0);
+  const int vec_out = (ow & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  if (lpr == 1) hipLaunchKernelGGL(gather_rows_sum4_kernel<1>, grid, dim3(256), 0, st, Y, perm, un, bias, out, (long long)n_units, w, ow, relu ? 1 : 0, vec_out);
+  else if (lpr == 2) hipLaunchKernelGGL(gather_rows_sum4_kernel<2>, grid, dim3(256), 0, st, Y, perm, un, bias, out, (long long)n_units, w, ow, relu ? 1 : 0, vec_out);
+  else hipLaunchKernelGGL(gather_rows_sum4_kernel<4>, grid, dim3(256), 0, st, Y, perm, un, bias, out, (long long)n_units, w, ow, relu ? 1 : 0, vec_out);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
