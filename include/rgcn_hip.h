@@ -47,9 +47,14 @@ RGCN_API const char *rgcn_last_error(void);
 /* first 16 hex digits of the SHA-256 over the library sources (every .hip / .cpp / .h under csrc plus this header) at build time: profiles/ carry
  * it, bench.py reports whether the committed counter files were taken on THIS binary (no reference counterpart) */
 RGCN_API const char *rgcn_csrc_sha(void);
+/* Test helper (no counterpart in the reference; changes no result): fills the LDS of every CU with quiet-NaN bit patterns -- one
+ * workgroup per CU writes its whole 160 KiB allocation and exits.  LDS keeps its contents between kernels, so a kernel that reads a word
+ * it never wrote (and relies on multiplying it by zero) computes NaN afterwards instead of getting away with yesterday's finite
+ * garbage: tests/test_gpu_parity.py runs the tile kernels behind it (round 5: that is how the fused tile backward lost its dcomps in
+ * 1 of 25 runs). */
+RGCN_API int rgcn_poison_lds(void *stream);
 /* Tuning options: the library never reads the environment -- whoever hosts it (torch_rgcn/routes.py) decides and says so here.
- * Names: basis_vec4, block_lds, block_pipe, bwd_nw, bwd_d, bwd_waves, bwd_u, gemm_bm, spmm_u, wgrad_rg, wgrad_u,
- * distmult_one_launch, rank_tile (all of them choose between kernels that compute the same result), and bwd_abl / rank_ablate:
+ * Names: bwd_nw, gemm_bm, spmm_u, wgrad_rg, wgrad_u (all of them choose between kernels that compute the same result), and bwd_abl:
  * timing experiments with WRONG results that exist in the ablation build only (make -C torch-rgcn_amd/csrc abl) -- the shipped
  * library refuses a non-zero value (RGCN_EUNSUPPORTED).  Process-wide; set them before launching from several threads.  No
  * reference counterpart (the reference has no native layer). */

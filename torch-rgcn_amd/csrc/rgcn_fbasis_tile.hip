@@ -1183,7 +1183,10 @@ __global__ __launch_bounds__(TW) void fbn_bwd_kernel(
           const float vm = __shfl(c_x.ev, w0 + min(c, n16 - 1), 64);       // val of message c rides on the A operand: D[m][b] comes out scaled
           const FK<NKD> v = *reinterpret_cast<const FK<NKD> *>(xt + min(c, n16 - 1) * ts + nl * d + min(NKD * k, d - 1));
 #pragma unroll
-          for (int ks = 0; ks < NKD; ++ks) av[ks] = vm * v.f[ks];                                    // (features past d meet zeros of bt)
+          for (int ks = 0; ks < NKD; ++ks) av[ks] = NKD * k + ks < d ? vm * v.f[ks] : 0.f;
+          // (K positions past d are zeroed HERE: they are read from whatever follows the row in LDS -- the neighbour slot, or padding nobody
+          // ever wrote -- and "they meet zeros of bt" only holds while that garbage is finite: NaN x 0 is NaN.  Found as comps.grad full of
+          // NaN in 1 of 25 runs of the full-size AM test, and in every launch of a process whose LDS padding happened to hold NaN patterns)
         }
         int rq[4];
 #pragma unroll
@@ -1411,6 +1414,28 @@ extern "C" int rgcn_fbasis_tile_fwd_f32(const float *bases, const float *comps, 
 #undef FBT_FWD1
 #undef FBT_FWD2
 #undef FBT_FWD3
+  HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(1024) void poison_lds_kernel(int n_words) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  for (int i = threadIdx.x; i < n_words; i += 1024) lds[i] = __int_as_float(0x7fc00000 | (i & 0xffff));
+  __syncthreads();
+  if (lds[(threadIdx.x * 37) % n_words] == 0.f) asm volatile("s_nop 0");     // (keeps the stores: nothing else reads them)
+}
+}  // namespace
+
+extern "C" int rgcn_poison_lds(void *stream) {
+  const int bytes = 160 * 1024;
+  static bool raised = false;
+  if (!raised) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    raised = true;
+  }
+  // one workgroup per CU holds the whole LDS, so 4 x the CU count of them visit every CU at least once
+  hipLaunchKernelGGL(poison_lds_kernel, dim3((unsigned)(4 * n_cus())), dim3(1024), bytes, (hipStream_t)stream, bytes / 4);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

@@ -1137,6 +1137,13 @@ def bwd_blk_rows(n_nodes, num_rels, deterministic=False, device=None, diag4=Fals
     return max(rows, min(cap, 128))      # small graphs: fewer, taller tiles (fuller buckets, fewer dW flushes) rather than one per CU
 
 
+def poison_lds(device=None):
+    """test helper: every CU's LDS filled with NaN patterns (rgcn_poison_lds) -- a kernel that reads LDS words it never wrote shows it"""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with _on(dev):
+        _check(lib().rgcn_poison_lds(_stream(dev)), "poison_lds")
+
+
 def spmm_blk_rows(n_nodes, device=None):
     """tile height of the forward plan for the block-tile FORWARD kernel (rgcn_spmm_blk_f32): the tallest tile up to 1000 rows that gives
     every CU the same number of tiles; 0 for graphs too small to fill the chip with one tile per workgroup"""

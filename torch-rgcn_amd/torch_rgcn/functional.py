@@ -604,7 +604,9 @@ def _split_k(K, M, N):
     tiles = -(-M // 128) * -(-N // 128)
     # (at most 64 slices: past that the partial products' round trip through HBM costs more than the extra workgroups buy --
     # tools/splitk_probe.py, WN18's dbases = ag^T g, K = 40,943: 64 slices 122.7 us, the former choice of 79 133.7, 128 142.0)
-    return int(max(1, min(64, (4 * 256) // max(tiles, 1), K // 512)))
+    # short K (the weight assembly's adjoint: K = relations, a few hundred) is ONE workgroup's serial loop of K / 16 steps, each a global
+    # round trip with nothing to overlap it (32 us for K = 267): slices of at least three steps
+    return int(max(1, min(64, (4 * 256) // max(tiles, 1), K // 512 if K >= 8192 else K // 48)))
 
 
 class _MatmulMFMA(torch.autograd.Function):
