@@ -15,6 +15,12 @@ os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")       # before the 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("RGCN_TEST_FILL_UNINITIALIZED") == "1":
+        # the thorough (slower) form for global memory: every torch.empty() comes back full of NaN, so a kernel that reads a buffer (or
+        # the padding columns of one) before anything wrote it shows up as NaN instead of depending on what the allocator handed out
+        import torch
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        torch.utils.deterministic.fill_uninitialized_memory = True
     # a fresh checkout has no built artefacts (they are git-ignored): build the HIP library and the C oracle once
     lib = os.path.join(PKG, "torch_rgcn", "lib", "librgcn_hip.so")
     ora = os.path.join(ROOT, "oracle", "_build")
