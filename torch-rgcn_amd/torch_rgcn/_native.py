@@ -99,11 +99,20 @@ def _dp(t):
 # HIP events on the stream the kernels are launched on (torch's current stream), recorded
 # around every launch while profiling is on; bench.py uses this for the roofline figures.
 _PROF = None
+_PROF_ON = True
 
 
 def profile_start():
-    global _PROF
-    _PROF = {}
+    global _PROF, _PROF_ON
+    _PROF, _PROF_ON = {}, True
+
+
+def profile_enable(on):
+    """timers on / off without ending the profile: a HIP event pair around a launch costs ~9 us of GPU time (the launches before and after
+    it cannot overlap their tails and heads), so a caller that times a whole loop as well samples the per-launch timers -- bench.py brackets
+    the launches of every fourth step"""
+    global _PROF_ON
+    _PROF_ON = bool(on)
 
 
 def profile_stop():
@@ -131,7 +140,7 @@ class _Timed:
 
 def _timed(name):
     # (no events inside a stream capture: recording them there is an error -- a captured step is timed as a whole, by its replay)
-    return _NOCTX if (_PROF is None or torch.cuda.is_current_stream_capturing()) else _Timed(name)
+    return _NOCTX if (_PROF is None or not _PROF_ON or torch.cuda.is_current_stream_capturing()) else _Timed(name)
 
 
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
