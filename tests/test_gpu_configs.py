@@ -107,6 +107,41 @@ def test_am_full_size_block_layer_properties():
         assert rel_err(layer(X).detach(), ref.cpu().numpy()) < 1e-5
 
 
+def test_am_full_size_dense_layer_one_launch_forward_properties():
+    """full-size AM, featured layer with DENSE weights at R = 267 (the shipped model's second layer, at width 16): the forward is ONE launch of
+    the block-tile forward kernel on 930-row tiles (four float4 of the tile per thread at the hand-over: the shape only this graph reaches) --
+    linear in X, equal to the two-pass route, and the (relation, subject) group counts with W_r[0, 0] = 1"""
+    from torch_rgcn import _native
+    from torch_rgcn.layers import RelationalGraphConvolutionNC
+    N, R0 = AM["N"], AM["R0"]
+    tp = _am_graph()
+    layer = RelationalGraphConvolutionNC(triples=torch.from_numpy(tp), num_nodes=N, num_relations=2 * R0 + 1, in_features=16, out_features=16).to(DEV)
+    with torch.no_grad():
+        layer.bias.normal_()
+        a, b = torch.randn(N, 16, device=DEV), torch.randn(N, 16, device=DEV)
+        _native.profile_start()
+        ya, yb, yab = layer(a), layer(b), layer(0.5 * a + 2.0 * b)
+        prof = _native.profile_stop()
+        assert "spmm_blk" in prof and "spmm_scatter" not in prof, sorted(prof)
+        assert rel_err(yab - layer.bias, (0.5 * (ya - layer.bias) + 2.0 * (yb - layer.bias)).cpu().numpy()) < 1e-5
+        with routes.override(spmm_csr="0"):
+            two = RelationalGraphConvolutionNC(triples=torch.from_numpy(tp), num_nodes=N, num_relations=2 * R0 + 1, in_features=16,
+                                               out_features=16).to(DEV)
+            two.load_state_dict(layer.state_dict())
+            _native.profile_start()
+            yt = two(a)
+            assert "spmm_scatter" in _native.profile_stop()
+        assert rel_err(ya, yt.cpu().numpy()) < 1e-5
+        assert torch.equal(layer.forward_activated(a, "relu"), torch.relu(ya))
+        layer.weights.fill_(0.0)
+        layer.weights[:, 0, 0] = 1.0
+        layer.bias.zero_()
+        y = layer(torch.ones(N, 16, device=DEV))[:, 0]
+        key = torch.from_numpy(tp[:, 1] * N + tp[:, 0]).to(DEV)
+        cnt = torch.bincount(torch.unique(key) % N, minlength=N).float()
+        assert torch.allclose(y, cnt, rtol=1e-5, atol=1e-5)
+
+
 def test_am_full_size_featureless_basis40_properties():
     """AM as shipped (nc-AM.yaml: featureless first layer, basis 40, hidden 10): the source-major kernels at full size.
     With comps = 1/B and bases = 1 the output row is the number of (relation, subject) groups of the node; linear in bases."""
