@@ -153,6 +153,17 @@ class _MeanSquare(torch.autograd.Function):
         return out * (g * (2.0 / out.numel()))
 
 
+def _backend_version(backend):
+    """what the line says about the collective library -- never worth the headline number: any failure here is reported as text"""
+    try:
+        if backend == "nccl":
+            v = torch.cuda.nccl.version()
+            return "RCCL " + (".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v))
+        return f"{backend} (torch {torch.__version__})"
+    except Exception as exc:  # noqa: BLE001
+        return f"{backend} (version query failed: {type(exc).__name__})"
+
+
 def make_step(l1, l2, X):
     """THE timed step: layer 1 (horizontal flag) with its ReLU fused, layer 2 (vertical flag), loss = mean(out^2), backward to X and
     to both layers' parameters (tests/test_gpu_parity.py::test_bench_step_composition_vs_cpu_port checks exactly this callable)"""
@@ -445,7 +456,7 @@ def main():
                      "messages_per_rank": [int(c) for c in counts.tolist()],
                      # what the backend itself saw (the driver's SCALE record can be checked for "RCCL ran with N ranks")
                      "world_size_seen_by_backend": dist.get_world_size(group), "backend": str(dist.get_backend(group)),
-                     "backend_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else f"gloo (torch {torch.__version__})"),
+                     "backend_version": _backend_version(backend),
                      "overlap": "side-stream" if chosen[1] > 0 else "none",
                      "model": "per step 4 x all-reduce of N x d fp32 (2 forward outputs, 2 feature gradients); a ring moves "
                               "2(G-1)/G x 64 MB over each rank's slowest link, a direct reduce-scatter + all-gather "
