@@ -847,16 +847,19 @@ __global__ __launch_bounds__(TW) void fbn_dcomps_kernel(
           strip_store<GS>(gs, gq, n16, lane);
         }
         float av[NKD];
+        // A operand lane (k, row c) = G row of message pm(c) = 4 (c & 3) + (c >> 2), feature 4 ks + k: the rows in 4 x 4-transposed message order, so that
+        // D's row 4 k + e is message 4 e + k and the e-th table update below is skipped whole for a node of at most 4 e messages (fbn_bwd_kernel)
+        const int pm = min(4 * (c & 3) + (c >> 2), n16 - 1);
 #pragma unroll
-        for (int ks = 0; ks < NKD; ++ks) av[ks] = gs[min(c, n16 - 1) * GS + 4 * ks + k];       // A operand lane (k, m) = G row of message m, feature 4 ks + k
+        for (int ks = 0; ks < NKD; ++ks) av[ks] = gs[pm * GS + 4 * ks + k];
         int rq[4];
         float vq[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {                       // D's rows of this lane: messages 4 k + e
-          const int src = (g0 & 63) + min(4 * k + e, n16 - 1);
+        for (int e = 0; e < 4; ++e) {                       // D's rows of this lane: row 4 k + e = message 4 e + k
+          const int src = (g0 & 63) + min(4 * e + k, n16 - 1);
           rq[e] = __shfl(c_x.er, src, 64);
           const float vs = __shfl(c_x.ev, src, 64);
-          vq[e] = (4 * k + e < n16) ? vs : 0.f;
+          vq[e] = (4 * e + k < n16) ? vs : 0.f;
         }
 #pragma unroll
         for (int tb2 = 0; tb2 < NBTM; ++tb2)
@@ -867,7 +870,7 @@ __global__ __launch_bounds__(TW) void fbn_dcomps_kernel(
             if (16 * tb2 + c < B && !FBT_ABL(8)) {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
-                if (4 * k + e < n16)
+                if (4 * e + k < n16)
                   __hip_atomic_fetch_add(dcl + rq[e] * B + 16 * tb2 + c, (double)(vq[e] * acc[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
           }
@@ -1180,8 +1183,13 @@ __global__ __launch_bounds__(TW) void fbn_bwd_kernel(
           if (4 * q < n16 && c < d) xt[(4 * q + k) * ts + nl * d + c] = gp[q];
         float av[NKD];
         {
-          const float vm = __shfl(c_x.ev, w0 + min(c, n16 - 1), 64);       // val of message c rides on the A operand: D[m][b] comes out scaled
-          const FK<NKD> v = *reinterpret_cast<const FK<NKD> *>(xt + min(c, n16 - 1) * ts + nl * d + min(NKD * k, d - 1));
+          // A row c holds message pm = 4 (c & 3) + (c >> 2) -- the 4 x 4 transpose of the row index -- so that D's row 4 k + e is message 4 e + k:
+          // the e-th table update below then covers messages 4 e .. 4 e + 3 and is SKIPPED whole (no lane active) when the node has no more
+          // than 4 e messages.  With rows in message order every one of the four updates ran for any node of 4 or more messages, half empty:
+          // 12 ds_add_f64 per node and 16-row tile of bases at AM's 8 messages per node instead of 6.
+          const int pm = min(4 * (c & 3) + (c >> 2), n16 - 1);
+          const float vm = __shfl(c_x.ev, w0 + pm, 64);       // val of the row's message rides on the A operand: D[m][b] comes out scaled
+          const FK<NKD> v = *reinterpret_cast<const FK<NKD> *>(xt + pm * ts + nl * d + min(NKD * k, d - 1));
 #pragma unroll
           for (int ks = 0; ks < NKD; ++ks) av[ks] = NKD * k + ks < d ? vm * v.f[ks] : 0.f;
           // (K positions past d are zeroed HERE: they are read from whatever follows the row in LDS -- the neighbour slot, or padding nobody
@@ -1190,7 +1198,7 @@ __global__ __launch_bounds__(TW) void fbn_bwd_kernel(
         }
         int rq[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) rq[e] = __shfl(c_x.er, w0 + min(4 * k + e, n16 - 1), 64);       // D's rows of this lane: messages 4 k + e
+        for (int e = 0; e < 4; ++e) rq[e] = __shfl(c_x.er, w0 + min(4 * e + k, n16 - 1), 64);       // D's rows of this lane: row 4 k + e = message 4 e + k
 #pragma unroll
         for (int tb2 = 0; tb2 < NBTM; ++tb2)
           if (tb2 < nbt) {
@@ -1200,7 +1208,7 @@ __global__ __launch_bounds__(TW) void fbn_bwd_kernel(
             if (16 * tb2 + c < B && !FBT_ABL(8)) {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
-                if (4 * k + e < n16)
+                if (4 * e + k < n16)
                   __hip_atomic_fetch_add(dcl + rq[e] * B + 16 * tb2 + c, (double)acc[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
           }
