@@ -322,7 +322,24 @@ __global__ __launch_bounds__(WG) void gemm_panel_kernel(const float *__restrict_
 
 // C[i] = bias[i % N] + sum_s partial[s][i]   (fixed order)
 __global__ __launch_bounds__(WG) void sum_slices_kernel(const float *__restrict__ partial, const float *__restrict__ bias,
-                                                        float *__restrict__ C, long long n, int N, int S, long long ldc) {
+                                                        float *__restrict__ C, long long n, int N, int S, long long ldc, int vec) {
+  if (vec) {           // n, N, ldc multiples of 4, aligned: 16 bytes per lane and four slices in flight (64 slices of a 400 x 200 product: 17 -> 7 us);
+                       // the slices are added in the same order as below
+    const long long n4 = n >> 2;
+    for (long long i4 = (long long)blockIdx.x * WG + threadIdx.x; i4 < n4; i4 += (long long)gridDim.x * WG) {
+      const long long idx = 4 * i4;
+      f32x4 a = bias ? *reinterpret_cast<const f32x4 *>(bias + idx % N) : f32x4{0.f, 0.f, 0.f, 0.f};
+      int s = 0;
+      for (; s + 3 < S; s += 4) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(partial + (size_t)s * n + idx), v1 = *reinterpret_cast<const f32x4 *>(partial + (size_t)(s + 1) * n + idx);
+        const f32x4 v2 = *reinterpret_cast<const f32x4 *>(partial + (size_t)(s + 2) * n + idx), v3 = *reinterpret_cast<const f32x4 *>(partial + (size_t)(s + 3) * n + idx);
+        a += v0; a += v1; a += v2; a += v3;
+      }
+      for (; s < S; ++s) a += *reinterpret_cast<const f32x4 *>(partial + (size_t)s * n + idx);
+      *reinterpret_cast<f32x4 *>(C + (idx / N) * ldc + idx % N) = a;
+    }
+    return;
+  }
   for (long long idx = (long long)blockIdx.x * WG + threadIdx.x; idx < n; idx += (long long)gridDim.x * WG) {
     float a = bias ? bias[idx % N] : 0.f;
     for (int s = 0; s < S; ++s) a += partial[(size_t)s * n + idx];
@@ -612,6 +629,8 @@ extern "C" int rgcn_gemm_f32(const float *A, const float *B, const float *bias, 
   const int kps = (int)(((K + S - 1) / S + GK - 1) / GK * GK);
   S = K > 0 ? (int)((K + kps - 1) / kps) : 1;
   float *out = S > 1 ? scratch : C;
+  const int sum_vec = (N & 3) == 0 && (ldc & 3) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(scratch) | reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0;
   const long long ldo = S > 1 ? N : ldc, sstride = S > 1 ? (long long)M * N : 0;
   // 64-row tiles when they spread better over the 256 CUs: rounds of 128-row tile work on the busiest CU
   const int bm_env = rgcn_option_value(RGCN_OPT_GEMM_BM);
@@ -648,7 +667,7 @@ extern "C" int rgcn_gemm_f32(const float *A, const float *B, const float *bias, 
       if (S > 1) {
         const long long n = (long long)M * N;
         hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)std::min<long long>((n + WG - 1) / WG, 4096)), dim3(WG), 0, st, scratch,
-                           bias, C, n, (int)N, S, (long long)ldc);
+                           bias, C, n, (int)N, S, (long long)ldc, sum_vec);
       }
       HIP_TRY(hipGetLastError());
       return RGCN_OK;
@@ -672,7 +691,7 @@ extern "C" int rgcn_gemm_f32(const float *A, const float *B, const float *bias, 
   if (S > 1) {
     const long long n = (long long)M * N;
     hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)std::min<long long>((n + WG - 1) / WG, 4096)), dim3(WG), 0, st, scratch,
-                       bias, C, n, (int)N, S, (long long)ldc);
+                       bias, C, n, (int)N, S, (long long)ldc, sum_vec);
   }
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
