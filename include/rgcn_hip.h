@@ -565,7 +565,8 @@ RGCN_API int rgcn_gemm_f32(const float *A, const float *B, const float *bias, fl
  * plan (rgcn_dev_plan_fill with tile_rows >= n_dst; work items of <= 8 chunks = 128 slots of one relation) as the row
  * blocks of an LDS-tiled MFMA GEMM with gathered rows:
  *   rgcn_rel_rows_f32               Y[slot, :] = val[slot] * Xs[p_src[slot], :] @ W[rel]        (Y: [slots, d_out], slot order)
- *   rgcn_segment_gather_sum_wide_f32  out[row, :] = bias + sum_j Y[perm[j], :] over the row's CSR range (any width)
+ *   rgcn_segment_gather_sum_wide_f32  out[row, :] = bias + sum_j Y[perm[j], :] over the row's CSR range (any width; the sum of a row is
+ *                                   carried in doubles and rounded once: a hub row is a chain of as many additions as it has messages)
  *   rgcn_rel_wgrad_f32              dW[rel] += sum_slots Xs[p_src[slot], :]^T (val[slot] G[p_dst[slot], :])   (dW zeroed first,
  *                                   fp32 atomics across the items of a relation)
  * The feature gradient is rgcn_rel_rows_f32 on the transposed relation-major plan with G and W^T. */

@@ -17,6 +17,9 @@ Sets:
   g7_eval_*  utils/misc.py evaluate(): filtered and raw ranks (ties included) of an LP encoder + DistMult model
   g8_sampler utils/misc.py edge_neighborhood(): picks under two np.random seeds
   g9_lp_loader utils/data.py load_link_prediction_data() on a tiny text dataset
+  g10_nc_loader utils/data.py load_node_classification_data() on a tiny AIFB-layout dataset
+  g11_dup_*  NC layers on graphs of thousands of PARALLEL edges between one or two nodes: inputs on which the reference's own fp32
+             round-off (a chain of equal terms per output element) is above 1e-4 of the exact result
 """
 import os
 import sys
@@ -525,10 +528,37 @@ def g10():
          file_test=np.asarray([list(r) for r in G10_TEST]), **res)
 
 
+def g11():
+    """Thousands of parallel edges (the same triple repeated): every output element of torch.sparse.mm is ONE chain of that many fp32
+    additions of equal terms, whose rounding residue repeats at every step.  The fixture records what the reference returns; the tests
+    measure how far that -- and the HIP path -- is from the oracle's doubles (tests/test_oracle_golden.py, tests/test_gpu_parity.py)."""
+    cases = (("wide", 1, 1, 9000, 3, 100, None), ("basis", 2, 1, 20000, 100, 100, {"type": "basis", "num_bases": 2}),
+             ("featureless", 2, 1, 20000, None, 100, None))
+    for tag, N, R0, E, d_in, d_out, decomp in cases:
+        gen = torch.Generator().manual_seed(1100 + E + d_out)
+        T = torch.stack([torch.randint(0, N, (E,), generator=gen), torch.randint(0, R0, (E,), generator=gen),
+                         torch.randint(0, N, (E,), generator=gen)], dim=1)
+        Tp = add_inverse_and_self(T, N, R0)
+        layer = RelationalGraphConvolutionNC(triples=Tp, num_nodes=N, num_relations=2 * R0 + 1, in_features=d_in, out_features=d_out,
+                                             decomposition=decomp, vertical_stacking=False)
+        seeded_params(layer, gen)
+        X = None if d_in is None else torch.randn(N, d_in, generator=gen).requires_grad_(True)
+        out = layer(X) if X is not None else layer()
+        g = torch.randn(out.shape, generator=gen)
+        grads_of(layer, out, g, extra=() if X is None else (X,))
+        arrs = {"triples": T.numpy().astype(np.int32), "num_nodes": N, "num_rels": R0, "g": g.numpy(), "out": out.detach().numpy()}
+        if X is not None:
+            arrs.update(X=X.detach().numpy(), grad_X=X.grad.numpy())
+        for n, p_ in layer.named_parameters():
+            arrs[f"param_{n}"] = p_.detach().numpy()
+            arrs[f"grad_{n}"] = p_.grad.numpy()
+        save(f"g11_dup_{tag}", **arrs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
         if only and fn.__name__ not in only:
             continue
         fn()

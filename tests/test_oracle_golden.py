@@ -181,6 +181,43 @@ def test_g6_mid():
         assert rel_err(got, d[key]) < 5e-5, key
 
 
+# ---- G11 thousands of parallel edges: where the REFERENCE's own fp32 round-off passes 1e-4 ----
+
+G11 = ("g11_dup_wide", "g11_dup_basis", "g11_dup_featureless")
+
+
+def g11_case(name):
+    """-> (reference tensors, oracle tensors, inputs) of one G11 fixture, keyed out / dX / <parameter>"""
+    d = load_golden(name)
+    N, R0 = int(d["num_nodes"]), int(d["num_rels"])
+    R = 2 * R0 + 1
+    tp = oracle.add_inverse_and_self(d["triples"].astype(np.int64), N, R0)
+    params = params_of(d)
+    bias = params.pop("bias", None)
+    X = d["X"] if "X" in d else None
+    res = oracle.nc_layer(tp, N, R, X, params, mode_of(name, params), bias, False, d["g"])
+    ref = {"out": d["out"], **{n: d[f"grad_{n}"] for n in params}}
+    got = {"out": res["out"], **res["grads"]}
+    if X is not None:
+        ref["dX"], got["dX"] = d["grad_X"], res["dX"]
+    if bias is not None:
+        ref["bias"], got["bias"] = d["grad_bias"], res["db"]
+    return ref, got, (d, tp, N, R)
+
+
+def test_g11_parallel_edges_reference_round_off():
+    """9,000 .. 20,000 copies of the same few triples: every output element of the reference is one chain of that many fp32 additions
+    of equal terms (torch.sparse.mm), and its distance from the oracle's doubles is ABOVE the 1e-4 the parity tests otherwise use --
+    the fixture pins that observation, and bounds it: parity on such an input is only defined to the reference's own round-off."""
+    worst = {}
+    for name in G11:
+        ref, got, _ = g11_case(name)
+        assert set(ref) == set(got)
+        worst[name] = max(rel_err(ref[k], got[k]) for k in ref)
+        assert worst[name] < 5e-3, (name, worst[name])
+    assert max(worst.values()) > 1e-4, worst
+
+
 # ---- G5 DistMult ----
 
 def test_g5_distmult():

@@ -10,7 +10,8 @@ fails=0
 for case in range(400):
     N = int(rng.choice([1, 2, 3, 5, 8, 17, 63, 64, 65, 127, 128, 129, 300, 777, 2049]))
     R0 = int(rng.integers(1, 9))
-    E = int(rng.choice([0, 1, 2, 3, 15, 16, 17, 50, 400, 2500, 9000]))
+    E = min(int(rng.choice([0, 1, 2, 3, 15, 16, 17, 50, 400, 2500, 9000])), 200 * N)   # (thousands of parallel edges between 1-2 nodes: chains
+    #   of equal fp32 terms, where the reference itself is > 1e-4 from the oracle's doubles -- that case has its own fixtures, tests/golden/g11_*)
     mode = str(rng.choice(["none", "none", "basis", "block", "diag"]))
     featureless = bool(rng.random() < 0.25) and mode != "diag"
     vertical = bool(rng.random() < 0.5) and not featureless

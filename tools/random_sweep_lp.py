@@ -50,6 +50,8 @@ for case in range(cases):
     decomp = {"none": None, "basis": {"type": "basis", "num_bases": int(rng.integers(1, 5))},
               "block": {"type": "block", "num_blocks": nb}}[mode]
     tag = f"case {case}: N={N} R0={R0} E={E} mode={mode} nb={nb} vertical={vertical} d=({d_in},{d_out}) training={training} p={p_self} {sl_type}"
+    if os.environ.get("SWEEP_VERBOSE"):        # (a case that takes the process down is the last one printed)
+        print(tag, flush=True)
     try:
         layer = RelationalGraphConvolutionLP(num_nodes=N, num_relations=R, in_features=d_in, out_features=d_out,
                                              edge_dropout={"general": 0.5, "self_loop": p_self, "self_loop_type": sl_type},

@@ -563,6 +563,9 @@ __global__ __launch_bounds__(WG) void rel_wgrad_kernel(
 }
 
 // out[row, :] = bias + sum_{j in rowptr[row] .. rowptr[row+1]} Y[perm[j], :]   (rows of any width; one wave per row)
+// The sums are carried in DOUBLES and rounded once: a destination with thousands of messages (a hub, or one edge repeated 9,000 times)
+// is a chain of that many additions per lane, and in fp32 a chain of EQUAL terms drifts by the same rounding residue at every step
+// (1.5e-4 relative at 18,001 terms, found by the randomised sweep).  The kernel waits for memory either way (v_add_f64 is full rate).
 __global__ __launch_bounds__(WG) void segment_gather_sum_wide_kernel(const float *__restrict__ Y, const int *__restrict__ perm,
                                                                      const int *__restrict__ rowptr, const float *__restrict__ bias,
                                                                      float *__restrict__ out, long long n_rows, int d, int relu_out) {
@@ -573,23 +576,26 @@ __global__ __launch_bounds__(WG) void segment_gather_sum_wide_kernel(const float
     const int e0 = rowptr[row], e1 = rowptr[row + 1];
     for (int f0 = 0; f0 < d; f0 += 256) {
       const int f = f0 + 4 * lane;
-      f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+      double sa[4], sb[4] = {0., 0., 0., 0.};
       if (f < d) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a[q] = (bias && f + q < d) ? bias[f + q] : 0.f;
+        for (int q = 0; q < 4; ++q) sa[q] = (bias && f + q < d) ? (double)bias[f + q] : 0.;
         for (int e = e0; e < e1; e += 2) {
           const float *ya = Y + (size_t)perm[e] * d, *yb = Y + (size_t)perm[min(e + 1, e1 - 1)] * d;
-          const float wb = (e + 1 < e1) ? 1.f : 0.f;
+          const bool two = e + 1 < e1;
           if (vec) {
-            a += *reinterpret_cast<const f32x4 *>(ya + f);
-            b += *reinterpret_cast<const f32x4 *>(yb + f) * wb;
+            const f32x4 va = *reinterpret_cast<const f32x4 *>(ya + f), vb = *reinterpret_cast<const f32x4 *>(yb + f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { sa[q] += (double)va[q]; sb[q] += two ? (double)vb[q] : 0.; }
           } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              if (f + q < d) { a[q] += ya[f + q]; b[q] += yb[f + q] * wb; }
+              if (f + q < d) { sa[q] += (double)ya[f + q]; sb[q] += two ? (double)yb[f + q] : 0.; }
           }
         }
-        a += b;
+        f32x4 a;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = (float)(sa[q] + sb[q]);
         if (relu_out) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) a[q] = fmaxf(a[q], 0.f);

@@ -980,9 +980,10 @@ def spmm_slabs(X, W, bias, plan, n_slabs, after_slab):
 def _slot_perm(p, n_msg, dev):
     """destination-major position -> slot of the relation-major plan `p` (cached on the plan)"""
     if getattr(p, "_inv", None) is None:
-        live = p.dst >= 0
+        dst, aux = p.dst[:p.m_pad], p.aux[:p.m_pad]        # (a plan without messages keeps one-element placeholders nobody wrote)
+        live = dst >= 0
         inv = torch.zeros(max(n_msg, 1), dtype=torch.int32, device=dev)
-        inv[p.aux[live].long()] = torch.arange(p.dst.shape[0], device=dev, dtype=torch.int32)[live]
+        inv[aux[live].long()] = torch.arange(p.m_pad, device=dev, dtype=torch.int32)[live]
         p._inv = inv
     return p._inv
 
