@@ -365,11 +365,13 @@ RGCN_API int rgcn_spmm_blk_f32(const float *X, const float *W_packed, const floa
  * two-pass path: one wave per work item gathers G[p_src] and X[p_dst] once per message and produces
  *   Y[slot, :] = val G[p_src] W_r^T   (slot order; pass 2 = rgcn_segment_gather_sum_f32 sums them per destination -> dX)
  *   dW[r]    += val X[p_dst]^T G[p_src]   (one flush of 256 fp32 atomics per item; dW is zeroed first)
- * i.e. two random row reads per message instead of the three of rgcn_spmm_scatter_f32 + rgcn_wgrad_f32.  d = 16 only. */
+ * i.e. two random row reads per message instead of the three of rgcn_spmm_scatter_f32 + rgcn_wgrad_f32.  d = 16 only.
+ * flags: RGCN_F_RELU -- X = relu(.) of the producing layer (models.py:194): every transformed row is masked with X[p_dst] > 0 as it is
+ * written, so the summed dX already is the gradient BEFORE that ReLU (the producer skips its threshold_backward launch). */
 RGCN_API int rgcn_bwd_scatter_dw_f32(const float *G, const float *X, const float *Wt_packed, float *Y, float *dW,
                                      const int32_t *p_src, const int32_t *p_dst, const float *p_val,
                                      const int32_t *chunk_rel, const int32_t *items, int64_t n_items, int32_t R, int32_t d,
-                                     void *stream);
+                                     int32_t flags, void *stream);
 /* Wp[r][16k+f][c] = W[r][f][4k+c]: fragments of W_r^T straight from W (the feature-gradient kernels multiply by W^T). */
 RGCN_API int rgcn_pack_w16t_f32(const float *W, float *Wp, int32_t R, void *stream);
 /* rgcn_pack_w16_f32 and rgcn_pack_w16t_f32 in ONE launch (a training step needs both: forward and fused backward of the

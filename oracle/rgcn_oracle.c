@@ -257,10 +257,14 @@ int oracle_rgcn_forward(const int64_t *Tp, const float *val, int64_t M,
       }
     }
   }
-  if (rc == ORACLE_OK)
+  if (rc == ORACLE_OK) {         /* (independent elements: the rounding loop may be split over the threads) */
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nt) schedule(static)
+#endif
     for (int64_t n = 0; n < N; ++n)
       for (int64_t j = 0; j < d_out; ++j)
         out[n * d_out + j] = (float)(acc[n * d_out + j] + (bias ? (double)bias[j] : 0.0));
+  }
   free(acc);
   return rc;
 }
@@ -321,13 +325,22 @@ int oracle_rgcn_backward(const int64_t *Tp, const float *val, int64_t M,
   }
   if (rc == ORACLE_OK) {
     if (aW) for (int64_t t = 0; t < wsz; ++t) dW[t] = (float)aW[t];
-    if (aX) for (int64_t t = 0; t < N * d_in; ++t) dX[t] = (float)aX[t];
-    if (db)
-      for (int64_t j = 0; j < d_out; ++j) {
-        double a = 0.0;
-        for (int64_t n = 0; n < N; ++n) a += (double)g[n * d_out + j];
-        db[j] = (float)a;
+    if (aX) {
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nt) schedule(static)
+#endif
+      for (int64_t t = 0; t < N * d_in; ++t) dX[t] = (float)aX[t];
+    }
+    if (db) {                    /* one pass over g, every column's sum still in row order (was: one strided pass per column) */
+      double *a = (double *)calloc(NZ(d_out), sizeof(double));
+      if (!a) rc = ORACLE_ENOMEM;
+      else {
+        for (int64_t n = 0; n < N; ++n)
+          for (int64_t j = 0; j < d_out; ++j) a[j] += (double)g[n * d_out + j];
+        for (int64_t j = 0; j < d_out; ++j) db[j] = (float)a[j];
+        free(a);
       }
+    }
   }
   free(aW);
   free(aX);

@@ -97,12 +97,13 @@ for case in range(cases):
         r2 = oracle.nc_layer(tp, N, R, a, P2, m2, b2, v2, g)
         # (an element of h within round-off of 0 may sit on the other side in the float64 composition: the mask is the step's own)
         r1 = oracle.nc_layer(tp, N, R, X, P1, m1, b1, False, (r2["dX"] * (seen["a"].detach().cpu().numpy()[:, :h.shape[1]] > 0)).astype(np.float32))
+        gin = {"l2": g, "l1": r2["dX"] * (seen["a"].detach().cpu().numpy()[:, :h.shape[1]] > 0)}
         errs = {"logits": rel_err(logits, lg), "loss": abs(loss.item() - ref_loss.item()) / max(abs(ref_loss.item()), 1.0)}      # (one labelled node: a loss near 0)
         for lname, layer, res in (("l1", first, r1), ("l2", second, r2)):
             for n, gv in res["grads"].items():
                 errs[f"{lname}.{n}"] = rel_err(getattr(layer, n).grad, gv)
-            if layer.bias is not None:
-                errs[f"{lname}.bias"] = rel_err(layer.bias.grad, res["db"])
+            if layer.bias is not None:       # a column sum of signed terms (two classes: +a and -a with a ~ 1e-5 of the terms): measured against the sum of |terms|
+                errs[f"{lname}.bias"] = float(np.abs(layer.bias.grad.cpu().numpy() - res["db"]).max() / max(np.abs(gin[lname]).sum(0).max(), 1e-30))
         if emb:
             errs["embeddings"] = rel_err(model.node_embeddings.grad, r1["dX"])
         bad = {k: v for k, v in errs.items() if not v < TOL}

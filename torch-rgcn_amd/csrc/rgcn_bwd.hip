@@ -463,7 +463,9 @@ __global__ __launch_bounds__(64 * NW, 4) void bwd_lean_d16_kernel(
 // Y[slot] = val G[s] W_r^T (summed per destination by pass 2, rgcn_segment_gather_sum_f32) and the item's share of dW_r,
 // which stays in 4 accumulator registers for the whole item (runs are long in relation-major order): one flush of 256
 // atomics per item, no staging, no barriers.
-template <int U>
+// RELU: the feature gradient leaves masked with X > 0 (X = relu(...) of the producing layer, whose backward then skips its own masking launch):
+// the lane that writes features 4k .. 4k+3 of a slot's transformed row holds the same features of X[p_dst] already.
+template <int U, bool RELU>
 __global__ __launch_bounds__(WG) void bwd_scatter_dw_d16_kernel(
     const float *__restrict__ G, const float *__restrict__ X, const float *__restrict__ Wtp, float *__restrict__ Y,
     float *__restrict__ dW, const int *__restrict__ p_src, const int *__restrict__ p_dst, const float *__restrict__ p_val,
@@ -511,6 +513,10 @@ __global__ __launch_bounds__(WG) void bwd_scatter_dw_d16_kernel(
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, sc[1], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, sc[2], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, sc[3], acc, 0, 0, 0);
+      if (RELU) {
+        acc[0] = x[j].x > 0.f ? acc[0] : 0.f; acc[1] = x[j].y > 0.f ? acc[1] : 0.f;
+        acc[2] = x[j].z > 0.f ? acc[2] : 0.f; acc[3] = x[j].w > 0.f ? acc[3] : 0.f;
+      }
       if (live) *reinterpret_cast<f32x4 *>(Y + ((size_t)min(c + j, last) * RGCN_CHUNK + m) * 16 + 4 * k) = acc;
       // dW_r += (X[o])^T (val G[s]): both operands through the LDS scratch into K-over-messages layout
       float bv[4], av[4];
@@ -717,7 +723,7 @@ extern "C" int rgcn_bwd_lean_f32(const float *G, const float *X, const float *Wt
 extern "C" int rgcn_bwd_scatter_dw_f32(const float *G, const float *X, const float *Wt_packed, float *Y, float *dW,
                                        const int32_t *p_src, const int32_t *p_dst, const float *p_val,
                                        const int32_t *chunk_rel, const int32_t *items, int64_t n_items, int32_t R, int32_t d,
-                                       void *stream) {
+                                       int32_t flags, void *stream) {
   if (!G || !X || !Wt_packed || !Y || !dW || R <= 0 || n_items < 0 || (n_items && (!p_src || !p_dst || !p_val || !chunk_rel || !items))) {
     rgcn_set_error("bwd_scatter_dw: bad argument");
     return RGCN_EINVAL;
@@ -726,8 +732,13 @@ extern "C" int rgcn_bwd_scatter_dw_f32(const float *G, const float *X, const flo
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(zero_async(dW, (size_t)R * 256 * sizeof(float), st));
   if (!n_items) return RGCN_OK;
-  hipLaunchKernelGGL(bwd_scatter_dw_d16_kernel<4>, dim3((unsigned)((n_items + WG / 64 - 1) / (WG / 64))), dim3(WG), 0, st, G, X,
-                     Wt_packed, Y, dW, p_src, p_dst, p_val, chunk_rel, reinterpret_cast<const int2 *>(items), (int)n_items);
+  const dim3 grid((unsigned)((n_items + WG / 64 - 1) / (WG / 64)));
+  if (flags & RGCN_F_RELU)
+    hipLaunchKernelGGL((bwd_scatter_dw_d16_kernel<4, true>), grid, dim3(WG), 0, st, G, X, Wt_packed, Y, dW, p_src, p_dst, p_val, chunk_rel,
+                       reinterpret_cast<const int2 *>(items), (int)n_items);
+  else
+    hipLaunchKernelGGL((bwd_scatter_dw_d16_kernel<4, false>), grid, dim3(WG), 0, st, G, X, Wt_packed, Y, dW, p_src, p_dst, p_val, chunk_rel,
+                       reinterpret_cast<const int2 *>(items), (int)n_items);
   HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

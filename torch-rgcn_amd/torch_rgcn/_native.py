@@ -1062,9 +1062,10 @@ def wgrad_wide(X, G, scatter_plan, num_rels):
     return dW
 
 
-def bwd_two_pass_fused(G, X, W, scatter_plan, csr):
+def bwd_two_pass_fused(G, X, W, scatter_plan, csr, relu=False):
     """(dX, dW) of the hidden-16 layer on a sparse-bucket graph: relation-major pass producing the transformed rows AND dW
-    (rgcn_bwd_scatter_dw_f32), then the per-destination sum of the rows."""
+    (rgcn_bwd_scatter_dw_f32), then the per-destination sum of the rows.  relu: X = relu(.) of the producing layer -- dX comes back
+    masked with X > 0 (RGCN_F_RELU)."""
     _req(G, "grad_output"); _req(X, "features"); _req(W, "weights")
     p = scatter_plan
     dev = G.device
@@ -1077,7 +1078,7 @@ def bwd_two_pass_fused(G, X, W, scatter_plan, csr):
     with _on(dev), _timed("bwd_scatter_dw"):
         _check(lib().rgcn_bwd_scatter_dw_f32(_dp(G), _dp(X), _dp(Wtp), _dp(Y), _dp(dW), _dp(p.src), _dp(p.dst), _dp(p.val),
                                              _dp(p.chunk_rel), _dp(p.items), c_i64(p.n_items), c_i32(W.shape[0]), c_i32(16),
-                                             _stream(dev)), "bwd_scatter_dw")
+                                             c_i32(F_RELU if relu else 0), _stream(dev)), "bwd_scatter_dw")
     with _on(dev), _timed("segment_sum"):
         _segment_gather_sum(Y, p._inv, csr, None, dX, False)
     return dX, dW

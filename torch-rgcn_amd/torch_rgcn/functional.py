@@ -222,6 +222,9 @@ class _RelationalMP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, W, bias, graph, relu=False, blocks=None, in_token=None):
         ctx.in_token = in_token                      # X = relu(...) of a layer that fused the activation (see _ReluToken)
+        # H itself, kept alive until the backward: at padded widths (AM: hidden 10) the tensor saved below is the [N, 16] buffer behind it, the
+        # caller's H is a temporary, and _ReluToken.observed() must still be able to ask it whether anybody watches its gradient
+        ctx.h_ref = X if in_token is not None else None
         ctx.out_token = _ReluToken(private=relu == "private") if relu else None
         relu = bool(relu)
         x_padded_view = W.shape[1] % 16 != 0 and _zero_padded_rows(X, W.shape[1] + (-W.shape[1] % 16))
@@ -306,7 +309,9 @@ class _RelationalMP(torch.autograd.Function):
         if both is None and sparse and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and routes.get("bwd", "fused") != "split" \
                 and routes.get("twopass", "gather") == "gather" and not deterministic():
             # sparse buckets: relation-major walk, G[s] and X[o] gathered once each for dX's rows and dW together
-            both = _native.bwd_two_pass_fused(g, X, W, graph.scatter_plan("bwd"), graph.csr("bwd"))
+            # (the producer's ReLU mask rides on the transformed rows: same condition as for the fused kernels above)
+            masked = ctx.in_token is not None and ctx.in_token.private and not ctx.in_token.observed()
+            both = _native.bwd_two_pass_fused(g, X, W, graph.scatter_plan("bwd"), graph.csr("bwd"), relu=masked)
         if both is not None:
             dX, dW = both
         else:
@@ -320,9 +325,10 @@ class _RelationalMP(torch.autograd.Function):
                 dW = _weight_gradient(X, W, g, graph)
         if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
             db = _native.colsum(g)
+        res = _unpad_blocks(ctx.dims, dX, dW, db, getattr(ctx, "dx_view", False))
         if masked:
-            ctx.in_token.mark(dX)                     # dX already is the gradient BEFORE the producer's ReLU
-        return (*_unpad_blocks(ctx.dims, dX, dW, db, getattr(ctx, "dx_view", False)), None, None, None, None)
+            ctx.in_token.mark(res[0])                 # the tensor autograd is handed (a view or a crop of dX for padded widths) already is the
+        return (*res, None, None, None, None)         # gradient BEFORE the producer's ReLU
 
 
 def _join_shards(partial, group, mode="allreduce"):
