@@ -47,7 +47,7 @@ import torch.distributed as dist  # noqa: E402
 
 METRIC = "edges/s/GPU (fwd+bwd) 2-layer RGCN, 1M nodes/10M edges/50 rels, h=16"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def fwd_bytes(M, N, d_in, d_out):
@@ -61,7 +61,7 @@ def bwd_bytes(M, N, d_in, d_out, x_needs_grad=True):
 
 
 def _profile_json(name):
-    for rnd in (PROFILE_ROUND, "r04", "r03", "r02", "r01"):
+    for rnd in (PROFILE_ROUND, "r05", "r04", "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")) as f:
                 return json.load(f), f"profiles/{rnd}_{name}.json"
@@ -255,6 +255,106 @@ def self_launch(n):
         return proc.returncode or 1
     print(result[-1], flush=True)
     return 0
+
+
+LINE_TARGET_BYTES = 4096     # what the line aims for
+LINE_LIMIT_BYTES = 8192      # the driver keeps an 8 KB tail of stdout: a longer line cannot be parsed (round 5's was 27 KB: unmeasured)
+
+_ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches_per_step", "share_of_step",
+              "algorithmic_bytes_per_launch", "traffic", "traffic_over_algorithmic", "traffic_source", "step_frac",
+              "step_algorithmic_bytes")
+_CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
+_COMM_KEYS = ("collective", "collectives_per_step", "bytes_per_collective", "compute_alone_ms_per_step", "collectives_alone_ms_per_step",
+              "exposed_ms_per_step", "allreduce_algbw_GBs", "world_size_seen_by_backend", "backend", "backend_version", "overlap")
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if k in d}
+
+
+def _kernel_summary(r):
+    """the few numbers of a roofline block that belong on the line (the rest lives in the detail file)"""
+    out = _pick(r, _ROOF_KEYS)
+    if out.get("traffic") and out.get("algorithmic_bytes_per_launch"):
+        out["traffic_over_algorithmic"] = round(out["traffic"] / out["algorithmic_bytes_per_launch"], 3)
+    if r.get("traffic_static"):
+        out["traffic_source"] = str(r["traffic_static"]).split(":")[0] + " (static, csrc match: " + str(r.get("traffic_static_csrc_match")) + ")"
+    return out
+
+
+def compact_line(res, detail_path=None):
+    """The ONE stdout line: the contract's keys + `roofline` + `cpu_baseline` (+ `comm` for N > 1), nothing that grows with the number of
+    kernels or configs.  Everything else -- per-config lines, per-kernel counters, the forward/backward sub-blocks, notes -- is the detail
+    file's.  Asserted < LINE_LIMIT_BYTES (tests/test_bench_line.py runs this on a canned result)."""
+    line = _pick(res, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                       "dtype", "data", "per_gpu_edges_per_s", "step_ms_median", "step_ms_min", "graph_build_ms", "csrc_sha"))
+    line["config"] = _pick(res.get("config") or {}, ("workload", "sharding"))
+    roof = res.get("roofline")
+    if roof:
+        r = _kernel_summary(roof)
+        for side in ("forward", "backward"):
+            if side in roof:
+                r[side] = _pick(_kernel_summary(roof[side]), ("kernel", "avg_launch_ms", "frac", "algorithmic_bytes_per_launch", "traffic",
+                                                             "traffic_over_algorithmic"))
+                r[side]["kernel"] = str(r[side].get("kernel", "")).split(" ")[0]
+        r["kernel"] = str(r.get("kernel", ""))[:120]
+        line["roofline"] = r
+    else:
+        line["roofline"] = None
+    if res.get("sustained"):
+        line["sustained_ms_per_step"] = res["sustained"].get("ms_per_step")
+    if res.get("comm"):
+        line["comm"] = _pick(res["comm"], _COMM_KEYS)
+        line["comm"]["candidates_ms_per_step"] = res["comm"].get("candidates_ms_per_step")
+    if res.get("sharded_vs_unsharded"):
+        line["sharded_vs_unsharded"] = _pick(res["sharded_vs_unsharded"], ("max_rel_err",))
+    if isinstance(res.get("cpu_baseline"), dict):
+        line["cpu_baseline"] = _pick(res["cpu_baseline"], _CPU_KEYS)
+        line["cpu_baseline"]["sample"] = str(line["cpu_baseline"].get("sample", ""))[:200]
+    if isinstance(res.get("configs"), list):     # one short entry per secondary config; their full lines are in the detail file
+        line["configs_ms"] = {f"{i}:" + " ".join(str(c.get("baseline_config", "")).split()[:3])[:28]: c.get("ms_per_step", c.get("failed"))
+                              for i, c in enumerate(res["configs"]) if isinstance(c, dict)}
+    if detail_path:
+        line["detail"] = detail_path
+    text = json.dumps(line, allow_nan=False)
+    if len(text) >= LINE_TARGET_BYTES:           # past the target: drop the optional blocks, largest first, until it fits
+        for k in ("configs_ms", "sustained_ms_per_step", "step_ms_median", "step_ms_min", "per_gpu_edges_per_s"):
+            line.pop(k, None)
+            text = json.dumps(line, allow_nan=False)
+            if len(text) < LINE_TARGET_BYTES:
+                break
+    assert len(text) < LINE_LIMIT_BYTES, f"bench line is {len(text)} bytes (limit {LINE_LIMIT_BYTES})"
+    assert "\n" not in text
+    return text
+
+
+def _no_nan(o):
+    """json.dumps(allow_nan=False)-safe copy: NaN / inf become None (a strict parser must read both the line and the detail file)"""
+    if isinstance(o, float):
+        return o if np.isfinite(o) else None
+    if isinstance(o, dict):
+        return {str(k): _no_nan(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_no_nan(v) for v in o]
+    if isinstance(o, (np.floating, np.integer)):
+        return _no_nan(o.item())
+    return o
+
+
+def emit(res):
+    """detail -> bench_detail.json (+ stderr); the compact line -> stdout, LAST"""
+    res = _no_nan(res)
+    path = os.environ.get("RGCN_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+    rel = None
+    try:
+        with open(path, "w") as f:
+            json.dump(res, f, indent=1, allow_nan=False)
+        rel = os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    except OSError as exc:
+        print(f"bench.py: detail file not written ({exc})", file=sys.stderr)
+    print("bench.py detail: " + json.dumps(res, allow_nan=False), file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    print(compact_line(res, rel), flush=True)
 
 
 def host_ram_gb():
@@ -589,8 +689,7 @@ def main():
     if group is not None:
         dist.destroy_process_group()   # RCCL prints its banner here; keep the JSON line last
     if res is not None:
-        sys.stdout.flush()
-        print(json.dumps(res), flush=True)
+        emit(res)
 
 
 if __name__ == "__main__":
