@@ -411,6 +411,11 @@ def main():
         else:
             dist.init_process_group(backend, **extra)
         group = dist.group.WORLD
+        seen = dist.get_world_size(group)
+        if seen != args.gpus:      # the line's n_gpus must be what the collective library ran with, not what the command line asked for
+            print(f"bench.py: --gpus {args.gpus} but the {backend} backend sees {seen} rank(s)", file=sys.stderr)
+            dist.destroy_process_group()
+            return 3
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     mode = "single" if group is None else ("weak" if args.weak else "strong")
 

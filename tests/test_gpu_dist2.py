@@ -224,11 +224,35 @@ def _run_bench(extra_args, env_extra=None, world=2):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
            "--nodes", "200000", "--edges", "1000000", "--rels", "20"] + extra_args
-    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    return json.loads(lines[0])
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        env["RGCN_BENCH_DETAIL"] = os.path.join(tmp, "detail.json")
+        out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        with open(env["RGCN_BENCH_DETAIL"]) as f:
+            detail = json.load(f)
+    return _line_and_detail(lines[0], detail)
+
+
+def _line_and_detail(text, detail):
+    """the ONE stdout line is the compact record (< 8 KB, the contract's keys, comm summary); the assertions below read the detail file,
+    after checking that the line says the same thing"""
+    import json
+    assert len(text) < 8192, len(text)
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert line[k] == detail[k], k
+    assert line["config"] == {k: detail["config"][k] for k in ("workload", "sharding")}
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch"):
+        assert k in line["roofline"], k
+    assert line["roofline"]["frac"] == detail["roofline"]["frac"]
+    if "comm" in detail:
+        for k in ("collective", "world_size_seen_by_backend", "backend", "exposed_ms_per_step", "compute_alone_ms_per_step"):
+            assert line["comm"][k] == detail["comm"][k], k
+    assert "cpu_baseline" not in line or set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    return detail
 
 
 def test_bench_contract_with_two_ranks_on_one_gpu():
@@ -288,10 +312,75 @@ def test_plain_bench_command_launches_its_own_ranks():
     env.update(RGCN_BENCH_ONE_DEVICE="1", RGCN_DIST_BACKEND="gloo")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--nodes", "100000",
            "--edges", "500000", "--rels", "10"]
-    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1 and lines[-1].startswith("{"), out.stdout[-2000:]
-    res = json.loads(lines[-1])
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        env["RGCN_BENCH_DETAIL"] = os.path.join(tmp, "detail.json")
+        out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1 and lines[-1].startswith("{"), out.stdout[-2000:]
+        with open(env["RGCN_BENCH_DETAIL"]) as f:
+            res = _line_and_detail(lines[-1], json.load(f))
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "strong" and "relation-sharded x2" in res["config"]["sharding"]
     assert abs(res["value"] - 500_000 / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]
+
+
+def _hub_owner_worker(rank, world, port, outdir):
+    """a hub whose relation ONE rank owns.  That rank's tall-tile backward plan has hub pieces (the fused slab-by-slab
+    backward does not take them), the other rank's has none: left to themselves the ranks would pick different routes and post all-reduces
+    over different row ranges.  The route is agreed over the group (functional._all_ranks_agree); sharded == unsharded."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "torch-rgcn_amd")):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    from oracle import oracle
+    from torch_rgcn import _native
+    from torch_rgcn.dist import shard_layer
+    from torch_rgcn.layers import RelationalGraphConvolutionNC
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        N, R0, E = 60_000, 4, 600_000
+        T = oracle.synthetic_triples(N, R0, E, seed=23)
+        T[: E // 3, 1] = 0                                   # a third of the triples: relation 0 ...
+        T[: E // 3, 2] = 7                                   # ... into ONE object: a hub row of the transposed plan, in relation 0 only
+        tp = torch.from_numpy(oracle.add_inverse_and_self(T, N, R0))
+        res = {}
+        for sharded in (False, True):
+            torch.manual_seed(0)
+            layer = RelationalGraphConvolutionNC(triples=tp, num_nodes=N, num_relations=2 * R0 + 1, in_features=16, out_features=16).to(dev)
+            with torch.no_grad():
+                layer.bias.normal_()
+            if sharded:
+                shard_layer(layer, dist.group.WORLD, keep="lpt", comm="allreduce", slabs=3)
+            X = torch.randn(N, 16, device=dev, requires_grad=True)
+            out = layer(X)
+            out.backward(torch.cos(out.detach()))
+            wg = layer.weights.grad.clone()
+            if sharded:
+                dist.all_reduce(wg)
+                bp = layer._graph.bwd_blk_plan()
+                assert bp is not None, "the test wants the block-tile backward's plan (graph too small?)"
+                pieces = torch.tensor([_native._blk_units(bp)[2]], device=dev, dtype=torch.int64)
+                both = [torch.zeros_like(pieces) for _ in range(world)]
+                dist.all_gather(both, pieces)
+                both = [int(t.item()) for t in both]
+                assert (both[0] > 0) != (both[1] > 0), f"hub pieces per rank {both}: the scenario needs them on exactly one rank"
+                agreed = layer._graph._group_routes
+                assert agreed == {("bwd_fused_slabs", 3): False}, agreed
+            res[sharded] = [t.detach().cpu().numpy() for t in (out, X.grad, wg, layer.bias.grad)]
+        if rank == 0:
+            np.savez(os.path.join(outdir, "hub.npz"), **{f"{int(k)}_{i}": a for k, v in res.items() for i, a in enumerate(v)})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_hub_relation_owned_by_one_rank_routes_agree(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_hub_owner_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    z = np.load(os.path.join(str(tmp_path), "hub.npz"))
+    for i, name in enumerate(("out", "dX", "dW", "db")):
+        a, b = z[f"1_{i}"], z[f"0_{i}"]
+        assert np.abs(a - b).max() <= 3e-5 * np.abs(b).max(), name

@@ -365,6 +365,20 @@ def _join_shards(partial, group, mode="allreduce"):
     return partial
 
 
+def _all_ranks_agree(mine, graph, group, key, device):
+    """A route whose collectives differ from the fallback's (other row ranges, other slab cuts) may only be taken when EVERY rank of the
+    group can take it: hub pieces, for one, exist on the rank that owns a hub relation and nowhere else (ranks deciding on their
+    own would post mismatched all-reduces -- a hang or silently wrong dX).  One MIN all-reduce of the local eligibility per (graph, route),
+    cached on the graph: every rank reaches this call on its first backward (the conditions in front of it are rank-invariant)."""
+    import torch.distributed as dist
+    cache = graph.__dict__.setdefault("_group_routes", {})
+    if key not in cache:
+        flag = torch.tensor([1 if mine else 0], device=device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        cache[key] = bool(int(flag.item()))
+    return cache[key]
+
+
 class _ShardedRelationalMP(torch.autograd.Function):
     """Relation shard of the featured layer.  Features and upstream gradient are replicated; every rank computes the
     partial output (and, in backward, the partial feature gradient) of ITS relations and the partials are summed over
@@ -420,7 +434,8 @@ class _ShardedRelationalMP(torch.autograd.Function):
             # the fused backward slab by slab (round 5): the all-reduce of slab k's dX rows -- RCCL on its own stream -- runs under slab
             # k + 1's kernel; dW (owner-local rows) keeps adding across the slabs.  Plans with hub pieces keep the unfused slab path below.
             bp = graph.bwd_blk_plan()
-            if bp is not None and W.shape[1] == 16 and W.shape[2] == 16 and _native.bwd_fused_slabs_ok(bp):
+            mine = bp is not None and W.shape[1] == 16 and W.shape[2] == 16 and _native.bwd_fused_slabs_ok(bp)
+            if _all_ranks_agree(mine, graph, ctx.group, ("bwd_fused_slabs", ctx.n_slabs), g.device):
                 dX, dW, _ = _native.bwd_fused_slabs(g, X, W, bp, ctx.n_slabs,
                                                     lambda o, r0, r1: works.append(dist.all_reduce(o[r0:r1], group=ctx.group, async_op=True)))
                 both, joined = (dX, dW), True
