@@ -590,7 +590,8 @@ def main():
         value = total_edges / (ms * 1e-3)
         alg = fwd_bytes(M, N, d, d)
         launches = {k: (float(np.mean(v)), len(v) / n_sampled) for k, v in prof.items()}
-        spmm_key = "spmm" if "spmm" in launches else ("spmm_slab" if "spmm_slab" in launches else None)
+        spmm_key = next((k for k in ("spmm_blk", "spmm", "spmm_slab") if k in launches), None)
+        fwd_kernel = "spmm_blk_d16_kernel" if spmm_key == "spmm_blk" else "spmm_d16_kernel"
         roof = None
         step_alg = 2 * (fwd_bytes(M, N, d, d) + bwd_bytes(M, N, d, d))
         if spmm_key and mode != "strong":
@@ -599,9 +600,9 @@ def main():
             n_spmm = 2 if "bwd_fused" in launches else 4       # launches per step: 2 forward (+ 2 feature-gradient without the fused backward)
             if slabbed:   # one spmm = the slabs of one launch group
                 spmm_ms = float(np.sum(prof[spmm_key])) / (n_spmm * n_sampled)
-            fwd = kernel_roofline("spmm_d16_kernel (forward launches" + ("" if "bwd_fused" in launches else " and feature-gradient launches") + ")",
+            fwd = kernel_roofline(fwd_kernel + " (forward launches" + ("" if "bwd_fused" in launches else " and feature-gradient launches") + ")",
                                   spmm_ms, alg, "SURVEY 8(d) forward, one layer: M(4 d_in + 8) + N 4 d_out", ms, n_spmm,
-                                  ("spmm_d16_kernel",), "spmm")
+                                  (fwd_kernel,), "spmm_blk" if spmm_key == "spmm_blk" else "spmm")
             # the backward of one layer, whatever kernels it is made of (SURVEY 8d backward bytes)
             balg = bwd_bytes(M, N, d, d)
             bmodel = "SURVEY 8(d) backward, one layer: M(4 d_out + 8) + 2 N 4 d_in (X needs a gradient)"
@@ -639,7 +640,7 @@ def main():
                         "launches_per_step": per_step, "algorithmic_bytes_per_launch": int(alg_b), "bytes_model": model,
                         "share_of_step": round(per_step * t_ms / ms, 4)}
             n_spmm = 2 if "bwd_fused" in launches else 4
-            fwd = local("spmm_d16_kernel", spmm_ms, fwd_bytes(m_local, N, d, d), "SURVEY 8(d) forward on the local messages: M_local(4 d_in + 8) + N 4 d_out", n_spmm)
+            fwd = local(fwd_kernel, spmm_ms, fwd_bytes(m_local, N, d, d), "SURVEY 8(d) forward on the local messages: M_local(4 d_in + 8) + N 4 d_out", n_spmm)
             bwd = None
             if "bwd_fused" in launches:
                 bwd = local("fused backward (dX + dW from one gather per local message)", launches["bwd_fused"][0], bwd_bytes(m_local, N, d, d),

@@ -1,0 +1,53 @@
+"""The soft-window plan (torch_rgcn._native.build_softwin_plan, round 6) is made with torch ops, so its invariants are checked on the CPU:
+every live message sits in exactly one slot, a chunk holds ONE relation and ONE tile, the slots of a (tile, relation) bucket are sorted by
+source, the chunks of a tile by first source, pads are (dst -1, val 0), the tile pointers count chunks."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "torch-rgcn_amd"))
+
+
+@pytest.mark.parametrize("N,R,M,rows,masked", [(1000, 7, 20000, 128, False), (1000, 7, 20000, 128, True), (37, 3, 11, 16, False),
+                                                (500, 1, 3000, 977, False), (64, 5, 0, 16, False)])
+def test_softwin_plan_invariants(N, R, M, rows, masked):
+    from torch_rgcn import _native
+    rng = np.random.default_rng(N + M)
+    dst = torch.from_numpy(rng.integers(0, N, M).astype(np.int32))
+    src = torch.from_numpy(rng.integers(0, N, M).astype(np.int32))
+    rel = torch.from_numpy(rng.integers(0, R, M).astype(np.int32))
+    val = torch.from_numpy(rng.random(M).astype(np.float32) + 0.5)
+    alive = torch.from_numpy((rng.random(M) < 0.7).astype(np.uint8)) if masked else None
+    p = _native.build_softwin_plan(dst, src, rel, val, alive, N, N, R, rows)
+    live = np.ones(M, bool) if alive is None else alive.numpy() != 0
+    assert p.n_messages == int(live.sum()) and p.m_pad == 16 * p.n_chunks and p.n_tiles == -(-N // rows)
+    S, D, V = p.src.numpy()[:p.m_pad], p.dst.numpy()[:p.m_pad], p.val.numpy()[:p.m_pad]
+    real = D >= 0
+    assert int(real.sum()) == p.n_messages and np.all(V[~real] == 0.0)
+    crel = p.chunk_rel.numpy()[:p.n_chunks]
+    # the multiset of (dst, src, rel, val) is the live message list
+    got = sorted(zip(D[real].tolist(), S[real].tolist(), np.repeat(crel, 16)[real].tolist(), V[real].tolist()))
+    want = sorted(zip(dst.numpy()[live].tolist(), src.numpy()[live].tolist(), rel.numpy()[live].tolist(), val.numpy()[live].tolist()))
+    assert got == want
+    tp = p.tile_ptr.numpy()
+    assert tp[0] == 0 and tp[p.n_tiles] == p.n_chunks and np.all(np.diff(tp) >= 0)
+    rp = p.run_ptr.numpy().reshape(p.n_tiles, R + 1)
+    assert np.array_equal(rp[:, 0], tp[:-1]) and np.array_equal(rp[:, R], tp[1:])
+    for t in range(p.n_tiles):
+        firsts = []
+        seen = {}
+        for c in range(tp[t], tp[t + 1]):
+            d, s = D[16 * c:16 * c + 16], S[16 * c:16 * c + 16]
+            k = int((d >= 0).sum())
+            assert k >= 1 and np.all(d[:k] >= 0) and np.all(d[k:] < 0)            # real slots first, a chunk never starts with a pad
+            assert np.all(d[:k] // rows == t)
+            assert np.all(np.diff(s[:k]) >= 0)                                    # sorted by source inside the chunk
+            firsts.append(int(s[0]))
+            r = int(crel[c])
+            assert seen.get(r, -1) <= int(s[0])                                   # ... and from chunk to chunk of one bucket
+            seen[r] = int(s[k - 1])
+        assert firsts == sorted(firsts)                                           # the tile's chunks: by first source

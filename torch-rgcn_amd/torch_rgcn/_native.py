@@ -472,6 +472,75 @@ def build_plan_device(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_ro
     return p
 
 
+def build_softwin_plan(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_rows):
+    """Plan of tall workgroup-owned tiles for the block-tile kernels (rgcn_spmm_blk_f32, rgcn_bwd_own_f32) in SOFT-WINDOW order (round 6):
+
+      * inside a (tile, relation) bucket the slots are sorted by SOURCE row -- the block-tile kernels add with ds_add_f64 and the chunk
+        records carry every slot's tile row, so the order of the slots of a bucket is free -- hence the 16 sources of a chunk span
+        1 / (chunks per bucket) of the table (S1, 977-row tiles: 203 messages per bucket, 13 chunks, ~5 MB of X);
+      * the chunks of a tile are ordered by their first source, whatever their relation.
+
+    Every workgroup then sweeps the source table once per tile and all workgroups sweep roughly together: the row gathers of the whole
+    chip fall into a few MB at any time.  tools/micro/gather_window.hip: S1's 21 M row reads take 0.19-0.22 ms in window-major order
+    against 0.375 ms uniformly random (profiles/r06_gather_window.txt); the forward kernel on this plan 0.327 ms against 0.398 on the same
+    tiles in destination order (tools/softwin_probe.py) -- at the plain (tile, relation) padding (1.04), no window buckets to pad.
+
+    Made with torch ops (two sorts, a histogram, two scans): one-off preprocessing of STATIC graphs; per-call graphs keep
+    build_plan_device.  Same fields as BuiltPlan; run_ptr holds only a tile's first and end chunk (entries 0 and R of its row) -- all the
+    block-tile kernels read -- and there is no packed slot array."""
+    dev = dst.device
+    M = dst.shape[0]
+    n_tiles = (n_dst + tile_rows - 1) // tile_rows
+    nbk = n_tiles * num_rels
+    live = None if alive is None else (alive != 0)
+    d64, s64, r64 = dst.long(), src.long(), rel.long()
+    bucket = torch.div(d64, tile_rows, rounding_mode="floor") * num_rels + r64
+    key = bucket * n_src + s64
+    if live is not None:
+        key = torch.where(live, key, torch.full_like(key, nbk * n_src))       # dropped messages sort behind everything
+    perm = torch.argsort(key)
+    n_live = M if live is None else int(live.sum().item())
+    perm = perm[:n_live]
+    bs = bucket[perm]
+    cnt = torch.bincount(bs, minlength=nbk)
+    padded = (cnt + (CHUNK - 1)) // CHUNK * CHUNK
+    base = torch.cumsum(padded, 0) - padded
+    first = torch.cumsum(cnt, 0) - cnt
+    slot = base[bs] + (torch.arange(n_live, device=dev) - first[bs])
+    m_pad = int(padded.sum().item())
+    n_chunks = m_pad // CHUNK
+    S = torch.zeros(max(m_pad, 1), dtype=torch.int32, device=dev)
+    D = torch.full((max(m_pad, 1),), -1, dtype=torch.int32, device=dev)
+    V = torch.zeros(max(m_pad, 1), dtype=torch.float32, device=dev)
+    S[slot], D[slot], V[slot] = src[perm].to(torch.int32), dst[perm].to(torch.int32), val[perm]
+    cb = torch.repeat_interleave(torch.arange(nbk, device=dev), padded // CHUNK, output_size=n_chunks)    # bucket of every chunk
+    ctile = torch.div(cb, num_rels, rounding_mode="floor")
+    cperm = torch.argsort(ctile * n_src + S[:m_pad:CHUNK].long())              # inside a tile: by the chunk's first source (a real slot)
+    idx = (cperm[:, None] * CHUNK + torch.arange(CHUNK, device=dev)[None, :]).reshape(-1)
+    p = BuiltPlan()
+    p.device = dev
+    p.n_dst, p.n_src, p.num_rels, p.tile_rows = n_dst, n_src, num_rels, tile_rows
+    p.n_tiles, p.m_pad, p.n_chunks, p.n_messages = n_tiles, m_pad, n_chunks, n_live
+    if m_pad:
+        p.src, p.dst, p.val = S[idx].contiguous(), D[idx].contiguous(), V[idx].contiguous()
+    else:
+        p.src, p.dst, p.val = S, D, V
+    p.chunk_rel = (cb % num_rels)[cperm].to(torch.int32).contiguous() if n_chunks else _i32(0, dev)
+    tcnt = torch.bincount(ctile, minlength=n_tiles)
+    tend = torch.cumsum(tcnt, 0)
+    p.tile_ptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), tend]).to(torch.int32)
+    p.run_ptr = torch.zeros(n_tiles * (num_rels + 1), dtype=torch.int32, device=dev)
+    p.run_ptr[0::num_rels + 1] = (tend - tcnt).to(torch.int32)
+    p.run_ptr[num_rels::num_rels + 1] = tend.to(torch.int32)
+    p.pack, p.aux = None, None
+    p.soft_windows = True
+    p.units_host = np.zeros((0, 4), np.int32)      # (not None: _blk_units cuts hub tiles into pieces from tile_ptr)
+    p.n_units, p.n_split, p.units = n_tiles, 0, None
+    p.n_items, p.items = 0, _i32(2, dev).view(1, 2)
+    p.max_run_chunks = int(padded.max().item()) // CHUNK if nbk else 0
+    return p
+
+
 class CsrPlan:
     """destination-major CSR (rowptr, src, rel, val) built on the device: the layout of the basis kernels"""
 

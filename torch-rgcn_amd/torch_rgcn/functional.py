@@ -50,6 +50,15 @@ def _fwd_blk(graph, relu):
     return plan
 
 
+def _fwd_win(graph, relu):
+    """the forward plan in soft-window order (graph.win_plan) for rgcn_spmm_blk_f32, or None; the ReLU epilogue needs tiles that are not cut
+    into hub pieces (as _fwd_blk)"""
+    plan = graph.win_plan("fwd") if hasattr(graph, "win_plan") else None
+    if plan is None or (relu and _native._blk_units(plan)[2]):
+        return None
+    return plan
+
+
 def _pad_blocks(X, W, bias, graph=None):
     """Widths up to 64 run on the MFMA block kernels (hidden-16 scheme over blocks of 16 features) with operands
     zero-padded to multiples of 16: a 40-byte row costs the same 128-byte fabric request as a 64-byte one, and these
@@ -254,6 +263,10 @@ class _RelationalMP(torch.autograd.Function):
                 out = _native.spmm_blk(X, W, b, _fwd_blk(graph, fused_relu), relu=fused_relu)
             elif _sparse_buckets(graph, W):
                 out = _native.spmm_two_pass(X, W, b, graph.scatter_plan("fwd"), graph.csr("fwd"), relu=fused_relu)
+            elif W.shape[1] == 16 and W.shape[2] == 16 and _fwd_win(graph, fused_relu) is not None:
+                # dense buckets on a large static graph (S1): tall workgroup-owned tiles walked in soft-window order -- the whole chip gathers
+                # from a few MB of X at any time (0.33 ms against 0.42 on the wave-owned tiles, tools/softwin_probe.py)
+                out = _native.spmm_blk(X, W, b, _fwd_win(graph, fused_relu), relu=fused_relu)
             else:
                 out = _spmm_blocked(X, W, b, graph.fwd_plan, relu=fused_relu, graph=graph, kind="fwd")
         ctx.w16 = w16.pair(W)

@@ -142,6 +142,30 @@ class RelGraph:
         plan = self._plan("fwd", rows)
         return plan if plan.run_ptr is not None and plan.n_src < (1 << 26) else None
 
+    def win_plan(self, kind, rows=None):
+        """plan of tall workgroup-owned tiles in SOFT-WINDOW order (_native.build_softwin_plan: buckets sorted by source, a tile's chunks
+        ordered by first source) for the block-tile kernels, or None where it does not apply or does not pay: static graphs with a
+        device-side message list, large enough for one tile per workgroup, with at least `softwin_min_chunks` (4) chunks per
+        (tile, relation) bucket on average -- the span of a chunk's sources is 1 / that of the table -- and without forced tile heights,
+        RGCN_SOFTWIN=0 or RGCN_DETERMINISTIC=1 (the tile is summed in arrival order)."""
+        if routes.get("softwin", "auto") == "0" or routes.get("deterministic", "0") == "1" or routes.is_set("tile_rows") or \
+                self._dev is None or self.sync_free or getattr(self, "per_call", False):
+            return None
+        if rows is None:
+            rows = _native.spmm_blk_rows(self.num_nodes, self.device)
+        if not rows or self.num_nodes >= (1 << 26):
+            return None
+        n_tiles = -(-self.num_nodes // rows)
+        if routes.get("softwin", "auto") != "1" and \
+                self.num_messages < int(routes.get("softwin_min_chunks", "4")) * 16 * n_tiles * self.num_rels:
+            return None
+        key = ("win", kind, rows)
+        if key not in self._plans:
+            s, p, o, val, alive = self._dev
+            dst, src = (s, o) if kind == "fwd" else (o, s)
+            self._plans[key] = _native.build_softwin_plan(dst, src, p, val, alive, self.num_nodes, self.num_nodes, self.num_rels, rows)
+        return self._plans[key]
+
     def wgt_plan(self):
         """relation-major (single tile): long runs per relation for the weight gradient"""
         return self._plan("fwd", max(self.num_nodes, 1), int(routes.get("wgrad_item_chunks", "64")))
