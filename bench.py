@@ -613,6 +613,8 @@ def main():
                 if route == "blk" and not _native.bwd_blk_rows(N, 2 * R0 + 1, routes.flag("deterministic")):
                     route = "lean"
                 kname, kkey = {"blk": ("bwd_blk_d16_kernel", "bwd_blk"), "lean": ("bwd_lean_d16_kernel", "bwd_lean")}.get(route, ("bwd_fused_d16_kernel", "bwd_fused"))
+                if route == "blk" and routes.get("bwd_own", "1") != "0" and l2._graph.win_plan("bwd_own") is not None:
+                    kname, kkey = "bwd_own_d16_kernel", "bwd_own"       # round 6: relation-owner kernel on the soft-window plan
                 bwd = kernel_roofline(kname + " (dX + dW of one layer from one gather per message"
                                       + (" + dw_reduce)" if "dw_reduce" in launches else ")"), bms, balg, bmodel, ms, 2,
                                       (kname, "bwd_fused_d16_kernel") if kname != "bwd_fused_d16_kernel" else (kname,), kkey)

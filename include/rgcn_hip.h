@@ -350,6 +350,22 @@ RGCN_API int rgcn_bwd_blk_prepare_f32(const int32_t *p_pack, const int32_t *p_sr
 RGCN_API int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, const void *rec,
                               const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R, int32_t flags,
                               float *dbias, int64_t n_src, const int32_t *units, int64_t n_units, int64_t n_split, void *stream);
+/* The same backward, RELATION-OWNER form (round 6; the default on large static graphs with dense buckets -- S1): tall tiles (up to
+ * rgcn_bwd_own_max_rows() = 789 rows) walked in soft-window order.  LDS holds the dX tile (doubles, ds_add_f64), the X tile and 1 KiB of
+ * scratch per wave, no weight-gradient table: every relation belongs to ONE of the workgroup's rgcn_bwd_own_waves() waves, which walks
+ * that relation's chunks only and keeps its dW in registers for the life of the kernel (rgcn_bwd_own_units() relation slots per
+ * workgroup; one flush of global atomics at the end).
+ *   rec       chunk records of rgcn_bwd_blk_prepare_f32 whose relation word is  rel | local << 16  (local = the relation's slot in its
+ *             owner wave); inside a tile the chunks are grouped by owner wave
+ *   own_ptr   [n_tiles * waves + 1]: own_ptr[tile * waves + w] = first chunk of wave w in the tile
+ *   unit_rel  [units]: unit_rel[w * (units / waves) + local] = relation, -1 = unused slot
+ * flags: RGCN_F_RELU; dbias as rgcn_bwd_blk_f32.  No hub pieces.  Sums in arrival order.  Same autograd duals of layers.py:293-301. */
+RGCN_API int32_t rgcn_bwd_own_waves(void);
+RGCN_API int32_t rgcn_bwd_own_units(void);
+RGCN_API int32_t rgcn_bwd_own_max_rows(void);
+RGCN_API int rgcn_bwd_own_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, const void *rec,
+                              const int32_t *own_ptr, const int32_t *unit_rel, int64_t n_tiles, int32_t tile_rows, int64_t n_dst,
+                              int32_t R, int32_t flags, float *dbias, int64_t n_src, void *stream);
 /* The same walk as a FORWARD kernel (round 5): out[dst] = bias + sum val X[src] W_r (layers.py:293-301 at width 16) on the FORWARD plan cut
  * into tall tiles (one per workgroup, up to rgcn_spmm_blk_max_rows() = 1023 rows: 128 bytes of LDS per row, no weight table) with the chunk
  * records of rgcn_bwd_blk_prepare_f32.  For layers whose (tile, relation) buckets on the wave-owned tiles of rgcn_spmm_f32 are mostly

@@ -51,3 +51,52 @@ def test_softwin_plan_invariants(N, R, M, rows, masked):
             assert seen.get(r, -1) <= int(s[0])                                   # ... and from chunk to chunk of one bucket
             seen[r] = int(s[k - 1])
         assert firsts == sorted(firsts)                                           # the tile's chunks: by first source
+
+
+def test_own_relations_lpt_packing():
+    from torch_rgcn import _native
+    counts = [1000] + [200] * 100                     # S1's shape: the self-loop relation is five times the others
+    owner, local, unit_rel, balance = _native.own_relations(counts, 12, 9)
+    assert balance < 1.06
+    for r in range(101):
+        assert unit_rel[owner[r] * 9 + local[r]] == r and 0 <= local[r] < 9
+    assert sorted(int(u) for u in unit_rel if u >= 0) == list(range(101))
+    assert _native.own_relations([1] * 109, 12, 9) is None      # more relations than slots
+    owner, local, unit_rel, balance = _native.own_relations([5000, 1, 1, 1], 12, 9)
+    assert balance > 5                                # one dominant relation: its owner wave would hold every tile back
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_softwin_plan_with_relation_owners(masked):
+    from torch_rgcn import _native
+    N, R, M, rows, NW, K = 900, 20, 30000, 128, 12, 9
+    rng = np.random.default_rng(7)
+    dst = torch.from_numpy(rng.integers(0, N, M).astype(np.int32))
+    src = torch.from_numpy(rng.integers(0, N, M).astype(np.int32))
+    rel = torch.from_numpy(rng.integers(0, R, M).astype(np.int32))
+    val = torch.from_numpy(rng.random(M).astype(np.float32) + 0.5)
+    alive = torch.from_numpy((rng.random(M) < 0.6).astype(np.uint8)) if masked else None
+    p = _native.build_softwin_plan(dst, src, rel, val, alive, N, N, R, rows, own_waves=NW, own_per_wave=K)
+    live = np.ones(M, bool) if alive is None else alive.numpy() != 0
+    D, S, V = p.dst.numpy()[:p.m_pad], p.src.numpy()[:p.m_pad], p.val.numpy()[:p.m_pad]
+    packed = p.chunk_rel.numpy()[:p.n_chunks]
+    crel, cloc = packed & 0xFFFF, packed >> 16
+    unit_rel = p.unit_rel.numpy()
+    op = p.own_ptr.numpy()
+    assert op.shape[0] == p.n_tiles * NW + 1 and op[0] == 0 and op[-1] == p.n_chunks and np.all(np.diff(op) >= 0)
+    real = D >= 0
+    got = sorted(zip(D[real].tolist(), S[real].tolist(), np.repeat(crel, 16)[real].tolist(), V[real].tolist()))
+    want = sorted(zip(dst.numpy()[live].tolist(), src.numpy()[live].tolist(), rel.numpy()[live].tolist(), val.numpy()[live].tolist()))
+    assert got == want
+    owner_of = {int(r): (u // K, u % K) for u, r in enumerate(unit_rel) if r >= 0}
+    assert sorted(owner_of) == list(range(R))
+    tp = p.tile_ptr.numpy()
+    for t in range(p.n_tiles):
+        assert op[t * NW] == tp[t]
+        for w in range(NW):
+            firsts = []
+            for c in range(op[t * NW + w], op[t * NW + w + 1]):
+                assert owner_of[int(crel[c])] == (w, int(cloc[c]))          # the chunk is in ITS owner's range, with the owner's local number
+                assert D[16 * c] >= 0 and D[16 * c] // rows == t
+                firsts.append(int(S[16 * c]))
+            assert firsts == sorted(firsts)

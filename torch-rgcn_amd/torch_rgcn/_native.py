@@ -472,7 +472,28 @@ def build_plan_device(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_ro
     return p
 
 
-def build_softwin_plan(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_rows):
+def own_relations(counts, n_waves, per_wave):
+    """relation -> (wave, local number) for the relation-owner backward (rgcn_bwd_own_f32): greedy longest-processing-time packing of the
+    relations' message counts onto n_waves waves of at most per_wave relations each.  -> (owner[R], local[R], unit_rel[n_waves * per_wave]
+    (-1: unused), max load / mean load) or None when there are more relations than slots."""
+    counts = np.asarray(counts, dtype=np.int64)
+    R = len(counts)
+    if R > n_waves * per_wave:
+        return None
+    load, used = [0] * n_waves, [0] * n_waves
+    owner, local = np.zeros(R, np.int64), np.zeros(R, np.int64)
+    unit_rel = np.full(n_waves * per_wave, -1, np.int32)
+    for r in sorted(range(R), key=lambda r: (-int(counts[r]), r)):
+        w = min((i for i in range(n_waves) if used[i] < per_wave), key=lambda i: (load[i], i))
+        owner[r], local[r] = w, used[w]
+        unit_rel[w * per_wave + used[w]] = r
+        used[w] += 1
+        load[w] += int(counts[r])
+    mean = max(1.0, float(sum(load)) / n_waves)
+    return owner, local, unit_rel, max(load) / mean
+
+
+def build_softwin_plan(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_rows, own_waves=0, own_per_wave=0):
     """Plan of tall workgroup-owned tiles for the block-tile kernels (rgcn_spmm_blk_f32, rgcn_bwd_own_f32) in SOFT-WINDOW order (round 6):
 
       * inside a (tile, relation) bucket the slots are sorted by SOURCE row -- the block-tile kernels add with ds_add_f64 and the chunk
@@ -484,6 +505,11 @@ def build_softwin_plan(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_r
     chip fall into a few MB at any time.  tools/micro/gather_window.hip: S1's 21 M row reads take 0.19-0.22 ms in window-major order
     against 0.375 ms uniformly random (profiles/r06_gather_window.txt); the forward kernel on this plan 0.327 ms against 0.398 on the same
     tiles in destination order (tools/softwin_probe.py) -- at the plain (tile, relation) padding (1.04), no window buckets to pad.
+
+    own_waves > 0 (the relation-owner backward, rgcn_bwd_own_f32): every relation belongs to one of own_waves waves (own_relations: LPT
+    over the message counts, at most own_per_wave relations per wave); a tile's chunks are grouped by owner wave, each wave's chunks ordered
+    by first source: own_ptr[tile * own_waves + wave] = the wave's first chunk; chunk_rel carries the relation's local number in its high
+    half (rel | local << 16); unit_rel[wave * own_per_wave + local] = relation.  None when the relations do not fit the slots.
 
     Made with torch ops (two sorts, a histogram, two scans): one-off preprocessing of STATIC graphs; per-call graphs keep
     build_plan_device.  Same fields as BuiltPlan; run_ptr holds only a tile's first and end chunk (entries 0 and R of its row) -- all the
@@ -515,7 +541,17 @@ def build_softwin_plan(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_r
     S[slot], D[slot], V[slot] = src[perm].to(torch.int32), dst[perm].to(torch.int32), val[perm]
     cb = torch.repeat_interleave(torch.arange(nbk, device=dev), padded // CHUNK, output_size=n_chunks)    # bucket of every chunk
     ctile = torch.div(cb, num_rels, rounding_mode="floor")
-    cperm = torch.argsort(ctile * n_src + S[:m_pad:CHUNK].long())              # inside a tile: by the chunk's first source (a real slot)
+    own = None
+    if own_waves:
+        live_rel = r64 if live is None else r64[live]
+        own = own_relations(torch.bincount(live_rel, minlength=num_rels).cpu().numpy(), own_waves, own_per_wave)
+        if own is None:
+            return None
+        owner_t = torch.from_numpy(own[0]).to(dev)
+        cgroup = ctile * own_waves + owner_t[cb % num_rels]                     # (tile, owner wave) of every chunk
+    else:
+        cgroup = ctile
+    cperm = torch.argsort(cgroup * n_src + S[:m_pad:CHUNK].long())             # inside a tile (a wave's share of it): by the chunk's first source (a real slot)
     idx = (cperm[:, None] * CHUNK + torch.arange(CHUNK, device=dev)[None, :]).reshape(-1)
     p = BuiltPlan()
     p.device = dev
@@ -525,7 +561,14 @@ def build_softwin_plan(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_r
         p.src, p.dst, p.val = S[idx].contiguous(), D[idx].contiguous(), V[idx].contiguous()
     else:
         p.src, p.dst, p.val = S, D, V
-    p.chunk_rel = (cb % num_rels)[cperm].to(torch.int32).contiguous() if n_chunks else _i32(0, dev)
+    crel = cb % num_rels
+    if own is not None:
+        crel = crel | (torch.from_numpy(own[1]).to(dev)[crel] << 16)
+        gcnt = torch.bincount(cgroup, minlength=n_tiles * own_waves)
+        p.own_ptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(gcnt, 0)]).to(torch.int32)
+        p.unit_rel = torch.from_numpy(own[2]).to(dev)
+        p.own_waves, p.own_per_wave, p.own_balance = own_waves, own_per_wave, float(own[3])
+    p.chunk_rel = crel[cperm].to(torch.int32).contiguous() if n_chunks else _i32(0, dev)
     tcnt = torch.bincount(ctile, minlength=n_tiles)
     tend = torch.cumsum(tcnt, 0)
     p.tile_ptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), tend]).to(torch.int32)
@@ -1325,6 +1368,44 @@ def _blk_rec(plan):
                    "bwd_blk_prepare")
         plan._blk_rec = rec
     return rec
+
+
+def bwd_own_geometry():
+    """(waves per workgroup, relation slots per wave, tallest tile) of the relation-owner backward kernel (rgcn_bwd_own_f32)"""
+    L = lib()
+    nw = int(L.rgcn_bwd_own_waves())
+    return nw, int(L.rgcn_bwd_own_units()) // nw, int(L.rgcn_bwd_own_max_rows())
+
+
+def bwd_own_rows(n_nodes, device=None):
+    """tile height of the relation-owner backward's plan: the tallest tile the kernel's LDS holds that gives every CU the same number of
+    tiles (S1: 782 rows, 5 tiles per CU); 0 for graphs too small to fill the chip with one tile per workgroup"""
+    if n_nodes < _BLK_MIN_NODES:
+        return 0
+    cap = min(bwd_own_geometry()[2], int(routes.get("own_rows_cap", "789")))
+    n_cu = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).multi_processor_count
+    per_cu = -(-n_nodes // (n_cu * cap))
+    return -(-n_nodes // (n_cu * per_cu))
+
+
+def bwd_own(G, X, W, plan, relu=False, want_db=False):
+    """(dX, dW[, db]) of the hidden-16 layer from one walk of a soft-window plan with relation ownership (build_softwin_plan(own_waves=...)):
+    rgcn_bwd_own_f32 -- dX tile in LDS doubles, every relation's dW in the registers of its owner wave, X rows of the tile from global memory.
+    relu: X is the output of a ReLU and dX is wanted BEFORE it.  Sums in arrival order (not bit-reproducible)."""
+    _req(G, "grad_output"); _req(X, "features"); _req(W, "weights")
+    assert W.shape[1:] == (16, 16) and G.shape == (plan.n_src, 16) and X.shape == (plan.n_dst, 16) and W.shape[0] == plan.num_rels
+    assert getattr(plan, "own_ptr", None) is not None, "bwd_own: a plan made with build_softwin_plan(own_waves=...)"
+    dev = G.device
+    Wtp = pack_w16t(W)
+    dX = torch.empty((plan.n_dst, 16), device=dev, dtype=torch.float32)
+    buf = torch.empty(W.numel() + 16, device=dev, dtype=torch.float32)       # dW and db back to back: one fill zeroes both
+    dW, db = buf[:W.numel()].view_as(W), buf[W.numel():]
+    rec = _blk_rec(plan)
+    with _on(dev), _timed("bwd_fused"):
+        _check(lib().rgcn_bwd_own_f32(_dp(G), _dp(X), _dp(Wtp), _dp(dX), _dp(dW), _dp(rec), _dp(plan.own_ptr), _dp(plan.unit_rel),
+                                      c_i64(plan.n_tiles), c_i32(plan.tile_rows), c_i64(plan.n_dst), c_i32(W.shape[0]),
+                                      c_i32(F_RELU if relu else 0), _dp(db) if want_db else None, c_i64(plan.n_src), _stream(dev)), "bwd_own")
+    return (dX, dW, db if want_db else None)
 
 
 def bwd_fused_relu_ok(plan, diag4=False):

@@ -201,6 +201,12 @@ def _fused_backward(X, W, g, graph, relu_in=False, want_db=False, diag4=False, s
     sums G's columns on the side (block-tile kernel), else None."""
     if W.shape[1] != 16 or W.shape[2] != 16 or routes.get("bwd", "fused") == "split":
         return None
+    if not diag4 and not sparse and routes.get("bwd_own", "1") != "0" and _native.bwd_route() == "blk" and hasattr(graph, "win_plan"):
+        # large static graph with dense buckets (S1): tall tiles in soft-window order, every relation's dW in the registers of its owner wave
+        op = graph.win_plan("bwd_own")
+        if op is not None and not _native._blk_units(op)[2]:
+            dX, dW, db = _native.bwd_own(g, X, W, op, relu=relu_in, want_db=True)
+            return dX, dW, relu_in, (db if want_db else None)
     bp = graph.bwd_blk_plan(diag4, sparse)                  # tall tiles, one per workgroup -- or the wave-owned 64-row plan
     diag4 = diag4 and bp is not None and _native._bwd_blk_plan(bp, True)   # block-diagonal W (4 x 4 blocks): only on the block-tile kernel
     if bp is None or not _native._bwd_blk_plan(bp, diag4):

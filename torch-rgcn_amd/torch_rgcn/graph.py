@@ -152,7 +152,7 @@ class RelGraph:
                 self._dev is None or self.sync_free or getattr(self, "per_call", False):
             return None
         if rows is None:
-            rows = _native.spmm_blk_rows(self.num_nodes, self.device)
+            rows = _native.bwd_own_rows(self.num_nodes, self.device) if kind == "bwd_own" else _native.spmm_blk_rows(self.num_nodes, self.device)
         if not rows or self.num_nodes >= (1 << 26):
             return None
         n_tiles = -(-self.num_nodes // rows)
@@ -163,7 +163,18 @@ class RelGraph:
         if key not in self._plans:
             s, p, o, val, alive = self._dev
             dst, src = (s, o) if kind == "fwd" else (o, s)
-            self._plans[key] = _native.build_softwin_plan(dst, src, p, val, alive, self.num_nodes, self.num_nodes, self.num_rels, rows)
+            own = {}
+            if kind == "bwd_own":     # transposed plan, a tile's chunks grouped by the wave that owns their relation (rgcn_bwd_own_f32)
+                nw, per_wave, max_rows = _native.bwd_own_geometry()
+                if rows > max_rows or self.num_rels > nw * per_wave:
+                    self._plans[key] = None
+                    return None
+                own = {"own_waves": nw, "own_per_wave": per_wave}
+            plan = _native.build_softwin_plan(dst, src, p, val, alive, self.num_nodes, self.num_nodes, self.num_rels, rows, **own)
+            # a wave that owns far more messages than the others holds every tile back: such graphs keep the block-tile kernel
+            if plan is not None and own and plan.own_balance > float(routes.get("own_balance", "1.25")):
+                plan = None
+            self._plans[key] = plan
         return self._plans[key]
 
     def wgt_plan(self):
