@@ -11,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "torch-rgcn_amd")
-PLAIN = {"RGCN_HIP_LIB", "RGCN_SYNTHETIC", "RGCN_DATA", "RGCN_CPU_THREADS", "RGCN_DIST_BACKEND", "RGCN_FORCE_DIST", "RGCN_BENCH_ONE_DEVICE"}
+PLAIN = {"RGCN_HIP_LIB", "RGCN_SYNTHETIC", "RGCN_DATA", "RGCN_CPU_THREADS", "RGCN_DIST_BACKEND", "RGCN_FORCE_DIST", "RGCN_BENCH_ONE_DEVICE", "RGCN_BENCH_DETAIL"}
 SEMANTIC = {"RGCN_DEFERRED_CHECKS", "RGCN_DETERMINISTIC", "RGCN_SYNTHETIC", "RGCN_BWD_ABL"}
 ENV_READ = re.compile(r'(?:os\.environ\.get\(\s*|os\.environ\[\s*|getenv\(\s*|setdefault\(\s*)"(RGCN_[A-Z0-9_]+)"|"(RGCN_[A-Z0-9_]+)"\s+(?:not\s+)?in\s+os\.environ')
 

@@ -39,6 +39,8 @@ def pick_tile_rows(width, n_rows=None):
 
 
 _MAX_CELLS = 2 ** 34      # 64 GiB per counting table
+_SOFTWIN_MIN_CHUNKS = 4   # soft-window plans: chunks per (tile, relation) bucket, on average, from which the source order pays
+_OWN_MAX_IMBALANCE = 1.25  # relation-owner backward: largest (messages of the busiest wave) / (mean over the waves) it is used at
 
 
 class RelGraph:
@@ -145,7 +147,7 @@ class RelGraph:
     def win_plan(self, kind, rows=None):
         """plan of tall workgroup-owned tiles in SOFT-WINDOW order (_native.build_softwin_plan: buckets sorted by source, a tile's chunks
         ordered by first source) for the block-tile kernels, or None where it does not apply or does not pay: static graphs with a
-        device-side message list, large enough for one tile per workgroup, with at least `softwin_min_chunks` (4) chunks per
+        device-side message list, large enough for one tile per workgroup, with at least _SOFTWIN_MIN_CHUNKS (4) chunks per
         (tile, relation) bucket on average -- the span of a chunk's sources is 1 / that of the table -- and without forced tile heights,
         RGCN_SOFTWIN=0 or RGCN_DETERMINISTIC=1 (the tile is summed in arrival order)."""
         if routes.get("softwin", "auto") == "0" or routes.get("deterministic", "0") == "1" or routes.is_set("tile_rows") or \
@@ -157,7 +159,7 @@ class RelGraph:
             return None
         n_tiles = -(-self.num_nodes // rows)
         if routes.get("softwin", "auto") != "1" and \
-                self.num_messages < int(routes.get("softwin_min_chunks", "4")) * 16 * n_tiles * self.num_rels:
+                self.num_messages < _SOFTWIN_MIN_CHUNKS * 16 * n_tiles * self.num_rels:
             return None
         key = ("win", kind, rows)
         if key not in self._plans:
@@ -172,7 +174,7 @@ class RelGraph:
                 own = {"own_waves": nw, "own_per_wave": per_wave}
             plan = _native.build_softwin_plan(dst, src, p, val, alive, self.num_nodes, self.num_nodes, self.num_rels, rows, **own)
             # a wave that owns far more messages than the others holds every tile back: such graphs keep the block-tile kernel
-            if plan is not None and own and plan.own_balance > float(routes.get("own_balance", "1.25")):
+            if plan is not None and own and plan.own_balance > _OWN_MAX_IMBALANCE:
                 plan = None
             self._plans[key] = plan
         return self._plans[key]
