@@ -243,6 +243,82 @@ def nc_layer(triples_plus, N, R, X, params, mode, bias=None, vertical=False, g=N
     return layer(triples_plus, val, N, R, X, params, mode, bias, g)
 
 
+def nc_layer_rows(triples_plus, N, R, X, params, mode, bias=None, vertical=False, g=None, out_rows=None, src_rows=None, rel_rows=None):
+    """RelationalGraphConvolutionNC.forward (layers.py:222-308) + autograd duals on SAMPLED rows of a graph too large to walk whole in a
+    test (full-size AM: 13.6 M messages, a 2.67 GB bases table): the normalisation is the full graph's (nc_edge_norm), then
+
+      out[out_rows]                          from the messages whose subject is sampled,
+      dX[src_rows] / dbases[:, src_rows]     from the messages whose object is sampled,
+      the gradient rows of rel_rows          (weights / blocks / comps) from the messages of those relations,
+      db                                     = column sums of g.
+
+    Every returned row is exact -- it sums ALL the messages that touch it.  Featured layers go through the same C loops as nc_layer
+    (rgcn_forward / rgcn_backward on the filtered message list); the featureless basis layer (layers.py:241-242, 286-288: W = the
+    R x N x d table einsum('rb,bio->rio')) is evaluated in float64 numpy without the table.  -> dict of the sampled rows."""
+    Tp = _i64(triples_plus).reshape(-1, 3)
+    val = nc_edge_norm(Tp, N, R, vertical)
+    s, p, o = Tp[:, 0], Tp[:, 1], Tp[:, 2]
+    res = {}
+    featureless = X is None
+    if featureless:
+        assert mode == "basis", "featureless sampled rows: basis decomposition (the dense table is what the sampling avoids)"
+        comps, bases = params["comps"].astype(np.float64), params["bases"].astype(np.float64)          # [R, B], [B, N, d]
+    else:
+        W = expand_weights(params, mode)
+    if out_rows is not None:
+        out_rows = np.asarray(out_rows, np.int64)
+        sel = np.isin(s, out_rows)
+        if featureless:
+            pos = np.searchsorted(np.sort(out_rows), s[sel])
+            order = np.argsort(out_rows)
+            msg = np.einsum("mb,bmd->md", comps[p[sel]] * val[sel, None].astype(np.float64), bases[:, o[sel], :])
+            tmp = np.zeros((len(out_rows), bases.shape[2]), np.float64)
+            np.add.at(tmp, pos, msg)
+            outv = np.empty_like(tmp)
+            outv[order] = tmp
+            if bias is not None:
+                outv += np.asarray(bias, np.float64)
+            res["out"] = outv.astype(np.float32)
+        else:
+            res["out"] = rgcn_forward(Tp[sel], val[sel], N, R, X, W, bias)[out_rows]
+    if g is not None:
+        g = _f32(g)
+        res["db"] = g.astype(np.float64).sum(0).astype(np.float32)
+        if src_rows is not None:
+            src_rows = np.asarray(src_rows, np.int64)
+            sel = np.isin(o, src_rows)
+            if featureless:      # dbases[b, o, :] = sum over the messages sent by o of comps[r, b] val g[s, :]
+                order = np.argsort(src_rows)
+                pos = np.searchsorted(src_rows[order], o[sel])
+                contrib = (comps[p[sel]] * val[sel, None].astype(np.float64))[:, :, None] * g[s[sel]].astype(np.float64)[:, None, :]   # [m, B, d]
+                tmp = np.zeros((len(src_rows),) + contrib.shape[1:], np.float64)
+                np.add.at(tmp, pos, contrib)
+                db_rows = np.empty_like(tmp)
+                db_rows[order] = tmp
+                res["dbases_rows"] = np.transpose(db_rows, (1, 0, 2)).astype(np.float32)             # [B, rows, d]
+            else:
+                res["dX"] = rgcn_backward(Tp[sel], val[sel], N, R, X, W, g, True)[0][src_rows]
+        if rel_rows is not None:
+            rel_rows = np.asarray(rel_rows, np.int64)
+            sel = np.isin(p, rel_rows)
+            if featureless:      # dcomps[r, b] = sum over the messages of r of val <bases[b, o, :], g[s, :]>
+                dc = np.zeros((R, comps.shape[1]), np.float64)
+                idx = np.nonzero(sel)[0]
+                for a in range(0, len(idx), 1 << 18):
+                    ii = idx[a:a + (1 << 18)]
+                    part = np.einsum("bmd,md->mb", bases[:, o[ii], :], g[s[ii]].astype(np.float64) * val[ii, None].astype(np.float64))
+                    np.add.at(dc, p[ii], part)
+                res["dcomps_rows"] = dc[rel_rows].astype(np.float32)
+            else:
+                dW = rgcn_backward(Tp[sel], val[sel], N, R, X, W, g, False)[1]
+                grads = contract_weight_grads(dW, params, mode)
+                if mode == "basis":     # (dbases sums over ALL relations: not a per-relation row)
+                    res["grads_rows"] = {"comps": grads["comps"][rel_rows]}
+                else:
+                    res["grads_rows"] = {k: v[rel_rows] for k, v in grads.items() if v.shape[0] >= R - 1}
+    return res
+
+
 def lp_layer(triples, N, R, X, params, mode, bias=None, vertical=False, keep_mask=None, g=None):
     """RelationalGraphConvolutionLP.forward (layers.py:450-565), deterministic parts:
     the self-loop Bernoulli mask is an input; the dense dropout of the block path

@@ -170,6 +170,71 @@ def test_am_full_size_featureless_basis40_properties():
     assert torch.allclose(layer.bases.grad[:, :, 0], layer.bases.grad[:, :, d - 1], rtol=1e-4, atol=1e-5)
 
 
+def _am_samples(seed):
+    rng = np.random.default_rng(seed)
+    N, R = AM["N"], 2 * AM["R0"] + 1
+    return (np.sort(rng.choice(N, 20_000, replace=False)), np.sort(rng.choice(N, 2_000, replace=False)),
+            np.sort(np.concatenate([rng.choice(R - 1, 31, replace=False), [R - 1]])))          # 31 relations and the self-loop relation
+
+
+@pytest.mark.parametrize("mode", ["block", "none"])
+def test_am_full_size_featured_layer_sampled_rows_vs_oracle(mode):
+    """full-size AM against the ORACLE, not against properties: the featured block-diagonal layer (BASELINE configs[2]:
+    block CSR forward, block-tile backward with RGCN_F_DIAG4 on ~400-row tiles) and the dense R = 267 layer (block-tile forward on 930-row
+    tiles, relation-major backward) -- out on 20,000 sampled rows, dX on 2,000 sampled sources, the weight-gradient rows of 32 sampled
+    relations (self loops included), db; each sampled row sums ALL the messages that touch it (oracle.nc_layer_rows)."""
+    from torch_rgcn.layers import RelationalGraphConvolutionNC
+    N, R0 = AM["N"], AM["R0"]
+    R = 2 * R0 + 1
+    tp = _am_graph()
+    out_rows, src_rows, rel_rows = _am_samples(41)
+    torch.manual_seed(41)
+    layer = RelationalGraphConvolutionNC(triples=torch.from_numpy(tp), num_nodes=N, num_relations=R, in_features=16, out_features=16,
+                                         decomposition={"type": "block", "num_blocks": 4} if mode == "block" else None).to(DEV)
+    with torch.no_grad():
+        layer.bias.normal_()
+    rng = np.random.default_rng(42)
+    Xh = rng.random((N, 16), dtype=np.float32) * 2 - 1
+    gh = rng.random((N, 16), dtype=np.float32) * 2 - 1
+    X = torch.from_numpy(Xh).to(DEV).requires_grad_(True)
+    out = layer(X)
+    out.backward(torch.from_numpy(gh).to(DEV))
+    params = {n: p.detach().cpu().numpy() for n, p in layer.named_parameters() if n != "bias"}
+    ref = oracle.nc_layer_rows(tp, N, R, Xh, params, mode, layer.bias.detach().cpu().numpy(), False, gh, out_rows, src_rows, rel_rows)
+    assert rel_err(out[torch.from_numpy(out_rows).to(DEV)], ref["out"]) < TOL
+    assert rel_err(X.grad[torch.from_numpy(src_rows).to(DEV)], ref["dX"]) < TOL
+    assert rel_err(layer.bias.grad, ref["db"]) < TOL
+    name = "blocks" if mode == "block" else "weights"
+    assert rel_err(getattr(layer, name).grad[torch.from_numpy(rel_rows).to(DEV)], ref["grads_rows"][name]) < TOL
+
+
+def test_am_full_size_featureless_basis40_sampled_rows_vs_oracle():
+    """AM as shipped, first layer (featureless, basis 40, hidden 10: the 2.67 GB bases table through the in-place tile
+    kernels) at FULL size against the oracle on sampled rows: out (20,000 rows), dbases (the rows of 2,000 sampled nodes, all 40 bases),
+    dcomps (32 relations incl. self loops), db."""
+    from torch_rgcn.layers import RelationalGraphConvolutionNC
+    N, R0, B, d = AM["N"], AM["R0"], 40, 10
+    R = 2 * R0 + 1
+    tp = _am_graph()
+    out_rows, src_rows, rel_rows = _am_samples(43)
+    torch.manual_seed(43)
+    layer = RelationalGraphConvolutionNC(triples=torch.from_numpy(tp), num_nodes=N, num_relations=R, in_features=None, out_features=d,
+                                         decomposition={"type": "basis", "num_bases": B}).to(DEV)
+    with torch.no_grad():
+        layer.bias.normal_()
+        layer.comps.normal_()
+        layer.bases.uniform_(-1.0, 1.0)
+    gh = np.random.default_rng(44).random((N, d), dtype=np.float32) * 2 - 1
+    out = layer()
+    out.backward(torch.from_numpy(gh).to(DEV))
+    params = {"comps": layer.comps.detach().cpu().numpy(), "bases": layer.bases.detach().cpu().numpy()}
+    ref = oracle.nc_layer_rows(tp, N, R, None, params, "basis", layer.bias.detach().cpu().numpy(), False, gh, out_rows, src_rows, rel_rows)
+    assert rel_err(out[torch.from_numpy(out_rows).to(DEV)], ref["out"]) < TOL
+    assert rel_err(layer.bases.grad[:, torch.from_numpy(src_rows).to(DEV), :], ref["dbases_rows"]) < TOL
+    assert rel_err(layer.comps.grad[torch.from_numpy(rel_rows).to(DEV)], ref["dcomps_rows"]) < TOL
+    assert rel_err(layer.bias.grad, ref["db"]) < TOL
+
+
 def test_mutag_full_shape_layers_vs_oracle():
     """MUTAG at its full shape: the NodeClassifier's two layers (featureless basis-30 16-wide; featured basis-30 16 -> 2,
     vertical) against the oracle"""
