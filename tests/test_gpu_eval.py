@@ -227,3 +227,33 @@ def test_s_penalty_value_and_gradients_match_the_gather_formulation():
         assert abs(pen.item() - ref.item()) < 1e-5 * abs(ref.item())
         assert (gn - rn).abs().max().item() < 1e-5 * rn.abs().max().item()
         assert (gr - rr).abs().max().item() < 1e-5 * rr.abs().max().item()
+
+
+def test_bce_head_of_nothing_is_nan_like_aten():
+    """F.binary_cross_entropy_with_logits of zero elements is NaN with an empty gradient, not an error"""
+    from torch_rgcn import _native
+    dev = torch.device("cuda:0")
+    loss, ds = _native.bce_head(torch.empty(0, device=dev), torch.empty(0, device=dev))
+    assert torch.isnan(loss).all() and ds.shape == (0,)
+    want = torch.nn.functional.binary_cross_entropy_with_logits(torch.empty(0, device=dev), torch.empty(0, device=dev))
+    assert torch.isnan(want)
+
+
+def test_bce_head_workspaces_are_per_stream():
+    """two streams launching the one-launch BCE head concurrently must not share a ticket / partial workspace"""
+    from torch_rgcn import _native
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    x, y = torch.randn(300_000, device=dev), (torch.rand(300_000, device=dev) > 0.5).float()
+    want = torch.nn.functional.binary_cross_entropy_with_logits(x, y)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    got = []
+    for _ in range(20):
+        for st in (s1, s2):
+            with torch.cuda.stream(st):
+                got.append(_native.bce_head(x, y)[0])
+    torch.cuda.synchronize()
+    assert len({k for k in _native._BCE_WS if k[0] == dev}) >= 2
+    for g in got:
+        assert abs(g.item() - want.item()) < 1e-5 * abs(want.item())

@@ -849,7 +849,7 @@ __device__ __forceinline__ void table_flush_ordered(const double *dcl, int n, do
   // once the exchanges have returned (they return the old value: waiting for it IS the acknowledgement).
   double seen = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) seen += __hip_atomic_exchange(mine + i, dcl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("" ::"v"(seen));                             // (the returned values are waited for, not used)
+  asm volatile("" ::"v"(seen) : "memory");                  // (the returned values are waited for, not used; "memory": the compiler may not move the ticket above this point)
   __syncthreads();
   if (threadIdx.x == 0) last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
   __syncthreads();

@@ -109,11 +109,14 @@ __global__ __launch_bounds__(HB) void bce_head_kernel(const float *__restrict__ 
   if (threadIdx.x == 0) {
     // one 128-byte line per block, by an agent-scope atomic exchange whose return is awaited before the ticket: see table_flush_ordered (rgcn_basis.hip)
     const double seen = __hip_atomic_exchange(partial + 16 * blockIdx.x, part[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("" ::"v"(seen));
-    is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    asm volatile("" ::"v"(seen) : "memory");                 // the exchange has RETURNED (its value is in a register) and nothing moves across
+    // release / acquire on the ticket: the order of partial and ticket does not rest on code generation; a tiny kernel, the
+    // L2 write-back of a release costs it nothing
+    is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
   }
   __syncthreads();
-  if (is_last) {                                            // the partials in block order, by the whole block (a lone thread's 256 dependent
+  if (is_last) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                            // the partials in block order, by the whole block (a lone thread's 256 dependent
                                                             // round trips took longer than the rest of the kernel)
     part[threadIdx.x] = threadIdx.x < gridDim.x ? __hip_atomic_load(partial + 16 * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
     __syncthreads();

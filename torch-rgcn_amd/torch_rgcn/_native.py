@@ -819,7 +819,7 @@ def fbasis_tile_bwd(bases, comps, g, plan, need_bases=True, need_comps=True, mod
     first columns of the zero-padded rows a width-16 layer hands back: taken in place)"""
     _req(bases, "bases"); _req(comps, "comps")
     B, N, d = bases.shape
-    if g.dim() == 2 and g.stride(1) == 1 and g.stride(0) >= g.shape[1] and g.data_ptr() % 16 == 0 and not g.is_contiguous():
+    if g.dim() == 2 and g.stride(1) == 1 and g.stride(0) >= g.shape[1] and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0 and not g.is_contiguous():
         g_stride = int(g.stride(0))
     else:
         _req(g, "grad")
@@ -883,16 +883,20 @@ def basis_dcomps(X, D, plan, R, B, d, swap=False):
 
 
 _TABLE_WS = {}
+_WS_KEEP = []
 
 
 def _table_workspace(dev, R, B):
-    """workspace of the kernels that reduce per-workgroup R x B tables in a fixed order: one per device (launches that use it are ordered
-    on the step's stream; a capture's warm-up runs create it before the capture), zeroed at creation (every launch leaves its ticket
-    zeroed), grown when a larger table comes along"""
-    key = dev
+    """workspace of the kernels that reduce per-workgroup R x B tables in a fixed order: one per (device, stream) -- launches on one stream
+    are ordered, two streams must not share the ticket and the partials --, zeroed at creation (every launch leaves its ticket
+    zeroed), replaced by a larger one when a larger table comes along; a capture has its own (the capture stream's, allocated from the
+    graph's pool) and a buffer a captured graph may still point at is never released"""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)      # per stream: two streams' launches would race on the ticket and the partials
     need = int(lib().rgcn_basis_sum_workspace_bytes(c_i32(R), c_i32(B)))
     ws = _TABLE_WS.get(key)
     if ws is None or ws.numel() < need:
+        if ws is not None and torch.cuda.is_current_stream_capturing():
+            _WS_KEEP.append(ws)       # an earlier capture on this stream has the smaller buffer's address baked into its kernels: it stays
         ws = _TABLE_WS[key] = torch.zeros(need, dtype=torch.uint8, device=dev)
     return ws
 
@@ -1715,9 +1719,12 @@ def bce_head(scores, labels):
     _req(scores, "scores"); _req(labels, "labels")
     assert scores.dim() == 1 and labels.shape == scores.shape
     dev = scores.device
-    ws = _BCE_WS.get(dev)
+    if scores.shape[0] == 0:      # F.binary_cross_entropy_with_logits of nothing: the mean over zero elements is NaN, the gradient is empty
+        return torch.full((1,), float("nan"), device=dev, dtype=torch.float32), torch.empty_like(scores)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)      # per stream (the ticket and the partials are the launch's own)
+    ws = _BCE_WS.get(key)
     if ws is None:        # zeroed once; every launch leaves it zeroed (allocated outside any capture: the first call is the warm-up's)
-        ws = _BCE_WS[dev] = torch.zeros(int(lib().rgcn_bce_head_workspace_bytes()), dtype=torch.uint8, device=dev)
+        ws = _BCE_WS[key] = torch.zeros(int(lib().rgcn_bce_head_workspace_bytes()), dtype=torch.uint8, device=dev)
     loss = torch.empty(1, device=dev, dtype=torch.float32)
     ds = torch.empty_like(scores)
     with _on(dev), _timed("bce_head"):

@@ -116,7 +116,10 @@ def _spmm_blocked(X, W, bias, plan_of, relu=False, graph=None, kind="fwd"):
 
 def _zero_padded_rows(t, wide):
     """t = the first columns of a contiguous, 16-byte aligned [N, wide] buffer whose other columns are ZERO (the producer said so)?"""
-    return getattr(t, "_rgcn_zero_padded", False) and _rows16(t) and t.stride(0) == wide
+    if not (getattr(t, "_rgcn_zero_padded", False) and _rows16(t) and t.stride(0) == wide):
+        return False
+    # the mark is a Python attribute: it survives set_() / resize_() / .data swaps of the tensor object -- the storage must still hold the rows
+    return t.untyped_storage().nbytes() >= (t.storage_offset() + t.shape[0] * wide) * t.element_size()
 
 
 def _unpad_blocks(dims, dX, dW, db, dx_view=False):
@@ -304,7 +307,7 @@ class _RelationalMP(torch.autograd.Function):
         graph = ctx.graph
         if ctx.dims is not None and ctx.dims[1] % 16:
             wide = ctx.dims[1] + (-ctx.dims[1] % 16)
-            if getattr(g, "_rgcn_zero_padded", False) and _rows16(g) and g.stride(0) == wide:
+            if _zero_padded_rows(g, wide):
                 g = torch.as_strided(g, (g.shape[0], wide), (wide, 1))       # MaskedCrossEntropy wrote the zero-padded rows already
             else:
                 g = _native.resize3(dense(g), (g.shape[0], wide))
@@ -439,7 +442,7 @@ class _ShardedRelationalMP(torch.autograd.Function):
         graph = ctx.graph
         if ctx.dims is not None and ctx.dims[1] % 16:
             wide = ctx.dims[1] + (-ctx.dims[1] % 16)
-            if getattr(g, "_rgcn_zero_padded", False) and _rows16(g) and g.stride(0) == wide:
+            if _zero_padded_rows(g, wide):
                 g = torch.as_strided(g, (g.shape[0], wide), (wide, 1))       # MaskedCrossEntropy wrote the zero-padded rows already
             else:
                 g = _native.resize3(dense(g), (g.shape[0], wide))
@@ -646,7 +649,9 @@ def _split_k(K, M, N):
     # tools/splitk_probe.py, WN18's dbases = ag^T g, K = 40,943: 64 slices 122.7 us, the former choice of 79 133.7, 128 142.0)
     # short K (the weight assembly's adjoint: K = relations, a few hundred) is ONE workgroup's serial loop of K / 16 steps, each a global
     # round trip with nothing to overlap it (32 us for K = 267): slices of at least three steps
-    return int(max(1, min(64, (4 * 256) // max(tiles, 1), K // 512 if K >= 8192 else K // 48)))
+    # slice length: 48 steps of K for short products, growing to 512 for long ones -- continuous in K (K // 48 below 8192 and K // 512
+    # from there on gave K = 8191 64 slices and K = 8192 16)
+    return int(max(1, min(64, (4 * 256) // max(tiles, 1), K // max(48, min(512, K // 16)))))
 
 
 class _MatmulMFMA(torch.autograd.Function):
