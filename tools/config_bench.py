@@ -599,6 +599,16 @@ def line_am_shipped(baseline_config):
                             "edges_per_s": round(E / ms_step * 1e3), "kernels_ms": allk, "roofline": roof}, "amshipped", models)
 
 
+def line_eval(cfg):
+    """the filtered ranking evaluator at WN18 size (reference utils/misc.py:60-110: 10,000 head / tail queries against 40,943
+    candidates each): whole evaluate() wall time, the score-all kernel against the fp32 MFMA peak, the oracle on a small sample"""
+    import eval_bench
+    r = eval_bench.run(test=5000, cpu_sample=8 if QUICK else 16)
+    return {"baseline_config": cfg, "workload": r["workload"], "step": "one filtered ranking evaluation (encode once, score all candidates, rank)",
+            "ms_per_step": round(1e3 * r["evaluate_wall_s"], 2), "queries_per_s": r["queries_per_s"], "mrr": r["mrr"],
+            "kernels_ms": r["kernels_ms_in_evaluate"], "roofline": r["roofline"], "cpu_baseline": r.get("cpu_baseline")}
+
+
 def secondary_lines():
     """one dict per BASELINE.json config 1-4 (dataset-shaped synthetic graphs), each with the dominant kernel's
     roofline; bounded to a few seconds each"""
@@ -615,7 +625,8 @@ def secondary_lines():
                lambda: line_featured("S1(iii): S1 graph, block-diagonal nb=4, 2 featured layers d=16", 1_000_000, 50, 10_000_000, 16,
                                      {"type": "block", "num_blocks": 4}, 0, "SURVEY 8(d) S1 variant (iii)", key="s1iii"),
                lambda: line_s2("SURVEY 8(d) S2 (secondary)"),
-               lambda: line_am_shipped("configs[2] AM as the reference ships it (nc-AM.yaml: featureless, basis 40, hidden 10)")):
+               lambda: line_am_shipped("configs[2] AM as the reference ships it (nc-AM.yaml: featureless, basis 40, hidden 10)"),
+               lambda: line_eval("configs[3] WN18 ranking evaluator (SURVEY 8 f-1)")):
         try:
             out.append(fn())
         except Exception as exc:  # noqa: BLE001
@@ -636,7 +647,7 @@ if __name__ == "__main__":
             fn = {"s2": lambda: line_s2("S2"), "amshipped": lambda: line_am_shipped("AM shipped"),
                   "aifb": lambda: line_node_classifier("AIFB-shaped", 8285, 45, 29043, 16, 4, None, 176, "AIFB", key="aifb"),
                   "mutag": lambda: line_node_classifier("MUTAG-shaped", 23644, 23, 74227, 16, 2, {"type": "basis", "num_bases": 30}, 340, "MUTAG", key="mutag"),
-                  "wn18": lambda: line_wn18("WN18"), "am": lambda: line_featured("AM block", 1_666_764, 133, 5_988_321, 16, {"type": "block", "num_blocks": 4}, 2, "AM", key="am"),
+                  "wn18": lambda: line_wn18("WN18"), "eval": lambda: line_eval("WN18 ranking evaluator"), "am": lambda: line_featured("AM block", 1_666_764, 133, 5_988_321, 16, {"type": "block", "num_blocks": 4}, 2, "AM", key="am"),
                   "s1ii": lambda: line_featured("S1(ii)", 1_000_000, 50, 10_000_000, 16, {"type": "basis", "num_bases": 10}, 0, "S1(ii)", key="s1ii"),
                   "s1iii": lambda: line_featured("S1(iii)", 1_000_000, 50, 10_000_000, 16, {"type": "block", "num_blocks": 4}, 0, "S1(iii)", key="s1iii")}[nm]
             print(json.dumps(fn()), flush=True)

@@ -40,6 +40,13 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=48)
     ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
+    print(json.dumps(run(a.test, 0 if a.no_cpu else a.cpu_sample)), flush=True)
+
+
+def run(test=5000, cpu_sample=48):
+    """-> the result dict (bench.py's detail file carries it as the evaluator line: tools/config_bench.py line_eval)"""
+    import types
+    a = types.SimpleNamespace(test=test, cpu_sample=cpu_sample, no_cpu=cpu_sample <= 0)
     N, R0, d, Q = 40_943, 18, 200, a.test
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -90,7 +97,7 @@ def main():
                                "sample": f"{len(sample)} test triples ({2 * len(sample)} queries) through oracle.evaluate "
                                          f"(reference algorithm incl. the [bn, N, 3] expansion; decoder only -- the reference "
                                          f"also re-runs the encoder per batch of {16}), {cpu:.1f} s; ranks equal the GPU's"}
-    print(json.dumps(res), flush=True)
+    return res
 
 
 if __name__ == "__main__":

@@ -12,25 +12,25 @@ for SET in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_RDREQ_64B_sum TCC
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "GRBM_GUI_ACTIVE GRBM_TA_BUSY" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/k$i" -o p -- python tools/kbench.py --what spmm,bwd --iters 3 > "$OUT/k$i.log" 2>&1
-  RGCN_BWD_KERNEL=lean timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/kl$i" -o p -- python tools/kbench.py --what bwd --iters 3 > "$OUT/kl$i.log" 2>&1
+  # the shipped S1 route (round 6: rgcn_spmm_blk_f32 on the soft-window plan, rgcn_bwd_own_f32) and, for comparison, round 5's
+  # (wave-owned forward, 218-row block-tile backward: RGCN_SOFTWIN=0)
+  timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/k$i" -o p -- python tools/s1_kernels.py --iters 3 > "$OUT/k$i.log" 2>&1
+  RGCN_SOFTWIN=0 timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/kl$i" -o p -- python tools/s1_kernels.py --iters 3 > "$OUT/kl$i.log" 2>&1
 done
 python - "$OUT" <<'PY'
 import collections, csv, glob, json, sys
 out = sys.argv[1]
 per = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(out + "/k*/*counter_collection.csv"):
+for f in glob.glob(out + "/k*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         per[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-keys = {"spmm": "spmm_d16_kernel", "bwd_fused": "bwd_fused_d16_kernel<4, true", "bwd_fused_deterministic": "bwd_fused_d16_kernel<4, false",
-        "bwd_blk": "bwd_blk_d16_kernel<false, false, 1>", "bwd_lean": "bwd_lean_d16_kernel<16, 3, true, false", "bwd_lean_deterministic": "bwd_lean_d16_kernel<16, 3, false, false",
-        "wgrad_tiled": "wgrad_tiled_d16_kernel"}
+keys = {"spmm": "spmm_d16_kernel", "spmm_blk": "spmm_blk_d16_kernel", "bwd_own": "bwd_own_d16_kernel", "bwd_blk": "bwd_blk_d16_kernel<true, false, 1>"}
 import os, subprocess
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "torch-rgcn_amd"))
 from torch_rgcn import _native
 head = open(".git_head_for_profiles").read().strip() if os.path.exists(".git_head_for_profiles") else "unknown"
-meta = {"csrc_sha": _native.csrc_sha(), "git_head": head, "command": "tools/pmc_passes.sh (rocprofv3 --pmc, separate passes, tools/kbench.py --what spmm,bwd at S1)"}
-detail = {"_meta": meta, "_how": "tools/pmc_passes.sh: separate rocprofv3 --pmc passes over tools/kbench.py --what spmm,bwd,wtiled (S1 launches); means per launch. "
+meta = {"csrc_sha": _native.csrc_sha(), "git_head": head, "command": "tools/pmc_passes.sh (rocprofv3 --pmc, separate passes, tools/s1_kernels.py: the S1 forward and backward launches of the shipped route, and with RGCN_SOFTWIN=0)"}
+detail = {"_meta": meta, "_how": "tools/pmc_passes.sh: separate rocprofv3 --pmc passes over tools/s1_kernels.py (S1 launches); means per launch. "
                   "GRBM_GUI_ACTIVE is summed over the 8 XCDs: MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)"}
 kernels = {"_meta": meta}
 for name, c in per.items():

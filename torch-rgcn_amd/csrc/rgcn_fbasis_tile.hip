@@ -662,7 +662,10 @@ __global__ __launch_bounds__(TW) void fbn_fwd_kernel(
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k = lane >> 4, c = lane & 15;
-  const int nks = (B + 3) >> 2, BP = 4 * nks;
+  // row stride of the coefficient table: ODD.  The A operand is ctab[r_m * BP + 4 ks + k] for the 16 relations r_m of a chunk: with
+  // BP = 40 (B = 40) the rows start at banks 8 r mod 32 -- four bank groups for sixteen rows, SQ_LDS_BANK_CONFLICT 0.62 of the LDS cycles
+  // (profiles/r05_amshipped_pmc.json); an odd stride spreads the rows over all 32 banks
+  const int nks = (B + 3) >> 2, BP = 4 * nks + 1;
   float *ctab = lds;                                        // [R][BP], zero padded
   float *tb = lds + ((R * BP + 3) & ~3);
   float *yb = tb + 2 * B * ts + wave * (16 * 16);
@@ -1318,7 +1321,7 @@ inline bool tile_shape(int R, int B, int d, long long N, TileShape &s) {
   s.lds_dc = (size_t)R * B * 8 + 16 + strips + 2 * (size_t)B * s.ts_b * 4;
   s.lds_db = 2 * (size_t)B * s.ts_b * 8 + strips + (size_t)R * B * 4;
   s.nks = (B + 3) / 4;                                      // one wave per node (mode 1): K steps of the forward's MFMAs
-  s.lds_fwd_n = ((size_t)((R * 4 * s.nks + 3) & ~3) + 2 * (size_t)B * s.ts_f + (size_t)TWV * 16 * 16) * 4;
+  s.lds_fwd_n = ((size_t)((R * (4 * s.nks + 1) + 3) & ~3) + 2 * (size_t)B * s.ts_f + (size_t)TWV * 16 * 16) * 4;
   s.lds_db_n = 2 * (size_t)B * s.ts_f * 4 + strips + (size_t)R * B * 4;
   // dbases with 32-node tiles (two nodes per wave): row stride 32 d + 4, B x 8 d pieces
   s.lds_db_n2 = 2 * (size_t)B * (2 * TN * d + 4) * 4 + 2 * strips + (size_t)R * B * 4;       // (strips of 32 rows)
