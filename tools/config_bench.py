@@ -193,7 +193,7 @@ def _count_launches(step):
         return {"failed": f"{type(exc).__name__}: {exc}"[:120]}
 
 
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 # the kernels behind a timed tag of torch_rgcn._native (HIP-event timers) as rocprofv3 names them: (substrings, kernels per call of the tag)
 TAG_KERNELS = {
     "fbasis_tile_fwd": (("fbn_fwd_kernel", "fbt_fwd_kernel"), 1), "gather_rows_sum4": (("gather_rows_sum4_kernel",), 1),
@@ -212,7 +212,7 @@ _PMC_CACHE = {}
 
 
 def _pmc_file(line_key):
-    """the committed counter summary of this line (tools/prof.sh lines -> profiles/r05_<line>_pmc.json), or None"""
+    """the committed counter summary of this line (tools/prof.sh lines -> profiles/r06_<line>_pmc.json), or None"""
     if line_key not in _PMC_CACHE:
         try:
             with open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{line_key}_pmc.json")) as f:
