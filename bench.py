@@ -135,7 +135,10 @@ def kernel_roofline(kernel, avg_ms, alg_bytes, bytes_model, step_ms, launches_pe
             "pmc": pmc_detail(pmc_key) if pmc_key else None,
             # context, STATIC: the random gather of one 64-byte row per message is served as whole 128-byte lines whatever the load
             # flavour (tools/micro/gather64.hip) -- a kernel that does nothing but S1's gather takes this long per pass
-            "gather_only_floor_ms_static": 0.373, "gather_only_floor_source": "profiles/r04_gather64.txt"}
+            "gather_only_floor_ms_static": 0.373, "gather_only_floor_source": "profiles/r04_gather64.txt",
+            # ... in RANDOM order.  In window-major order (the whole chip reading from 1-4 MB of the table at a time) the same reads take 0.19-0.22 ms
+            # (tools/micro/gather_window.hip): the order round 6's soft-window plans approximate with ~5 MB spans
+            "gather_window_major_floor_ms_static": 0.2, "gather_window_major_source": "profiles/r06_gather_window.txt"}
 
 
 class _MeanSquare(torch.autograd.Function):
