@@ -56,20 +56,26 @@ def test_softwin_plan_invariants(N, R, M, rows, masked):
 def test_own_relations_lpt_packing():
     from torch_rgcn import _native
     counts = [1000] + [200] * 100                     # S1's shape: the self-loop relation is five times the others
-    owner, local, unit_rel, balance = _native.own_relations(counts, 12, 9)
-    assert balance < 1.06
+    parts, base, owner, local, unit_rel, balance = _native.own_relations(counts, 12, 9)
+    assert balance < 1.06 and parts.sum() <= 108 and parts[0] >= 1 and all(parts[1:] == 1)
     for r in range(101):
-        assert unit_rel[owner[r] * 9 + local[r]] == r and 0 <= local[r] < 9
-    assert sorted(int(u) for u in unit_rel if u >= 0) == list(range(101))
+        for q in range(parts[r]):
+            u = base[r] + q
+            assert unit_rel[owner[u] * 9 + local[u]] == r and 0 <= local[u] < 9
+    assert sorted(set(int(u) for u in unit_rel if u >= 0)) == list(range(101)) and int((unit_rel >= 0).sum()) == parts.sum()
     assert _native.own_relations([1] * 109, 12, 9) is None      # more relations than slots
-    owner, local, unit_rel, balance = _native.own_relations([5000, 1, 1, 1], 12, 9)
-    assert balance > 5                                # one dominant relation: its owner wave would hold every tile back
+    # one dominant relation: cut into parts, so that its chunks spread over the waves
+    parts, base, owner, local, unit_rel, balance = _native.own_relations([5000, 1, 1, 1], 12, 9)
+    assert parts[0] >= 12 and balance < 1.3
+    # a graph with ONE relation (self loops only): every wave owns a part
+    parts, base, owner, local, unit_rel, balance = _native.own_relations([4096], 12, 9)
+    assert parts[0] >= 12 and len(set(owner.tolist())) == 12 and balance < 1.2
 
 
-@pytest.mark.parametrize("masked", [False, True])
-def test_softwin_plan_with_relation_owners(masked):
+@pytest.mark.parametrize("masked,R", [(False, 20), (True, 20), (False, 2), (True, 1)])
+def test_softwin_plan_with_relation_owners(masked, R):
     from torch_rgcn import _native
-    N, R, M, rows, NW, K = 900, 20, 30000, 128, 12, 9
+    N, M, rows, NW, K = 900, 30000, 128, 12, 9
     rng = np.random.default_rng(7)
     dst = torch.from_numpy(rng.integers(0, N, M).astype(np.int32))
     src = torch.from_numpy(rng.integers(0, N, M).astype(np.int32))
@@ -88,15 +94,14 @@ def test_softwin_plan_with_relation_owners(masked):
     got = sorted(zip(D[real].tolist(), S[real].tolist(), np.repeat(crel, 16)[real].tolist(), V[real].tolist()))
     want = sorted(zip(dst.numpy()[live].tolist(), src.numpy()[live].tolist(), rel.numpy()[live].tolist(), val.numpy()[live].tolist()))
     assert got == want
-    owner_of = {int(r): (u // K, u % K) for u, r in enumerate(unit_rel) if r >= 0}
-    assert sorted(owner_of) == list(range(R))
+    assert sorted(set(int(r) for r in unit_rel if r >= 0)) == list(range(R))
     tp = p.tile_ptr.numpy()
     for t in range(p.n_tiles):
         assert op[t * NW] == tp[t]
         for w in range(NW):
             firsts = []
             for c in range(op[t * NW + w], op[t * NW + w + 1]):
-                assert owner_of[int(crel[c])] == (w, int(cloc[c]))          # the chunk is in ITS owner's range, with the owner's local number
+                assert unit_rel[w * K + int(cloc[c])] == crel[c]           # the chunk is in the range of a wave that owns (a part of) its relation
                 assert D[16 * c] >= 0 and D[16 * c] // rows == t
                 firsts.append(int(S[16 * c]))
             assert firsts == sorted(firsts)

@@ -473,24 +473,46 @@ def build_plan_device(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_ro
 
 
 def own_relations(counts, n_waves, per_wave):
-    """relation -> (wave, local number) for the relation-owner backward (rgcn_bwd_own_f32): greedy longest-processing-time packing of the
-    relations' message counts onto n_waves waves of at most per_wave relations each.  -> (owner[R], local[R], unit_rel[n_waves * per_wave]
-    (-1: unused), max load / mean load) or None when there are more relations than slots."""
+    """relation -> owner waves for the relation-owner backward (rgcn_bwd_own_f32).  The unit of ownership is a PART of a relation: a
+    relation much larger than a wave's fair share (the self-loop relation; the one relation of a graph with few of them) is cut into parts,
+    part q takes the relation's chunks q, q + parts, ... of every (tile, relation) bucket; every part has its own accumulator and they all
+    leave the CU into the same dW_r.  Parts are split greedily (largest part first) until no part exceeds half a wave's fair share or the
+    n_waves * per_wave slots are used up, then packed onto the waves by longest-processing-time, at most per_wave per wave.
+    -> (parts[R], unit_base[R], owner[U], local[U], unit_rel[n_waves * per_wave] (-1: unused), max load / mean load), U = sum(parts);
+    None when there are more relations than slots."""
+    import heapq
     counts = np.asarray(counts, dtype=np.int64)
     R = len(counts)
-    if R > n_waves * per_wave:
+    slots = n_waves * per_wave
+    if R > slots:
         return None
-    load, used = [0] * n_waves, [0] * n_waves
-    owner, local = np.zeros(R, np.int64), np.zeros(R, np.int64)
-    unit_rel = np.full(n_waves * per_wave, -1, np.int32)
-    for r in sorted(range(R), key=lambda r: (-int(counts[r]), r)):
+    parts = np.ones(R, np.int64)
+    target = max(1.0, float(counts.sum()) / n_waves)
+    heap = [(-float(counts[r]), r) for r in range(R)]
+    heapq.heapify(heap)
+    units = R
+    while units < slots and heap:
+        size, r = heap[0]
+        if -size <= 0.5 * target:
+            break
+        parts[r] += 1
+        units += 1
+        heapq.heapreplace(heap, (-float(counts[r]) / parts[r], r))
+    unit_base = np.cumsum(parts) - parts
+    U = int(parts.sum())
+    usize = np.concatenate([np.full(parts[r], counts[r] / parts[r]) for r in range(R)]) if R else np.zeros(0)
+    urel = np.repeat(np.arange(R), parts)
+    load, used = [0.0] * n_waves, [0] * n_waves
+    owner, local = np.zeros(U, np.int64), np.zeros(U, np.int64)
+    unit_rel = np.full(slots, -1, np.int32)
+    for u in sorted(range(U), key=lambda u: (-usize[u], u)):
         w = min((i for i in range(n_waves) if used[i] < per_wave), key=lambda i: (load[i], i))
-        owner[r], local[r] = w, used[w]
-        unit_rel[w * per_wave + used[w]] = r
+        owner[u], local[u] = w, used[w]
+        unit_rel[w * per_wave + used[w]] = urel[u]
         used[w] += 1
-        load[w] += int(counts[r])
+        load[w] += usize[u]
     mean = max(1.0, float(sum(load)) / n_waves)
-    return owner, local, unit_rel, max(load) / mean
+    return parts, unit_base, owner, local, unit_rel, max(load) / mean
 
 
 def build_softwin_plan(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_rows, own_waves=0, own_per_wave=0):
@@ -506,10 +528,11 @@ def build_softwin_plan(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_r
     against 0.375 ms uniformly random (profiles/r06_gather_window.txt); the forward kernel on this plan 0.327 ms against 0.398 on the same
     tiles in destination order (tools/softwin_probe.py) -- at the plain (tile, relation) padding (1.04), no window buckets to pad.
 
-    own_waves > 0 (the relation-owner backward, rgcn_bwd_own_f32): every relation belongs to one of own_waves waves (own_relations: LPT
-    over the message counts, at most own_per_wave relations per wave); a tile's chunks are grouped by owner wave, each wave's chunks ordered
-    by first source: own_ptr[tile * own_waves + wave] = the wave's first chunk; chunk_rel carries the relation's local number in its high
-    half (rel | local << 16); unit_rel[wave * own_per_wave + local] = relation.  None when the relations do not fit the slots.
+    own_waves > 0 (the relation-owner backward, rgcn_bwd_own_f32): every relation -- a large one: every PART of it -- belongs to one of
+    own_waves waves (own_relations: LPT over the message counts, at most own_per_wave units per wave); a tile's chunks are grouped by owner
+    wave, each wave's chunks ordered by first source: own_ptr[tile * own_waves + wave] = the wave's first chunk; chunk_rel carries the unit's
+    local number in its high half (rel | local << 16); unit_rel[wave * own_per_wave + local] = relation.  None when the relations do not
+    fit the slots.
 
     Made with torch ops (two sorts, a histogram, two scans): one-off preprocessing of STATIC graphs; per-call graphs keep
     build_plan_device.  Same fields as BuiltPlan; run_ptr holds only a tile's first and end chunk (entries 0 and R of its row) -- all the
@@ -547,8 +570,12 @@ def build_softwin_plan(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_r
         own = own_relations(torch.bincount(live_rel, minlength=num_rels).cpu().numpy(), own_waves, own_per_wave)
         if own is None:
             return None
-        owner_t = torch.from_numpy(own[0]).to(dev)
-        cgroup = ctile * own_waves + owner_t[cb % num_rels]                     # (tile, owner wave) of every chunk
+        parts_t, ubase_t = torch.from_numpy(own[0]).to(dev), torch.from_numpy(own[1]).to(dev)
+        owner_t, local_t = torch.from_numpy(own[2]).to(dev), torch.from_numpy(own[3]).to(dev)
+        crel0 = cb % num_rels
+        first_chunk = torch.cumsum(padded // CHUNK, 0) - padded // CHUNK          # first chunk of every bucket (bucket-major layout)
+        cunit = ubase_t[crel0] + (torch.arange(n_chunks, device=dev) - first_chunk[cb]) % parts_t[crel0]      # chunk j of its bucket -> part j % parts
+        cgroup = ctile * own_waves + owner_t[cunit]                             # (tile, owner wave) of every chunk
     else:
         cgroup = ctile
     cperm = torch.argsort(cgroup * n_src + S[:m_pad:CHUNK].long())             # inside a tile (a wave's share of it): by the chunk's first source (a real slot)
@@ -563,11 +590,11 @@ def build_softwin_plan(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_r
         p.src, p.dst, p.val = S, D, V
     crel = cb % num_rels
     if own is not None:
-        crel = crel | (torch.from_numpy(own[1]).to(dev)[crel] << 16)
+        crel = crel | (local_t[cunit] << 16)
         gcnt = torch.bincount(cgroup, minlength=n_tiles * own_waves)
         p.own_ptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(gcnt, 0)]).to(torch.int32)
-        p.unit_rel = torch.from_numpy(own[2]).to(dev)
-        p.own_waves, p.own_per_wave, p.own_balance = own_waves, own_per_wave, float(own[3])
+        p.unit_rel = torch.from_numpy(own[4]).to(dev)
+        p.own_waves, p.own_per_wave, p.own_balance = own_waves, own_per_wave, float(own[5])
     p.chunk_rel = crel[cperm].to(torch.int32).contiguous() if n_chunks else _i32(0, dev)
     tcnt = torch.bincount(ctile, minlength=n_tiles)
     tend = torch.cumsum(tcnt, 0)
