@@ -435,6 +435,8 @@ def main():
     t_b = time.perf_counter()
     for layer in (l1, l2):
         g = layer._graph_on(device)
+        if group is None and g.win_plan("fwd") is not None and g.win_plan("bwd_own") is not None:
+            continue          # round 6, one GPU: the soft-window plans are the only ones the step walks (forward, relation-owner backward)
         g.fwd_plan(d)
         if group is not None or g.bwd_blk_plan() is None:      # (sharded ranks may fall back to spmm on the wave-owned plan)
             g.bwd_plan(d)
