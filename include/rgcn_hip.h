@@ -366,6 +366,32 @@ RGCN_API int32_t rgcn_bwd_own_max_rows(void);
 RGCN_API int rgcn_bwd_own_f32(const float *G, const float *X, const float *Wt_packed, float *dX, float *dW, const void *rec,
                               const int32_t *own_ptr, const int32_t *unit_rel, int64_t n_tiles, int32_t tile_rows, int64_t n_dst,
                               int32_t R, int32_t flags, float *dbias, int64_t n_src, void *stream);
+/* Soft-window plans (round 6), built on the device: the relation-tile plan of rgcn_spmm_blk_f32 / rgcn_bwd_own_f32 in the order those
+ * kernels are fast on -- what replaces the reference's per-forward stack_matrices -> sum_sparse -> sparse COO pipeline (utils.py:143-166, :71-97;
+ * layers.py:255-279) for them.  Messages (dst <- src, rel, val; alive may be NULL) are bucketed by (dst / tile_rows, rel), every bucket padded to a
+ * multiple of 16 slots (pad: dst = -1, val = 0), the slots of a bucket sorted by src, the chunks (16 slots) of a tile ordered by their first source.
+ *   rgcn_softwin_tmp_bytes(n)   device scratch for sorting / scanning up to n elements (pass it as tmp to both calls; n >= M, buckets + 1, groups + 1)
+ *   rgcn_softwin_order          keys [M], keys_sorted [M], order [M], order_sorted [M]: scratch; bucket_cnt / bucket_base / bucket_first
+ *                               [n_tiles * R + 1]: live messages per bucket, first slot of every bucket (entry n_tiles * R = m_pad), first live
+ *                               message of every bucket in sorted order (last entry = number of live messages).  The caller reads m_pad and n_live back.
+ *   rgcn_softwin_fill           s_src / s_dst / s_val [m_pad], ckeys / ckeys_sorted / cidx / cidx_sorted / crel [m_pad / 16]: scratch; group_cnt
+ *                               [groups + 1]: scratch.  Outputs p_src / p_dst / p_val [m_pad], chunk_rel [m_pad / 16], group_ptr [groups + 1]
+ *                               (first chunk of every group).  own_waves = 0: a group is a tile (group_ptr = the tile pointer).  own_waves > 0
+ *                               (rgcn_bwd_own_f32): a group is (tile, owner wave); relation r is cut into parts[r] units unit_base[r] .. , chunk j of a
+ *                               bucket belongs to unit unit_base[r] + j % parts[r], owned by wave unit_owner[u] under the local number unit_local[u];
+ *                               chunk_rel = rel | local << 16. */
+RGCN_API int64_t rgcn_softwin_tmp_bytes(int64_t n);
+RGCN_API int rgcn_softwin_order(const int32_t *dst, const int32_t *src, const int32_t *rel, const uint8_t *alive, int64_t M, int64_t n_dst,
+                                int64_t n_src, int32_t R, int32_t tile_rows, uint64_t *keys, uint64_t *keys_sorted, int32_t *order,
+                                int32_t *order_sorted, int32_t *bucket_cnt, int32_t *bucket_base, int32_t *bucket_first, void *tmp,
+                                int64_t tmp_bytes, void *stream);
+RGCN_API int rgcn_softwin_fill(const int32_t *dst, const int32_t *src, const float *val, const uint64_t *keys_sorted, const int32_t *order_sorted,
+                               int64_t n_live, int64_t n_dst, int64_t n_src, int32_t R, int32_t tile_rows, const int32_t *bucket_base,
+                               const int32_t *bucket_first, int64_t m_pad, const int32_t *parts, const int32_t *unit_base,
+                               const int32_t *unit_owner, const int32_t *unit_local, int32_t own_waves, int32_t *s_src, int32_t *s_dst, float *s_val,
+                               uint64_t *ckeys, uint64_t *ckeys_sorted, int32_t *cidx, int32_t *cidx_sorted, int32_t *crel, int32_t *group_cnt,
+                               int32_t *p_src, int32_t *p_dst, float *p_val, int32_t *chunk_rel, int32_t *group_ptr, void *tmp, int64_t tmp_bytes,
+                               void *stream);
 /* The same walk as a FORWARD kernel (round 5): out[dst] = bias + sum val X[src] W_r (layers.py:293-301 at width 16) on the FORWARD plan cut
  * into tall tiles (one per workgroup, up to rgcn_spmm_blk_max_rows() = 1023 rows: 128 bytes of LDS per row, no weight table) with the chunk
  * records of rgcn_bwd_blk_prepare_f32.  For layers whose (tile, relation) buckets on the wave-owned tiles of rgcn_spmm_f32 are mostly

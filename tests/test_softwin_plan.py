@@ -12,30 +12,32 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "torch-rgcn_amd"))
 
 
-@pytest.mark.parametrize("N,R,M,rows,masked", [(1000, 7, 20000, 128, False), (1000, 7, 20000, 128, True), (37, 3, 11, 16, False),
-                                                (500, 1, 3000, 977, False), (64, 5, 0, 16, False)])
-def test_softwin_plan_invariants(N, R, M, rows, masked):
-    from torch_rgcn import _native
-    rng = np.random.default_rng(N + M)
+def random_messages(N, R, M, masked, seed):
+    rng = np.random.default_rng(seed)
     dst = torch.from_numpy(rng.integers(0, N, M).astype(np.int32))
     src = torch.from_numpy(rng.integers(0, N, M).astype(np.int32))
     rel = torch.from_numpy(rng.integers(0, R, M).astype(np.int32))
     val = torch.from_numpy(rng.random(M).astype(np.float32) + 0.5)
     alive = torch.from_numpy((rng.random(M) < 0.7).astype(np.uint8)) if masked else None
-    p = _native.build_softwin_plan(dst, src, rel, val, alive, N, N, R, rows)
-    live = np.ones(M, bool) if alive is None else alive.numpy() != 0
+    return dst, src, rel, val, alive
+
+
+def check_plan(p, dst, src, rel, val, alive, N, R, rows):
+    """the invariants of a soft-window plan without owners (the plan's tensors may live on the GPU)"""
+    M = dst.shape[0]
+    live = np.ones(M, bool) if alive is None else alive.cpu().numpy() != 0
     assert p.n_messages == int(live.sum()) and p.m_pad == 16 * p.n_chunks and p.n_tiles == -(-N // rows)
-    S, D, V = p.src.numpy()[:p.m_pad], p.dst.numpy()[:p.m_pad], p.val.numpy()[:p.m_pad]
+    S, D, V = (t.cpu().numpy()[:p.m_pad] for t in (p.src, p.dst, p.val))
     real = D >= 0
     assert int(real.sum()) == p.n_messages and np.all(V[~real] == 0.0)
-    crel = p.chunk_rel.numpy()[:p.n_chunks]
+    crel = p.chunk_rel.cpu().numpy()[:p.n_chunks]
     # the multiset of (dst, src, rel, val) is the live message list
     got = sorted(zip(D[real].tolist(), S[real].tolist(), np.repeat(crel, 16)[real].tolist(), V[real].tolist()))
-    want = sorted(zip(dst.numpy()[live].tolist(), src.numpy()[live].tolist(), rel.numpy()[live].tolist(), val.numpy()[live].tolist()))
+    want = sorted(zip(dst.cpu().numpy()[live].tolist(), src.cpu().numpy()[live].tolist(), rel.cpu().numpy()[live].tolist(), val.cpu().numpy()[live].tolist()))
     assert got == want
-    tp = p.tile_ptr.numpy()
+    tp = p.tile_ptr.cpu().numpy()
     assert tp[0] == 0 and tp[p.n_tiles] == p.n_chunks and np.all(np.diff(tp) >= 0)
-    rp = p.run_ptr.numpy().reshape(p.n_tiles, R + 1)
+    rp = p.run_ptr.cpu().numpy().reshape(p.n_tiles, R + 1)
     assert np.array_equal(rp[:, 0], tp[:-1]) and np.array_equal(rp[:, R], tp[1:])
     for t in range(p.n_tiles):
         firsts = []
@@ -51,6 +53,14 @@ def test_softwin_plan_invariants(N, R, M, rows, masked):
             assert seen.get(r, -1) <= int(s[0])                                   # ... and from chunk to chunk of one bucket
             seen[r] = int(s[k - 1])
         assert firsts == sorted(firsts)                                           # the tile's chunks: by first source
+
+
+@pytest.mark.parametrize("N,R,M,rows,masked", [(1000, 7, 20000, 128, False), (1000, 7, 20000, 128, True), (37, 3, 11, 16, False),
+                                                (500, 1, 3000, 977, False), (64, 5, 0, 16, False)])
+def test_softwin_plan_invariants(N, R, M, rows, masked):
+    from torch_rgcn import _native
+    dst, src, rel, val, alive = random_messages(N, R, M, masked, N + M)
+    check_plan(_native.build_softwin_plan(dst, src, rel, val, alive, N, N, R, rows), dst, src, rel, val, alive, N, R, rows)
 
 
 def test_own_relations_lpt_packing():
@@ -72,30 +82,21 @@ def test_own_relations_lpt_packing():
     assert parts[0] >= 12 and len(set(owner.tolist())) == 12 and balance < 1.2
 
 
-@pytest.mark.parametrize("masked,R", [(False, 20), (True, 20), (False, 2), (True, 1)])
-def test_softwin_plan_with_relation_owners(masked, R):
-    from torch_rgcn import _native
-    N, M, rows, NW, K = 900, 30000, 128, 12, 9
-    rng = np.random.default_rng(7)
-    dst = torch.from_numpy(rng.integers(0, N, M).astype(np.int32))
-    src = torch.from_numpy(rng.integers(0, N, M).astype(np.int32))
-    rel = torch.from_numpy(rng.integers(0, R, M).astype(np.int32))
-    val = torch.from_numpy(rng.random(M).astype(np.float32) + 0.5)
-    alive = torch.from_numpy((rng.random(M) < 0.6).astype(np.uint8)) if masked else None
-    p = _native.build_softwin_plan(dst, src, rel, val, alive, N, N, R, rows, own_waves=NW, own_per_wave=K)
-    live = np.ones(M, bool) if alive is None else alive.numpy() != 0
-    D, S, V = p.dst.numpy()[:p.m_pad], p.src.numpy()[:p.m_pad], p.val.numpy()[:p.m_pad]
-    packed = p.chunk_rel.numpy()[:p.n_chunks]
+def check_owner_plan(p, dst, src, rel, val, alive, N, R, rows, NW, K):
+    M = dst.shape[0]
+    live = np.ones(M, bool) if alive is None else alive.cpu().numpy() != 0
+    D, S, V = (t.cpu().numpy()[:p.m_pad] for t in (p.dst, p.src, p.val))
+    packed = p.chunk_rel.cpu().numpy()[:p.n_chunks]
     crel, cloc = packed & 0xFFFF, packed >> 16
-    unit_rel = p.unit_rel.numpy()
-    op = p.own_ptr.numpy()
+    unit_rel = p.unit_rel.cpu().numpy()
+    op = p.own_ptr.cpu().numpy()
     assert op.shape[0] == p.n_tiles * NW + 1 and op[0] == 0 and op[-1] == p.n_chunks and np.all(np.diff(op) >= 0)
     real = D >= 0
     got = sorted(zip(D[real].tolist(), S[real].tolist(), np.repeat(crel, 16)[real].tolist(), V[real].tolist()))
-    want = sorted(zip(dst.numpy()[live].tolist(), src.numpy()[live].tolist(), rel.numpy()[live].tolist(), val.numpy()[live].tolist()))
+    want = sorted(zip(dst.cpu().numpy()[live].tolist(), src.cpu().numpy()[live].tolist(), rel.cpu().numpy()[live].tolist(), val.cpu().numpy()[live].tolist()))
     assert got == want
     assert sorted(set(int(r) for r in unit_rel if r >= 0)) == list(range(R))
-    tp = p.tile_ptr.numpy()
+    tp = p.tile_ptr.cpu().numpy()
     for t in range(p.n_tiles):
         assert op[t * NW] == tp[t]
         for w in range(NW):
@@ -103,5 +104,16 @@ def test_softwin_plan_with_relation_owners(masked, R):
             for c in range(op[t * NW + w], op[t * NW + w + 1]):
                 assert unit_rel[w * K + int(cloc[c])] == crel[c]           # the chunk is in the range of a wave that owns (a part of) its relation
                 assert D[16 * c] >= 0 and D[16 * c] // rows == t
+                k = int((D[16 * c:16 * c + 16] >= 0).sum())
+                assert np.all(np.diff(S[16 * c:16 * c + k]) >= 0)
                 firsts.append(int(S[16 * c]))
             assert firsts == sorted(firsts)
+
+
+@pytest.mark.parametrize("masked,R", [(False, 20), (True, 20), (False, 2), (True, 1)])
+def test_softwin_plan_with_relation_owners(masked, R):
+    from torch_rgcn import _native
+    N, M, rows, NW, K = 900, 30000, 128, 12, 9
+    dst, src, rel, val, alive = random_messages(N, R, M, masked, 7)
+    p = _native.build_softwin_plan(dst, src, rel, val, alive, N, N, R, rows, own_waves=NW, own_per_wave=K)
+    check_owner_plan(p, dst, src, rel, val, alive, N, R, rows, NW, K)

@@ -40,6 +40,7 @@ def lib():
         L.rgcn_bwd_fused_scratch_floats.restype = ctypes.c_int64
         L.rgcn_bwd_lean_slot_bytes.restype = ctypes.c_int64
         L.rgcn_bwd_blk_rec_bytes.restype = ctypes.c_int64
+        L.rgcn_softwin_tmp_bytes.restype = ctypes.c_int64
         L.rgcn_colsum_scratch_floats.restype = ctypes.c_int64
         L.rgcn_gemm_scratch_floats.restype = ctypes.c_int64
         L.rgcn_basis_sum_workspace_bytes.restype = ctypes.c_int64
@@ -515,6 +516,72 @@ def own_relations(counts, n_waves, per_wave):
     return parts, unit_base, owner, local, unit_rel, max(load) / mean
 
 
+def build_softwin_plan_device(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_rows, own_waves=0, own_per_wave=0):
+    """build_softwin_plan through the C ABI (rgcn_softwin_order / rgcn_softwin_fill: two rocPRIM radix sorts, a histogram, three scans, four small
+    kernels): the form the layers use on the GPU.  Two host reads (m_pad / live messages / the relations' message counts; nothing else)."""
+    dev = dst.device
+    M = dst.shape[0]
+    n_tiles = (n_dst + tile_rows - 1) // tile_rows
+    nbk = n_tiles * num_rels
+    n_groups = n_tiles * max(own_waves, 1)
+    L = lib()
+    tmp_bytes = int(L.rgcn_softwin_tmp_bytes(c_i64(max(M, nbk + 1, n_groups + 1))))
+    tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
+    keys = torch.empty(2 * max(M, 1), dtype=torch.int64, device=dev)
+    order = torch.empty(2 * max(M, 1), dtype=torch.int32, device=dev)
+    bucket_cnt, bucket_base, bucket_first = _i32(nbk + 1, dev), _i32(nbk + 1, dev), _i32(nbk + 1, dev)
+    with _on(dev):
+        _check(L.rgcn_softwin_order(_dp(dst), _dp(src), _dp(rel), _dp(alive), c_i64(M), c_i64(n_dst), c_i64(n_src), c_i32(num_rels), c_i32(tile_rows),
+                                    _dp(keys[:max(M, 1)]), _dp(keys[max(M, 1):]), _dp(order[:max(M, 1)]), _dp(order[max(M, 1):]), _dp(bucket_cnt),
+                                    _dp(bucket_base), _dp(bucket_first), _dp(tmp), c_i64(tmp_bytes), _stream(dev)), "softwin_order")
+    rel_counts = bucket_cnt[:nbk].view(n_tiles, num_rels).sum(0, dtype=torch.int64)
+    host = torch.cat([bucket_base[nbk:nbk + 1].long(), bucket_first[nbk:nbk + 1].long(), bucket_cnt[:nbk].max().view(1).long(), rel_counts]).cpu().numpy()
+    m_pad, n_live, max_cnt = int(host[0]), int(host[1]), int(host[2])
+    own = None
+    if own_waves:
+        own = own_relations(host[3:], own_waves, own_per_wave)
+        if own is None:
+            return None
+    n_chunks = m_pad // CHUNK
+    p = BuiltPlan()
+    p.device = dev
+    p.n_dst, p.n_src, p.num_rels, p.tile_rows = n_dst, n_src, num_rels, tile_rows
+    p.n_tiles, p.m_pad, p.n_chunks, p.n_messages = n_tiles, m_pad, n_chunks, n_live
+    p.src, p.dst = _i32(m_pad, dev), _i32(m_pad, dev)
+    p.val = torch.empty(max(m_pad, 1), dtype=torch.float32, device=dev)
+    p.chunk_rel = _i32(n_chunks, dev)
+    group_ptr = _i32(n_groups + 1, dev)
+    stage = _i32(2 * max(m_pad, 1), dev)
+    stage_val = torch.empty(max(m_pad, 1), dtype=torch.float32, device=dev)
+    ckeys = torch.empty(2 * max(n_chunks, 1), dtype=torch.int64, device=dev)
+    cidx, crel, group_cnt = _i32(2 * max(n_chunks, 1), dev), _i32(n_chunks, dev), _i32(n_groups + 1, dev)
+    tabs = [None] * 4
+    if own is not None:
+        tabs = [torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev) for a in own[:4]]
+    nc1, mp1 = max(n_chunks, 1), max(m_pad, 1)
+    with _on(dev):
+        _check(L.rgcn_softwin_fill(_dp(dst), _dp(src), _dp(val), _dp(keys[max(M, 1):]), _dp(order[max(M, 1):]), c_i64(n_live), c_i64(n_dst), c_i64(n_src),
+                                   c_i32(num_rels), c_i32(tile_rows), _dp(bucket_base), _dp(bucket_first), c_i64(m_pad), _dp(tabs[0]), _dp(tabs[1]),
+                                   _dp(tabs[2]), _dp(tabs[3]), c_i32(own_waves), _dp(stage[:mp1]), _dp(stage[mp1:]), _dp(stage_val), _dp(ckeys[:nc1]),
+                                   _dp(ckeys[nc1:]), _dp(cidx[:nc1]), _dp(cidx[nc1:]), _dp(crel), _dp(group_cnt), _dp(p.src), _dp(p.dst), _dp(p.val),
+                                   _dp(p.chunk_rel), _dp(group_ptr), _dp(tmp), c_i64(tmp_bytes), _stream(dev)), "softwin_fill")
+    p.tile_ptr = group_ptr[::max(own_waves, 1)].contiguous()
+    p.run_ptr = torch.zeros(n_tiles * (num_rels + 1), dtype=torch.int32, device=dev)
+    p.run_ptr[0::num_rels + 1] = p.tile_ptr[:-1]
+    p.run_ptr[num_rels::num_rels + 1] = p.tile_ptr[1:]
+    if own is not None:
+        p.own_ptr = group_ptr
+        p.unit_rel = torch.from_numpy(own[4]).to(dev)
+        p.own_waves, p.own_per_wave, p.own_balance = own_waves, own_per_wave, float(own[5])
+    p.pack, p.aux = None, None
+    p.soft_windows = True
+    p.units_host = np.zeros((0, 4), np.int32)      # (not None: _blk_units cuts hub tiles into pieces from tile_ptr)
+    p.n_units, p.n_split, p.units = n_tiles, 0, None
+    p.n_items, p.items = 0, _i32(2, dev).view(1, 2)
+    p.max_run_chunks = (max_cnt + CHUNK - 1) // CHUNK
+    return p
+
+
 def build_softwin_plan(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_rows, own_waves=0, own_per_wave=0):
     """Plan of tall workgroup-owned tiles for the block-tile kernels (rgcn_spmm_blk_f32, rgcn_bwd_own_f32) in SOFT-WINDOW order (round 6):
 
@@ -534,10 +601,13 @@ def build_softwin_plan(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_r
     local number in its high half (rel | local << 16); unit_rel[wave * own_per_wave + local] = relation.  None when the relations do not
     fit the slots.
 
-    Made with torch ops (two sorts, a histogram, two scans): one-off preprocessing of STATIC graphs; per-call graphs keep
-    build_plan_device.  Same fields as BuiltPlan; run_ptr holds only a tile's first and end chunk (entries 0 and R of its row) -- all the
+    On the GPU this is build_softwin_plan_device (the C ABI: rgcn_softwin_order / rgcn_softwin_fill); the body below is the same procedure in
+    torch ops (two sorts, a histogram, two scans) -- CPU tensors (tests/test_softwin_plan.py checks the invariants on it) and
+    RGCN_SOFTWIN_BUILD=torch.  One-off preprocessing of STATIC graphs; per-call graphs keep build_plan_device.  Same fields as BuiltPlan; run_ptr holds only a tile's first and end chunk (entries 0 and R of its row) -- all the
     block-tile kernels read -- and there is no packed slot array."""
     dev = dst.device
+    if dev.type == "cuda" and routes.get("softwin_build", "device") != "torch":
+        return build_softwin_plan_device(dst, src, rel, val, alive, n_dst, n_src, num_rels, tile_rows, own_waves, own_per_wave)
     M = dst.shape[0]
     n_tiles = (n_dst + tile_rows - 1) // tile_rows
     nbk = n_tiles * num_rels
