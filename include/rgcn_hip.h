@@ -351,7 +351,7 @@ RGCN_API int rgcn_bwd_blk_f32(const float *G, const float *X, const float *Wt_pa
                               const int32_t *run_ptr, int64_t n_tiles, int32_t tile_rows, int64_t n_dst, int32_t R, int32_t flags,
                               float *dbias, int64_t n_src, const int32_t *units, int64_t n_units, int64_t n_split, void *stream);
 /* The same backward, RELATION-OWNER form (round 6; the default on large static graphs with dense buckets -- S1): tall tiles (up to
- * rgcn_bwd_own_max_rows() = 789 rows) walked in soft-window order.  LDS holds the dX tile (doubles, ds_add_f64), the X tile and 1 KiB of
+ * rgcn_bwd_own_max_rows() = 767 rows) walked in soft-window order.  LDS holds the dX tile (doubles, ds_add_f64), the X tile and 1 KiB of
  * scratch per wave, no weight-gradient table: every relation belongs to ONE of the workgroup's rgcn_bwd_own_waves() waves, which walks
  * that relation's chunks only and keeps its dW in registers for the life of the kernel (rgcn_bwd_own_units() relation slots per
  * workgroup; one flush of global atomics at the end).

@@ -7,14 +7,17 @@
 // of the table at any time (tools/micro/gather_window.hip).  The plan gives that order for free when a (tile, relation) bucket holds many
 // chunks (_native.build_softwin_plan: buckets sorted by source, a tile's chunks ordered by first source) -- which wants tiles of ~1000
 // rows, and the block-tile kernel (rgcn_bwd_blk.hip) holds 218: its LDS keeps every relation's dW (R KiB) next to the X and dX tiles.
-// Here dW sits in REGISTERS.  Every relation belongs to one of the workgroup's NW waves (LPT over the relations' message counts, made
-// with the plan); a wave walks only the chunks of its relations and keeps their K <= 9 accumulators (the MFMA's 16 x 16 D fragment:
-// 4 registers each) in a register vector indexed by the chunk's local relation number (wave-uniform: s_set_gpr_idx_on + v_mov), the dW
-// products accumulate in them directly.  No LDS table, no compare-and-swap adds, no dirty flags; the registers leave the CU once, at
-// the end of the kernel (the same R KiB of global atomics per workgroup as the block-tile kernel's one flush).
+// Here dW sits in REGISTERS.  Every relation -- every part of a large one -- belongs to one of the workgroup's NW waves (LPT over the
+// message counts, made with the plan); a wave walks only the chunks of its units and keeps their K accumulators (the MFMA's 16 x 16 D
+// fragment: 4 registers each) in a <32 x float> register vector indexed by the chunk's local number (wave-uniform: s_set_gpr_idx_on +
+// v_mov), the dW products accumulate in them directly.  No LDS table, no compare-and-swap adds, no dirty flags; the registers leave the
+// CU once, at the end of the kernel (the same R KiB of global atomics per workgroup as the block-tile kernel's one flush).
 // LDS = the dX tile in doubles (128 bytes per row, ds_add_f64 as in the block-tile kernel) + the X tile (64 bytes per row: A operand of
-// the dW products, ReLU mask of the epilogue) + 1 KiB of transposition scratch per wave: tiles of up to 789 rows (S1: 782 rows, 1279
-// tiles, 5 per CU; a bucket holds 162 messages = 10-11 chunks of ~6 MB source span).  12 waves per workgroup (152 registers per lane).
+// the dW products, ReLU mask of the epilogue) + 1 KiB of transposition scratch per wave: tiles of up to 767 rows (S1: 652 rows, 1534
+// tiles, 6 per CU; a bucket holds 135 messages = 8-9 chunks of ~8 MB source span).
+// Shape: 16 waves x 8 units x 3 chunks per loop trip (124 VGPRs).  Measured at S1 (tools/r6_own_variants.sh, bench.py's per-launch
+// average): 12 waves x 9 units x 4 chunks (152 VGPRs, the first shipped form) 0.460 ms; 16 x 7 x 4 (128 VGPRs, 11 spilled) 0.454;
+// 16 x 8 x 3 **0.437** -- the loads in flight per CU are the same 48 chunks, the fourth wave per SIMD hides the LDS and MFMA phases.
 // Measured and dropped on the way (tools/r6_own_abl.sh, profiles/r06_own_ablation.txt): the X rows read from global memory instead of an
 // LDS tile (tiles of 977 rows fit then): 16 more loads per four chunks, +0.09 ms; accumulators updated by indexed adds: +0.03 ms.
 //
@@ -34,8 +37,14 @@ constexpr int OWN_REC = 176;
 constexpr int OWN_REC_ROWS = 128;
 constexpr int OWN_REC_HDR = 160;
 constexpr int OWN_LDS_MAX = 160 * 1024;
-constexpr int OWN_NW = 12;           // waves per workgroup
-constexpr int OWN_K = 9;             // relations per wave (accumulators in registers)
+#ifndef RGCN_OWN_NW
+#define RGCN_OWN_NW 16
+#define RGCN_OWN_K 8
+#define RGCN_OWN_U 3
+#endif
+constexpr int OWN_NW = RGCN_OWN_NW;  // waves per workgroup
+constexpr int OWN_K = RGCN_OWN_K;    // relations per wave (accumulators in registers)
+constexpr int OWN_U = RGCN_OWN_U;    // chunks per loop trip
 constexpr int OWN_MAX_ROWS = (OWN_LDS_MAX - OWN_NW * BW_SCR2 * 4 - 64) / 192;      // 789: dX tile (doubles) + X tile + the waves' scratch
 
 // the first 8 accumulators of a wave: ONE register vector indexed by the chunk's local relation number (a <32 x float> is the largest
@@ -52,9 +61,10 @@ __global__ __launch_bounds__(64 * NW) void bwd_own_d16_kernel(
     const float *__restrict__ G, const float *__restrict__ X, const float *__restrict__ Wtp, float *__restrict__ dX,
     float *__restrict__ dWout, const char *__restrict__ rec, const int *__restrict__ own_ptr, int n_tiles, int tile_rows, int n_dst,
     float *__restrict__ dbias, int n_src, const int *__restrict__ unit_rel) {
-  constexpr int U = 4, NT = 64 * NW;
+  constexpr int U = OWN_U, NT = 64 * NW;
   constexpr int TQ = (OWN_MAX_ROWS * 4 + NT - 1) / NT;            // float4 of a tile a thread carries / converts per tile, at most
-  static_assert(K == 9, "8 indexed accumulators + 1");
+  static_assert(K <= 9, "8 indexed accumulators + 1");
+  constexpr bool EXT = K == 9;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -176,10 +186,12 @@ __global__ __launch_bounds__(64 * NW) void bwd_own_d16_kernel(
       // X rows of the slots come from the X tile; the products accumulate IN the wave's register accumulator of the chunk's relation
 #pragma unroll
       for (int h = 0; h < U && !(ABL & 2); h += 2) {
-        float bv[2][4], av[2][4];
+        constexpr int P = 2;
+        float bv[P][4], av[P][4];
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
+        for (int jj = 0; jj < P; ++jj) {
           const int j = h + jj;
+          if (j >= U) break;
           asm volatile("" ::: "memory");
           *reinterpret_cast<f32x4 *>(xs_wr) = sc[j];
           asm volatile("" ::: "memory");
@@ -189,37 +201,22 @@ __global__ __launch_bounds__(64 * NW) void bwd_own_d16_kernel(
           for (int t4 = 0; t4 < 4; ++t4) av[jj][t4] = *reinterpret_cast<const float *>(lds + (xrd + ro[j][t4]));
           asm volatile("" ::: "memory");
         }
-        f32x4 aw[2];
-        bool ext[2];
-        int li[2];
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          const int lr = (ABL & 4) ? 0 : (int)((unsigned)hd_[h + jj] >> 16);
-          ext[jj] = lr >= 8;                         // (wave-uniform selects, not multiplications by 0 / 1: an Inf stays in ITS relation)
-          li[jj] = 4 * (lr & 7);
-        }
         // (two chunks of one pair may share their relation: the second reads what the first wrote)
-        {
-          const f32x4 in0 = f32x4{accs[li[0]], accs[li[0] + 1], accs[li[0] + 2], accs[li[0] + 3]};
-          aw[0] = f32x4{ext[0] ? acc8[0] : in0[0], ext[0] ? acc8[1] : in0[1], ext[0] ? acc8[2] : in0[2], ext[0] ? acc8[3] : in0[3]};
 #pragma unroll
-          for (int t4 = 0; t4 < 4; ++t4) aw[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][t4], bv[0][t4], aw[0], 0, 0, 0);
-          accs[li[0]] = ext[0] ? in0[0] : aw[0][0];
-          accs[li[0] + 1] = ext[0] ? in0[1] : aw[0][1];
-          accs[li[0] + 2] = ext[0] ? in0[2] : aw[0][2];
-          accs[li[0] + 3] = ext[0] ? in0[3] : aw[0][3];
-          acc8 = f32x4{ext[0] ? aw[0][0] : acc8[0], ext[0] ? aw[0][1] : acc8[1], ext[0] ? aw[0][2] : acc8[2], ext[0] ? aw[0][3] : acc8[3]};
-        }
-        {
-          const f32x4 in1 = f32x4{accs[li[1]], accs[li[1] + 1], accs[li[1] + 2], accs[li[1] + 3]};
-          aw[1] = f32x4{ext[1] ? acc8[0] : in1[0], ext[1] ? acc8[1] : in1[1], ext[1] ? acc8[2] : in1[2], ext[1] ? acc8[3] : in1[3]};
+        for (int jj = 0; jj < P; ++jj) {
+          if (h + jj >= U) break;
+          const int lr = (ABL & 4) ? 0 : (int)((unsigned)hd_[h + jj] >> 16);
+          const bool ext = EXT && lr >= 8;           // (wave-uniform selects, not multiplications by 0 / 1: an Inf stays in ITS relation)
+          const int li = 4 * (lr & 7);
+          const f32x4 in0 = f32x4{accs[li], accs[li + 1], accs[li + 2], accs[li + 3]};
+          f32x4 aw = EXT ? f32x4{ext ? acc8[0] : in0[0], ext ? acc8[1] : in0[1], ext ? acc8[2] : in0[2], ext ? acc8[3] : in0[3]} : in0;
 #pragma unroll
-          for (int t4 = 0; t4 < 4; ++t4) aw[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][t4], bv[1][t4], aw[1], 0, 0, 0);
-          accs[li[1]] = ext[1] ? in1[0] : aw[1][0];
-          accs[li[1] + 1] = ext[1] ? in1[1] : aw[1][1];
-          accs[li[1] + 2] = ext[1] ? in1[2] : aw[1][2];
-          accs[li[1] + 3] = ext[1] ? in1[3] : aw[1][3];
-          acc8 = f32x4{ext[1] ? aw[1][0] : acc8[0], ext[1] ? aw[1][1] : acc8[1], ext[1] ? aw[1][2] : acc8[2], ext[1] ? aw[1][3] : acc8[3]};
+          for (int t4 = 0; t4 < 4; ++t4) aw = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj][t4], bv[jj][t4], aw, 0, 0, 0);
+          accs[li] = ext ? in0[0] : aw[0];
+          accs[li + 1] = ext ? in0[1] : aw[1];
+          accs[li + 2] = ext ? in0[2] : aw[2];
+          accs[li + 3] = ext ? in0[3] : aw[3];
+          if (EXT) acc8 = f32x4{ext ? aw[0] : acc8[0], ext ? aw[1] : acc8[1], ext ? aw[2] : acc8[2], ext ? aw[3] : acc8[3]};
         }
       }
       // ---- phase 3: the tile update, one ds_add_f64 per slot quarter: the 16 lanes of a quarter wave add to the 16 features of one row
