@@ -47,6 +47,13 @@
 namespace {
 
 constexpr int BLK_NW = 16;
+// chunks per loop trip of the forward kernel (rgcn_spmm_blk_f32).  FEWER is faster on the soft-window plan (S1, bench.py's per-launch average,
+// one box: 6 chunks 0.343 ms, 4: 0.325, 3: 0.325, 2: 0.317, 1: 0.314): what sets the gather's time is the span of sources the chip reads at one
+// time, and the chunks a wave has in flight widen it; AM's layer-2 forward (destination order, sparse buckets) does not care (0.292 / 0.293 / 0.295)
+#ifndef RGCN_BLK_FWD_U
+#define RGCN_BLK_FWD_U 1
+#endif
+constexpr int BLK_FWD_U = RGCN_BLK_FWD_U;
 constexpr int BLK_REC = 176;          // bytes per chunk record: 16 x {source row << 6, val} | 16 x u16 tile row | relation | 12 spare
 constexpr int BLK_REC_ROWS = 128;
 constexpr int BLK_REC_HDR = 160;
@@ -465,7 +472,7 @@ __global__ __launch_bounds__(64 * BLK_NW) void spmm_blk_d16_kernel(
     const float *__restrict__ X, const float *__restrict__ Wp, const float *__restrict__ bias, float *__restrict__ out,
     const char *__restrict__ rec, const int *__restrict__ run_ptr, int n_tiles, int tile_rows, int n_dst, int R,
     const int4 *__restrict__ units, int n_units) {
-  constexpr int U = 4, NW = BLK_NW, NT = 64 * BLK_NW;
+  constexpr int U = BLK_FWD_U, NW = BLK_NW, NT = 64 * BLK_NW;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;

@@ -15,9 +15,10 @@
 // LDS = the dX tile in doubles (128 bytes per row, ds_add_f64 as in the block-tile kernel) + the X tile (64 bytes per row: A operand of
 // the dW products, ReLU mask of the epilogue) + 1 KiB of transposition scratch per wave: tiles of up to 767 rows (S1: 652 rows, 1534
 // tiles, 6 per CU; a bucket holds 135 messages = 8-9 chunks of ~8 MB source span).
-// Shape: 16 waves x 8 units x 3 chunks per loop trip (124 VGPRs).  Measured at S1 (tools/r6_own_variants.sh, bench.py's per-launch
+// Shape: 16 waves x 8 units x 2 chunks per loop trip.  Measured at S1 (tools/r6_own_variants.sh, bench.py's per-launch
 // average): 12 waves x 9 units x 4 chunks (152 VGPRs, the first shipped form) 0.460 ms; 16 x 7 x 4 (128 VGPRs, 11 spilled) 0.454;
-// 16 x 8 x 3 **0.437** -- the loads in flight per CU are the same 48 chunks, the fourth wave per SIMD hides the LDS and MFMA phases.
+// 16 x 8 x 3 0.437 -- the loads in flight per CU are the same 48 chunks, the fourth wave per SIMD hides the LDS and MFMA phases;
+// 16 x 8 x 2 **0.432**, 16 x 8 x 1 0.447 (fewer chunks in flight narrow the span of sources the chip reads at one time).
 // Measured and dropped on the way (tools/r6_own_abl.sh, profiles/r06_own_ablation.txt): the X rows read from global memory instead of an
 // LDS tile (tiles of 977 rows fit then): 16 more loads per four chunks, +0.09 ms; accumulators updated by indexed adds: +0.03 ms.
 //
@@ -40,7 +41,7 @@ constexpr int OWN_LDS_MAX = 160 * 1024;
 #ifndef RGCN_OWN_NW
 #define RGCN_OWN_NW 16
 #define RGCN_OWN_K 8
-#define RGCN_OWN_U 3
+#define RGCN_OWN_U 2
 #endif
 constexpr int OWN_NW = RGCN_OWN_NW;  // waves per workgroup
 constexpr int OWN_K = RGCN_OWN_K;    // relations per wave (accumulators in registers)
