@@ -54,6 +54,14 @@ constexpr int BLK_NW = 16;
 #define RGCN_BLK_FWD_U 1
 #endif
 constexpr int BLK_FWD_U = RGCN_BLK_FWD_U;
+// chunks per loop trip of the block-tile backward (rgcn_bwd_blk_f32).  Rounds 3-5 ran 4 -- on the 128-VGPR cliff, 6 registers spilled outside the
+// loop; round 6 measured 3 (S1 on this kernel 0.483 -> 0.461 ms per launch; AM-shaped block-diagonal layer, DIAG4 on 509-row tiles, 0.515 -> 0.504;
+// AIFB 0.032, MUTAG 0.037 -> 0.035) and 2 (AM 0.520).  (A first measurement of 3 showed 0.435 for AM: the pair loop of the dW part indexed a fourth
+// chunk that was not there and the compiler dropped the work -- test_am_tenth_scale_block_diagonal_layer_vs_oracle caught it.)
+#ifndef RGCN_BLK_BWD_U
+#define RGCN_BLK_BWD_U 3
+#endif
+constexpr int BLK_BWD_U = RGCN_BLK_BWD_U;
 constexpr int BLK_REC = 176;          // bytes per chunk record: 16 x {source row << 6, val} | 16 x u16 tile row | relation | 12 spare
 constexpr int BLK_REC_ROWS = 128;
 constexpr int BLK_REC_HDR = 160;
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
     int R, float *__restrict__ dbias, int n_src,
     const int4 *__restrict__ units, int n_units) {      // units: {tile, first chunk, end chunk, flags}: a hub tile arrives in pieces (RGCN_U_SHARED:
                                                         // their dX rows are ADDED to a zeroed dX); NULL: one unit per tile (n_units = n_tiles)
-  constexpr int U = 4, NW = BLK_NW, NT = 64 * BLK_NW;
+  constexpr int U = BLK_BWD_U, NW = BLK_NW, NT = 64 * BLK_NW;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -305,6 +313,7 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj) {
             const int j = h + jj;
+            if (j >= U) break;    // (odd U: the last pair is a single chunk)
             if (ABL & 32) {       // no LDS round trips: the operands are whatever the lane holds
 #pragma unroll
               for (int t4 = 0; t4 < 4; ++t4) { bv[jj][t4] = sc[j][t4]; av[jj][t4] = __builtin_bit_cast(float, ro[j][t4]); }
@@ -320,12 +329,13 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
             }
           }
 #pragma unroll
-          for (int jj = 0; jj < 2; ++jj) aw[h + jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int jj = 0; jj < 2; ++jj)
+            if (h + jj < U) aw[h + jj] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
-              aw[h + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj][t4], bv[jj][t4], aw[h + jj], 0, 0, 0);
+              if (h + jj < U) aw[h + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj][t4], bv[jj][t4], aw[h + jj], 0, 0, 0);
         }
         // relation bookkeeping (wave-uniform): consecutive chunks of one relation accumulate in registers
 #pragma unroll
