@@ -54,6 +54,12 @@ constexpr int BLK_NW = 16;
 #define RGCN_BLK_FWD_U 1
 #endif
 constexpr int BLK_FWD_U = RGCN_BLK_FWD_U;
+#ifndef RGCN_BLK_FWD_NW
+#define RGCN_BLK_FWD_NW 16
+#endif
+constexpr int BLK_FWD_NW = RGCN_BLK_FWD_NW;    // waves per workgroup of the forward kernel (16, 8 or 4).  S1, waves x chunks per trip: 16 x 1 0.316 ms,
+                                               // 8 x 2 0.364, 8 x 1 0.499, 4 x 4 0.477, 4 x 2 0.623: sixteen chunks in flight per CU, on as many waves as fit
+constexpr int BLK_FWD_TQS = 16 / BLK_FWD_NW;   // a thread's share of the tile at the hand-over grows accordingly
 // chunks per loop trip of the block-tile backward (rgcn_bwd_blk_f32).  Rounds 3-5 ran 4 -- on the 128-VGPR cliff, 6 registers spilled outside the
 // loop; round 6 measured 3 (S1 on this kernel 0.483 -> 0.461 ms per launch; AM-shaped block-diagonal layer, DIAG4 on 509-row tiles, 0.515 -> 0.504;
 // AIFB 0.032, MUTAG 0.037 -> 0.035) and 2 (AM 0.520).  (A first measurement of 3 showed 0.435 for AM: the pair loop of the dW part indexed a fourth
@@ -478,11 +484,11 @@ __global__ __launch_bounds__(64 * BLK_NW) void bwd_blk_d16_kernel(
 // instead of ~2 on 64-row ones); until round 5 that layer's forward was two passes over a [M, 16] intermediate (0.40 + 0.22 ms).
 // TQ = ceil(tile_rows / 256): float4 of the tile a thread converts and stores per tile.
 template <bool RELU, int TQ>
-__global__ __launch_bounds__(64 * BLK_NW) void spmm_blk_d16_kernel(
+__global__ __launch_bounds__(64 * BLK_FWD_NW) void spmm_blk_d16_kernel(
     const float *__restrict__ X, const float *__restrict__ Wp, const float *__restrict__ bias, float *__restrict__ out,
     const char *__restrict__ rec, const int *__restrict__ run_ptr, int n_tiles, int tile_rows, int n_dst, int R,
     const int4 *__restrict__ units, int n_units) {
-  constexpr int U = BLK_FWD_U, NW = BLK_NW, NT = 64 * BLK_NW;
+  constexpr int U = BLK_FWD_U, NW = BLK_FWD_NW, NT = 64 * BLK_FWD_NW;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -494,7 +500,7 @@ __global__ __launch_bounds__(64 * BLK_NW) void spmm_blk_d16_kernel(
     if (units) return units[u];
     return int4{u, run_ptr[(size_t)u * (R + 1)], run_ptr[(size_t)u * (R + 1) + R], 0};
   };
-  auto static_quads = [](int n) { return max(1, min(4, (3 * n) / (4 * BLK_NW))); };
+  auto static_quads = [](int n) { return max(1, min(4, (3 * n) / (4 * BLK_FWD_NW))); };
   int un = blockIdx.x;
   int4 unit = unit_of(un);
   int row0 = __builtin_amdgcn_readfirstlane(unit.x) * tile_rows;
@@ -783,22 +789,22 @@ extern "C" int rgcn_spmm_blk_f32(const float *X, const float *W_packed, const fl
       if (e != hipSuccess) return e;
       raised = true;
     }
-    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64 * BLK_NW), lds, st, X, W_packed, bias, out, static_cast<const char *>(rec), run_ptr, (int)n_tiles,
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(64 * BLK_FWD_NW), lds, st, X, W_packed, bias, out, static_cast<const char *>(rec), run_ptr, (int)n_tiles,
                        tile_rows, (int)n_dst, R, reinterpret_cast<const int4 *>(units), (int)n_units);
     return hipGetLastError();
   };
   static bool r[8] = {false, false, false, false, false, false, false, false};
   const int tq = (tile_rows + 255) / 256;
   if (relu) {
-    if (tq == 1) HIP_TRY(launch(spmm_blk_d16_kernel<true, 1>, r[0]));
-    else if (tq == 2) HIP_TRY(launch(spmm_blk_d16_kernel<true, 2>, r[1]));
-    else if (tq == 3) HIP_TRY(launch(spmm_blk_d16_kernel<true, 3>, r[2]));
-    else HIP_TRY(launch(spmm_blk_d16_kernel<true, 4>, r[3]));
+    if (tq == 1) HIP_TRY(launch(spmm_blk_d16_kernel<true, 1 * BLK_FWD_TQS>, r[0]));
+    else if (tq == 2) HIP_TRY(launch(spmm_blk_d16_kernel<true, 2 * BLK_FWD_TQS>, r[1]));
+    else if (tq == 3) HIP_TRY(launch(spmm_blk_d16_kernel<true, 3 * BLK_FWD_TQS>, r[2]));
+    else HIP_TRY(launch(spmm_blk_d16_kernel<true, 4 * BLK_FWD_TQS>, r[3]));
   } else {
-    if (tq == 1) HIP_TRY(launch(spmm_blk_d16_kernel<false, 1>, r[4]));
-    else if (tq == 2) HIP_TRY(launch(spmm_blk_d16_kernel<false, 2>, r[5]));
-    else if (tq == 3) HIP_TRY(launch(spmm_blk_d16_kernel<false, 3>, r[6]));
-    else HIP_TRY(launch(spmm_blk_d16_kernel<false, 4>, r[7]));
+    if (tq == 1) HIP_TRY(launch(spmm_blk_d16_kernel<false, 1 * BLK_FWD_TQS>, r[4]));
+    else if (tq == 2) HIP_TRY(launch(spmm_blk_d16_kernel<false, 2 * BLK_FWD_TQS>, r[5]));
+    else if (tq == 3) HIP_TRY(launch(spmm_blk_d16_kernel<false, 3 * BLK_FWD_TQS>, r[6]));
+    else HIP_TRY(launch(spmm_blk_d16_kernel<false, 4 * BLK_FWD_TQS>, r[7]));
   }
   return RGCN_OK;
 }

@@ -1373,7 +1373,7 @@ def spmm_blk_rows(n_nodes, device=None):
     every CU the same number of tiles; 0 for graphs too small to fill the chip with one tile per workgroup"""
     if n_nodes < _BLK_MIN_NODES or routes.get("spmm_csr", "1") == "0":
         return 0
-    cap = min(1000, int(lib().rgcn_spmm_blk_max_rows()))
+    cap = min(1000, int(lib().rgcn_spmm_blk_max_rows()), int(routes.get("fwd_rows_cap", "1000")))
     n_cu = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).multi_processor_count
     per_cu = -(-n_nodes // (n_cu * cap))
     return -(-n_nodes // (n_cu * per_cu))

@@ -22,7 +22,7 @@ NAMES = (
     "deterministic", "relabel", "tile_rows", "bwd_tile_rows", "bwd", "bwd_kernel", "bwd_blk_cap", "twopass", "pad16",
     "featureless_csr", "dist_comm", "dist_slabs", "deferred_checks", "block_path", "block_fwd", "basis_path",
     "wgrad_tiles", "wgrad_item_chunks", "wgrad", "spmm_csr", "sparse_path", "graph_build", "fbasis_inplace_mb", "fbasis",
-    "distmult_bwd", "diag_path", "capture", "fbasis_tile", "pad16_view", "softwin", "softwin_build", "bwd_own", "own_rows_cap",
+    "distmult_bwd", "diag_path", "capture", "fbasis_tile", "pad16_view", "softwin", "softwin_build", "bwd_own", "own_rows_cap", "fwd_rows_cap",
 )
 NATIVE = ("bwd_nw", "gemm_bm", "spmm_u", "wgrad_rg", "wgrad_u", "bwd_abl")
 
