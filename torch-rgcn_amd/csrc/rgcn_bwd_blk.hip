@@ -63,7 +63,7 @@ constexpr int BLK_FWD_TQS = 16 / BLK_FWD_NW;   // a thread's share of the tile a
 // chunks per loop trip of the block-tile backward (rgcn_bwd_blk_f32).  Rounds 3-5 ran 4 -- on the 128-VGPR cliff, 6 registers spilled outside the
 // loop; round 6 measured 3 (S1 on this kernel 0.483 -> 0.461 ms per launch; AM-shaped block-diagonal layer, DIAG4 on 509-row tiles, 0.515 -> 0.504;
 // AIFB 0.032, MUTAG 0.037 -> 0.035) and 2 (AM 0.520).  (A first measurement of 3 showed 0.435 for AM: the pair loop of the dW part indexed a fourth
-// chunk that was not there and the compiler dropped the work -- test_am_tenth_scale_block_diagonal_layer_vs_oracle caught it.)
+// chunk that was not there and the compiler dropped the work -- the AM tenth-scale parity test (tests/test_gpu_configs.py) caught it.)
 #ifndef RGCN_BLK_BWD_U
 #define RGCN_BLK_BWD_U 3
 #endif
