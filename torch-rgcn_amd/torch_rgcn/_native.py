@@ -525,7 +525,8 @@ def build_softwin_plan_device(dst, src, rel, val, alive, n_dst, n_src, num_rels,
     nbk = n_tiles * num_rels
     n_groups = n_tiles * max(own_waves, 1)
     L = lib()
-    tmp_bytes = int(L.rgcn_softwin_tmp_bytes(c_i64(max(M, nbk + 1, n_groups + 1))))
+    # (the chunks sorted in the second step number at most M / 16 + one per non-empty bucket)
+    tmp_bytes = int(L.rgcn_softwin_tmp_bytes(c_i64(max(M, nbk + 1, n_groups + 1, M // CHUNK + min(nbk, M) + 1))))
     tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
     keys = torch.empty(2 * max(M, 1), dtype=torch.int64, device=dev)
     order = torch.empty(2 * max(M, 1), dtype=torch.int32, device=dev)
