@@ -11,7 +11,8 @@ DEV = torch.device("cuda:0")
 
 
 @pytest.mark.parametrize("N,R,M,rows,masked", [(1000, 7, 20000, 128, False), (1000, 7, 20000, 128, True), (37, 3, 11, 16, False),
-                                                (500, 1, 3000, 977, False), (64, 5, 0, 16, False), (70_000, 11, 400_000, 274, True)])
+                                                (500, 1, 3000, 977, False), (64, 5, 0, 16, False), (70_000, 11, 400_000, 274, True),
+                                                (6400, 100, 10_000, 64, False)])        # (as many chunks as messages: one nearly empty bucket each)
 def test_device_built_plan_invariants(N, R, M, rows, masked):
     from torch_rgcn import _native, routes
     dst, src, rel, val, alive = random_messages(N, R, M, masked, N + M)
